@@ -1,0 +1,149 @@
+/*
+ * sbwtgpu.h -- C ABI of the MI355X (gfx950) k-mer search path for plain-matrix SBWT indexes.
+ *
+ * This is the drop-in boundary: the functions below are what a binding in the reference
+ * (algbio/SBWT, C++17) would call instead of running its CPU loop.  Each entry point cites
+ * the reference interface it replaces (paths relative to the reference repository root).
+ * INTEGRATION.md shows the reference-side glue.
+ *
+ * Conventions
+ *   - plain C, no C++/torch types; all sizes/ranks are int64_t like the reference's API.
+ *   - return value: 0 = ok, negative = error (codes below); sbwtgpu_last_error() gives the
+ *     message (thread-local).  Nothing throws or aborts across this boundary.
+ *   - ownership: handles are owned by the library (destroy them); every buffer is owned by
+ *     the caller and only borrowed for the duration of the call (index_create copies).
+ *   - threading: a handle is immutable after creation; concurrent query calls on one handle
+ *     are allowed (host-buffer calls use a private stream each).
+ *   - "host" entry points take host pointers and do H2D/D2H themselves; "_dev" entry points
+ *     take device pointers on the index's device plus a hipStream_t (as void*), enqueue
+ *     asynchronously and never synchronise.
+ *   - bit vectors are arrays of little-endian uint64_t words, bit i of the vector is bit
+ *     (i % 64) of word i / 64 -- the sdsl::bit_vector convention used by the reference.
+ */
+#ifndef SBWTGPU_H
+#define SBWTGPU_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SBWTGPU_OK                      0
+#define SBWTGPU_ERR_INVALID_ARG        -1
+#define SBWTGPU_ERR_NO_DEVICE          -2   /* no usable HIP device / wrong device index */
+#define SBWTGPU_ERR_HIP                -3   /* a HIP runtime call failed */
+#define SBWTGPU_ERR_NO_STREAMING       -4   /* "Error: streaming search support not built" (SBWT.hh:546-547) */
+#define SBWTGPU_ERR_PRECALC_TOO_LONG   -5   /* precalc > 20 (SBWT.hh:619-621) */
+#define SBWTGPU_ERR_PRECALC_GT_K       -6   /* precalc > k  (SBWT.hh:623-624) */
+#define SBWTGPU_ERR_NOT_SINGLETON      -7   /* "Bug: k-mer search did not give a singleton interval" (SBWT.hh:410-413) */
+#define SBWTGPU_ERR_OOM                -8
+#define SBWTGPU_ERR_READ_TOO_LONG      -9   /* a single read of >= 2^31 bases */
+
+typedef struct sbwtgpu_index sbwtgpu_index;
+
+/* What sbwt::SBWT<SubsetMatrixRank<sdsl::bit_vector, sdsl::rank_support_v5<>>> holds
+ * (include/sbwt/SBWT.hh:36-45, include/sbwt/SubsetMatrixRank.hh:19-23).  Rank supports
+ * are not passed: the library builds its own device-side directory from the bits. */
+typedef struct {
+    int64_t         n_nodes;      /* number of columns (SBWT.hh:43); > 0 (the root always exists) */
+    const uint64_t *A_bits;       /* ceil(n_nodes/64) words each */
+    const uint64_t *C_bits;
+    const uint64_t *G_bits;
+    const uint64_t *T_bits;
+    const uint64_t *suffix_group_starts; /* NULL => no streaming support (SBWT.hh:253) */
+    int64_t         k;            /* SBWT.hh:45 */
+    int64_t         n_kmers;      /* SBWT.hh:44 (informational) */
+    int64_t         precalc_k;    /* SBWT.hh:41; 0 => no precalc table */
+    const int64_t  *precalc;      /* 4^precalc_k (first,second) pairs as loaded from an index
+                                     file (SBWT.hh:40,510), or NULL => computed on the device
+                                     (do_kmer_prefix_precalc, SBWT.hh:616-645) */
+} sbwtgpu_index_desc;
+
+typedef struct {
+    int64_t n_nodes, n_kmers, k, precalc_k;
+    int64_t C[4];                 /* SBWT.hh:344-349 */
+    int32_t has_streaming_support;
+    int32_t device;
+    int64_t device_precalc_k;     /* depth of the library's own device-side prefix table (>= precalc_k) */
+    int64_t blob_bytes;           /* size of the device image (what index_bcast moves) */
+} sbwtgpu_index_info;
+
+/* ---- library ---- */
+const char *sbwtgpu_version(void);
+const char *sbwtgpu_last_error(void);
+int         sbwtgpu_device_count(int *count);
+
+/* ---- index life cycle ---- */
+/* Replaces SBWT(A,C,G,T,ssup,k,n_kmers,precalc_k) ctor (SBWT.hh:335-353) and the tail of
+ * SBWT::load (SBWT.hh:500-516): builds the device image (interleaved 64-column blocks with
+ * rank counts), the C array, and the prefix table(s), on HIP device `device`. */
+int  sbwtgpu_index_create(const sbwtgpu_index_desc *desc, int device, sbwtgpu_index **out);
+void sbwtgpu_index_destroy(sbwtgpu_index *idx);
+int  sbwtgpu_index_get_info(const sbwtgpu_index *idx, sbwtgpu_index_info *info);
+/* get_precalc() (SBWT.hh:131): copies the 4^precalc_k (first,second) pairs to host memory. */
+int  sbwtgpu_index_get_precalc(const sbwtgpu_index *idx, int64_t *out_pairs);
+
+/* ---- multi-GPU replication (no reference equivalent) ---- */
+/* One process per GPU (torch.distributed / any launcher): rank 0 exports the device image,
+ * the launcher broadcasts header (host bytes) and blob (device bytes, e.g. RCCL broadcast over
+ * xGMI), every other rank adopts the received bytes.  The blob is position independent. */
+int  sbwtgpu_index_export_header(const sbwtgpu_index *idx, void *header_out, int64_t header_cap,
+                                 int64_t *header_bytes);
+int  sbwtgpu_index_blob(const sbwtgpu_index *idx, void **dev_ptr, int64_t *bytes);
+/* Adopts a caller-owned device blob (must stay alive and unchanged while the handle lives). */
+int  sbwtgpu_index_adopt(const void *header, int64_t header_bytes, void *dev_blob, int64_t blob_bytes,
+                         int device, sbwtgpu_index **out);
+/* Single-process form used by the C++ CLI (--gpus N): replicates `root` onto the listed
+ * devices with one RCCL ncclBroadcast; out[i] receives the handle for devs[i] (out[i] == root
+ * where devs[i] is the root's device). */
+int  sbwtgpu_index_bcast(sbwtgpu_index *root, int n_dev, const int *devs, sbwtgpu_index **out);
+
+/* ---- queries, host buffers ---- */
+/* SubsetMatrixRank::rank(pos, c) (SubsetMatrixRank.hh:31-37) for n (pos, sym) pairs;
+ * pos in [0, n_nodes]; sym is the ASCII char; non-ACGT (upper case) => 0. */
+int  sbwtgpu_rank_batch(const sbwtgpu_index *idx, const int64_t *pos, const char *sym, int64_t n,
+                        int64_t *out);
+/* SBWT::streaming_search(const char*, int64_t) (SBWT.hh:544-581) for n_reads reads:
+ * read r = bases[read_off[r] .. read_off[r+1]); its max(0, len-k+1) results are written to
+ * out[out_off[r] ..] (out_off[r+1]-out_off[r] must equal that count).  -1 = not found.
+ * Returns SBWTGPU_ERR_NO_STREAMING where the reference throws. */
+int  sbwtgpu_streaming_search_batch(const sbwtgpu_index *idx, const char *bases, const int64_t *read_off,
+                                    int64_t n_reads, int64_t *out, const int64_t *out_off);
+/* The non-streaming loop of run_queries_not_streaming (src/CLI/sbwt_search.cpp:78-84):
+ * out[out_off[r] + i] = SBWT::search(read_r + i) (SBWT.hh:389-415).  Works with or without
+ * streaming support. */
+int  sbwtgpu_search_batch(const sbwtgpu_index *idx, const char *bases, const int64_t *read_off,
+                          int64_t n_reads, int64_t *out, const int64_t *out_off);
+/* SBWT::update_sbwt_interval(S, len, I) (SBWT.hh:422-437) for n independent queries:
+ * query q extends interval (first[q], second[q]) by bases[off[q] .. off[q+1]) in place. */
+int  sbwtgpu_update_interval_batch(const sbwtgpu_index *idx, const char *bases, const int64_t *off,
+                                   int64_t n, int64_t *first, int64_t *second);
+/* SBWT::forward(node, c) (SBWT.hh:368-381) for n (node, sym) pairs. */
+int  sbwtgpu_forward_batch(const sbwtgpu_index *idx, const int64_t *node, const char *sym, int64_t n,
+                           int64_t *out);
+
+/* ---- queries, device buffers (asynchronous on `stream`) ---- */
+/* Scratch the search kernels need: the 2-bit re-encoding of the bases (total_bases/2 + 64
+ * bytes) plus a work-queue header.  The caller allocates it once and may reuse it across
+ * calls on the same stream. */
+int64_t sbwtgpu_search_workspace_bytes(int64_t total_bases);
+int  sbwtgpu_streaming_search_dev(const sbwtgpu_index *idx, const char *d_bases, int64_t total_bases,
+                                  const int64_t *d_read_off, int64_t n_reads, int64_t *d_out,
+                                  const int64_t *d_out_off, void *d_workspace, int64_t workspace_bytes,
+                                  void *stream);
+int  sbwtgpu_search_dev(const sbwtgpu_index *idx, const char *d_bases, int64_t total_bases,
+                        const int64_t *d_read_off, int64_t n_reads, int64_t *d_out,
+                        const int64_t *d_out_off, void *d_workspace, int64_t workspace_bytes,
+                        void *stream);
+int  sbwtgpu_rank_dev(const sbwtgpu_index *idx, const int64_t *d_pos, const char *d_sym, int64_t n,
+                      int64_t *d_out, void *stream);
+/* After the stream has been synchronised: status word of the last search on this workspace
+ * (0, or SBWTGPU_ERR_NOT_SINGLETON). */
+int  sbwtgpu_workspace_status(const void *d_workspace, void *stream, int *status);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

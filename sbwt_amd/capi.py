@@ -1,0 +1,274 @@
+"""ctypes binding of the C ABI in include/sbwtgpu.h (libsbwtgpu.so).
+
+Plumbing only: tests and bench.py call the HIP path through this exactly as a C/C++ host
+would.  There is no Python or CPU implementation of any query behind these calls -- if the
+shared library is missing, importing/using this module fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Sequence
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libsbwtgpu.so")
+
+OK = 0
+ERR_INVALID_ARG = -1
+ERR_NO_DEVICE = -2
+ERR_HIP = -3
+ERR_NO_STREAMING = -4
+ERR_PRECALC_TOO_LONG = -5
+ERR_PRECALC_GT_K = -6
+ERR_NOT_SINGLETON = -7
+ERR_OOM = -8
+ERR_READ_TOO_LONG = -9
+
+# every symbol include/sbwtgpu.h declares (checked by tests/test_abi.py)
+EXPORTED_SYMBOLS = [
+    "sbwtgpu_version", "sbwtgpu_last_error", "sbwtgpu_device_count",
+    "sbwtgpu_index_create", "sbwtgpu_index_destroy", "sbwtgpu_index_get_info", "sbwtgpu_index_get_precalc",
+    "sbwtgpu_index_export_header", "sbwtgpu_index_blob", "sbwtgpu_index_adopt", "sbwtgpu_index_bcast",
+    "sbwtgpu_rank_batch", "sbwtgpu_streaming_search_batch", "sbwtgpu_search_batch",
+    "sbwtgpu_update_interval_batch", "sbwtgpu_forward_batch",
+    "sbwtgpu_search_workspace_bytes", "sbwtgpu_streaming_search_dev", "sbwtgpu_search_dev",
+    "sbwtgpu_rank_dev", "sbwtgpu_workspace_status",
+]
+
+
+class SbwtGpuError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"sbwtgpu error {code}: {msg}")
+        self.code = code
+        self.msg = msg
+
+
+class IndexDesc(C.Structure):
+    _fields_ = [
+        ("n_nodes", C.c_int64),
+        ("A_bits", C.c_void_p), ("C_bits", C.c_void_p), ("G_bits", C.c_void_p), ("T_bits", C.c_void_p),
+        ("suffix_group_starts", C.c_void_p),
+        ("k", C.c_int64), ("n_kmers", C.c_int64), ("precalc_k", C.c_int64),
+        ("precalc", C.c_void_p),
+    ]
+
+
+class IndexInfo(C.Structure):
+    _fields_ = [
+        ("n_nodes", C.c_int64), ("n_kmers", C.c_int64), ("k", C.c_int64), ("precalc_k", C.c_int64),
+        ("C", C.c_int64 * 4),
+        ("has_streaming_support", C.c_int32), ("device", C.c_int32),
+        ("device_precalc_k", C.c_int64), ("blob_bytes", C.c_int64),
+    ]
+
+
+_lib: Optional[C.CDLL] = None
+
+
+def lib() -> C.CDLL:
+    """Loads libsbwtgpu.so (built by `python -m sbwt_amd.build` / __graft_entry__.build())."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} is missing: build it with `python -m sbwt_amd.build` "
+                          "(there is no CPU fallback for the GPU search path)")
+    L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    vp, i64, ci = C.c_void_p, C.c_int64, C.c_int
+    L.sbwtgpu_version.restype = C.c_char_p
+    L.sbwtgpu_last_error.restype = C.c_char_p
+    L.sbwtgpu_device_count.argtypes = [C.POINTER(ci)]
+    L.sbwtgpu_index_create.argtypes = [C.POINTER(IndexDesc), ci, C.POINTER(vp)]
+    L.sbwtgpu_index_destroy.argtypes = [vp]
+    L.sbwtgpu_index_destroy.restype = None
+    L.sbwtgpu_index_get_info.argtypes = [vp, C.POINTER(IndexInfo)]
+    L.sbwtgpu_index_get_precalc.argtypes = [vp, vp]
+    L.sbwtgpu_index_export_header.argtypes = [vp, vp, i64, C.POINTER(i64)]
+    L.sbwtgpu_index_blob.argtypes = [vp, C.POINTER(vp), C.POINTER(i64)]
+    L.sbwtgpu_index_adopt.argtypes = [vp, i64, vp, i64, ci, C.POINTER(vp)]
+    L.sbwtgpu_index_bcast.argtypes = [vp, ci, C.POINTER(ci), C.POINTER(vp)]
+    L.sbwtgpu_rank_batch.argtypes = [vp, vp, vp, i64, vp]
+    L.sbwtgpu_streaming_search_batch.argtypes = [vp, vp, vp, i64, vp, vp]
+    L.sbwtgpu_search_batch.argtypes = [vp, vp, vp, i64, vp, vp]
+    L.sbwtgpu_update_interval_batch.argtypes = [vp, vp, vp, i64, vp, vp]
+    L.sbwtgpu_forward_batch.argtypes = [vp, vp, vp, i64, vp]
+    L.sbwtgpu_search_workspace_bytes.argtypes = [i64]
+    L.sbwtgpu_search_workspace_bytes.restype = i64
+    L.sbwtgpu_streaming_search_dev.argtypes = [vp, vp, i64, vp, i64, vp, vp, vp, i64, vp]
+    L.sbwtgpu_search_dev.argtypes = [vp, vp, i64, vp, i64, vp, vp, vp, i64, vp]
+    L.sbwtgpu_rank_dev.argtypes = [vp, vp, vp, i64, vp, vp]
+    L.sbwtgpu_workspace_status.argtypes = [vp, vp, C.POINTER(ci)]
+    _lib = L
+    return L
+
+
+def _check(rc: int) -> None:
+    if rc != OK:
+        raise SbwtGpuError(rc, lib().sbwtgpu_last_error().decode(errors="replace"))
+
+
+def device_count() -> int:
+    n = C.c_int(0)
+    rc = lib().sbwtgpu_device_count(C.byref(n))
+    return n.value if rc == OK else 0
+
+
+def _words(a) -> np.ndarray:
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    return a
+
+
+def concat_reads(reads: Sequence[bytes]):
+    """bases / read_off arrays for a list of byte strings."""
+    lens = np.fromiter((len(r) for r in reads), dtype=np.int64, count=len(reads))
+    off = np.zeros(len(reads) + 1, dtype=np.int64)
+    np.cumsum(lens, out=off[1:])
+    bases = np.frombuffer(b"".join(reads), dtype=np.uint8).copy() if len(reads) else np.zeros(0, np.uint8)
+    return bases, off
+
+
+def out_offsets(read_off: np.ndarray, k: int) -> np.ndarray:
+    lens = np.diff(read_off)
+    m = np.maximum(lens - k + 1, 0)
+    off = np.zeros(len(read_off), dtype=np.int64)
+    np.cumsum(m, out=off[1:])
+    return off
+
+
+class Index:
+    """Owning wrapper of a `sbwtgpu_index*` (one GPU)."""
+
+    def __init__(self, handle: int, keepalive=None):
+        self._h = C.c_void_p(handle)
+        self._keep = keepalive
+        info = IndexInfo()
+        _check(lib().sbwtgpu_index_get_info(self._h, C.byref(info)))
+        self.n_nodes, self.n_kmers, self.k = info.n_nodes, info.n_kmers, info.k
+        self.precalc_k = info.precalc_k
+        self.C = [info.C[i] for i in range(4)]
+        self.has_streaming_support = bool(info.has_streaming_support)
+        self.device = info.device
+        self.device_precalc_k = info.device_precalc_k
+        self.blob_bytes = info.blob_bytes
+
+    @property
+    def handle(self) -> C.c_void_p:
+        return self._h
+
+    @classmethod
+    def create(cls, A, Cb, G, T, ssup, n_nodes: int, k: int, n_kmers: int = 0, precalc_k: int = 0,
+               precalc=None, device: int = 0) -> "Index":
+        A, Cb, G, T = _words(A), _words(Cb), _words(G), _words(T)
+        s = _words(ssup) if ssup is not None else None
+        pc = np.ascontiguousarray(precalc, dtype=np.int64) if precalc is not None else None
+        d = IndexDesc(n_nodes, A.ctypes.data, Cb.ctypes.data, G.ctypes.data, T.ctypes.data,
+                      s.ctypes.data if s is not None else None, k, n_kmers, precalc_k,
+                      pc.ctypes.data if pc is not None else None)
+        h = C.c_void_p()
+        _check(lib().sbwtgpu_index_create(C.byref(d), device, C.byref(h)))
+        return cls(h.value)
+
+    @classmethod
+    def adopt(cls, header: bytes, dev_ptr: int, blob_bytes: int, device: int, keepalive=None) -> "Index":
+        h = C.c_void_p()
+        buf = C.create_string_buffer(header, len(header))
+        _check(lib().sbwtgpu_index_adopt(buf, len(header), C.c_void_p(dev_ptr), blob_bytes, device, C.byref(h)))
+        return cls(h.value, keepalive=keepalive)
+
+    def close(self) -> None:
+        if self._h:
+            lib().sbwtgpu_index_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- replication helpers ----
+    def export_header(self) -> bytes:
+        n = C.c_int64(0)
+        _check(lib().sbwtgpu_index_export_header(self._h, None, 0, C.byref(n)))
+        buf = C.create_string_buffer(n.value)
+        _check(lib().sbwtgpu_index_export_header(self._h, buf, n.value, C.byref(n)))
+        return buf.raw[: n.value]
+
+    def blob(self):
+        p, n = C.c_void_p(), C.c_int64(0)
+        _check(lib().sbwtgpu_index_blob(self._h, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def get_precalc(self) -> np.ndarray:
+        out = np.zeros((4 ** self.precalc_k if self.precalc_k else 0, 2), dtype=np.int64)
+        if self.precalc_k:
+            _check(lib().sbwtgpu_index_get_precalc(self._h, out.ctypes.data))
+        return out
+
+    # ---- host-buffer queries ----
+    def rank(self, pos, sym) -> np.ndarray:
+        pos = np.ascontiguousarray(pos, dtype=np.int64)
+        sym = np.ascontiguousarray(sym, dtype=np.uint8)
+        out = np.empty(len(pos), dtype=np.int64)
+        _check(lib().sbwtgpu_rank_batch(self._h, pos.ctypes.data, sym.ctypes.data, len(pos), out.ctypes.data))
+        return out
+
+    def _search(self, fn, bases, read_off, out_off=None):
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        read_off = np.ascontiguousarray(read_off, dtype=np.int64)
+        if out_off is None:
+            out_off = out_offsets(read_off, self.k)
+        out_off = np.ascontiguousarray(out_off, dtype=np.int64)
+        out = np.full(int(out_off[-1]) if len(out_off) else 0, -12345, dtype=np.int64)
+        _check(fn(self._h, bases.ctypes.data, read_off.ctypes.data, len(read_off) - 1, out.ctypes.data,
+                  out_off.ctypes.data))
+        return out, out_off
+
+    def streaming_search(self, bases, read_off, out_off=None):
+        return self._search(lib().sbwtgpu_streaming_search_batch, bases, read_off, out_off)
+
+    def search(self, bases, read_off, out_off=None):
+        return self._search(lib().sbwtgpu_search_batch, bases, read_off, out_off)
+
+    def streaming_search_reads(self, reads: Sequence[bytes]):
+        bases, off = concat_reads(reads)
+        out, oo = self.streaming_search(bases, off)
+        return [out[oo[i]:oo[i + 1]] for i in range(len(reads))]
+
+    def search_reads(self, reads: Sequence[bytes]):
+        bases, off = concat_reads(reads)
+        out, oo = self.search(bases, off)
+        return [out[oo[i]:oo[i + 1]] for i in range(len(reads))]
+
+    def update_interval(self, bases, off, first, second):
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        off = np.ascontiguousarray(off, dtype=np.int64)
+        first = np.array(first, dtype=np.int64)
+        second = np.array(second, dtype=np.int64)
+        _check(lib().sbwtgpu_update_interval_batch(self._h, bases.ctypes.data, off.ctypes.data, len(first),
+                                                   first.ctypes.data, second.ctypes.data))
+        return first, second
+
+    def forward(self, node, sym) -> np.ndarray:
+        node = np.ascontiguousarray(node, dtype=np.int64)
+        sym = np.ascontiguousarray(sym, dtype=np.uint8)
+        out = np.empty(len(node), dtype=np.int64)
+        _check(lib().sbwtgpu_forward_batch(self._h, node.ctypes.data, sym.ctypes.data, len(node), out.ctypes.data))
+        return out
+
+    # ---- device-buffer queries (raw pointers; torch tensors' data_ptr() go here) ----
+    def streaming_search_dev(self, d_bases: int, total_bases: int, d_read_off: int, n_reads: int, d_out: int,
+                             d_out_off: int, d_ws: int, ws_bytes: int, stream: int = 0, streaming: bool = True):
+        fn = lib().sbwtgpu_streaming_search_dev if streaming else lib().sbwtgpu_search_dev
+        _check(fn(self._h, d_bases, total_bases, d_read_off, n_reads, d_out, d_out_off, d_ws, ws_bytes, stream))
+
+    def workspace_status(self, d_ws: int, stream: int = 0) -> int:
+        st = C.c_int(0)
+        _check(lib().sbwtgpu_workspace_status(d_ws, stream, C.byref(st)))
+        return st.value
+
+
+def search_workspace_bytes(total_bases: int) -> int:
+    return int(lib().sbwtgpu_search_workspace_bytes(total_bases))

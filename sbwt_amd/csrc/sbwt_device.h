@@ -1,0 +1,74 @@
+// sbwt_device.h -- device-side data layout shared by the kernels and the C-ABI host code.
+//
+// Device image ("blob") of a plain-matrix SBWT index, one contiguous allocation:
+//
+//   [ blocks   : n_blocks x 64 B ]   n_blocks = n_nodes/64 + 1  (so pos == n_nodes is addressable)
+//   [ ptab     : 4^p_dev x 16 B  ]   device prefix table, (first,second) int64 pairs
+//   [ ftab     : 4^p_file x 16 B ]   the index file's own table (only if p_file != p_dev, p_file > 0)
+//   [ mega     : 4 x n_mega x 8 B]   absolute (C[c] + rank_c) at every 2^31-column boundary
+//
+// One 64-byte block covers 64 consecutive columns and carries everything both query kinds need,
+// as four 16-byte quads, quad c for symbol c in {A,C,G,T}:
+//
+//   quad c = { bits_c[31:0], bits_c[63:32], cnt_c, ssup_piece }
+//     bits_c     the 64 bits of column c's row for these columns (sdsl bit order: LSB first)
+//     cnt_c      C[c] + rank_c(block start) - mega[c][block_start >> 31]   (u32)
+//     ssup_piece low 32 bits of the block's suffix_group_starts word in quads 0 and 2,
+//                high 32 bits in quads 1 and 3 (so either quad pair {0,1} / {2,3} holds the
+//                whole word)
+//
+// A search LF step (SBWT.hh:430-431) therefore needs ONE 16-byte quad per rank position; a
+// streaming step (SBWT.hh:562-575) needs the 32-byte quad pair that contains quad c -- both
+// inside one 64-byte line.  This replaces sdsl's per-column rank_support_v5 (2 cache lines per
+// rank) and the separate suffix_group_starts vector (a third line).
+#pragma once
+#include <stdint.h>
+
+#define SBWT_MEGA_SHIFT 31          // columns per mega block = 2^31
+#define SBWT_GROUP_BASES 32         // bases per packed read group
+
+struct SbwtIndexView {
+    const uint4 *blocks;            // n_blocks * 4 quads
+    const longlong2 *ptab;          // device prefix table, depth p_dev (nullptr if p_dev == 0)
+    const unsigned long long *mega; // [4][n_mega]
+    long long n_nodes;
+    long long C[4];
+    int k;
+    int p_dev;
+    int n_mega;
+    int has_ssup;
+};
+
+// Position-independent description of a blob (what index_export_header hands out).
+struct SbwtBlobHeader {
+    uint64_t magic;                 // 'SBWTGPU1'
+    int64_t n_nodes, n_kmers, k, p_file, p_dev;
+    int64_t C[4];
+    int64_t n_blocks, n_mega;
+    int64_t off_blocks, off_ptab, off_ftab, off_mega, blob_bytes;
+    int32_t has_ssup;
+    int32_t reserved;
+};
+#define SBWT_BLOB_MAGIC 0x3155504754574253ull   // "SBWTGPU1" little endian
+
+// Workspace header (first 256 bytes of the search workspace).
+struct SbwtWorkHeader {
+    unsigned long long ticket;      // next read to hand out
+    int status;                     // 0 or SBWTGPU_ERR_NOT_SINGLETON
+    int pad[61];
+};
+static_assert(sizeof(SbwtWorkHeader) == 256, "workspace header is 256 bytes");
+
+// launchers implemented in sbwt_kernels.hip (all asynchronous on `stream`)
+void sbwt_launch_encode(const char *d_bases, long long total_bases, uint4 *d_packed, SbwtWorkHeader *ws,
+                        hipStream_t stream);
+void sbwt_launch_search(const SbwtIndexView &ix, const uint4 *d_packed, const long long *d_read_off,
+                        const long long *d_out_off, long long *d_out, long long n_reads, SbwtWorkHeader *ws,
+                        int streaming, hipStream_t stream);
+void sbwt_launch_rank(const SbwtIndexView &ix, const long long *d_pos, const char *d_sym, long long n,
+                      long long *d_out, hipStream_t stream);
+void sbwt_launch_precalc(const SbwtIndexView &ix, int p, longlong2 *d_table, hipStream_t stream);
+void sbwt_launch_update_interval(const SbwtIndexView &ix, const char *d_bases, const long long *d_off, long long n,
+                                 long long *d_first, long long *d_second, hipStream_t stream);
+void sbwt_launch_forward(const SbwtIndexView &ix, const long long *d_node, const char *d_sym, long long n,
+                         long long *d_out, hipStream_t stream);

@@ -1,0 +1,434 @@
+// sbwt_kernels.hip -- hand-written HIP kernels (gfx950 / CDNA4) for the plain-matrix SBWT
+// k-mer search path.  Integer / bit-manipulation only; the bound is random 64-byte-line
+// gathers from the index image (HBM / Infinity Cache), so the design rules are: one dependent
+// memory round trip per query step, 16-byte vector loads, all 64 lanes of a wave kept busy by
+// a work queue, no MFMA.
+//
+// Reference semantics restated here (paths relative to the reference repo):
+//   SBWT::streaming_search      include/sbwt/SBWT.hh:544-581
+//   SBWT::search                include/sbwt/SBWT.hh:389-415
+//   SBWT::update_sbwt_interval  include/sbwt/SBWT.hh:422-437
+//   SBWT::forward               include/sbwt/SBWT.hh:368-381
+//   SBWT::do_kmer_prefix_precalc include/sbwt/SBWT.hh:616-645
+//   SubsetMatrixRank::rank      include/sbwt/SubsetMatrixRank.hh:31-37
+#include <hip/hip_runtime.h>
+#include "sbwt_device.h"
+
+typedef unsigned long long u64;
+typedef long long i64;
+
+#define SBWT_ERR_NOT_SINGLETON (-7)
+
+// ---------------------------------------------------------------------------------------------
+// small helpers
+// ---------------------------------------------------------------------------------------------
+// ASCII -> 0..3 for A,C,G,T (globals.hh:38-47); only meaningful when the validity bit is set.
+__device__ __forceinline__ unsigned dna_code(unsigned b) { return ((b >> 1) & 3u) ^ ((b >> 2) & 1u); }
+__device__ __forceinline__ bool is_ACGT(unsigned b) { return b == 'A' || b == 'C' || b == 'G' || b == 'T'; }
+__device__ __forceinline__ u64 quad_bits(const uint4 &q) { return (u64)q.x | ((u64)q.y << 32); }
+__device__ __forceinline__ u64 low_mask(int n) { return (1ull << n) - 1ull; }   // n in [0,63]
+
+// streaming (read-once / write-once) 16-byte accesses that should not displace the index in L2
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 ld_stream(const uint4 *p) {
+    u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p));
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+
+// value of (C[c] + rank_c(pos)) from the quad of pos's block
+template <bool MEGA>
+__device__ __forceinline__ u64 quad_rank(const SbwtIndexView &ix, const uint4 &q, i64 pos, int c) {
+    u64 v = (u64)q.z + (u64)__popcll(quad_bits(q) & low_mask((int)(pos & 63)));
+    if (MEGA) v += ix.mega[(i64)c * ix.n_mega + (pos >> SBWT_MEGA_SHIFT)];
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_encode: ASCII bases -> packed groups of 32 bases (coalesced streaming pre-pass)
+//   group = { codes[31:0], codes[63:32], validU, validRaw }
+//   codes   2 bits per base, base t of the group at bits 2t..2t+1 (toupper'd, globals.hh:38-47)
+//   validU  bit t set iff toupper(base) is ACGT   (streaming step validates this: SBWT.hh:565-568)
+//   validRaw bit t set iff base itself is ACGT    (search validates the raw char: SBWT.hh:398-399,427-428)
+// Also resets the workspace header for the search launch that follows on the same stream.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_encode(const unsigned char *__restrict__ bases, i64 total,
+                                                uint4 *__restrict__ packed, i64 n_groups,
+                                                SbwtWorkHeader *ws, int aligned16) {
+    i64 g = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (g == 0) { ws->ticket = 0; ws->status = 0; }
+    if (g >= n_groups) return;
+    i64 base = g * SBWT_GROUP_BASES;
+    u64 codes = 0;
+    unsigned vu = 0, vr = 0;
+    if (aligned16 && base + SBWT_GROUP_BASES <= total) {
+        const uint4 *src = reinterpret_cast<const uint4 *>(bases + base);
+        uint4 x0 = ld_stream(src), x1 = ld_stream(src + 1);
+        unsigned w[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+#pragma unroll
+        for (int d = 0; d < 8; d++) {
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                unsigned b = (w[d] >> (8 * t)) & 0xFFu;
+                unsigned up = b & 0xDFu;
+                int pos = d * 4 + t;
+                codes |= (u64)dna_code(up) << (2 * pos);
+                vu |= (unsigned)is_ACGT(up) << pos;
+                vr |= (unsigned)is_ACGT(b) << pos;
+            }
+        }
+    } else {
+        for (int pos = 0; pos < SBWT_GROUP_BASES; pos++) {
+            if (base + pos < total) {
+                unsigned b = bases[base + pos];
+                unsigned up = b & 0xDFu;
+                codes |= (u64)dna_code(up) << (2 * pos);
+                vu |= (unsigned)is_ACGT(up) << pos;
+                vr |= (unsigned)is_ACGT(b) << pos;
+            }
+        }
+    }
+    packed[g] = make_uint4((unsigned)codes, (unsigned)(codes >> 32), vu, vr);
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_search: streaming_search (streaming != 0) or the per-k-mer search loop (streaming == 0).
+//
+// One lane owns one read at a time and walks it as a small state machine; every loop iteration
+// performs exactly one dependent gather from the index image for every busy lane, whatever its
+// state, so that lanes in different states do not serialise their memory round trips:
+//   M_STREAM  one-step extension of the previous answer (SBWT.hh:562-575): the 32-byte quad
+//             pair holding the suffix-group word and column c of the block of the previous answer
+//   M_INIT    start of a full search (SBWT.hh:389-404): one 16-byte prefix-table entry
+//   M_STEP    one update_sbwt_interval character (SBWT.hh:425-433): quad c at `first` and, if it
+//             lies in another block, quad c at `second+1`
+// Finished lanes pull the next read from a device-wide ticket counter, so lanes stay busy although
+// a read with a mismatch costs ~10x one without.
+// ---------------------------------------------------------------------------------------------
+#define M_IDLE 0
+#define M_STREAM 1
+#define M_INIT 2
+#define M_STEP 3
+
+template <bool MEGA>
+__global__ void __launch_bounds__(256) k_search(SbwtIndexView ix, const uint4 *__restrict__ packed,
+                                                const i64 *__restrict__ read_off,
+                                                const i64 *__restrict__ out_off, i64 *__restrict__ out,
+                                                i64 n_reads, SbwtWorkHeader *ws, int streaming) {
+    const int lane = threadIdx.x & 63;
+    const int k = ix.k, p = ix.p_dev;
+    const i64 last_node = ix.n_nodes - 1;
+
+    int mode = M_IDLE;
+    bool dead = false;
+    i64 P0 = 0, obase = 0;
+    int m = 0, i = 0, j = 0;
+    i64 a = -1, l = 0, r = 0;
+    i64 tag = -1;
+    uint4 g0 = make_uint4(0, 0, 0, 0), g1 = make_uint4(0, 0, 0, 0);
+
+    for (;;) {
+        // ---- hand out reads to idle lanes ----
+        bool want = (mode == M_IDLE) && !dead;
+        u64 need = __ballot(want);
+        if (need) {
+            int leader = __ffsll((i64)need) - 1;
+            u64 first = 0;
+            if (lane == leader) first = atomicAdd(&ws->ticket, (u64)__popcll(need));
+            first = __shfl(first, leader);
+            if (want) {
+                u64 rd = first + (u64)__popcll(need & low_mask(lane));
+                if (rd < (u64)n_reads) {
+                    i64 s = read_off[rd], e = read_off[rd + 1];
+                    P0 = s;
+                    obase = out_off[rd];
+                    m = (int)(e - s) - k + 1;
+                    i = 0;
+                    if (m > 0) {
+                        if (p > 0) mode = M_INIT;
+                        else { mode = M_STEP; l = 0; r = last_node; j = 0; }
+                    }
+                } else {
+                    dead = true;
+                }
+            }
+        }
+        if (__ballot(!dead) == 0) break;
+
+        // ---- bases: make sure the group pair holding the next needed base(s) is in registers ----
+        const bool act = (mode != M_IDLE);
+        const int q = (mode == M_STREAM) ? (i + k - 1) : ((mode == M_INIT) ? i : (i + j));
+        const i64 P = P0 + q;
+        if (act && (P >> 5) != tag) {
+            tag = P >> 5;
+            g0 = packed[tag];
+            g1 = packed[tag + 1];
+        }
+        const int s = (int)(P & 31);
+        const u64 codes0 = quad_bits(g0);
+        const int c = (int)((codes0 >> (2 * s)) & 3ull);
+
+        // ---- form this iteration's gather addresses ----
+        const uint4 *a1 = nullptr, *a2 = nullptr;
+        bool emit = false;
+        i64 res = -1;
+        if (mode == M_STREAM) {
+            if ((g0.z >> s) & 1u) {
+                a1 = ix.blocks + (((a >> 6) << 2) + (c & 2));
+                a2 = a1 + 1;
+            } else {
+                emit = true;   // non-ACGT after toupper -> -1 (SBWT.hh:568)
+            }
+        } else if (mode == M_INIT) {
+            u64 w = codes0 >> (2 * s);
+            if (s) w |= quad_bits(g1) << (64 - 2 * s);
+            u64 vr = (((u64)g1.w << 32) | (u64)g0.w) >> s;
+            u64 vm = low_mask(p);
+            if ((vr & vm) == vm) a1 = reinterpret_cast<const uint4 *>(ix.ptab + (w & low_mask(2 * p)));
+            else emit = true;  // non-ACGT among the first p chars (SBWT.hh:398-399)
+        } else if (mode == M_STEP) {
+            if ((g0.w >> s) & 1u) {
+                a1 = ix.blocks + (((l >> 6) << 2) + c);
+                const uint4 *t = ix.blocks + ((((r + 1) >> 6) << 2) + c);
+                if (t != a1) a2 = t;
+            } else {
+                emit = true;   // raw char invalid (SBWT.hh:427-428)
+            }
+        }
+
+        // ---- the one dependent round trip of this iteration ----
+        uint4 v1 = make_uint4(0, 0, 0, 0), v2 = make_uint4(0, 0, 0, 0);
+        if (a1) v1 = *a1;
+        if (a2) v2 = *a2;
+
+        // ---- consume ----
+        if (a1) {
+            if (mode == M_STREAM) {
+                u64 ss = (u64)v1.w | ((u64)v2.w << 32);
+                uint4 mine = (c & 1) ? v2 : v1;
+                const int b = (int)(a & 63);
+                u64 msk = ss & ((2ull << b) - 1ull);
+                i64 blk = a >> 6;
+                while (msk == 0) {   // suffix group starts in an earlier block (rare)
+                    if (blk == 0) { msk = 1; break; }   // cannot happen: column 0 is always marked
+                    blk--;
+                    const uint4 *pa = ix.blocks + ((blk << 2) + (c & 2));
+                    uint4 e = pa[0], o = pa[1];
+                    msk = (u64)e.w | ((u64)o.w << 32);
+                    mine = (c & 1) ? o : e;
+                }
+                const int gb = 63 - __clzll((i64)msk);
+                const u64 bits = quad_bits(mine);
+                u64 val = (u64)mine.z + (u64)__popcll(bits & low_mask(gb));
+                if (MEGA) val += ix.mega[(i64)c * ix.n_mega + (((blk << 6) | gb) >> SBWT_MEGA_SHIFT)];
+                // node_left == node_right  <=>  column c has its bit set at the group start (SBWT.hh:572-575)
+                res = ((bits >> gb) & 1ull) ? (i64)val : -1;
+                emit = true;
+            } else if (mode == M_INIT) {
+                l = (i64)quad_bits(v1);
+                r = (i64)((u64)v1.z | ((u64)v1.w << 32));
+                if (l == -1) {
+                    emit = true;                       // SBWT.hh:424
+                } else if (p == k) {
+                    emit = true;
+                    res = l;
+                    if (l != r) ws->status = SBWT_ERR_NOT_SINGLETON;
+                } else {
+                    j = p;
+                    mode = M_STEP;
+                }
+            } else {   // M_STEP
+                if (!a2) v2 = v1;
+                u64 va = quad_rank<MEGA>(ix, v1, l, c);
+                u64 vb = quad_rank<MEGA>(ix, v2, r + 1, c);
+                l = (i64)va;
+                r = (i64)vb - 1;
+                if (l > r) {
+                    emit = true;                       // SBWT.hh:433
+                } else if (++j == k) {
+                    emit = true;
+                    res = l;
+                    if (l != r) ws->status = SBWT_ERR_NOT_SINGLETON;   // SBWT.hh:410-413
+                }
+            }
+        }
+
+        // ---- write one k-mer result and pick the next state ----
+        if (emit) {
+            out[obase + i] = res;
+            i++;
+            if (i == m) {
+                mode = M_IDLE;
+            } else if (streaming && res != -1) {
+                mode = M_STREAM;                       // SBWT.hh:560-
+                a = res;
+            } else if (p > 0) {
+                mode = M_INIT;                         // SBWT.hh:557-559
+            } else {
+                mode = M_STEP; l = 0; r = last_node; j = 0;   // SBWT.hh:408
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_rank: SubsetMatrixRank::rank(pos, c) for n independent (pos, sym) pairs
+// ---------------------------------------------------------------------------------------------
+template <bool MEGA>
+__global__ void __launch_bounds__(256) k_rank(SbwtIndexView ix, const i64 *__restrict__ pos,
+                                              const char *__restrict__ sym, i64 n, i64 *__restrict__ out) {
+    i64 t = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n) return;
+    unsigned b = (unsigned char)sym[t];
+    i64 ps = pos[t];
+    i64 res = 0;
+    if (is_ACGT(b)) {
+        int c = (int)dna_code(b);
+        uint4 q = ix.blocks[((ps >> 6) << 2) + c];
+        res = (i64)quad_rank<MEGA>(ix, q, ps, c) - ix.C[c];
+    }
+    out[t] = res;
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_precalc: do_kmer_prefix_precalc (SBWT.hh:616-645): entry d = interval of the p-mer whose
+// i-th char is (d >> 2i) & 3, starting from {0, n_nodes-1}
+// ---------------------------------------------------------------------------------------------
+template <bool MEGA>
+__global__ void __launch_bounds__(256) k_precalc(SbwtIndexView ix, int p, longlong2 *__restrict__ table) {
+    u64 d = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (d >= (1ull << (2 * p))) return;
+    i64 l = 0, r = ix.n_nodes - 1;
+    for (int i = 0; i < p; i++) {
+        int c = (int)((d >> (2 * i)) & 3ull);
+        uint4 q1 = ix.blocks[((l >> 6) << 2) + c];
+        uint4 q2 = ix.blocks[(((r + 1) >> 6) << 2) + c];
+        l = (i64)quad_rank<MEGA>(ix, q1, l, c);
+        r = (i64)quad_rank<MEGA>(ix, q2, r + 1, c) - 1;
+        if (l > r) { l = -1; r = -1; break; }
+    }
+    table[d] = make_longlong2(l, r);
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_update_interval: SBWT::update_sbwt_interval (SBWT.hh:422-437), one lane per query
+// ---------------------------------------------------------------------------------------------
+template <bool MEGA>
+__global__ void __launch_bounds__(256) k_update_interval(SbwtIndexView ix, const char *__restrict__ bases,
+                                                         const i64 *__restrict__ off, i64 n,
+                                                         i64 *__restrict__ first, i64 *__restrict__ second) {
+    i64 t = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n) return;
+    i64 l = first[t], r = second[t];
+    if (l == -1) return;
+    for (i64 i = off[t]; i < off[t + 1]; i++) {
+        unsigned b = (unsigned char)bases[i];
+        if (!is_ACGT(b)) { l = -1; r = -1; break; }      // raw char validated (SBWT.hh:427-428)
+        int c = (int)dna_code(b);
+        uint4 q1 = ix.blocks[((l >> 6) << 2) + c];
+        uint4 q2 = ix.blocks[(((r + 1) >> 6) << 2) + c];
+        l = (i64)quad_rank<MEGA>(ix, q1, l, c);
+        r = (i64)quad_rank<MEGA>(ix, q2, r + 1, c) - 1;
+        if (l > r) { l = -1; r = -1; break; }
+    }
+    first[t] = l;
+    second[t] = r;
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_forward: SBWT::forward (SBWT.hh:368-381), one lane per (node, sym)
+// ---------------------------------------------------------------------------------------------
+template <bool MEGA>
+__global__ void __launch_bounds__(256) k_forward(SbwtIndexView ix, const i64 *__restrict__ node,
+                                                 const char *__restrict__ sym, i64 n, i64 *__restrict__ out) {
+    i64 t = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n) return;
+    unsigned b = (unsigned char)sym[t];
+    i64 res = -1;                                          // rank() of a non-ACGT char is 0 -> r1 == r2 -> -1
+    if (is_ACGT(b)) {
+        int c = (int)dna_code(b);
+        i64 v = node[t];
+        i64 blk = v >> 6;
+        const uint4 *pa = ix.blocks + ((blk << 2) + (c & 2));
+        uint4 e = pa[0], o = pa[1];
+        u64 msk = ((u64)e.w | ((u64)o.w << 32)) & ((2ull << (v & 63)) - 1ull);
+        while (msk == 0 && blk > 0) {
+            blk--;
+            pa = ix.blocks + ((blk << 2) + (c & 2));
+            e = pa[0]; o = pa[1];
+            msk = (u64)e.w | ((u64)o.w << 32);
+        }
+        if (msk == 0) msk = 1;
+        int gb = 63 - __clzll((i64)msk);
+        uint4 mine = (c & 1) ? o : e;
+        u64 bits = quad_bits(mine);
+        if ((bits >> gb) & 1ull) res = (i64)quad_rank<MEGA>(ix, mine, (blk << 6) | gb, c);
+    }
+    out[t] = res;
+}
+
+// ---------------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------------
+static inline unsigned grid_for(i64 n) { return (unsigned)((n + 255) / 256); }
+
+void sbwt_launch_encode(const char *d_bases, long long total_bases, uint4 *d_packed, SbwtWorkHeader *ws,
+                        hipStream_t stream) {
+    i64 n_groups = (total_bases + SBWT_GROUP_BASES - 1) / SBWT_GROUP_BASES + 2;
+    int aligned = ((uintptr_t)d_bases & 15) == 0;
+    hipLaunchKernelGGL(k_encode, dim3(grid_for(n_groups)), dim3(256), 0, stream,
+                       reinterpret_cast<const unsigned char *>(d_bases), (i64)total_bases, d_packed, n_groups, ws,
+                       aligned);
+}
+
+void sbwt_launch_search(const SbwtIndexView &ix, const uint4 *d_packed, const long long *d_read_off,
+                        const long long *d_out_off, long long *d_out, long long n_reads, SbwtWorkHeader *ws,
+                        int streaming, hipStream_t stream) {
+    if (n_reads <= 0) return;
+    // persistent-style grid: enough 256-thread workgroups to fill 256 CUs x 8 workgroups, never
+    // more lanes than reads
+    i64 want = (n_reads + 255) / 256;
+    unsigned grid = (unsigned)(want < 2048 ? want : 2048);
+    if (ix.n_mega > 1)
+        hipLaunchKernelGGL(k_search<true>, dim3(grid), dim3(256), 0, stream, ix, d_packed, d_read_off, d_out_off,
+                           d_out, (i64)n_reads, ws, streaming);
+    else
+        hipLaunchKernelGGL(k_search<false>, dim3(grid), dim3(256), 0, stream, ix, d_packed, d_read_off, d_out_off,
+                           d_out, (i64)n_reads, ws, streaming);
+}
+
+void sbwt_launch_rank(const SbwtIndexView &ix, const long long *d_pos, const char *d_sym, long long n,
+                      long long *d_out, hipStream_t stream) {
+    if (n <= 0) return;
+    if (ix.n_mega > 1)
+        hipLaunchKernelGGL(k_rank<true>, dim3(grid_for(n)), dim3(256), 0, stream, ix, d_pos, d_sym, (i64)n, d_out);
+    else
+        hipLaunchKernelGGL(k_rank<false>, dim3(grid_for(n)), dim3(256), 0, stream, ix, d_pos, d_sym, (i64)n, d_out);
+}
+
+void sbwt_launch_precalc(const SbwtIndexView &ix, int p, longlong2 *d_table, hipStream_t stream) {
+    i64 n = 1ll << (2 * p);
+    if (ix.n_mega > 1)
+        hipLaunchKernelGGL(k_precalc<true>, dim3(grid_for(n)), dim3(256), 0, stream, ix, p, d_table);
+    else
+        hipLaunchKernelGGL(k_precalc<false>, dim3(grid_for(n)), dim3(256), 0, stream, ix, p, d_table);
+}
+
+void sbwt_launch_update_interval(const SbwtIndexView &ix, const char *d_bases, const long long *d_off, long long n,
+                                 long long *d_first, long long *d_second, hipStream_t stream) {
+    if (n <= 0) return;
+    if (ix.n_mega > 1)
+        hipLaunchKernelGGL(k_update_interval<true>, dim3(grid_for(n)), dim3(256), 0, stream, ix, d_bases, d_off,
+                           (i64)n, d_first, d_second);
+    else
+        hipLaunchKernelGGL(k_update_interval<false>, dim3(grid_for(n)), dim3(256), 0, stream, ix, d_bases, d_off,
+                           (i64)n, d_first, d_second);
+}
+
+void sbwt_launch_forward(const SbwtIndexView &ix, const long long *d_node, const char *d_sym, long long n,
+                         long long *d_out, hipStream_t stream) {
+    if (n <= 0) return;
+    if (ix.n_mega > 1)
+        hipLaunchKernelGGL(k_forward<true>, dim3(grid_for(n)), dim3(256), 0, stream, ix, d_node, d_sym, (i64)n, d_out);
+    else
+        hipLaunchKernelGGL(k_forward<false>, dim3(grid_for(n)), dim3(256), 0, stream, ix, d_node, d_sym, (i64)n, d_out);
+}

@@ -1,0 +1,624 @@
+// sbwtgpu_capi.cpp -- implementation of the C ABI declared in include/sbwtgpu.h.
+// Host-side glue only: builds the device image of an index, owns device memory, and enqueues
+// the kernels of sbwt_kernels.hip.  There is deliberately no CPU query path in this library:
+// every query entry point runs on the GPU or fails with an error code.
+#include <hip/hip_runtime.h>
+
+#include <dlfcn.h>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../../include/sbwtgpu.h"
+#include "sbwt_device.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return fail(e_ == hipErrorOutOfMemory ? SBWTGPU_ERR_OOM : SBWTGPU_ERR_HIP,         \
+                        "%s failed: %s", #expr, hipGetErrorString(e_));                        \
+    } while (0)
+
+int default_device_precalc() {
+    const char *e = getenv("SBWTGPU_DEVICE_PRECALC");
+    int v = e ? atoi(e) : 10;
+    if (v < 0) v = 0;
+    if (v > 14) v = 14;
+    return v;
+}
+
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = false;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        ok = (hipSetDevice(dev) == hipSuccess);
+    }
+    ~DeviceGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+}  // namespace
+
+struct sbwtgpu_index {
+    SbwtBlobHeader h;
+    int device = 0;
+    char *blob = nullptr;       // device
+    bool owns_blob = true;
+    SbwtIndexView view() const {
+        SbwtIndexView v;
+        v.blocks = reinterpret_cast<const uint4 *>(blob + h.off_blocks);
+        v.ptab = h.p_dev > 0 ? reinterpret_cast<const longlong2 *>(blob + h.off_ptab) : nullptr;
+        v.mega = reinterpret_cast<const unsigned long long *>(blob + h.off_mega);
+        v.n_nodes = h.n_nodes;
+        for (int i = 0; i < 4; i++) v.C[i] = h.C[i];
+        v.k = (int)h.k;
+        v.p_dev = (int)h.p_dev;
+        v.n_mega = (int)h.n_mega;
+        v.has_ssup = h.has_ssup;
+        return v;
+    }
+};
+
+extern "C" {
+
+const char *sbwtgpu_version(void) { return "sbwtgpu 0.1 (gfx950)"; }
+const char *sbwtgpu_last_error(void) { return g_err; }
+
+int sbwtgpu_device_count(int *count) {
+    if (!count) return fail(SBWTGPU_ERR_INVALID_ARG, "count is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        *count = 0;
+        return fail(SBWTGPU_ERR_NO_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e));
+    }
+    *count = n;
+    return SBWTGPU_OK;
+}
+
+static inline int64_t align256(int64_t x) { return (x + 255) & ~(int64_t)255; }
+
+int sbwtgpu_index_create(const sbwtgpu_index_desc *d, int device, sbwtgpu_index **out) {
+    if (!d || !out) return fail(SBWTGPU_ERR_INVALID_ARG, "desc/out is NULL");
+    *out = nullptr;
+    if (d->n_nodes <= 0 || !d->A_bits || !d->C_bits || !d->G_bits || !d->T_bits)
+        return fail(SBWTGPU_ERR_INVALID_ARG, "n_nodes must be > 0 and the four bit vectors non-NULL");
+    if (d->k <= 0 || d->k > 255) return fail(SBWTGPU_ERR_INVALID_ARG, "k must be in [1,255]");
+    if (d->precalc_k < 0) return fail(SBWTGPU_ERR_INVALID_ARG, "precalc_k < 0");
+    if (d->precalc_k > 20)
+        return fail(SBWTGPU_ERR_PRECALC_TOO_LONG,
+                    "Error: Can't precalc longer than 20-mers (would take over 4^20 = 2^40 bytes");
+    if (d->precalc_k > d->k)
+        return fail(SBWTGPU_ERR_PRECALC_GT_K, "Error: Precalc length is longer than k (%lld > %lld)",
+                    (long long)d->precalc_k, (long long)d->k);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(SBWTGPU_ERR_NO_DEVICE, "no HIP device");
+    if (device < 0 || device >= ndev) return fail(SBWTGPU_ERR_NO_DEVICE, "device %d out of range", device);
+    DeviceGuard guard(device);
+    if (!guard.ok) return fail(SBWTGPU_ERR_NO_DEVICE, "hipSetDevice(%d) failed", device);
+
+    const int64_t n = d->n_nodes;
+    const int64_t nw = (n + 63) / 64;
+    const int64_t n_blocks = n / 64 + 1;
+    const int64_t n_mega = (n >> SBWT_MEGA_SHIFT) + 1;
+    int64_t p_file = d->precalc_k;
+    int64_t p_dev = default_device_precalc();
+    if (p_dev < p_file) p_dev = p_file;
+    if (p_dev > d->k) p_dev = d->k;
+
+    sbwtgpu_index *idx = new (std::nothrow) sbwtgpu_index();
+    if (!idx) return fail(SBWTGPU_ERR_OOM, "out of host memory");
+    SbwtBlobHeader &h = idx->h;
+    memset(&h, 0, sizeof(h));
+    h.magic = SBWT_BLOB_MAGIC;
+    h.n_nodes = n;
+    h.n_kmers = d->n_kmers;
+    h.k = d->k;
+    h.p_file = p_file;
+    h.p_dev = p_dev;
+    h.n_blocks = n_blocks;
+    h.n_mega = n_mega;
+    h.has_ssup = d->suffix_group_starts ? 1 : 0;
+    h.off_blocks = 0;
+    h.off_ptab = align256(n_blocks * 64);
+    int64_t ptab_bytes = p_dev > 0 ? (int64_t)16 << (2 * p_dev) : 0;
+    h.off_ftab = align256(h.off_ptab + ptab_bytes);
+    int64_t ftab_bytes = (p_file > 0 && p_file != p_dev) ? (int64_t)16 << (2 * p_file) : 0;
+    if (ftab_bytes == 0) h.off_ftab = h.off_ptab;   // the same table serves both
+    h.off_mega = align256(h.off_ftab + (ftab_bytes ? ftab_bytes : ptab_bytes));
+    h.blob_bytes = align256(h.off_mega + 4 * n_mega * 8);
+    idx->device = device;
+
+    // C array (SBWT.hh:344-349): C[0] = 1 (ghost dollar into the root), C[i+1] = C[i] + rank(n, sigma_i)
+    const uint64_t *cols[4] = {d->A_bits, d->C_bits, d->G_bits, d->T_bits};
+    auto word = [&](const uint64_t *v, int64_t w) -> uint64_t {
+        if (w >= nw) return 0;
+        uint64_t x = v[w];
+        if (w == nw - 1 && (n & 63)) x &= (~0ull) >> (64 - (n & 63));
+        return x;
+    };
+    int64_t tot[4] = {0, 0, 0, 0};
+    for (int c = 0; c < 4; c++)
+        for (int64_t w = 0; w < nw; w++) tot[c] += __builtin_popcountll(word(cols[c], w));
+    h.C[0] = 1;
+    for (int c = 1; c < 4; c++) h.C[c] = h.C[c - 1] + tot[c - 1];
+
+    // interleaved blocks + mega table, built on the host in one pass, then uploaded
+    std::vector<uint32_t> blocks;
+    std::vector<uint64_t> mega;
+    try {
+        blocks.resize((size_t)n_blocks * 16);
+        mega.assign((size_t)(4 * n_mega), 0);
+    } catch (...) {
+        delete idx;
+        return fail(SBWTGPU_ERR_OOM, "out of host memory building the index image");
+    }
+    {
+        uint64_t run[4] = {(uint64_t)h.C[0], (uint64_t)h.C[1], (uint64_t)h.C[2], (uint64_t)h.C[3]};
+        uint64_t mbase[4] = {0, 0, 0, 0};
+        const int64_t blocks_per_mega = (int64_t)1 << (SBWT_MEGA_SHIFT - 6);
+        for (int64_t b = 0; b < n_blocks; b++) {
+            if (b % blocks_per_mega == 0) {
+                int64_t mb = b / blocks_per_mega;
+                // a single mega block keeps base 0 so that cnt alone is the absolute value
+                for (int c = 0; c < 4; c++) {
+                    mbase[c] = (n_mega > 1) ? run[c] : 0;
+                    mega[(size_t)(c * n_mega + mb)] = mbase[c];
+                }
+            }
+            uint64_t s = d->suffix_group_starts ? word(d->suffix_group_starts, b) : 0;
+            uint32_t *q = &blocks[(size_t)b * 16];
+            for (int c = 0; c < 4; c++) {
+                uint64_t bits = word(cols[c], b);
+                q[4 * c + 0] = (uint32_t)bits;
+                q[4 * c + 1] = (uint32_t)(bits >> 32);
+                q[4 * c + 2] = (uint32_t)(run[c] - mbase[c]);
+                q[4 * c + 3] = (c & 1) ? (uint32_t)(s >> 32) : (uint32_t)s;
+                run[c] += (uint64_t)__builtin_popcountll(bits);
+            }
+        }
+    }
+
+    hipError_t e = hipMalloc((void **)&idx->blob, (size_t)h.blob_bytes);
+    if (e != hipSuccess) {
+        delete idx;
+        return fail(SBWTGPU_ERR_OOM, "hipMalloc(%lld bytes) for the index image: %s", (long long)h.blob_bytes,
+                    hipGetErrorString(e));
+    }
+    int rc = SBWTGPU_OK;
+    do {
+        if ((e = hipMemset(idx->blob, 0, (size_t)h.blob_bytes)) != hipSuccess) break;
+        if ((e = hipMemcpy(idx->blob + h.off_blocks, blocks.data(), (size_t)n_blocks * 64, hipMemcpyHostToDevice)) !=
+            hipSuccess)
+            break;
+        if ((e = hipMemcpy(idx->blob + h.off_mega, mega.data(), (size_t)(4 * n_mega * 8), hipMemcpyHostToDevice)) !=
+            hipSuccess)
+            break;
+        SbwtIndexView v = idx->view();
+        if (p_dev > 0) sbwt_launch_precalc(v, (int)p_dev, reinterpret_cast<longlong2 *>(idx->blob + h.off_ptab), 0);
+        if (ftab_bytes) {
+            if (d->precalc) {
+                if ((e = hipMemcpy(idx->blob + h.off_ftab, d->precalc, (size_t)ftab_bytes, hipMemcpyHostToDevice)) !=
+                    hipSuccess)
+                    break;
+            } else {
+                sbwt_launch_precalc(v, (int)p_file, reinterpret_cast<longlong2 *>(idx->blob + h.off_ftab), 0);
+            }
+        }
+        if ((e = hipGetLastError()) != hipSuccess) break;
+        e = hipDeviceSynchronize();
+    } while (0);
+    if (e != hipSuccess) {
+        rc = fail(SBWTGPU_ERR_HIP, "building the index image: %s", hipGetErrorString(e));
+        (void)hipFree(idx->blob);
+        delete idx;
+        return rc;
+    }
+    *out = idx;
+    return SBWTGPU_OK;
+}
+
+void sbwtgpu_index_destroy(sbwtgpu_index *idx) {
+    if (!idx) return;
+    if (idx->blob && idx->owns_blob) {
+        DeviceGuard guard(idx->device);
+        (void)hipFree(idx->blob);
+    }
+    delete idx;
+}
+
+int sbwtgpu_index_get_info(const sbwtgpu_index *idx, sbwtgpu_index_info *info) {
+    if (!idx || !info) return fail(SBWTGPU_ERR_INVALID_ARG, "idx/info is NULL");
+    info->n_nodes = idx->h.n_nodes;
+    info->n_kmers = idx->h.n_kmers;
+    info->k = idx->h.k;
+    info->precalc_k = idx->h.p_file;
+    for (int i = 0; i < 4; i++) info->C[i] = idx->h.C[i];
+    info->has_streaming_support = idx->h.has_ssup;
+    info->device = idx->device;
+    info->device_precalc_k = idx->h.p_dev;
+    info->blob_bytes = idx->h.blob_bytes;
+    return SBWTGPU_OK;
+}
+
+int sbwtgpu_index_get_precalc(const sbwtgpu_index *idx, int64_t *out_pairs) {
+    if (!idx || !out_pairs) return fail(SBWTGPU_ERR_INVALID_ARG, "idx/out is NULL");
+    if (idx->h.p_file == 0) return SBWTGPU_OK;
+    DeviceGuard guard(idx->device);
+    HIP_TRY(hipMemcpy(out_pairs, idx->blob + idx->h.off_ftab, (size_t)16 << (2 * idx->h.p_file),
+                      hipMemcpyDeviceToHost));
+    return SBWTGPU_OK;
+}
+
+// ---- replication ---------------------------------------------------------------------------
+int sbwtgpu_index_export_header(const sbwtgpu_index *idx, void *header_out, int64_t cap, int64_t *bytes) {
+    if (!idx || !bytes) return fail(SBWTGPU_ERR_INVALID_ARG, "idx/bytes is NULL");
+    *bytes = (int64_t)sizeof(SbwtBlobHeader);
+    if (!header_out) return SBWTGPU_OK;   // size query
+    if (cap < (int64_t)sizeof(SbwtBlobHeader)) return fail(SBWTGPU_ERR_INVALID_ARG, "header buffer too small");
+    memcpy(header_out, &idx->h, sizeof(SbwtBlobHeader));
+    return SBWTGPU_OK;
+}
+
+int sbwtgpu_index_blob(const sbwtgpu_index *idx, void **dev_ptr, int64_t *bytes) {
+    if (!idx || !dev_ptr || !bytes) return fail(SBWTGPU_ERR_INVALID_ARG, "NULL argument");
+    *dev_ptr = idx->blob;
+    *bytes = idx->h.blob_bytes;
+    return SBWTGPU_OK;
+}
+
+int sbwtgpu_index_adopt(const void *header, int64_t header_bytes, void *dev_blob, int64_t blob_bytes, int device,
+                        sbwtgpu_index **out) {
+    if (!header || !dev_blob || !out) return fail(SBWTGPU_ERR_INVALID_ARG, "NULL argument");
+    if (header_bytes != (int64_t)sizeof(SbwtBlobHeader)) return fail(SBWTGPU_ERR_INVALID_ARG, "bad header size");
+    SbwtBlobHeader h;
+    memcpy(&h, header, sizeof(h));
+    if (h.magic != SBWT_BLOB_MAGIC) return fail(SBWTGPU_ERR_INVALID_ARG, "bad header magic");
+    if (h.blob_bytes != blob_bytes) return fail(SBWTGPU_ERR_INVALID_ARG, "blob size does not match its header");
+    sbwtgpu_index *idx = new (std::nothrow) sbwtgpu_index();
+    if (!idx) return fail(SBWTGPU_ERR_OOM, "out of host memory");
+    idx->h = h;
+    idx->device = device;
+    idx->blob = static_cast<char *>(dev_blob);
+    idx->owns_blob = false;
+    *out = idx;
+    return SBWTGPU_OK;
+}
+
+// RCCL is loaded lazily so that single-GPU use never needs it.
+int sbwtgpu_index_bcast(sbwtgpu_index *root, int n_dev, const int *devs, sbwtgpu_index **out) {
+    if (!root || n_dev <= 0 || !devs || !out) return fail(SBWTGPU_ERR_INVALID_ARG, "NULL/empty argument");
+    bool only_root = true;
+    for (int i = 0; i < n_dev; i++) only_root = only_root && (devs[i] == root->device);
+    if (only_root) {
+        for (int i = 0; i < n_dev; i++) out[i] = root;
+        return SBWTGPU_OK;
+    }
+    typedef void *comm_t;
+    typedef int (*init_all_t)(comm_t *, int, const int *);
+    typedef int (*bcast_t)(const void *, void *, size_t, int, int, comm_t, hipStream_t);
+    typedef int (*grp_t)(void);
+    typedef int (*destroy_t)(comm_t);
+    void *lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) return fail(SBWTGPU_ERR_HIP, "cannot load librccl.so: %s", dlerror());
+    init_all_t init_all = (init_all_t)dlsym(lib, "ncclCommInitAll");
+    bcast_t bcast = (bcast_t)dlsym(lib, "ncclBroadcast");
+    grp_t gstart = (grp_t)dlsym(lib, "ncclGroupStart"), gend = (grp_t)dlsym(lib, "ncclGroupEnd");
+    destroy_t destroy = (destroy_t)dlsym(lib, "ncclCommDestroy");
+    if (!init_all || !bcast || !gstart || !gend || !destroy) return fail(SBWTGPU_ERR_HIP, "RCCL symbols missing");
+    int root_rank = -1;
+    for (int i = 0; i < n_dev; i++)
+        if (devs[i] == root->device) root_rank = i;
+    if (root_rank < 0) return fail(SBWTGPU_ERR_INVALID_ARG, "the root's device must be in devs[]");
+    std::vector<comm_t> comms((size_t)n_dev);
+    std::vector<hipStream_t> streams((size_t)n_dev);
+    std::vector<sbwtgpu_index *> made((size_t)n_dev, nullptr);
+    int rc = SBWTGPU_OK;
+    for (int i = 0; i < n_dev && rc == SBWTGPU_OK; i++) {
+        if (hipSetDevice(devs[i]) != hipSuccess || hipStreamCreate(&streams[i]) != hipSuccess)
+            rc = fail(SBWTGPU_ERR_HIP, "cannot set up device %d", devs[i]);
+        if (rc == SBWTGPU_OK && i != root_rank) {
+            sbwtgpu_index *c = new (std::nothrow) sbwtgpu_index();
+            if (!c || hipMalloc((void **)&c->blob, (size_t)root->h.blob_bytes) != hipSuccess) {
+                delete c;
+                rc = fail(SBWTGPU_ERR_OOM, "hipMalloc on device %d", devs[i]);
+                break;
+            }
+            c->h = root->h;
+            c->device = devs[i];
+            made[i] = c;
+        }
+    }
+    if (rc == SBWTGPU_OK && init_all(comms.data(), n_dev, devs) != 0) rc = fail(SBWTGPU_ERR_HIP, "ncclCommInitAll failed");
+    if (rc == SBWTGPU_OK) {
+        gstart();
+        for (int i = 0; i < n_dev; i++) {
+            (void)hipSetDevice(devs[i]);
+            void *buf = (i == root_rank) ? (void *)root->blob : (void *)made[i]->blob;
+            if (bcast(buf, buf, (size_t)root->h.blob_bytes, /*ncclChar*/ 0, root_rank, comms[i], streams[i]) != 0)
+                rc = fail(SBWTGPU_ERR_HIP, "ncclBroadcast failed");
+        }
+        gend();
+        for (int i = 0; i < n_dev; i++) {
+            (void)hipSetDevice(devs[i]);
+            (void)hipStreamSynchronize(streams[i]);
+            destroy(comms[i]);
+        }
+    }
+    for (int i = 0; i < n_dev; i++) {
+        (void)hipSetDevice(devs[i]);
+        (void)hipStreamDestroy(streams[i]);
+    }
+    (void)hipSetDevice(root->device);
+    if (rc != SBWTGPU_OK) {
+        for (auto *c : made) sbwtgpu_index_destroy(c);
+        return rc;
+    }
+    for (int i = 0; i < n_dev; i++) out[i] = (i == root_rank) ? root : made[i];
+    return SBWTGPU_OK;
+}
+
+// ---- device-pointer entry points -----------------------------------------------------------
+int64_t sbwtgpu_search_workspace_bytes(int64_t total_bases) {
+    if (total_bases < 0) total_bases = 0;
+    int64_t groups = (total_bases + SBWT_GROUP_BASES - 1) / SBWT_GROUP_BASES + 2;
+    return (int64_t)sizeof(SbwtWorkHeader) + groups * 16;
+}
+
+static int search_dev_common(const sbwtgpu_index *idx, const char *d_bases, int64_t total_bases,
+                             const int64_t *d_read_off, int64_t n_reads, int64_t *d_out, const int64_t *d_out_off,
+                             void *d_ws, int64_t ws_bytes, void *stream, int streaming) {
+    if (!idx) return fail(SBWTGPU_ERR_INVALID_ARG, "idx is NULL");
+    if (streaming && !idx->h.has_ssup)
+        return fail(SBWTGPU_ERR_NO_STREAMING, "Error: streaming search support not built");
+    if (n_reads < 0 || total_bases < 0) return fail(SBWTGPU_ERR_INVALID_ARG, "negative size");
+    if (n_reads == 0) return SBWTGPU_OK;
+    if (!d_bases || !d_read_off || !d_out_off || !d_ws) return fail(SBWTGPU_ERR_INVALID_ARG, "NULL device pointer");
+    if (ws_bytes < sbwtgpu_search_workspace_bytes(total_bases))
+        return fail(SBWTGPU_ERR_INVALID_ARG, "workspace too small (%lld < %lld)", (long long)ws_bytes,
+                    (long long)sbwtgpu_search_workspace_bytes(total_bases));
+    if (((uintptr_t)d_ws & 15) != 0) return fail(SBWTGPU_ERR_INVALID_ARG, "workspace must be 16-byte aligned");
+    DeviceGuard guard(idx->device);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    SbwtWorkHeader *ws = static_cast<SbwtWorkHeader *>(d_ws);
+    uint4 *packed = reinterpret_cast<uint4 *>(static_cast<char *>(d_ws) + sizeof(SbwtWorkHeader));
+    sbwt_launch_encode(d_bases, total_bases, packed, ws, st);
+    sbwt_launch_search(idx->view(), packed, reinterpret_cast<const long long *>(d_read_off),
+                       reinterpret_cast<const long long *>(d_out_off), reinterpret_cast<long long *>(d_out), n_reads,
+                       ws, streaming, st);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(SBWTGPU_ERR_HIP, "kernel launch: %s", hipGetErrorString(e));
+    return SBWTGPU_OK;
+}
+
+int sbwtgpu_streaming_search_dev(const sbwtgpu_index *idx, const char *d_bases, int64_t total_bases,
+                                 const int64_t *d_read_off, int64_t n_reads, int64_t *d_out,
+                                 const int64_t *d_out_off, void *d_ws, int64_t ws_bytes, void *stream) {
+    return search_dev_common(idx, d_bases, total_bases, d_read_off, n_reads, d_out, d_out_off, d_ws, ws_bytes, stream,
+                             1);
+}
+
+int sbwtgpu_search_dev(const sbwtgpu_index *idx, const char *d_bases, int64_t total_bases, const int64_t *d_read_off,
+                       int64_t n_reads, int64_t *d_out, const int64_t *d_out_off, void *d_ws, int64_t ws_bytes,
+                       void *stream) {
+    return search_dev_common(idx, d_bases, total_bases, d_read_off, n_reads, d_out, d_out_off, d_ws, ws_bytes, stream,
+                             0);
+}
+
+int sbwtgpu_rank_dev(const sbwtgpu_index *idx, const int64_t *d_pos, const char *d_sym, int64_t n, int64_t *d_out,
+                     void *stream) {
+    if (!idx) return fail(SBWTGPU_ERR_INVALID_ARG, "idx is NULL");
+    if (n < 0) return fail(SBWTGPU_ERR_INVALID_ARG, "negative size");
+    if (n == 0) return SBWTGPU_OK;
+    if (!d_pos || !d_sym || !d_out) return fail(SBWTGPU_ERR_INVALID_ARG, "NULL device pointer");
+    DeviceGuard guard(idx->device);
+    sbwt_launch_rank(idx->view(), reinterpret_cast<const long long *>(d_pos), d_sym, n,
+                     reinterpret_cast<long long *>(d_out), static_cast<hipStream_t>(stream));
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(SBWTGPU_ERR_HIP, "kernel launch: %s", hipGetErrorString(e));
+    return SBWTGPU_OK;
+}
+
+int sbwtgpu_workspace_status(const void *d_ws, void *stream, int *status) {
+    if (!d_ws || !status) return fail(SBWTGPU_ERR_INVALID_ARG, "NULL argument");
+    SbwtWorkHeader hdr;
+    HIP_TRY(hipMemcpyAsync(&hdr, d_ws, sizeof(hdr), hipMemcpyDeviceToHost, static_cast<hipStream_t>(stream)));
+    HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+    *status = hdr.status;
+    return SBWTGPU_OK;
+}
+
+// ---- host-buffer entry points --------------------------------------------------------------
+namespace {
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf() {
+        if (p) (void)hipFree(p);
+    }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16); }
+};
+struct Stream {
+    hipStream_t s = nullptr;
+    ~Stream() {
+        if (s) (void)hipStreamDestroy(s);
+    }
+};
+}  // namespace
+
+static int check_reads(const int64_t *read_off, const int64_t *out_off, int64_t n_reads, int64_t k) {
+    for (int64_t r = 0; r < n_reads; r++) {
+        int64_t len = read_off[r + 1] - read_off[r];
+        if (len < 0) return fail(SBWTGPU_ERR_INVALID_ARG, "read_off is not non-decreasing at read %lld", (long long)r);
+        if (len >= ((int64_t)1 << 31)) return fail(SBWTGPU_ERR_READ_TOO_LONG, "read %lld has >= 2^31 bases", (long long)r);
+        int64_t m = len - k + 1;
+        if (m < 0) m = 0;
+        if (out_off[r + 1] - out_off[r] != m)
+            return fail(SBWTGPU_ERR_INVALID_ARG, "out_off[%lld+1]-out_off[%lld] must be max(0,len-k+1) = %lld",
+                        (long long)r, (long long)r, (long long)m);
+    }
+    return SBWTGPU_OK;
+}
+
+static int search_host_common(const sbwtgpu_index *idx, const char *bases, const int64_t *read_off, int64_t n_reads,
+                              int64_t *out, const int64_t *out_off, int streaming) {
+    if (!idx) return fail(SBWTGPU_ERR_INVALID_ARG, "idx is NULL");
+    if (streaming && !idx->h.has_ssup)
+        return fail(SBWTGPU_ERR_NO_STREAMING, "Error: streaming search support not built");
+    if (n_reads < 0) return fail(SBWTGPU_ERR_INVALID_ARG, "negative n_reads");
+    if (n_reads == 0) return SBWTGPU_OK;
+    if (!read_off || !out_off) return fail(SBWTGPU_ERR_INVALID_ARG, "NULL offsets");
+    int rc = check_reads(read_off, out_off, n_reads, idx->h.k);
+    if (rc != SBWTGPU_OK) return rc;
+    const int64_t base0 = read_off[0], total = read_off[n_reads] - base0;
+    const int64_t out0 = out_off[0], n_out = out_off[n_reads] - out0;
+    if (total > 0 && !bases) return fail(SBWTGPU_ERR_INVALID_ARG, "bases is NULL");
+    if (n_out > 0 && !out) return fail(SBWTGPU_ERR_INVALID_ARG, "out is NULL");
+    if (n_out == 0) return SBWTGPU_OK;
+
+    DeviceGuard guard(idx->device);
+    Stream st;
+    HIP_TRY(hipStreamCreateWithFlags(&st.s, hipStreamNonBlocking));
+    DevBuf d_bases, d_roff, d_ooff, d_out, d_ws;
+    const int64_t ws_bytes = sbwtgpu_search_workspace_bytes(total);
+    HIP_TRY(d_bases.alloc((size_t)total + 16));
+    HIP_TRY(d_roff.alloc((size_t)(n_reads + 1) * 8));
+    HIP_TRY(d_ooff.alloc((size_t)(n_reads + 1) * 8));
+    HIP_TRY(d_out.alloc((size_t)n_out * 8));
+    HIP_TRY(d_ws.alloc((size_t)ws_bytes));
+    // offsets are rebased so that device buffers start at 0
+    std::vector<int64_t> ro((size_t)n_reads + 1), oo((size_t)n_reads + 1);
+    for (int64_t r = 0; r <= n_reads; r++) {
+        ro[(size_t)r] = read_off[r] - base0;
+        oo[(size_t)r] = out_off[r] - out0;
+    }
+    HIP_TRY(hipMemcpyAsync(d_bases.p, bases + base0, (size_t)total, hipMemcpyHostToDevice, st.s));
+    HIP_TRY(hipMemcpyAsync(d_roff.p, ro.data(), (size_t)(n_reads + 1) * 8, hipMemcpyHostToDevice, st.s));
+    HIP_TRY(hipMemcpyAsync(d_ooff.p, oo.data(), (size_t)(n_reads + 1) * 8, hipMemcpyHostToDevice, st.s));
+    rc = search_dev_common(idx, (const char *)d_bases.p, total, (const int64_t *)d_roff.p, n_reads, (int64_t *)d_out.p,
+                           (const int64_t *)d_ooff.p, d_ws.p, ws_bytes, st.s, streaming);
+    if (rc != SBWTGPU_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(out + out0, d_out.p, (size_t)n_out * 8, hipMemcpyDeviceToHost, st.s));
+    SbwtWorkHeader hdr;
+    HIP_TRY(hipMemcpyAsync(&hdr, d_ws.p, sizeof(hdr), hipMemcpyDeviceToHost, st.s));
+    HIP_TRY(hipStreamSynchronize(st.s));
+    if (hdr.status != 0)
+        return fail(SBWTGPU_ERR_NOT_SINGLETON, "Bug: k-mer search did not give a singleton interval");
+    return SBWTGPU_OK;
+}
+
+int sbwtgpu_streaming_search_batch(const sbwtgpu_index *idx, const char *bases, const int64_t *read_off,
+                                   int64_t n_reads, int64_t *out, const int64_t *out_off) {
+    return search_host_common(idx, bases, read_off, n_reads, out, out_off, 1);
+}
+
+int sbwtgpu_search_batch(const sbwtgpu_index *idx, const char *bases, const int64_t *read_off, int64_t n_reads,
+                         int64_t *out, const int64_t *out_off) {
+    return search_host_common(idx, bases, read_off, n_reads, out, out_off, 0);
+}
+
+int sbwtgpu_rank_batch(const sbwtgpu_index *idx, const int64_t *pos, const char *sym, int64_t n, int64_t *out) {
+    if (!idx) return fail(SBWTGPU_ERR_INVALID_ARG, "idx is NULL");
+    if (n < 0) return fail(SBWTGPU_ERR_INVALID_ARG, "negative n");
+    if (n == 0) return SBWTGPU_OK;
+    if (!pos || !sym || !out) return fail(SBWTGPU_ERR_INVALID_ARG, "NULL argument");
+    for (int64_t t = 0; t < n; t++)
+        if (pos[t] < 0 || pos[t] > idx->h.n_nodes)
+            return fail(SBWTGPU_ERR_INVALID_ARG, "pos[%lld] = %lld outside [0, n_nodes]", (long long)t, (long long)pos[t]);
+    DeviceGuard guard(idx->device);
+    Stream st;
+    HIP_TRY(hipStreamCreateWithFlags(&st.s, hipStreamNonBlocking));
+    DevBuf d_pos, d_sym, d_out;
+    HIP_TRY(d_pos.alloc((size_t)n * 8));
+    HIP_TRY(d_sym.alloc((size_t)n));
+    HIP_TRY(d_out.alloc((size_t)n * 8));
+    HIP_TRY(hipMemcpyAsync(d_pos.p, pos, (size_t)n * 8, hipMemcpyHostToDevice, st.s));
+    HIP_TRY(hipMemcpyAsync(d_sym.p, sym, (size_t)n, hipMemcpyHostToDevice, st.s));
+    int rc = sbwtgpu_rank_dev(idx, (const int64_t *)d_pos.p, (const char *)d_sym.p, n, (int64_t *)d_out.p, st.s);
+    if (rc != SBWTGPU_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(out, d_out.p, (size_t)n * 8, hipMemcpyDeviceToHost, st.s));
+    HIP_TRY(hipStreamSynchronize(st.s));
+    return SBWTGPU_OK;
+}
+
+int sbwtgpu_update_interval_batch(const sbwtgpu_index *idx, const char *bases, const int64_t *off, int64_t n,
+                                  int64_t *first, int64_t *second) {
+    if (!idx) return fail(SBWTGPU_ERR_INVALID_ARG, "idx is NULL");
+    if (n < 0) return fail(SBWTGPU_ERR_INVALID_ARG, "negative n");
+    if (n == 0) return SBWTGPU_OK;
+    if (!off || !first || !second) return fail(SBWTGPU_ERR_INVALID_ARG, "NULL argument");
+    const int64_t base0 = off[0], total = off[n] - base0;
+    if (total < 0 || (total > 0 && !bases)) return fail(SBWTGPU_ERR_INVALID_ARG, "bad bases/offsets");
+    for (int64_t t = 0; t < n; t++) {
+        if (off[t + 1] < off[t]) return fail(SBWTGPU_ERR_INVALID_ARG, "off is not non-decreasing");
+        if (first[t] != -1 && (first[t] < 0 || second[t] >= idx->h.n_nodes || second[t] < -1))
+            return fail(SBWTGPU_ERR_INVALID_ARG, "interval %lld out of range", (long long)t);
+    }
+    DeviceGuard guard(idx->device);
+    Stream st;
+    HIP_TRY(hipStreamCreateWithFlags(&st.s, hipStreamNonBlocking));
+    DevBuf d_bases, d_off, d_f, d_s;
+    HIP_TRY(d_bases.alloc((size_t)total + 16));
+    HIP_TRY(d_off.alloc((size_t)(n + 1) * 8));
+    HIP_TRY(d_f.alloc((size_t)n * 8));
+    HIP_TRY(d_s.alloc((size_t)n * 8));
+    std::vector<int64_t> o((size_t)n + 1);
+    for (int64_t t = 0; t <= n; t++) o[(size_t)t] = off[t] - base0;
+    if (total) HIP_TRY(hipMemcpyAsync(d_bases.p, bases + base0, (size_t)total, hipMemcpyHostToDevice, st.s));
+    HIP_TRY(hipMemcpyAsync(d_off.p, o.data(), (size_t)(n + 1) * 8, hipMemcpyHostToDevice, st.s));
+    HIP_TRY(hipMemcpyAsync(d_f.p, first, (size_t)n * 8, hipMemcpyHostToDevice, st.s));
+    HIP_TRY(hipMemcpyAsync(d_s.p, second, (size_t)n * 8, hipMemcpyHostToDevice, st.s));
+    sbwt_launch_update_interval(idx->view(), (const char *)d_bases.p, (const long long *)d_off.p, n,
+                                (long long *)d_f.p, (long long *)d_s.p, st.s);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(first, d_f.p, (size_t)n * 8, hipMemcpyDeviceToHost, st.s));
+    HIP_TRY(hipMemcpyAsync(second, d_s.p, (size_t)n * 8, hipMemcpyDeviceToHost, st.s));
+    HIP_TRY(hipStreamSynchronize(st.s));
+    return SBWTGPU_OK;
+}
+
+int sbwtgpu_forward_batch(const sbwtgpu_index *idx, const int64_t *node, const char *sym, int64_t n, int64_t *out) {
+    if (!idx) return fail(SBWTGPU_ERR_INVALID_ARG, "idx is NULL");
+    if (!idx->h.has_ssup)
+        return fail(SBWTGPU_ERR_NO_STREAMING, "Error: Streaming support required for SBWT::forward");
+    if (n < 0) return fail(SBWTGPU_ERR_INVALID_ARG, "negative n");
+    if (n == 0) return SBWTGPU_OK;
+    if (!node || !sym || !out) return fail(SBWTGPU_ERR_INVALID_ARG, "NULL argument");
+    for (int64_t t = 0; t < n; t++)
+        if (node[t] < 0 || node[t] >= idx->h.n_nodes)
+            return fail(SBWTGPU_ERR_INVALID_ARG, "node[%lld] out of range", (long long)t);
+    DeviceGuard guard(idx->device);
+    Stream st;
+    HIP_TRY(hipStreamCreateWithFlags(&st.s, hipStreamNonBlocking));
+    DevBuf d_node, d_sym, d_out;
+    HIP_TRY(d_node.alloc((size_t)n * 8));
+    HIP_TRY(d_sym.alloc((size_t)n));
+    HIP_TRY(d_out.alloc((size_t)n * 8));
+    HIP_TRY(hipMemcpyAsync(d_node.p, node, (size_t)n * 8, hipMemcpyHostToDevice, st.s));
+    HIP_TRY(hipMemcpyAsync(d_sym.p, sym, (size_t)n, hipMemcpyHostToDevice, st.s));
+    sbwt_launch_forward(idx->view(), (const long long *)d_node.p, (const char *)d_sym.p, n, (long long *)d_out.p, st.s);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out, d_out.p, (size_t)n * 8, hipMemcpyDeviceToHost, st.s));
+    HIP_TRY(hipStreamSynchronize(st.s));
+    return SBWTGPU_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,75 @@
+"""Seeded synthetic genomes and reads: coli3.fna and the pan-genome are not available
+offline, so tests and bench.py generate stand-ins with fixed seeds (numpy PCG64 => identical bytes
+on every box).
+"""
+from __future__ import annotations
+
+from typing import List, Tuple
+
+import numpy as np
+
+ACGT = np.frombuffer(b"ACGT", dtype=np.uint8)
+
+
+def random_genome(n: int, seed: int) -> np.ndarray:
+    rng = np.random.Generator(np.random.PCG64(seed))
+    return ACGT[rng.integers(0, 4, size=n, dtype=np.uint8)]
+
+
+def mutate(genome: np.ndarray, rate: float, seed: int) -> np.ndarray:
+    """Per-base substitutions with probability `rate` (always to a different base)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    g = genome.copy()
+    hit = np.nonzero(rng.random(len(g)) < rate)[0]
+    code = np.zeros(256, dtype=np.uint8)
+    code[ACGT] = np.arange(4, dtype=np.uint8)
+    shift = rng.integers(1, 4, size=len(hit), dtype=np.uint8)
+    g[hit] = ACGT[(code[g[hit]] + shift) & 3]
+    return g
+
+
+def coli3_like(genome_len: int = 5_000_000, divergence: float = 0.05) -> List[np.ndarray]:
+    """G-small of SURVEY 8d: genome 0 random (seed 1), genomes 1,2 = 5 % substituted copies (seeds 2,3)."""
+    g0 = random_genome(genome_len, 1)
+    return [g0, mutate(g0, divergence, 2), mutate(g0, divergence, 3)]
+
+
+def pan_like(n_derived: int = 64, genome_len: int = 5_000_000, divergence: float = 0.02) -> List[np.ndarray]:
+    """G-pan of SURVEY 8d: genome 0 + n_derived copies at 2 % divergence (seeds 100..)."""
+    g0 = random_genome(genome_len, 1)
+    return [g0] + [mutate(g0, divergence, 100 + i) for i in range(n_derived)]
+
+
+def sample_reads(genomes: List[np.ndarray], n_reads: int, read_len: int, sub_rate: float, seed: int
+                 ) -> Tuple[np.ndarray, np.ndarray]:
+    """Uniform (genome, offset) substrings with per-base substitutions; returns (bases, read_off)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    lens = np.array([len(g) for g in genomes])
+    cat = np.concatenate(genomes)
+    starts = np.concatenate([[0], np.cumsum(lens)[:-1]])
+    which = rng.integers(0, len(genomes), size=n_reads)
+    off = (rng.random(n_reads) * (lens[which] - read_len + 1)).astype(np.int64) + starts[which]
+    bases = np.empty(n_reads * read_len, dtype=np.uint8)
+    chunk = max(1, (1 << 24) // max(read_len, 1))
+    ar = np.arange(read_len, dtype=np.int64)
+    for lo in range(0, n_reads, chunk):
+        hi = min(n_reads, lo + chunk)
+        bases[lo * read_len: hi * read_len] = cat[(off[lo:hi, None] + ar[None, :]).ravel()]
+    if sub_rate > 0:
+        bases = mutate(bases, sub_rate, seed + 1)
+    read_off = np.arange(n_reads + 1, dtype=np.int64) * read_len
+    return bases, read_off
+
+
+def random_reads(n_reads: int, read_len: int, seed: int) -> Tuple[np.ndarray, np.ndarray]:
+    """All-miss stress set: uniform random reads."""
+    return random_genome(n_reads * read_len, seed), np.arange(n_reads + 1, dtype=np.int64) * read_len
+
+
+def inject(bases: np.ndarray, n: int, char: int, seed: int) -> np.ndarray:
+    """Overwrite n random positions with `char` (e.g. ord('N'))."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    b = bases.copy()
+    if len(b) and n:
+        b[rng.integers(0, len(b), size=n)] = char
+    return b

@@ -1,0 +1,32 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def _gpu_available() -> bool:
+    try:
+        from sbwt_amd import capi
+        return capi.device_count() > 0
+    except Exception:
+        return False
+
+
+@pytest.fixture(scope="session")
+def gpu():
+    """GPU tests must run the HIP path or fail loudly -- never skip silently on a GPU box."""
+    from sbwt_amd import capi
+    capi.lib()  # raises ImportError if libsbwtgpu.so is missing
+    n = capi.device_count()
+    if n <= 0:
+        pytest.fail("no HIP device visible: -m gpu tests need a GPU (there is no CPU fallback)")
+    return 0

@@ -1,0 +1,215 @@
+"""GPU parity tests proper: the HIP path, called through the C ABI (include/sbwtgpu.h), must be
+bit-identical to the oracle on the reference's known-answer vectors, on seeded synthetic inputs,
+and on the edge cases the reference tests (empty/short/ragged reads, N and lower-case characters,
+no streaming support, pos == n_nodes)."""
+import json
+import os
+import random
+
+import numpy as np
+import pytest
+
+from bruteforce import BruteSBWT, kmer_set
+from oracle import OracleIndex, print_vector
+from sbwt_amd import capi, synth
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+KATS = json.load(open(os.path.join(HERE, "golden", "ref_kats.json")))
+
+
+def b(s):
+    return s.encode()
+
+
+def gpu_index_from_oracle(orc: OracleIndex, precalc_from_file: bool = False) -> capi.Index:
+    cols = orc.columns()
+    return capi.Index.create(cols[0], cols[1], cols[2], cols[3], orc.ssup_words(), orc.n_nodes, orc.k,
+                             orc.n_kmers, orc.precalc_k, orc.precalc() if precalc_from_file else None)
+
+
+def oracle_batch(orc: OracleIndex, bases, off, streaming=True):
+    out = []
+    for r in range(len(off) - 1):
+        s = bases[off[r]:off[r + 1]].tobytes()
+        out.append(orc.streaming_search(s) if streaming else orc.search_all(s))
+    return np.concatenate(out) if out else np.zeros(0, np.int64)
+
+
+def test_cli_kat_exact_output(gpu):
+    kat = KATS["cli_end_to_end"]
+    orc = OracleIndex.build([b(s) for s in kat["seqs"]], kat["k"], True, True, kat["precalc"])
+    idx = gpu_index_from_oracle(orc)
+    assert idx.n_nodes == 87 and idx.C == [1, 25, 43, 59] and idx.precalc_k == 4
+    res = idx.streaming_search_reads([b(q) for q in kat["queries"]])
+    assert b"".join(print_vector(r) for r in res) == kat["expected_output"].encode()
+    res = idx.search_reads([b(q) for q in kat["queries"]])
+    assert b"".join(print_vector(r) for r in res) == kat["expected_output"].encode()
+    # the device-computed prefix table equals do_kmer_prefix_precalc of the oracle
+    assert np.array_equal(idx.get_precalc(), orc.precalc())
+
+
+@pytest.mark.parametrize("case", KATS["small_cases"]["cases"], ids=lambda c: c["name"])
+@pytest.mark.parametrize("precalc", [0, 2])
+def test_small_cases_exhaustive(gpu, case, precalc):
+    k, seqs = case["k"], case["seqs"]
+    orc = OracleIndex.build([b(s) for s in seqs], k, True, False, min(precalc, k))
+    idx = gpu_index_from_oracle(orc)
+    brute = BruteSBWT(seqs, k)
+    kmers = ["".join("ACGT"[(m >> (2 * i)) & 3] for i in range(k)) for m in range(4 ** k)] + ["N" * k]
+    got = idx.search_reads([b(x) for x in kmers])
+    truth = kmer_set(seqs, k)
+    for x, g in zip(kmers, got):
+        assert len(g) == 1
+        assert g[0] == (brute.rank_of[x] if x in truth else -1)
+
+
+def test_serialization_strings_streaming_and_N(gpu):
+    kat = KATS["serialization_strings"]
+    k = kat["k"]
+    orc = OracleIndex.build([b(s) for s in kat["seqs"]], k, True, False, kat["precalc"])
+    idx = gpu_index_from_oracle(orc, precalc_from_file=True)
+    rnd = random.Random(5)
+    inputs = kat["seqs"] + ["".join(rnd.choice("ACGT") for _ in range(100)), "N" * 100]
+    got = idx.streaming_search_reads([b(s) for s in inputs])
+    for s, g in zip(inputs, got):
+        assert np.array_equal(g, orc.streaming_search(b(s)))
+    assert list(got[-1]) == [-1] * (100 - k + 1)
+
+
+@pytest.fixture(scope="module")
+def genome_case():
+    k = 30
+    genomes = [synth.random_genome(200_000, 1)]
+    genomes.append(synth.mutate(genomes[0], 0.05, 2))
+    genomes.append(synth.mutate(genomes[0], 0.05, 3))
+    orc = OracleIndex.build([g.tobytes() for g in genomes], k, True, False, 8)
+    return genomes, orc
+
+
+def test_rank_batch_random_and_edges(gpu, genome_case):
+    genomes, orc = genome_case
+    idx = gpu_index_from_oracle(orc)
+    rng = np.random.default_rng(3)
+    n = orc.n_nodes
+    pos = np.concatenate([rng.integers(0, n + 1, size=5000),
+                          np.array([0, 1, 63, 64, 65, 127, 128, n - 1, n, (n // 64) * 64, max((n // 64) * 64 - 1, 0)])])
+    sym = rng.choice(np.frombuffer(b"ACGTNacgt$", dtype=np.uint8), size=len(pos))
+    got = idx.rank(pos, sym)
+    want = np.array([orc.rank(int(p), bytes([int(c)])) for p, c in zip(pos, sym)], dtype=np.int64)
+    assert np.array_equal(got, want)
+
+
+def test_streaming_parity_synthetic(gpu, genome_case):
+    genomes, orc = genome_case
+    idx = gpu_index_from_oracle(orc)
+    bases, off = synth.sample_reads(genomes, 4000, 150, 0.01, 42)
+    bases = synth.inject(bases, 60, ord("N"), 7)
+    bases = synth.inject(bases, 60, ord("c"), 8)         # lower-case: Q1/Q2 path dependence
+    bases = synth.inject(bases, 20, ord("n"), 9)
+    got, oo = idx.streaming_search(bases, off)
+    want = oracle_batch(orc, bases, off, True)
+    assert np.array_equal(got, want)
+    assert (got >= 0).mean() > 0.4                       # the case really exercises hits and misses
+    got2, _ = idx.search(bases, off)
+    assert np.array_equal(got2, oracle_batch(orc, bases, off, False))
+
+
+def test_all_miss_reads(gpu, genome_case):
+    genomes, orc = genome_case
+    idx = gpu_index_from_oracle(orc)
+    bases, off = synth.random_reads(1000, 100, 99)
+    got, _ = idx.streaming_search(bases, off)
+    assert np.array_equal(got, oracle_batch(orc, bases, off, True))
+
+
+def test_ragged_empty_and_short_reads(gpu, genome_case):
+    genomes, orc = genome_case
+    idx = gpu_index_from_oracle(orc)
+    g = genomes[0].tobytes()
+    rnd = random.Random(11)
+    reads = [b"", b"A", g[:29], g[:30], g[100:131], g[5000:5400], b"", g[777:777 + 64], b"N" * 40,
+             g[10:10 + 33].lower(), g[-30:], g[-31:]]
+    for _ in range(200):
+        L = rnd.choice([0, 1, 29, 30, 31, 32, 33, 63, 64, 65, 95, 96, 97, 150, 257])
+        s = rnd.randrange(0, len(g) - 300)
+        reads.append(g[s:s + L])
+    got = idx.streaming_search_reads(reads)
+    for r, gg in zip(reads, got):
+        assert np.array_equal(gg, orc.streaming_search(r)), r
+    got = idx.search_reads(reads)
+    for r, gg in zip(reads, got):
+        assert np.array_equal(gg, orc.search_all(r)), r
+
+
+def test_no_streaming_support_k63(gpu):
+    # config 5 of BASELINE.json: k=63 without suffix_group_starts -> non-streaming path
+    k = 63
+    genomes = [synth.random_genome(100_000, 5)]
+    genomes.append(synth.mutate(genomes[0], 0.03, 6))
+    orc = OracleIndex.build([g.tobytes() for g in genomes], k, False, False, 8)
+    idx = gpu_index_from_oracle(orc)
+    assert not idx.has_streaming_support
+    bases, off = synth.sample_reads(genomes, 1500, 150, 0.005, 42)
+    bases = synth.inject(bases, 10, ord("N"), 7)
+    with pytest.raises(capi.SbwtGpuError) as ei:
+        idx.streaming_search(bases, off)
+    assert ei.value.code == capi.ERR_NO_STREAMING and "streaming search support not built" in ei.value.msg
+    got, _ = idx.search(bases, off)
+    assert np.array_equal(got, oracle_batch(orc, bases, off, False))
+    assert (got >= 0).mean() > 0.3
+
+
+def test_update_interval_and_forward(gpu, genome_case):
+    genomes, orc = genome_case
+    idx = gpu_index_from_oracle(orc)
+    g = genomes[1].tobytes()
+    rnd = random.Random(21)
+    strs = [g[s:s + rnd.randrange(0, 40)] for s in (rnd.randrange(0, len(g) - 50) for _ in range(500))]
+    strs += [b"ACGTN", b"acgt", b""]
+    bases, off = capi.concat_reads(strs)
+    first = np.zeros(len(strs), dtype=np.int64)
+    second = np.full(len(strs), orc.n_nodes - 1, dtype=np.int64)
+    first[5], second[5] = -1, -1
+    f, s = idx.update_interval(bases, off, first, second)
+    for i, st in enumerate(strs):
+        assert (f[i], s[i]) == orc.update_interval(st, int(first[i]), int(second[i]))
+    # forward (SBWT.hh:368-381) from random found columns
+    bases2, off2 = synth.sample_reads(genomes, 300, 31, 0.0, 5)
+    cols, _ = idx.search(bases2, off2)
+    nodes = np.repeat(cols[cols >= 0][:300], 5)
+    sym = np.tile(np.frombuffer(b"ACGTN", dtype=np.uint8), len(nodes) // 5)
+    got = idx.forward(nodes, sym)
+    want = np.array([orc.forward(int(v), bytes([int(c)])) for v, c in zip(nodes, sym)], dtype=np.int64)
+    assert np.array_equal(got, want)
+
+
+def test_precalc_table_and_limits(gpu, genome_case):
+    genomes, orc = genome_case
+    idx = gpu_index_from_oracle(orc)                       # table computed on the device
+    assert np.array_equal(idx.get_precalc(), orc.precalc())
+    cols = orc.columns()
+    with pytest.raises(capi.SbwtGpuError) as ei:
+        capi.Index.create(cols[0], cols[1], cols[2], cols[3], None, orc.n_nodes, 30, 0, 21)
+    assert ei.value.code == capi.ERR_PRECALC_TOO_LONG
+    with pytest.raises(capi.SbwtGpuError) as ei:
+        capi.Index.create(cols[0], cols[1], cols[2], cols[3], None, orc.n_nodes, 5, 0, 6)
+    assert ei.value.code == capi.ERR_PRECALC_GT_K
+
+
+def test_streaming_equals_search_at_scale_properties(gpu, genome_case):
+    # size-independent properties at a larger batch: streaming == per-k-mer search (test_large.hh:104-115),
+    # every hit really is a valid column, and a checksum of checksums is stable across two runs
+    genomes, orc = genome_case
+    idx = gpu_index_from_oracle(orc)
+    bases, off = synth.sample_reads(genomes, 200_000, 150, 0.01, 4242)
+    a, oo = idx.streaming_search(bases, off)
+    bb, _ = idx.search(bases, off)
+    assert np.array_equal(a, bb)
+    assert a.min() >= -1 and a.max() < orc.n_nodes
+    a2, _ = idx.streaming_search(bases, off)
+    assert int(np.bitwise_xor.reduce(a * np.arange(1, len(a) + 1))) == int(np.bitwise_xor.reduce(a2 * np.arange(1, len(a2) + 1)))
+    # sample 2000 reads against the oracle
+    want = oracle_batch(orc, bases[: 2000 * 150], off[:2001], True)
+    assert np.array_equal(a[: len(want)], want)
