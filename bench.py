@@ -1,0 +1,277 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X k-mer streaming-search path (BASELINE.json).
+
+A "step" is one pass of the hot path (2-bit re-encoding of the bases + SBWT::streaming_search of
+every read) over this rank's batch of synthetic reads, inputs and outputs resident in HBM.
+
+Workload (BASELINE.json configs[1]): coli3-like synthetic genomes (3 x 5 Mbp, 5 % divergence;
+coli3.fna itself is not available offline), k=30, plain-matrix index with precalc 8 and streaming
+support, 10 M synthetic 150 bp reads per GPU with 1 % substitutions.  Reads are sharded across
+ranks (weak scaling: 10 M per GPU), the read-only index is built on rank 0 and replicated with one
+RCCL broadcast at load time; there are no per-step collectives.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]        (N>1: launched by torch.distributed.run)
+
+Prints ONE JSON line on rank 0 (contract in the task description) with `roofline` and, at N=1,
+`cpu_baseline` (the oracle = restated reference CPU path, timed on the host cores on a bounded
+sample of the same reads; the same sample doubles as a bit-exact parity check of the GPU output).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+from sbwt_amd import capi, hostlib, synth  # noqa: E402
+from sbwt_amd import dist as sdist  # noqa: E402
+
+K = 30
+PRECALC = 8
+READ_LEN = 150
+SUB_RATE = 0.01
+HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s peak
+# SURVEY 8d algorithmic bytes
+B_STREAM = 89                   # 1 base + 8 ssup word + (8 count + 64 block bits) + 8 out
+B_SEARCH_FIXED = K + 16 + 8     # k bases + 16 precalc entry + 8 out
+B_LF = 2 * 72                   # two ranks per interval update, (8 count + 64 block bits) each
+
+
+def log(msg: str) -> None:
+    print(f"[bench] {msg}", file=sys.stderr, flush=True)
+
+
+def gpu_reads(genomes, n_reads: int, seed: int, dev: torch.device) -> torch.Tensor:
+    """n_reads x READ_LEN substrings at uniform (genome, offset) with per-base substitutions,
+    generated on the GPU (seeded) so that the inputs are resident in HBM."""
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(seed)
+    lens = torch.tensor([len(g) for g in genomes], device=dev)
+    starts = torch.tensor(np.concatenate([[0], np.cumsum([len(g) for g in genomes])[:-1]]), device=dev)
+    cat = torch.from_numpy(np.concatenate(genomes)).to(dev)
+    code = torch.zeros(256, dtype=torch.uint8, device=dev)
+    acgt = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
+    code[acgt.long()] = torch.arange(4, dtype=torch.uint8, device=dev)
+    out = torch.empty(n_reads * READ_LEN, dtype=torch.uint8, device=dev)
+    ar = torch.arange(READ_LEN, device=dev)
+    chunk = 1 << 20
+    for lo in range(0, n_reads, chunk):
+        n = min(chunk, n_reads - lo)
+        which = torch.randint(0, len(genomes), (n,), device=dev, generator=gen)
+        u = torch.rand(n, device=dev, generator=gen, dtype=torch.float64)
+        off = (u * (lens[which] - READ_LEN + 1)).long() + starts[which]
+        r = cat[(off[:, None] + ar[None, :]).reshape(-1)]
+        hit = torch.rand(n * READ_LEN, device=dev, generator=gen) < SUB_RATE
+        shift = torch.randint(1, 4, (n * READ_LEN,), device=dev, generator=gen, dtype=torch.uint8)
+        sub = acgt[((code[r.long()] + shift) & 3).long()]
+        out[lo * READ_LEN:(lo + n) * READ_LEN] = torch.where(hit, sub, r)
+    return out
+
+
+def main() -> int:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--reads", type=int, default=int(os.environ.get("SBWT_BENCH_READS", 10_000_000)),
+                    help="reads per GPU")
+    ap.add_argument("--genome-len", type=int, default=int(os.environ.get("SBWT_BENCH_GENOME", 5_000_000)))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    if world != args.gpus:
+        log(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the search path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    # ---- index: built once on rank 0 (host sort-based builder), replicated by one broadcast ----
+    t0 = time.time()
+    genomes = synth.coli3_like(args.genome_len)
+    bits = None
+    if rank == 0:
+        bits = hostlib.build_bits([g.tobytes() for g in genomes], K, False, True, n_threads=os.cpu_count() or 1)
+        index = capi.Index.create(bits.cols[0], bits.cols[1], bits.cols[2], bits.cols[3], bits.ssup, bits.n_nodes, K,
+                                  bits.n_kmers, PRECALC, None, device=local_rank)
+        log(f"index: n_nodes={index.n_nodes} n_kmers={index.n_kmers} image={index.blob_bytes / 1e6:.1f} MB "
+            f"device_precalc={index.device_precalc_k} ({time.time() - t0:.1f} s)")
+    t_bcast = None
+    if world > 1:
+        hdr, blob = None, None
+        if rank == 0:
+            hdr = index.export_header()
+            blob = torch.empty(index.blob_bytes, dtype=torch.uint8, device=dev)
+            index.copy_blob(blob.data_ptr(), blob.numel(), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        dist.barrier()
+        tb = time.time()
+        hdr, blob = sdist.broadcast_blob(hdr, blob, dev, src=0)     # RCCL over xGMI, load time only
+        torch.cuda.synchronize()
+        t_bcast = time.time() - tb
+        if rank != 0:
+            index = capi.Index.adopt(hdr, blob.data_ptr(), blob.numel(), local_rank, keepalive=blob)
+
+    # ---- this rank's reads, resident in HBM ----
+    n_reads = args.reads
+    d_bases = gpu_reads(genomes, n_reads, 42 + rank, dev)
+    total_bases = d_bases.numel()
+    m = READ_LEN - K + 1
+    n_kmers = n_reads * m
+    d_roff = torch.arange(n_reads + 1, dtype=torch.int64, device=dev) * READ_LEN
+    d_ooff = torch.arange(n_reads + 1, dtype=torch.int64, device=dev) * m
+    d_out = torch.empty(n_kmers, dtype=torch.int64, device=dev)
+    ws_bytes = capi.search_workspace_bytes(total_bases)
+    d_ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step(ev=None):
+        index.encode_bases_dev(d_bases.data_ptr(), total_bases, d_ws.data_ptr(), ws_bytes, stream)
+        if ev is not None:
+            ev[0].record()
+        index.search_encoded_dev(total_bases, d_roff.data_ptr(), n_reads, d_out.data_ptr(), d_ooff.data_ptr(),
+                                 d_ws.data_ptr(), ws_bytes, True, stream)
+        if ev is not None:
+            ev[1].record()
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    torch.cuda.synchronize()
+    t_start = time.perf_counter()
+    for s in range(args.steps):
+        step(events[s])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t_start
+    if world > 1:
+        elapsed = sdist.max_over_ranks(elapsed, dev)
+
+    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in events]))
+    n_stream, n_search, n_lf, n_tab = index.workspace_stats(d_ws.data_ptr(), stream)
+    status = index.workspace_status(d_ws.data_ptr(), stream)
+    if status != 0:
+        raise SystemExit(f"search kernel reported status {status}")
+    # reference algorithm's interval updates >= those executed past the device table + the levels the
+    # deeper device table (device_precalc_k) replaced for every non-empty lookup
+    lf_ref = n_lf + (index.device_precalc_k - PRECALC) * n_tab
+    alg_bytes = B_STREAM * n_stream + B_SEARCH_FIXED * n_search + B_LF * lf_ref
+    nominal_bytes = B_STREAM * n_stream + (B_SEARCH_FIXED + B_LF * (K - PRECALC)) * n_search
+
+    total_kmers = n_kmers * world
+    value = total_kmers * args.steps / elapsed
+    result = {
+        "metric": "k-mers/sec (whole node), plain-matrix k=30 streaming search",
+        "value": value,
+        "unit": "k-mers/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "u64",
+        "data": "synthetic",
+        "config": {
+            "workload": "coli3-like synthetic genomes (3 x %d bp, 5%% divergence) k=30 plain-matrix precalc=8 "
+                        "streaming support; %d synthetic 150bp reads per GPU, 1%% substitutions; "
+                        "SBWT::streaming_search of every read" % (args.genome_len, n_reads),
+            "k": K, "precalc_k": PRECALC, "read_len": READ_LEN, "reads_per_gpu": n_reads,
+            "kmers_per_gpu": n_kmers, "n_nodes": index.n_nodes, "index_image_bytes": index.blob_bytes,
+            "parallelism": "reads sharded x%d, index replicated (one RCCL broadcast at load)" % world,
+        },
+        "roofline": {
+            "bound": "hbm",
+            "kernel": "k_search",
+            "achieved": alg_bytes / (kernel_ms * 1e-3) / 1e9,
+            "peak": HBM_PEAK_GBPS,
+            "unit": "GB/s",
+            "frac": alg_bytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+            "traffic": None,
+            "kernel_ms": kernel_ms,
+            "algorithmic_bytes_per_launch": alg_bytes,
+            "nominal_bytes_per_launch_survey_8d": nominal_bytes,
+            "work_per_launch": {"stream_steps": n_stream, "full_searches": n_search,
+                                "lf_steps_executed": n_lf, "lf_steps_reference_lower_bound": lf_ref},
+            "kernel_only_kmers_per_s": n_kmers / (kernel_ms * 1e-3),
+        },
+    }
+    if t_bcast is not None:
+        result["index_broadcast_s"] = t_bcast
+    traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(traffic_file):
+        try:
+            tj = json.load(open(traffic_file))
+            result["roofline"]["traffic"] = tj.get("hbm_bytes_per_launch")
+            result["roofline"]["traffic_source"] = tj.get("source")
+        except Exception:
+            pass
+
+    # ---- CPU baseline (restated reference CPU path = the oracle), rank 0 at N=1 only ----
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from oracle import OracleIndex  # test infrastructure: used here only as baseline + checker
+        orc = OracleIndex.from_bits(bits.cols[0], bits.cols[1], bits.cols[2], bits.cols[3], bits.ssup, bits.n_nodes,
+                                    K, bits.n_kmers, PRECALC)
+        cores = os.cpu_count() or 1
+        probe = min(n_reads, 20_000)
+        h_bases = d_bases[: probe * READ_LEN].cpu().numpy()
+        roff = np.arange(probe + 1, dtype=np.int64) * READ_LEN
+        ooff = np.arange(probe + 1, dtype=np.int64) * m
+        t1 = time.perf_counter()
+        orc.batch_search(h_bases, roff, ooff, 1)
+        per_read_1t = (time.perf_counter() - t1) / probe
+        sample = int(min(n_reads, max(probe, 20.0 / per_read_1t)))      # ~20 core-seconds of CPU work
+        h_bases = d_bases[: sample * READ_LEN].cpu().numpy()
+        roff = np.arange(sample + 1, dtype=np.int64) * READ_LEN
+        ooff = np.arange(sample + 1, dtype=np.int64) * m
+        t1 = time.perf_counter()
+        cpu_out, _ = orc.batch_search(h_bases, roff, ooff, cores)
+        wall = time.perf_counter() - t1
+        gpu_out = d_out[: sample * m].cpu().numpy()
+        parity = bool(np.array_equal(cpu_out, gpu_out))
+        result["cpu_baseline"] = {
+            "value": sample * m / wall,
+            "unit": "k-mers/s",
+            "cores": cores,
+            "kind": "port",
+            "sample": "first %d of the same reads (%d k-mers), oracle streaming_search, %d threads over "
+                      "contiguous read ranges, wall clock" % (sample, sample * m, cores),
+            "value_1thread": m / per_read_1t,
+            "gpu_output_bit_identical_on_sample": parity,
+        }
+        result["gpu_vs_cpu"] = value / (sample * m / wall)
+        if not parity:
+            print(json.dumps(result))
+            raise SystemExit("PARITY FAILURE: GPU output differs from the oracle on the baseline sample")
+
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -92,6 +92,9 @@ int  sbwtgpu_index_get_precalc(const sbwtgpu_index *idx, int64_t *out_pairs);
 int  sbwtgpu_index_export_header(const sbwtgpu_index *idx, void *header_out, int64_t header_cap,
                                  int64_t *header_bytes);
 int  sbwtgpu_index_blob(const sbwtgpu_index *idx, void **dev_ptr, int64_t *bytes);
+/* Copies the device image into caller-owned device memory (`bytes` must equal blob_bytes),
+ * asynchronously on `stream` -- e.g. into the tensor a launcher hands to its broadcast. */
+int  sbwtgpu_index_copy_blob(const sbwtgpu_index *idx, void *dst_dev, int64_t bytes, void *stream);
 /* Adopts a caller-owned device blob (must stay alive and unchanged while the handle lives). */
 int  sbwtgpu_index_adopt(const void *header, int64_t header_bytes, void *dev_blob, int64_t blob_bytes,
                          int device, sbwtgpu_index **out);
@@ -139,9 +142,22 @@ int  sbwtgpu_search_dev(const sbwtgpu_index *idx, const char *d_bases, int64_t t
                         void *stream);
 int  sbwtgpu_rank_dev(const sbwtgpu_index *idx, const int64_t *d_pos, const char *d_sym, int64_t n,
                       int64_t *d_out, void *stream);
-/* After the stream has been synchronised: status word of the last search on this workspace
+/* The two halves of the calls above, for callers that re-run a search on bases that are already
+ * encoded or that want to time the kernels separately: (1) 2-bit re-encoding of the bases into
+ * the workspace, (2) the search over an encoded workspace.  streaming != 0 selects
+ * streaming_search, 0 the per-k-mer search loop. */
+int  sbwtgpu_encode_bases_dev(const sbwtgpu_index *idx, const char *d_bases, int64_t total_bases,
+                              void *d_workspace, int64_t workspace_bytes, void *stream);
+int  sbwtgpu_search_encoded_dev(const sbwtgpu_index *idx, int64_t total_bases, const int64_t *d_read_off,
+                                int64_t n_reads, int64_t *d_out, const int64_t *d_out_off,
+                                void *d_workspace, int64_t workspace_bytes, int streaming, void *stream);
+/* Synchronises `stream`, then reports the status word of the last search on this workspace
  * (0, or SBWTGPU_ERR_NOT_SINGLETON). */
 int  sbwtgpu_workspace_status(const void *d_workspace, void *stream, int *status);
+/* Synchronises `stream`, then reports the work the last search on this workspace performed:
+ * stats[0] streaming one-step extensions, [1] full searches, [2] interval updates executed past the
+ * device prefix table, [3] device prefix-table lookups that returned a non-empty interval. */
+int  sbwtgpu_workspace_stats(const void *d_workspace, void *stream, int64_t stats[4]);
 
 #ifdef __cplusplus
 }

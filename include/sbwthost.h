@@ -1,0 +1,49 @@
+/*
+ * sbwthost.h -- C ABI of the GPU-free host helpers (libsbwthost.so): in-memory construction of the
+ * plain-matrix SBWT columns and the reference's index file format.  These sit either side of the
+ * hot path; tests and bench.py use them to make and move indexes.
+ */
+#ifndef SBWTHOST_H
+#define SBWTHOST_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct sbwthost_bits sbwthost_bits;     /* A/C/G/T(+ssup) bit vectors of one index */
+typedef struct sbwthost_file sbwthost_file;     /* a parsed index file */
+
+const char *sbwthost_last_error(void);
+
+/* Sort-based in-memory builder (same columns as NodeBOSSInMemoryConstructor.hh:98-213 / the KMC
+ * constructor of the reference).  seqs[i] has seq_lens[i] bytes; k-mers containing anything but
+ * upper-case ACGT are skipped.  2 <= k <= 64. */
+int  sbwthost_build(const char *const *seqs, const int64_t *seq_lens, int64_t n_seqs, int64_t k,
+                    int add_revcomp, int build_streaming_support, int n_threads, sbwthost_bits **out);
+void sbwthost_bits_free(sbwthost_bits *b);
+int  sbwthost_bits_info(const sbwthost_bits *b, int64_t *n_nodes, int64_t *n_kmers, int64_t *k, int *has_ssup);
+/* which: 0..3 = A,C,G,T, 4 = suffix_group_starts (NULL if absent); ceil(n_nodes/64) words */
+const uint64_t *sbwthost_bits_words(const sbwthost_bits *b, int which);
+
+/* Index files in the reference format: serialize_string("plain-matrix") (sbwt_build.cpp:142)
+ * followed by SBWT::serialize (SBWT.hh:462-491). */
+int  sbwthost_file_write(const char *path, int64_t n_nodes, const uint64_t *A, const uint64_t *C,
+                         const uint64_t *G, const uint64_t *T, const uint64_t *ssup /* nullable */,
+                         const int64_t C_array[4], const int64_t *precalc_pairs, int64_t precalc_k,
+                         int64_t n_kmers, int64_t k);
+int  sbwthost_file_read(const char *path, sbwthost_file **out);
+void sbwthost_file_free(sbwthost_file *f);
+int  sbwthost_file_info(const sbwthost_file *f, int64_t *n_nodes, int64_t *n_kmers, int64_t *k,
+                        int64_t *precalc_k, int64_t C_array[4], int *has_ssup);
+const uint64_t *sbwthost_file_words(const sbwthost_file *f, int which);
+const int64_t  *sbwthost_file_precalc(const sbwthost_file *f);
+
+/* FASTA/FASTQ(.gz) reader (SeqIO stand-in): concatenates all reads of `path`.
+ * *bases / *read_off are malloc'ed; free with sbwthost_free. */
+int  sbwthost_read_sequences(const char *path, char **bases, int64_t **read_off, int64_t *n_reads);
+void sbwthost_free(void *p);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -30,11 +30,12 @@ ERR_READ_TOO_LONG = -9
 EXPORTED_SYMBOLS = [
     "sbwtgpu_version", "sbwtgpu_last_error", "sbwtgpu_device_count",
     "sbwtgpu_index_create", "sbwtgpu_index_destroy", "sbwtgpu_index_get_info", "sbwtgpu_index_get_precalc",
-    "sbwtgpu_index_export_header", "sbwtgpu_index_blob", "sbwtgpu_index_adopt", "sbwtgpu_index_bcast",
+    "sbwtgpu_index_export_header", "sbwtgpu_index_blob", "sbwtgpu_index_copy_blob", "sbwtgpu_index_adopt", "sbwtgpu_index_bcast",
     "sbwtgpu_rank_batch", "sbwtgpu_streaming_search_batch", "sbwtgpu_search_batch",
     "sbwtgpu_update_interval_batch", "sbwtgpu_forward_batch",
     "sbwtgpu_search_workspace_bytes", "sbwtgpu_streaming_search_dev", "sbwtgpu_search_dev",
-    "sbwtgpu_rank_dev", "sbwtgpu_workspace_status",
+    "sbwtgpu_rank_dev", "sbwtgpu_encode_bases_dev", "sbwtgpu_search_encoded_dev",
+    "sbwtgpu_workspace_status", "sbwtgpu_workspace_stats",
 ]
 
 
@@ -87,6 +88,7 @@ def lib() -> C.CDLL:
     L.sbwtgpu_index_get_precalc.argtypes = [vp, vp]
     L.sbwtgpu_index_export_header.argtypes = [vp, vp, i64, C.POINTER(i64)]
     L.sbwtgpu_index_blob.argtypes = [vp, C.POINTER(vp), C.POINTER(i64)]
+    L.sbwtgpu_index_copy_blob.argtypes = [vp, vp, i64, vp]
     L.sbwtgpu_index_adopt.argtypes = [vp, i64, vp, i64, ci, C.POINTER(vp)]
     L.sbwtgpu_index_bcast.argtypes = [vp, ci, C.POINTER(ci), C.POINTER(vp)]
     L.sbwtgpu_rank_batch.argtypes = [vp, vp, vp, i64, vp]
@@ -100,6 +102,9 @@ def lib() -> C.CDLL:
     L.sbwtgpu_search_dev.argtypes = [vp, vp, i64, vp, i64, vp, vp, vp, i64, vp]
     L.sbwtgpu_rank_dev.argtypes = [vp, vp, vp, i64, vp, vp]
     L.sbwtgpu_workspace_status.argtypes = [vp, vp, C.POINTER(ci)]
+    L.sbwtgpu_encode_bases_dev.argtypes = [vp, vp, i64, vp, i64, vp]
+    L.sbwtgpu_search_encoded_dev.argtypes = [vp, i64, vp, i64, vp, vp, vp, i64, ci, vp]
+    L.sbwtgpu_workspace_stats.argtypes = [vp, vp, C.POINTER(i64)]
     _lib = L
     return L
 
@@ -201,6 +206,9 @@ class Index:
         _check(lib().sbwtgpu_index_blob(self._h, C.byref(p), C.byref(n)))
         return p.value, n.value
 
+    def copy_blob(self, dst_dev_ptr: int, nbytes: int, stream: int = 0) -> None:
+        _check(lib().sbwtgpu_index_copy_blob(self._h, dst_dev_ptr, nbytes, stream))
+
     def get_precalc(self) -> np.ndarray:
         out = np.zeros((4 ** self.precalc_k if self.precalc_k else 0, 2), dtype=np.int64)
         if self.precalc_k:
@@ -263,6 +271,20 @@ class Index:
                              d_out_off: int, d_ws: int, ws_bytes: int, stream: int = 0, streaming: bool = True):
         fn = lib().sbwtgpu_streaming_search_dev if streaming else lib().sbwtgpu_search_dev
         _check(fn(self._h, d_bases, total_bases, d_read_off, n_reads, d_out, d_out_off, d_ws, ws_bytes, stream))
+
+    def encode_bases_dev(self, d_bases: int, total_bases: int, d_ws: int, ws_bytes: int, stream: int = 0):
+        _check(lib().sbwtgpu_encode_bases_dev(self._h, d_bases, total_bases, d_ws, ws_bytes, stream))
+
+    def search_encoded_dev(self, total_bases: int, d_read_off: int, n_reads: int, d_out: int, d_out_off: int,
+                           d_ws: int, ws_bytes: int, streaming: bool = True, stream: int = 0):
+        _check(lib().sbwtgpu_search_encoded_dev(self._h, total_bases, d_read_off, n_reads, d_out, d_out_off, d_ws,
+                                                ws_bytes, int(streaming), stream))
+
+    def workspace_stats(self, d_ws: int, stream: int = 0):
+        """(n_stream, n_search, n_lf, n_tab_hit) of the last search on this workspace."""
+        st = (C.c_int64 * 4)()
+        _check(lib().sbwtgpu_workspace_stats(d_ws, stream, st))
+        return tuple(int(x) for x in st)
 
     def workspace_status(self, d_ws: int, stream: int = 0) -> int:
         st = C.c_int(0)

@@ -1,0 +1,347 @@
+// SBWT.hh -- host-side C++ mirror of the reference's plain-matrix index interface
+//   sbwt::SubsetMatrixRank   (reference include/sbwt/SubsetMatrixRank.hh:13-127)
+//   sbwt::SBWT               (reference include/sbwt/SBWT.hh:31-332)
+//   sbwt::plain_matrix_sbwt_t (reference include/sbwt/variants.hh:19)
+// with the same method names, argument meaning and error behaviour, so that code written against
+// the reference's search API compiles against this header.  Every query is executed by the HIP
+// library through the C ABI of include/sbwtgpu.h -- scalar calls are batches of one; use the
+// *_batch members for throughput.  There is no CPU query path here.
+#pragma once
+#include <cstdint>
+#include <cstring>
+#include <fstream>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../../include/sbwtgpu.h"
+#include "bitvector.hh"
+#include "globals.hh"
+#include "index_builder.hh"
+#include "index_file.hh"
+#include "seqio.hh"
+
+namespace sbwt {
+
+namespace detail {
+inline int &default_device() { static int d = 0; return d; }
+inline void gpu_check(int rc) {
+    if (rc != SBWTGPU_OK) {
+        const char *m = sbwtgpu_last_error();
+        // reference messages already start with "Error:"; pass them through unchanged
+        throw std::runtime_error(m && *m ? std::string(m) : "sbwtgpu error " + std::to_string(rc));
+    }
+}
+struct DeviceIndex {
+    sbwtgpu_index *h = nullptr;
+    ~DeviceIndex() { sbwtgpu_index_destroy(h); }
+};
+}  // namespace detail
+
+// Selects the HIP device new indexes are placed on (default 0).
+inline void set_default_device(int device) { detail::default_device() = device; }
+
+class SubsetMatrixRank {
+public:
+    // public like the reference (SubsetMatrixRank.hh:19-23); the rank supports live on the GPU
+    bit_vector A_bits, C_bits, G_bits, T_bits;
+
+    SubsetMatrixRank() {}
+    SubsetMatrixRank(const bit_vector &A, const bit_vector &C, const bit_vector &G, const bit_vector &T)
+        : A_bits(A), C_bits(C), G_bits(G), T_bits(T) {}
+
+    // Count of character c in subsets up to pos, not including pos (SubsetMatrixRank.hh:31-37)
+    int64_t rank(int64_t pos, char c) const {
+        int64_t out = 0;
+        detail::gpu_check(sbwtgpu_rank_batch(device().h, &pos, &c, 1, &out));
+        return out;
+    }
+    void rank_batch(const int64_t *pos, const char *sym, int64_t n, int64_t *out) const {
+        detail::gpu_check(sbwtgpu_rank_batch(device().h, pos, sym, n, out));
+    }
+    bool contains(int64_t pos, char c) const {   // SubsetMatrixRank.hh:39-48 (plain bit access)
+        switch (c) {
+            case 'A': return A_bits[pos];
+            case 'C': return C_bits[pos];
+            case 'G': return G_bits[pos];
+            case 'T': return T_bits[pos];
+            default: return false;
+        }
+    }
+    int64_t serialize(std::ostream &os) const {   // SubsetMatrixRank.hh:86-100
+        int64_t written = 0;
+        written += A_bits.serialize(os);
+        written += C_bits.serialize(os);
+        written += G_bits.serialize(os);
+        written += T_bits.serialize(os);
+        for (const bit_vector *v : {&A_bits, &C_bits, &G_bits, &T_bits}) {
+            rank_support_v5_blob rs;
+            rs.build(*v);
+            written += rs.serialize(os);
+        }
+        write_log("MatrixRank bit vectors total " + std::to_string((double)written / (double)A_bits.size() * 8) +
+                      " bits total per node",
+                  LogLevel::MINOR);
+        return written;
+    }
+    void load(std::istream &is) {                  // SubsetMatrixRank.hh:102-125
+        A_bits.load(is);
+        C_bits.load(is);
+        G_bits.load(is);
+        T_bits.load(is);
+        for (int i = 0; i < 4; i++) rank_support_v5_blob::skip(is);
+        dev_.reset();
+    }
+    // used by SBWT to share its (full) device image instead of building a second one
+    void attach(const std::shared_ptr<detail::DeviceIndex> &d) const { dev_ = d; }
+
+private:
+    const detail::DeviceIndex &device() const {
+        if (!dev_) {
+            sbwtgpu_index_desc d;
+            memset(&d, 0, sizeof(d));
+            d.n_nodes = A_bits.size();
+            d.A_bits = A_bits.data(); d.C_bits = C_bits.data(); d.G_bits = G_bits.data(); d.T_bits = T_bits.data();
+            d.k = 1;
+            auto p = std::make_shared<detail::DeviceIndex>();
+            detail::gpu_check(sbwtgpu_index_create(&d, detail::default_device(), &p->h));
+            dev_ = p;
+        }
+        return *dev_;
+    }
+    mutable std::shared_ptr<detail::DeviceIndex> dev_;
+};
+
+class SBWT {
+public:
+    struct BuildConfig {                           // SBWT.hh:61-71
+        std::vector<std::string> input_files;
+        int k = 30;
+        bool build_streaming_support = true;
+        int n_threads = 1;
+        int min_abundance = 1;                     // only 1 is supported by the in-memory builder
+        int max_abundance = 1000000000;
+        int ram_gigas = 2;
+        int precalc_k = 0;
+        std::string temp_dir = ".";
+    };
+
+    SBWT() : n_nodes(0), n_kmers(0), k(0) {}
+
+    // SBWT.hh:335-353
+    SBWT(const bit_vector &A_bits, const bit_vector &C_bits, const bit_vector &G_bits, const bit_vector &T_bits,
+         const bit_vector &streaming_support, int64_t k, int64_t number_of_kmers, int64_t precalc_k)
+        : subset_rank(A_bits, C_bits, G_bits, T_bits), suffix_group_starts(streaming_support),
+          n_nodes(A_bits.size()), n_kmers(number_of_kmers), k(k) {
+        check_precalc(precalc_k);
+        this->precalc_k = precalc_k;
+        make_device(nullptr);
+    }
+
+    // SBWT.hh:355-366 -- construction from sequence files.  The reference runs KMC + external sorting
+    // (out of scope); this uses the in-memory sort-based builder of index_builder.hh.
+    explicit SBWT(const BuildConfig &config) : n_nodes(0), n_kmers(0), k(0) {
+        if (config.min_abundance != 1 || config.max_abundance < 1000000000)
+            throw std::runtime_error("Error: abundance filtering is not supported by the in-memory builder");
+        std::vector<std::string> seqs;
+        for (const std::string &f : config.input_files) {
+            seq_io::Reader reader(f);
+            for (;;) {
+                int64_t len = reader.get_next_read_to_buffer();
+                if (len == 0) break;
+                seqs.emplace_back(reader.read_buf, (size_t)len);
+            }
+        }
+        PlainMatrixBits b = build_plain_matrix_bits(seqs, config.k, false, config.build_streaming_support, config.n_threads);
+        adopt_bits(b, config.precalc_k);
+    }
+
+    // from the builder's output
+    SBWT(const PlainMatrixBits &b, int64_t precalc_k) : n_nodes(0), n_kmers(0), k(0) { adopt_bits(b, precalc_k); }
+
+    // ---- accessors (SBWT.hh:111-157,253) ----
+    const SubsetMatrixRank &get_subset_rank_structure() const { return subset_rank; }
+    const bit_vector &get_streaming_support() const { return suffix_group_starts; }
+    const std::vector<int64_t> &get_C_array() const { return C; }
+    const std::vector<std::pair<int64_t, int64_t>> &get_precalc() const { return kmer_prefix_precalc; }
+    int64_t get_precalc_k() const { return precalc_k; }
+    int64_t number_of_subsets() const { return n_nodes; }
+    int64_t number_of_kmers() const { return n_kmers; }
+    int64_t get_k() const { return k; }
+    bool has_streaming_query_support() const { return suffix_group_starts.size() > 0; }
+    const sbwtgpu_index *device_handle() const { return dev_ ? dev_->h : nullptr; }
+
+    // ---- queries ----
+    int64_t search(const std::string &kmer) const { return search(kmer.c_str()); }   // SBWT.hh:383-387
+    int64_t search(const char *kmer) const {                                         // SBWT.hh:389-415
+        int64_t off[2] = {0, k}, ooff[2] = {0, 1}, out = -1;
+        int rc = sbwtgpu_search_batch(need_device(), kmer, off, 1, &out, ooff);
+        bug_exit(rc);
+        detail::gpu_check(rc);
+        return out;
+    }
+    std::vector<int64_t> streaming_search(const std::string &input) const {          // SBWT.hh:583-586
+        return streaming_search(input.c_str(), (int64_t)input.size());
+    }
+    std::vector<int64_t> streaming_search(const char *input, int64_t len) const {    // SBWT.hh:544-581
+        if (suffix_group_starts.size() == 0) throw std::runtime_error("Error: streaming search support not built");
+        std::vector<int64_t> ans;
+        if (len < k) return ans;
+        ans.resize((size_t)(len - k + 1));
+        int64_t off[2] = {0, len}, ooff[2] = {0, len - k + 1};
+        int rc = sbwtgpu_streaming_search_batch(need_device(), input, off, 1, ans.data(), ooff);
+        bug_exit(rc);
+        detail::gpu_check(rc);
+        return ans;
+    }
+    // Batched forms (new): read r = bases[read_off[r]..read_off[r+1]), results at out[out_off[r]..].
+    void streaming_search_batch(const char *bases, const int64_t *read_off, int64_t n_reads, int64_t *out,
+                                const int64_t *out_off) const {
+        if (suffix_group_starts.size() == 0) throw std::runtime_error("Error: streaming search support not built");
+        int rc = sbwtgpu_streaming_search_batch(need_device(), bases, read_off, n_reads, out, out_off);
+        bug_exit(rc);
+        detail::gpu_check(rc);
+    }
+    void search_batch(const char *bases, const int64_t *read_off, int64_t n_reads, int64_t *out,
+                      const int64_t *out_off) const {
+        int rc = sbwtgpu_search_batch(need_device(), bases, read_off, n_reads, out, out_off);
+        bug_exit(rc);
+        detail::gpu_check(rc);
+    }
+    std::pair<int64_t, int64_t> update_sbwt_interval(const std::string &S, std::pair<int64_t, int64_t> I) const {
+        return update_sbwt_interval(S.c_str(), (int64_t)S.size(), I);
+    }
+    std::pair<int64_t, int64_t> update_sbwt_interval(const char *S, int64_t S_length,
+                                                     std::pair<int64_t, int64_t> I) const {   // SBWT.hh:422-437
+        int64_t off[2] = {0, S_length};
+        detail::gpu_check(sbwtgpu_update_interval_batch(need_device(), S, off, 1, &I.first, &I.second));
+        return I;
+    }
+    // SBWT.hh:525-542
+    std::pair<std::pair<int64_t, int64_t>, int64_t> partial_search(const char *input, int64_t len) const {
+        int64_t l = 0, r = n_nodes - 1;
+        for (int64_t i = 0; i < len; i++) {
+            char c = (char)toupper((unsigned char)input[i]);
+            std::pair<int64_t, int64_t> nw = update_sbwt_interval(&c, 1, {l, r});
+            if (nw.first == -1) return {{l, r}, i};
+            l = nw.first;
+            r = nw.second;
+        }
+        return {{l, r}, len};
+    }
+    std::pair<std::pair<int64_t, int64_t>, int64_t> partial_search(const std::string &input) const {
+        return partial_search(input.c_str(), (int64_t)input.size());
+    }
+    int64_t forward(int64_t node, char c) const {                                    // SBWT.hh:368-381
+        if (!has_streaming_query_support()) throw std::runtime_error("Error: Streaming support required for SBWT::forward");
+        int64_t out = -1;
+        detail::gpu_check(sbwtgpu_forward_batch(need_device(), &node, &c, 1, &out));
+        return out;
+    }
+
+    // SBWT.hh:616-645: (re)computes the prefix table on the device and mirrors it on the host
+    void do_kmer_prefix_precalc(int64_t prefix_length) {
+        if (prefix_length == 0) return;
+        check_precalc(prefix_length);
+        precalc_k = prefix_length;
+        make_device(nullptr);
+    }
+
+    // ---- (de)serialisation, reference file format (SBWT.hh:462-522) ----
+    int64_t serialize(std::ostream &os) const {
+        IndexFileData f;
+        f.A_bits = subset_rank.A_bits; f.C_bits = subset_rank.C_bits;
+        f.G_bits = subset_rank.G_bits; f.T_bits = subset_rank.T_bits;
+        f.suffix_group_starts = suffix_group_starts;
+        f.C = C;
+        f.kmer_prefix_precalc = kmer_prefix_precalc;
+        f.precalc_k = precalc_k; f.n_nodes = n_nodes; f.n_kmers = n_kmers; f.k = k;
+        return f.serialize(os);
+    }
+    int64_t serialize(const std::string &filename) const {
+        std::ofstream out(filename, std::ios::binary);
+        if (!out.good()) throw std::runtime_error("Error opening file: " + filename);
+        return serialize(out);
+    }
+    void load(std::istream &is) {
+        IndexFileData f;
+        f.load(is);
+        subset_rank = SubsetMatrixRank(f.A_bits, f.C_bits, f.G_bits, f.T_bits);
+        suffix_group_starts = f.suffix_group_starts;
+        precalc_k = f.precalc_k; n_nodes = f.n_nodes; n_kmers = f.n_kmers; k = f.k;
+        // the file's prefix table is uploaded as is; C comes back from the device image
+        make_device(precalc_k ? (const int64_t *)f.kmer_prefix_precalc.data() : nullptr);
+    }
+    void load(const std::string &filename) {
+        std::ifstream in(filename, std::ios::binary);
+        if (!in.good()) throw std::runtime_error("Error opening file: " + filename);
+        load(in);
+    }
+
+private:
+    SubsetMatrixRank subset_rank;
+    bit_vector suffix_group_starts;
+    std::vector<int64_t> C;
+    std::vector<std::pair<int64_t, int64_t>> kmer_prefix_precalc;
+    int64_t precalc_k = 0;
+    int64_t n_nodes, n_kmers, k;
+    std::shared_ptr<detail::DeviceIndex> dev_;
+
+    void check_precalc(int64_t p) const {                 // SBWT.hh:619-624
+        if (p > 20)
+            throw std::runtime_error("Error: Can't precalc longer than 20-mers (would take over 4^20 = 2^40 bytes");
+        if (p > k)
+            throw std::runtime_error("Error: Precalc length is longer than k (" + std::to_string(p) + " > " +
+                                     std::to_string(k) + ")");
+    }
+    void adopt_bits(const PlainMatrixBits &b, int64_t precalc) {
+        subset_rank = SubsetMatrixRank(bit_vector(b.A.data(), b.n_nodes), bit_vector(b.C.data(), b.n_nodes),
+                                       bit_vector(b.G.data(), b.n_nodes), bit_vector(b.T.data(), b.n_nodes));
+        suffix_group_starts = b.ssup.empty() ? bit_vector() : bit_vector(b.ssup.data(), b.n_nodes);
+        n_nodes = b.n_nodes;
+        n_kmers = b.n_kmers;
+        k = b.k;
+        check_precalc(precalc);
+        precalc_k = precalc;
+        make_device(nullptr);
+    }
+    // Builds the device image; C array and prefix table come back from the device.
+    void make_device(const int64_t *file_precalc) {
+        sbwtgpu_index_desc d;
+        memset(&d, 0, sizeof(d));
+        d.n_nodes = n_nodes;
+        d.A_bits = subset_rank.A_bits.data(); d.C_bits = subset_rank.C_bits.data();
+        d.G_bits = subset_rank.G_bits.data(); d.T_bits = subset_rank.T_bits.data();
+        d.suffix_group_starts = suffix_group_starts.size() ? suffix_group_starts.data() : nullptr;
+        d.k = k;
+        d.n_kmers = n_kmers;
+        d.precalc_k = precalc_k;
+        d.precalc = file_precalc;
+        auto p = std::make_shared<detail::DeviceIndex>();
+        detail::gpu_check(sbwtgpu_index_create(&d, detail::default_device(), &p->h));
+        sbwtgpu_index_info info;
+        detail::gpu_check(sbwtgpu_index_get_info(p->h, &info));
+        C.assign(info.C, info.C + 4);
+        kmer_prefix_precalc.assign(precalc_k ? ((size_t)1 << (2 * precalc_k)) : 0, {0, 0});
+        static_assert(sizeof(std::pair<int64_t, int64_t>) == 16, "pair<int64,int64> must be 16 bytes");
+        if (precalc_k) detail::gpu_check(sbwtgpu_index_get_precalc(p->h, (int64_t *)kmer_prefix_precalc.data()));
+        dev_ = p;
+        subset_rank.attach(dev_);
+    }
+    const sbwtgpu_index *need_device() const {
+        if (!dev_) throw std::runtime_error("Error: the index is empty");
+        return dev_->h;
+    }
+    static void bug_exit(int rc) {                        // SBWT.hh:410-413
+        if (rc == SBWTGPU_ERR_NOT_SINGLETON) {
+            std::cerr << "Bug: k-mer search did not give a singleton interval" << std::endl;
+            exit(1);
+        }
+    }
+};
+
+typedef SBWT plain_matrix_sbwt_t;                         // variants.hh:19
+
+}  // namespace sbwt

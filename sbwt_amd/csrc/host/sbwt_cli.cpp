@@ -1,0 +1,326 @@
+// sbwt_cli.cpp -- the `sbwt` command: `search` with the reference's flags, output format and log
+// lines (reference src/CLI/sbwt_search.cpp, src/CLI/sbwt.cpp), running the queries on the GPU in
+// batches; plus a minimal in-memory `build` so that indexes can be produced without KMC.
+//
+//   sbwt search -o <out> -i <index> -q <query> [-z]        (sbwt_search.cpp:151-157)
+//   sbwt build  -i <in> -o <index> -k <k> [-p <precalc>] [--add-reverse-complements]
+//               [--no-streaming-support] [-t <threads>]      (subset of sbwt_build.cpp:40-55)
+// Extra, GPU-only flags of `search` (defaults keep the reference behaviour and output):
+//   --gpu <id>            HIP device to use (default 0)
+//   --batch-bases <n>     bases sent to the GPU per batch (default 256 Mi)
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <exception>
+#include <iostream>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "SBWT.hh"
+
+using namespace sbwt;
+using std::string;
+using std::vector;
+
+namespace {
+
+// what cxxopts throws for bad command lines is a std::exception that is not a runtime_error, so
+// main() prints it with the "Error: " prefix (sbwt.cpp:53-56)
+struct option_error : public std::exception {
+    string msg;
+    explicit option_error(string m) : msg(std::move(m)) {}
+    const char *what() const noexcept override { return msg.c_str(); }
+};
+
+struct OptSpec { string longname; char shortname; bool takes_value; string help; string def; };
+
+class Options {
+public:
+    explicit Options(vector<OptSpec> specs) : specs_(std::move(specs)) {}
+    void parse(int argc, char **argv) {
+        for (int i = 1; i < argc; i++) {
+            string a = argv[i];
+            const OptSpec *s = nullptr;
+            string val;
+            bool has_val = false;
+            if (a.rfind("--", 0) == 0) {
+                string name = a.substr(2);
+                size_t eq = name.find('=');
+                if (eq != string::npos) { val = name.substr(eq + 1); name = name.substr(0, eq); has_val = true; }
+                for (auto &x : specs_) if (x.longname == name) s = &x;
+                if (!s) throw option_error("Option ‘" + name + "’ does not exist");
+            } else if (a.size() == 2 && a[0] == '-') {
+                for (auto &x : specs_) if (x.shortname == a[1]) s = &x;
+                if (!s) throw option_error(string("Option ‘") + a[1] + "’ does not exist");
+            } else {
+                continue;   // positional arguments are ignored like in the reference
+            }
+            if (s->takes_value) {
+                if (!has_val) {
+                    if (i + 1 >= argc) throw option_error("Option ‘" + s->longname + "’ is missing an argument");
+                    val = argv[++i];
+                }
+                values_[s->longname] = val;
+            } else {
+                values_[s->longname] = "true";
+            }
+        }
+    }
+    bool count(const string &name) const { return values_.count(name) > 0; }
+    string get(const string &name) const {
+        auto it = values_.find(name);
+        if (it != values_.end()) return it->second;
+        for (auto &x : specs_)
+            if (x.longname == name && !x.def.empty()) return x.def;
+        throw option_error("Option ‘" + name + "’ has no value");
+    }
+    string help(const string &prog, const string &desc) const {
+        string h = desc + "\nUsage:\n  " + prog + " [OPTION...]\n\n";
+        for (auto &x : specs_) {
+            string l = "  ";
+            if (x.shortname) { l += "-"; l += x.shortname; l += ", "; } else l += "    ";
+            l += "--" + x.longname + (x.takes_value ? " arg" : "");
+            while (l.size() < 28) l += " ";
+            h += l + " " + x.help + (x.def.empty() ? "" : " (default: " + x.def + ")") + "\n";
+        }
+        return h;
+    }
+
+private:
+    vector<OptSpec> specs_;
+    std::map<string, string> values_;
+};
+
+// print_vector, sbwt_search.cpp:21-43: each value followed by one space, '\n' per read; -1 special
+// cased; 0 prints as an empty token (kept: that is what the reference emits)
+inline void print_vector(const int64_t *v, int64_t n, string &out) {
+    char buffer[32];
+    for (int64_t t = 0; t < n; t++) {
+        int64_t x = v[t];
+        int i = 0;
+        if (x == -1) { buffer[0] = '1'; buffer[1] = '-'; i = 2; }
+        else while (x > 0) { buffer[i++] = (char)('0' + (x % 10)); x /= 10; }
+        while (i > 0) out.push_back(buffer[--i]);
+        out.push_back(' ');
+    }
+    out.push_back('\n');
+}
+
+struct QueryStats { int64_t queries = 0; int64_t micros = 0; };
+
+// run_file + run_queries_streaming / run_queries_not_streaming (sbwt_search.cpp:46-105), batched
+QueryStats run_file(const string &infile, const string &outfile, const plain_matrix_sbwt_t &index, bool gzip_output,
+                    int64_t batch_bases) {
+    seq_io::Reader reader(infile);
+    seq_io::Buffered_ofstream writer(outfile, gzip_output);
+    const bool streaming = index.has_streaming_query_support();
+    write_log(string("Running ") + (streaming ? "streaming" : "non-streaming") + " queries from input file " + infile +
+                  " to output file " + outfile,
+              LogLevel::MAJOR);
+    const int64_t k = index.get_k();
+    QueryStats st;
+    vector<char> bases;
+    vector<int64_t> read_off{0}, out_off{0}, out;
+    string text;
+    bool eof = false;
+    while (!eof) {
+        bases.clear();
+        read_off.assign(1, 0);
+        out_off.assign(1, 0);
+        while ((int64_t)bases.size() < batch_bases) {
+            int64_t len = reader.get_next_read_to_buffer();
+            if (len == 0) { eof = true; break; }
+            bases.insert(bases.end(), reader.read_buf, reader.read_buf + len);
+            read_off.push_back((int64_t)bases.size());
+            out_off.push_back(out_off.back() + std::max<int64_t>(0, len - k + 1));
+        }
+        const int64_t n_reads = (int64_t)read_off.size() - 1;
+        if (n_reads == 0) break;
+        out.resize((size_t)out_off.back());
+        int64_t t0 = cur_time_micros();
+        if (streaming) index.streaming_search_batch(bases.data(), read_off.data(), n_reads, out.data(), out_off.data());
+        else index.search_batch(bases.data(), read_off.data(), n_reads, out.data(), out_off.data());
+        st.micros += cur_time_micros() - t0;
+        st.queries += out_off.back();
+        for (int64_t r = 0; r < n_reads; r++) {
+            print_vector(out.data() + out_off[(size_t)r], out_off[(size_t)r + 1] - out_off[(size_t)r], text);
+            if (text.size() > (1u << 22)) { writer.write(text.data(), (int64_t)text.size()); text.clear(); }
+        }
+        writer.write(text.data(), (int64_t)text.size());
+        text.clear();
+    }
+    write_log("us/query: " + std::to_string((double)st.micros / (double)st.queries) + " (excluding I/O etc)",
+              LogLevel::MAJOR);
+    return st;
+}
+
+int search_main(int argc, char **argv) {
+    int64_t micros_start = cur_time_micros();
+    set_log_level(LogLevel::MINOR);
+    Options opts({
+        {"out-file", 'o', true, "Output filename.", ""},
+        {"index-file", 'i', true, "Index input file.", ""},
+        {"query-file", 'q', true,
+         "The query in FASTA or FASTQ format, possibly gzipped. Multi-line FASTQ is not supported. If the file "
+         "extension is .txt, this is interpreted as a list of query files, one per line. In this case, --out-file is "
+         "also interpreted as a list of output files in the same manner, one line for each input file.", ""},
+        {"gzip-output", 'z', false,
+         "Writes output in gzipped form. This can shrink the output files by an order of magnitude.", ""},
+        {"gpu", 0, true, "HIP device to run on.", "0"},
+        {"batch-bases", 0, true, "Bases sent to the GPU per batch.", "268435456"},
+        {"help", 'h', false, "Print usage", ""},
+    });
+    opts.parse(argc, argv);
+    if (argc == 1 || opts.count("help")) {
+        std::cerr << opts.help(argv[0], "Query all k-mers of all input reads.") << std::endl;
+        exit(1);
+    }
+    string indexfile = opts.get("index-file");
+    check_readable(indexfile);
+
+    string queryfile = opts.get("query-file");
+    vector<string> input_files;
+    bool multi_file = queryfile.size() >= 4 && queryfile.substr(queryfile.size() - 4) == ".txt";
+    if (multi_file) input_files = readlines(queryfile);
+    else input_files = {queryfile};
+    for (const string &file : input_files) check_readable(file);
+
+    string outfile = opts.get("out-file");
+    bool gzip_output = opts.count("gzip-output");
+    vector<string> output_files;
+    if (multi_file) output_files = readlines(outfile);
+    else output_files = {outfile};
+    for (const string &file : output_files) check_writable(file);
+
+    set_default_device(atoi(opts.get("gpu").c_str()));
+    int64_t batch_bases = atoll(opts.get("batch-bases").c_str());
+    if (batch_bases < 1) batch_bases = 1;
+
+    std::ifstream in(indexfile, std::ios::binary);
+    if (!in.good()) throw std::runtime_error("Error opening file: " + indexfile);
+    string variant = load_string(in);
+    static const char *variants[] = {"plain-matrix", "rrr-matrix", "mef-matrix", "plain-split", "rrr-split",
+                                     "mef-split", "plain-concat", "mef-concat", "plain-subsetwt", "rrr-subsetwt"};
+    if (std::find(std::begin(variants), std::end(variants), variant) == std::end(variants)) {
+        std::cerr << "Error loading index from file: unrecognized variant specified in the file" << std::endl;
+        return 1;
+    }
+    write_log("Loading the index variant " + variant, LogLevel::MAJOR);
+    if (variant != "plain-matrix")
+        throw std::runtime_error("Error: only the plain-matrix variant is supported by the GPU search path (got " +
+                                 variant + ")");
+    plain_matrix_sbwt_t index;
+    index.load(in);
+
+    if (input_files.size() != output_files.size())   // run_queries, sbwt_search.cpp:111-115
+        throw std::runtime_error("Number of input and output files does not match (" +
+                                 std::to_string(input_files.size()) + " vs " + std::to_string(output_files.size()) + ")");
+    int64_t number_of_queries = 0;
+    for (size_t i = 0; i < input_files.size(); i++)
+        number_of_queries += run_file(input_files[i], output_files[i], index, gzip_output, batch_bases).queries;
+
+    int64_t total_micros = cur_time_micros() - micros_start;
+    write_log("us/query end-to-end: " + std::to_string((double)total_micros / (double)number_of_queries), LogLevel::MAJOR);
+    return 0;
+}
+
+int build_main(int argc, char **argv) {
+    set_log_level(LogLevel::MAJOR);
+    Options opts({
+        {"in-file", 'i', true,
+         "The input sequences as a FASTA or FASTQ file, possibly gzipped. If the file extension is .txt, the file is "
+         "interpreted as a list of input files, one file on each line.", ""},
+        {"out-file", 'o', true, "Output file for the constructed index.", ""},
+        {"kmer-length", 'k', true, "The k-mer length.", ""},
+        {"precalc-length", 'p', true, "Precalculate SBWT intervals of strings of this length.", "8"},
+        {"variant", 0, true, "The SBWT variant to build (only plain-matrix here).", "plain-matrix"},
+        {"add-reverse-complements", 0, false, "Also add the reverse complement of every k-mer to the index.", ""},
+        {"no-streaming-support", 0, false, "Do not build the streaming query support bit vector.", ""},
+        {"n-threads", 't', true, "Number of parallel threads.", "1"},
+        {"temp-dir", 'd', true, "Ignored (construction is in memory).", "."},
+        {"gpu", 0, true, "HIP device used for the prefix table.", "0"},
+        {"help", 'h', false, "Print usage", ""},
+    });
+    opts.parse(argc, argv);
+    if (argc == 1 || opts.count("help")) {
+        std::cerr << opts.help(argv[0], "Construct a plain-matrix SBWT (in memory).") << std::endl;
+        exit(1);
+    }
+    string variant = opts.get("variant");
+    if (variant != "plain-matrix") {
+        std::cerr << "Error: unknown variant: " << variant << std::endl;
+        return 1;
+    }
+    string out_file = opts.get("out-file");
+    check_writable(out_file);
+    string in_file = opts.get("in-file");
+    vector<string> input_files;
+    if (in_file.size() >= 4 && in_file.substr(in_file.size() - 4) == ".txt") input_files = readlines(in_file);
+    else input_files = {in_file};
+    for (const string &f : input_files) check_readable(f);
+    int64_t k = atoll(opts.get("kmer-length").c_str());
+    int64_t precalc = atoll(opts.get("precalc-length").c_str());
+    if (precalc > k) {   // sbwt_build.cpp:101-105
+        write_log("Warning: precalc length " + std::to_string(precalc) + " is longer than k = " + std::to_string(k), LogLevel::MAJOR);
+        write_log("Setting precalc length to " + std::to_string(k), LogLevel::MAJOR);
+        precalc = k;
+    }
+    set_default_device(atoi(opts.get("gpu").c_str()));
+    vector<string> seqs;
+    for (const string &f : input_files) {
+        seq_io::Reader reader(f);
+        for (;;) {
+            int64_t len = reader.get_next_read_to_buffer();
+            if (len == 0) break;
+            seqs.emplace_back(reader.read_buf, (size_t)len);
+        }
+    }
+    write_log("Building SBWT subset sequence in memory", LogLevel::MAJOR);
+    PlainMatrixBits bits = build_plain_matrix_bits(seqs, (int)k, opts.count("add-reverse-complements"),
+                                                   !opts.count("no-streaming-support"), atoi(opts.get("n-threads").c_str()));
+    plain_matrix_sbwt_t index(bits, 0);
+    write_log("Build SBWT for " + std::to_string(index.number_of_kmers()) + " distinct k-mers", LogLevel::MAJOR);
+    write_log("SBWT has " + std::to_string(index.number_of_subsets()) + " subsets", LogLevel::MAJOR);
+    std::ofstream out(out_file, std::ios::binary);
+    if (!out.good()) throw std::runtime_error("Error opening file: " + out_file);
+    serialize_string(variant, out);                       // sbwt_build.cpp:142
+    index.do_kmer_prefix_precalc(precalc);                // sbwt_build.cpp:157
+    int64_t bytes_written = index.serialize(out);
+    write_log("Built variant " + variant + " to file " + out_file, LogLevel::MAJOR);
+    write_log("Space on disk: " + std::to_string(bytes_written * 8.0 / (double)index.number_of_subsets()) +
+                  " bits per column, " + std::to_string(bytes_written * 8.0 / (double)index.number_of_kmers()) +
+                  " bits per k-mer",
+              LogLevel::MAJOR);
+    return 0;
+}
+
+const vector<string> commands = {"build", "search"};
+
+void print_help(char **argv) {
+    std::cerr << "Available commands: " << std::endl;
+    for (const string &S : commands) std::cerr << "   " << argv[0] << " " << S << std::endl;
+    std::cerr << "Running a command without arguments prints the usage instructions for the command." << std::endl;
+}
+
+}  // namespace
+
+int main(int argc, char **argv) {   // sbwt.cpp:19-57
+    if (argc == 1) { print_help(argv); return 0; }
+    string command = argv[1];
+    if (command == "--help" || command == "-h") { print_help(argv); return 0; }
+    for (int i = 1; i < argc; i++) argv[i - 1] = argv[i];
+    argc--;
+    try {
+        if (command == "build") return build_main(argc, argv);
+        else if (command == "search") return search_main(argc, argv);
+        else throw std::runtime_error("Invalid command: " + command);
+    } catch (const std::runtime_error &e) {
+        std::cerr << "Runtime error: " << e.what() << '\n';
+        return 1;
+    } catch (const std::exception &e) {
+        std::cerr << "Error: " << e.what() << '\n';
+        return 1;
+    }
+}

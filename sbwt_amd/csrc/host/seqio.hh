@@ -1,0 +1,197 @@
+// seqio.hh -- FASTA/FASTQ(.gz) reader and buffered (gz) writer with the observable behaviour the
+// reference gets from its SeqIO submodule (absent from the checkout): file format by
+// extension, optional .gz, multi-line FASTA, 4-line FASTQ, sequences upper-cased on read
+// [UPSTREAM-KNOWLEDGE], get_next_read_to_buffer() returning 0 at end of file.  I/O plumbing around
+// the GPU path, not part of it.
+#pragma once
+#include <zlib.h>
+
+#include <cctype>
+#include <cstdint>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace sbwt {
+namespace seq_io {
+
+enum Format { FASTA, FASTQ };
+struct FileFormat {
+    Format format;
+    bool gzipped;
+    std::string extension;   // with the leading dot, e.g. ".fna.gz"
+};
+
+inline FileFormat figure_out_file_format(std::string filename) {
+    bool gz = false;
+    std::string ext_gz;
+    if (filename.size() >= 3 && filename.substr(filename.size() - 3) == ".gz") {
+        filename = filename.substr(0, filename.size() - 3);
+        gz = true;
+        ext_gz = ".gz";
+    }
+    static const char *fasta[] = {".fasta", ".fna", ".ffn", ".faa", ".frn", ".fa"};
+    static const char *fastq[] = {".fastq", ".fq"};
+    for (int i = (int)filename.size() - 1; i >= 0; i--) {
+        if (filename[(size_t)i] == '.') {
+            std::string end = filename.substr((size_t)i);
+            for (const char *e : fasta)
+                if (end == e) return FileFormat{FASTA, gz, end + ext_gz};
+            for (const char *e : fastq)
+                if (end == e) return FileFormat{FASTQ, gz, end + ext_gz};
+            throw std::runtime_error("Unknown file format: " + filename);
+        }
+    }
+    throw std::runtime_error("Unknown file format: " + filename);
+}
+
+// gzread() passes plain files through unchanged, so one reader serves both.
+class Reader {
+public:
+    char *read_buf = nullptr;       // the current read, NUL-terminated (like SeqIO's read_buf)
+
+    explicit Reader(const std::string &filename) : filename_(filename) {
+        fmt_ = figure_out_file_format(filename).format;
+        f_ = gzopen(filename.c_str(), "rb");
+        if (!f_) throw std::runtime_error("Error opening file: " + filename);
+        gzbuffer(f_, 1 << 20);
+        buf_.resize(1 << 20);
+        seq_.reserve(1 << 10);
+    }
+    ~Reader() {
+        if (f_) gzclose(f_);
+    }
+    Reader(const Reader &) = delete;
+    Reader &operator=(const Reader &) = delete;
+
+    // Length of the next read (0 = end of file); the read is left in read_buf.
+    int64_t get_next_read_to_buffer() {
+        seq_.clear();
+        if (fmt_ == FASTA) {
+            int c = getc_();
+            if (c == -1) return finish(0);
+            if (c != '>') throw std::runtime_error("Error: FASTA header does not start with '>' in " + filename_);
+            skip_line();
+            for (;;) {
+                c = peekc_();
+                if (c == -1 || c == '>') break;
+                read_line_append();
+            }
+        } else {
+            int c = getc_();
+            if (c == -1) return finish(0);
+            if (c != '@') throw std::runtime_error("Error: FASTQ header does not start with '@' in " + filename_);
+            skip_line();
+            read_line_append();
+            c = getc_();
+            if (c != '+') throw std::runtime_error("Error: FASTQ separator line missing in " + filename_);
+            skip_line();
+            skip_line();            // quality line
+        }
+        for (char &ch : seq_) ch = (char)std::toupper((unsigned char)ch);
+        return finish((int64_t)seq_.size());
+    }
+
+    std::string get_next_read() {   // "" at end of file (tests/test_large.hh:39-45 usage)
+        int64_t len = get_next_read_to_buffer();
+        return std::string(read_buf, (size_t)len);
+    }
+
+private:
+    int64_t finish(int64_t len) {
+        seq_.push_back('\0');
+        read_buf = seq_.data();
+        seq_.pop_back();
+        return len;
+    }
+    bool fill() {
+        int n = gzread(f_, buf_.data(), (unsigned)buf_.size());
+        if (n < 0) throw std::runtime_error("Error reading file: " + filename_);
+        pos_ = 0;
+        end_ = (size_t)n;
+        return n > 0;
+    }
+    int getc_() {
+        if (pos_ == end_ && !fill()) return -1;
+        return (unsigned char)buf_[pos_++];
+    }
+    int peekc_() {
+        if (pos_ == end_ && !fill()) return -1;
+        return (unsigned char)buf_[pos_];
+    }
+    void skip_line() {
+        for (;;) {
+            if (pos_ == end_ && !fill()) return;
+            char *nl = (char *)memchr(buf_.data() + pos_, '\n', end_ - pos_);
+            if (nl) { pos_ = (size_t)(nl - buf_.data()) + 1; return; }
+            pos_ = end_;
+        }
+    }
+    void read_line_append() {
+        for (;;) {
+            if (pos_ == end_ && !fill()) return;
+            char *start = buf_.data() + pos_;
+            char *nl = (char *)memchr(start, '\n', end_ - pos_);
+            size_t n = nl ? (size_t)(nl - start) : end_ - pos_;
+            size_t keep = n;
+            if (keep && start[keep - 1] == '\r') keep--;
+            seq_.insert(seq_.end(), start, start + keep);
+            pos_ += n + (nl ? 1 : 0);
+            if (nl) return;
+        }
+    }
+    std::string filename_;
+    Format fmt_;
+    gzFile f_ = nullptr;
+    std::vector<char> buf_;
+    size_t pos_ = 0, end_ = 0;
+    std::vector<char> seq_;
+};
+
+// Buffered output, optionally gzip-compressed (-z of `sbwt search`, sbwt_search.cpp:120,126-137).
+class Buffered_ofstream {
+public:
+    Buffered_ofstream(const std::string &filename, bool gzip) : filename_(filename), gzip_(gzip) {
+        if (gzip_) {
+            gz_ = gzopen(filename.c_str(), "wb");
+            if (!gz_) throw std::runtime_error("Error opening file: " + filename);
+            gzbuffer(gz_, 1 << 20);
+        } else {
+            fp_ = fopen(filename.c_str(), "wb");
+            if (!fp_) throw std::runtime_error("Error opening file: " + filename);
+            setvbuf(fp_, nullptr, _IOFBF, 1 << 20);
+        }
+    }
+    ~Buffered_ofstream() { close(); }
+    Buffered_ofstream(const Buffered_ofstream &) = delete;
+    Buffered_ofstream &operator=(const Buffered_ofstream &) = delete;
+    void write(const char *data, int64_t n) {
+        if (n <= 0) return;
+        bool ok = gzip_ ? (gzwrite(gz_, data, (unsigned)n) == (int)n) : (fwrite(data, 1, (size_t)n, fp_) == (size_t)n);
+        if (!ok) throw std::runtime_error("Error writing to file " + filename_);
+    }
+    void close() {
+        if (gz_) { gzclose(gz_); gz_ = nullptr; }
+        if (fp_) { fclose(fp_); fp_ = nullptr; }
+    }
+
+private:
+    std::string filename_;
+    bool gzip_;
+    gzFile gz_ = nullptr;
+    FILE *fp_ = nullptr;
+};
+
+// FASTA writer used by tests and `sbwt build --add-reverse-complements`
+inline void write_fasta(const std::string &filename, const std::vector<std::string> &seqs, bool gzip) {
+    Buffered_ofstream out(filename, gzip);
+    for (const auto &s : seqs) {
+        out.write(">\n", 2);
+        out.write(s.data(), (int64_t)s.size());
+        out.write("\n", 1);
+    }
+}
+
+}  // namespace seq_io
+}  // namespace sbwt

@@ -55,7 +55,13 @@ struct SbwtBlobHeader {
 struct SbwtWorkHeader {
     unsigned long long ticket;      // next read to hand out
     int status;                     // 0 or SBWTGPU_ERR_NOT_SINGLETON
-    int pad[61];
+    int pad0;
+    // work done by the last search launch (for the roofline's algorithmic-byte accounting)
+    unsigned long long n_stream;    // streaming one-step extensions (SBWT.hh:562-575)
+    unsigned long long n_search;    // full searches started (SBWT.hh:389-415)
+    unsigned long long n_lf;        // interval updates executed past the device prefix table (SBWT.hh:430-431)
+    unsigned long long n_tab_hit;   // prefix-table lookups that returned a non-empty interval
+    unsigned long long pad[26];
 };
 static_assert(sizeof(SbwtWorkHeader) == 256, "workspace header is 256 bytes");
 

@@ -55,7 +55,7 @@ __global__ void __launch_bounds__(256) k_encode(const unsigned char *__restrict_
                                                 uint4 *__restrict__ packed, i64 n_groups,
                                                 SbwtWorkHeader *ws, int aligned16) {
     i64 g = (i64)blockIdx.x * 256 + threadIdx.x;
-    if (g == 0) { ws->ticket = 0; ws->status = 0; }
+    if (g == 0) { ws->ticket = 0; ws->status = 0; ws->n_stream = 0; ws->n_search = 0; ws->n_lf = 0; ws->n_tab_hit = 0; }
     if (g >= n_groups) return;
     i64 base = g * SBWT_GROUP_BASES;
     u64 codes = 0;
@@ -125,6 +125,7 @@ __global__ void __launch_bounds__(256) k_search(SbwtIndexView ix, const uint4 *_
     i64 a = -1, l = 0, r = 0;
     i64 tag = -1;
     uint4 g0 = make_uint4(0, 0, 0, 0), g1 = make_uint4(0, 0, 0, 0);
+    unsigned c_stream = 0, c_search = 0, c_lf = 0, c_tab = 0;   // per-lane work counters
 
     for (;;) {
         // ---- hand out reads to idle lanes ----
@@ -145,7 +146,7 @@ __global__ void __launch_bounds__(256) k_search(SbwtIndexView ix, const uint4 *_
                     i = 0;
                     if (m > 0) {
                         if (p > 0) mode = M_INIT;
-                        else { mode = M_STEP; l = 0; r = last_node; j = 0; }
+                        else { mode = M_STEP; l = 0; r = last_node; j = 0; c_search++; }
                     }
                 } else {
                     dead = true;
@@ -172,6 +173,7 @@ __global__ void __launch_bounds__(256) k_search(SbwtIndexView ix, const uint4 *_
         bool emit = false;
         i64 res = -1;
         if (mode == M_STREAM) {
+            c_stream++;
             if ((g0.z >> s) & 1u) {
                 a1 = ix.blocks + (((a >> 6) << 2) + (c & 2));
                 a2 = a1 + 1;
@@ -179,6 +181,7 @@ __global__ void __launch_bounds__(256) k_search(SbwtIndexView ix, const uint4 *_
                 emit = true;   // non-ACGT after toupper -> -1 (SBWT.hh:568)
             }
         } else if (mode == M_INIT) {
+            c_search++;
             u64 w = codes0 >> (2 * s);
             if (s) w |= quad_bits(g1) << (64 - 2 * s);
             u64 vr = (((u64)g1.w << 32) | (u64)g0.w) >> s;
@@ -226,6 +229,7 @@ __global__ void __launch_bounds__(256) k_search(SbwtIndexView ix, const uint4 *_
             } else if (mode == M_INIT) {
                 l = (i64)quad_bits(v1);
                 r = (i64)((u64)v1.z | ((u64)v1.w << 32));
+                c_tab += (l != -1);
                 if (l == -1) {
                     emit = true;                       // SBWT.hh:424
                 } else if (p == k) {
@@ -238,6 +242,7 @@ __global__ void __launch_bounds__(256) k_search(SbwtIndexView ix, const uint4 *_
                 }
             } else {   // M_STEP
                 if (!a2) v2 = v1;
+                c_lf++;
                 u64 va = quad_rank<MEGA>(ix, v1, l, c);
                 u64 vb = quad_rank<MEGA>(ix, v2, r + 1, c);
                 l = (i64)va;
@@ -265,8 +270,25 @@ __global__ void __launch_bounds__(256) k_search(SbwtIndexView ix, const uint4 *_
                 mode = M_INIT;                         // SBWT.hh:557-559
             } else {
                 mode = M_STEP; l = 0; r = last_node; j = 0;   // SBWT.hh:408
+                c_search++;
             }
         }
+    }
+
+    // ---- work counters: wave reduction, one atomic per counter per wave ----
+    u64 t0 = c_stream, t1 = c_search, t2 = c_lf, t3 = c_tab;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        t0 += __shfl_down(t0, off);
+        t1 += __shfl_down(t1, off);
+        t2 += __shfl_down(t2, off);
+        t3 += __shfl_down(t3, off);
+    }
+    if (lane == 0) {
+        atomicAdd(&ws->n_stream, t0);
+        atomicAdd(&ws->n_search, t1);
+        atomicAdd(&ws->n_lf, t2);
+        atomicAdd(&ws->n_tab_hit, t3);
     }
 }
 

@@ -285,6 +285,14 @@ int sbwtgpu_index_blob(const sbwtgpu_index *idx, void **dev_ptr, int64_t *bytes)
     return SBWTGPU_OK;
 }
 
+int sbwtgpu_index_copy_blob(const sbwtgpu_index *idx, void *dst_dev, int64_t bytes, void *stream) {
+    if (!idx || !dst_dev) return fail(SBWTGPU_ERR_INVALID_ARG, "NULL argument");
+    if (bytes != idx->h.blob_bytes) return fail(SBWTGPU_ERR_INVALID_ARG, "bytes must equal blob_bytes");
+    DeviceGuard guard(idx->device);
+    HIP_TRY(hipMemcpyAsync(dst_dev, idx->blob, (size_t)bytes, hipMemcpyDeviceToDevice, static_cast<hipStream_t>(stream)));
+    return SBWTGPU_OK;
+}
+
 int sbwtgpu_index_adopt(const void *header, int64_t header_bytes, void *dev_blob, int64_t blob_bytes, int device,
                         sbwtgpu_index **out) {
     if (!header || !dev_blob || !out) return fail(SBWTGPU_ERR_INVALID_ARG, "NULL argument");
@@ -384,30 +392,66 @@ int64_t sbwtgpu_search_workspace_bytes(int64_t total_bases) {
     return (int64_t)sizeof(SbwtWorkHeader) + groups * 16;
 }
 
-static int search_dev_common(const sbwtgpu_index *idx, const char *d_bases, int64_t total_bases,
-                             const int64_t *d_read_off, int64_t n_reads, int64_t *d_out, const int64_t *d_out_off,
-                             void *d_ws, int64_t ws_bytes, void *stream, int streaming) {
+static int search_dev_check(const sbwtgpu_index *idx, int64_t total_bases, int64_t n_reads, const void *d_ws,
+                            int64_t ws_bytes, int streaming) {
     if (!idx) return fail(SBWTGPU_ERR_INVALID_ARG, "idx is NULL");
     if (streaming && !idx->h.has_ssup)
         return fail(SBWTGPU_ERR_NO_STREAMING, "Error: streaming search support not built");
     if (n_reads < 0 || total_bases < 0) return fail(SBWTGPU_ERR_INVALID_ARG, "negative size");
-    if (n_reads == 0) return SBWTGPU_OK;
-    if (!d_bases || !d_read_off || !d_out_off || !d_ws) return fail(SBWTGPU_ERR_INVALID_ARG, "NULL device pointer");
+    if (!d_ws) return fail(SBWTGPU_ERR_INVALID_ARG, "NULL workspace");
     if (ws_bytes < sbwtgpu_search_workspace_bytes(total_bases))
         return fail(SBWTGPU_ERR_INVALID_ARG, "workspace too small (%lld < %lld)", (long long)ws_bytes,
                     (long long)sbwtgpu_search_workspace_bytes(total_bases));
     if (((uintptr_t)d_ws & 15) != 0) return fail(SBWTGPU_ERR_INVALID_ARG, "workspace must be 16-byte aligned");
+    return SBWTGPU_OK;
+}
+
+int sbwtgpu_encode_bases_dev(const sbwtgpu_index *idx, const char *d_bases, int64_t total_bases, void *d_ws,
+                             int64_t ws_bytes, void *stream) {
+    int rc = search_dev_check(idx, total_bases, 0, d_ws, ws_bytes, 0);
+    if (rc != SBWTGPU_OK) return rc;
+    if (total_bases > 0 && !d_bases) return fail(SBWTGPU_ERR_INVALID_ARG, "NULL device pointer");
     DeviceGuard guard(idx->device);
-    hipStream_t st = static_cast<hipStream_t>(stream);
     SbwtWorkHeader *ws = static_cast<SbwtWorkHeader *>(d_ws);
     uint4 *packed = reinterpret_cast<uint4 *>(static_cast<char *>(d_ws) + sizeof(SbwtWorkHeader));
-    sbwt_launch_encode(d_bases, total_bases, packed, ws, st);
-    sbwt_launch_search(idx->view(), packed, reinterpret_cast<const long long *>(d_read_off),
-                       reinterpret_cast<const long long *>(d_out_off), reinterpret_cast<long long *>(d_out), n_reads,
-                       ws, streaming, st);
+    sbwt_launch_encode(d_bases, total_bases, packed, ws, static_cast<hipStream_t>(stream));
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(SBWTGPU_ERR_HIP, "kernel launch: %s", hipGetErrorString(e));
     return SBWTGPU_OK;
+}
+
+int sbwtgpu_search_encoded_dev(const sbwtgpu_index *idx, int64_t total_bases, const int64_t *d_read_off,
+                               int64_t n_reads, int64_t *d_out, const int64_t *d_out_off, void *d_ws,
+                               int64_t ws_bytes, int streaming, void *stream) {
+    int rc = search_dev_check(idx, total_bases, n_reads, d_ws, ws_bytes, streaming);
+    if (rc != SBWTGPU_OK) return rc;
+    if (n_reads == 0) return SBWTGPU_OK;
+    if (!d_read_off || !d_out_off) return fail(SBWTGPU_ERR_INVALID_ARG, "NULL device pointer");
+    DeviceGuard guard(idx->device);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    SbwtWorkHeader *ws = static_cast<SbwtWorkHeader *>(d_ws);
+    // the ticket counter and the work counters restart with every search launch
+    hipError_t e = hipMemsetAsync(ws, 0, sizeof(SbwtWorkHeader), st);
+    if (e != hipSuccess) return fail(SBWTGPU_ERR_HIP, "hipMemsetAsync: %s", hipGetErrorString(e));
+    const uint4 *packed = reinterpret_cast<const uint4 *>(static_cast<char *>(d_ws) + sizeof(SbwtWorkHeader));
+    sbwt_launch_search(idx->view(), packed, reinterpret_cast<const long long *>(d_read_off),
+                       reinterpret_cast<const long long *>(d_out_off), reinterpret_cast<long long *>(d_out), n_reads,
+                       ws, streaming, st);
+    e = hipGetLastError();
+    if (e != hipSuccess) return fail(SBWTGPU_ERR_HIP, "kernel launch: %s", hipGetErrorString(e));
+    return SBWTGPU_OK;
+}
+
+static int search_dev_common(const sbwtgpu_index *idx, const char *d_bases, int64_t total_bases,
+                             const int64_t *d_read_off, int64_t n_reads, int64_t *d_out, const int64_t *d_out_off,
+                             void *d_ws, int64_t ws_bytes, void *stream, int streaming) {
+    int rc = search_dev_check(idx, total_bases, n_reads, d_ws, ws_bytes, streaming);
+    if (rc != SBWTGPU_OK) return rc;
+    if (n_reads == 0) return SBWTGPU_OK;
+    rc = sbwtgpu_encode_bases_dev(idx, d_bases, total_bases, d_ws, ws_bytes, stream);
+    if (rc != SBWTGPU_OK) return rc;
+    return sbwtgpu_search_encoded_dev(idx, total_bases, d_read_off, n_reads, d_out, d_out_off, d_ws, ws_bytes,
+                                      streaming, stream);
 }
 
 int sbwtgpu_streaming_search_dev(const sbwtgpu_index *idx, const char *d_bases, int64_t total_bases,
@@ -444,6 +488,18 @@ int sbwtgpu_workspace_status(const void *d_ws, void *stream, int *status) {
     HIP_TRY(hipMemcpyAsync(&hdr, d_ws, sizeof(hdr), hipMemcpyDeviceToHost, static_cast<hipStream_t>(stream)));
     HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
     *status = hdr.status;
+    return SBWTGPU_OK;
+}
+
+int sbwtgpu_workspace_stats(const void *d_ws, void *stream, int64_t stats[4]) {
+    if (!d_ws || !stats) return fail(SBWTGPU_ERR_INVALID_ARG, "NULL argument");
+    SbwtWorkHeader hdr;
+    HIP_TRY(hipMemcpyAsync(&hdr, d_ws, sizeof(hdr), hipMemcpyDeviceToHost, static_cast<hipStream_t>(stream)));
+    HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+    stats[0] = (int64_t)hdr.n_stream;
+    stats[1] = (int64_t)hdr.n_search;
+    stats[2] = (int64_t)hdr.n_lf;
+    stats[3] = (int64_t)hdr.n_tab_hit;
     return SBWTGPU_OK;
 }
 

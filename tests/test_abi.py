@@ -1,0 +1,59 @@
+"""CPU: the C-ABI libraries load and export every symbol their headers declare (no compute calls)."""
+import os
+import re
+
+from sbwt_amd import capi, hostlib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared(header, prefix):
+    text = open(os.path.join(ROOT, "include", header)).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(%s\w+)\s*\(" % prefix, text)))
+
+
+def test_sbwtgpu_exports_every_declared_symbol():
+    L = capi.lib()
+    names = declared("sbwtgpu.h", "sbwtgpu_")
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(L, n), n
+    assert sorted(capi.EXPORTED_SYMBOLS) == names
+    assert b"gfx950" in L.sbwtgpu_version()
+
+
+def test_sbwthost_exports_every_declared_symbol():
+    H = hostlib.lib()
+    names = declared("sbwthost.h", "sbwthost_")
+    for n in names:
+        assert hasattr(H, n), n
+    assert sorted(hostlib.EXPORTED_SYMBOLS) == names
+
+
+def test_no_gpu_is_an_error_not_a_fallback():
+    # without a device index_create must fail with NO_DEVICE; with one this test is a no-op
+    import numpy as np
+    if capi.device_count() > 0:
+        return
+    w = np.array([1], dtype=np.uint64)
+    try:
+        capi.Index.create(w, w, w, w, None, 10, 3)
+    except capi.SbwtGpuError as e:
+        assert e.code == capi.ERR_NO_DEVICE
+    else:
+        raise AssertionError("index_create succeeded without a GPU")
+
+
+def test_product_does_not_reference_the_oracle():
+    # the oracle is test infrastructure: nothing under sbwt_amd/ may include, import or link it
+    bad = []
+    for d, _, files in os.walk(os.path.join(ROOT, "sbwt_amd")):
+        for f in files:
+            if f == "build.py":       # the build driver compiles the checker; building is not using
+                continue
+            if f.endswith((".py", ".hh", ".h", ".cpp", ".hip")):
+                t = open(os.path.join(d, f), errors="replace").read()
+                if re.search(r"sbwt_oracle|liboracle|from oracle|import oracle|orc_", t):
+                    bad.append(os.path.join(d, f))
+    assert not bad, bad

@@ -1,0 +1,79 @@
+"""CPU, world_size 2 over gloo: the multi-GPU plumbing of bench.py (index image broadcast, read
+sharding, max-over-ranks timing) -- the same code path runs over RCCL on GPUs."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    from sbwt_amd import dist as sdist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cpu")
+    header, blob = None, None
+    if rank == 0:
+        header = bytes(range(200)) + b"SBWTGPU1"
+        blob = torch.arange(100_003, dtype=torch.int64).to(torch.uint8)
+    h, b = sdist.broadcast_blob(header, blob, dev, src=0)
+    ok = h == bytes(range(200)) + b"SBWTGPU1" and torch.equal(b, torch.arange(100_003, dtype=torch.int64).to(torch.uint8))
+    # ragged reads: contiguous shards balanced by bases cover everything exactly once, in order
+    lens = np.random.default_rng(5).integers(0, 400, size=1001)
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    lo, hi = sdist.contiguous_shard(off, rank, world)
+    mine = int(off[hi] - off[lo])
+    tot = sdist.sum_over_ranks([mine, hi - lo], dev)
+    mx = sdist.max_over_ranks(1.0 + rank, dev)
+    q.put((rank, ok, lo, hi, mine, tot, mx, int(off[-1])))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_broadcast_and_sharding_world2():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, ok0, lo0, hi0, m0, tot0, mx0, total), (r1, ok1, lo1, hi1, m1, tot1, mx1, _) = res
+    assert ok0 and ok1
+    assert lo0 == 0 and hi0 == lo1 and hi1 == 1001
+    assert tot0 == tot1 == [float(total), 1001.0]
+    assert mx0 == mx1 == 2.0
+    assert abs(m0 - m1) < 0.05 * total          # balanced by bases
+
+
+def test_contiguous_shard_edge_cases():
+    sys.path.insert(0, ROOT)
+    from sbwt_amd.dist import contiguous_shard
+    off = np.array([0, 10, 20, 30, 40], dtype=np.int64)
+    assert [contiguous_shard(off, r, 4) for r in range(4)] == [(0, 1), (1, 2), (2, 3), (3, 4)]
+    assert contiguous_shard(off, 0, 1) == (0, 4)
+    off = np.array([0], dtype=np.int64)
+    assert contiguous_shard(off, 1, 2) == (0, 0)
+    off = np.array([0, 0, 0, 100], dtype=np.int64)       # empty reads in front
+    parts = [contiguous_shard(off, r, 2) for r in range(2)]
+    assert parts[0][0] == 0 and parts[0][1] == parts[1][0] and parts[1][1] == 3

@@ -1,0 +1,120 @@
+"""GPU: the `sbwt` command (C++ host mirror, sbwt_amd/csrc/host/sbwt_cli.cpp) end to end, restating
+the reference's CLI.end_to_end_build_and_query (tests/test_CLI.hh:20-113): build k=6 index with
+reverse complements and precalc 4 from two gz FASTA files listed in a .txt, query 3 reads in four
+formats through list files, compare the output files byte for byte with the known answer, plain
+and gzipped; plus the error conventions of src/CLI/sbwt.cpp:42-57."""
+import gzip
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import OracleIndex, print_vector
+from sbwt_amd import hostlib, synth
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SBWT = os.path.join(ROOT, "sbwt_amd", "bin", "sbwt")
+KATS = json.load(open(os.path.join(ROOT, "tests", "golden", "ref_kats.json")))
+
+
+def run(*args, check=True):
+    p = subprocess.run([SBWT] + list(args), capture_output=True, timeout=300)
+    if check:
+        assert p.returncode == 0, p.stderr.decode()
+    return p
+
+
+def write_fasta(path, seqs, gz=False):
+    data = b"".join(b">s%d\n%s\n" % (i, s) for i, s in enumerate(seqs))
+    (gzip.open(path, "wb") if gz else open(path, "wb")).write(data)
+
+
+def write_fastq(path, seqs, gz=False):
+    data = b"".join(b"@s%d\n%s\n+\n%s\n" % (i, s, b"I" * len(s)) for i, s in enumerate(seqs))
+    (gzip.open(path, "wb") if gz else open(path, "wb")).write(data)
+
+
+def test_cli_end_to_end_build_and_query(gpu, tmp_path):
+    kat = KATS["cli_end_to_end"]
+    d = str(tmp_path)
+    f1, f2 = d + "/a.fna.gz", d + "/b.fna.gz"
+    write_fasta(f1, [s.encode() for s in kat["seqs"][:2]], gz=True)
+    write_fasta(f2, [s.encode() for s in kat["seqs"][2:]], gz=True)
+    open(d + "/in.txt", "w").write(f1 + "\n" + f2 + "\n")
+    index = d + "/index.sbwt"
+    run("build", "-i", d + "/in.txt", "-o", index, "-k", "6", "--add-reverse-complements", "--temp-dir", d,
+        "--precalc-length", "4")
+    f = hostlib.read_index_file(index)
+    assert (f.n_nodes, f.n_kmers, f.k, f.precalc_k, f.C) == (87, 73, 6, 4, [1, 25, 43, 59])
+
+    queries = [q.encode() for q in kat["queries"]]
+    q = [d + "/q1.fq", d + "/q2.fna", d + "/q3.fq.gz", d + "/q4.fna.gz"]
+    write_fastq(q[0], queries)
+    write_fasta(q[1], queries)
+    write_fastq(q[2], queries, gz=True)
+    write_fasta(q[3], queries, gz=True)
+    outs = [d + "/o%d.txt" % i for i in range(4)]
+    open(d + "/qlist.txt", "w").write("\n".join(q) + "\n")
+    open(d + "/olist.txt", "w").write("\n".join(outs) + "\n")
+    p = run("search", "-o", d + "/olist.txt", "-i", index, "-q", d + "/qlist.txt")
+    assert b"us/query: " in p.stderr and b"(excluding I/O etc)" in p.stderr and b"us/query end-to-end: " in p.stderr
+    for o in outs:
+        assert open(o, "rb").read() == kat["expected_output"].encode()
+    open(d + "/olist_gz.txt", "w").write("\n".join(o + ".gz" for o in outs) + "\n")
+    run("search", "-o", d + "/olist_gz.txt", "-i", index, "-q", d + "/qlist.txt", "--gzip-output")
+    for o in outs:
+        assert gzip.open(o + ".gz", "rb").read() == kat["expected_output"].encode()
+    # single file form, -z short flag
+    run("search", "-o", d + "/single.txt.gz", "-i", index, "-q", q[0], "-z")
+    assert gzip.open(d + "/single.txt.gz", "rb").read() == kat["expected_output"].encode()
+
+
+def test_cli_non_streaming_index_and_batches(gpu, tmp_path):
+    d = str(tmp_path)
+    genomes = [synth.random_genome(30_000, 4)]
+    write_fasta(d + "/g.fna", [genomes[0].tobytes()])
+    run("build", "-i", d + "/g.fna", "-o", d + "/ns.sbwt", "-k", "31", "--no-streaming-support")
+    run("build", "-i", d + "/g.fna", "-o", d + "/st.sbwt", "-k", "31", "-p", "5", "-t", "4")
+    bases, off = synth.sample_reads(genomes, 700, 120, 0.02, 4)
+    bases = synth.inject(bases, 15, ord("N"), 1)
+    reads = [bases[off[r]:off[r + 1]].tobytes() for r in range(700)] + [b"ACGT", b"A" * 31]
+    write_fastq(d + "/r.fastq", reads)
+    orc = OracleIndex.build([genomes[0].tobytes()], 31, True, False, 5)
+    want = b"".join(print_vector(orc.streaming_search(r)) for r in reads)
+    p = run("search", "-o", d + "/ns.out", "-i", d + "/ns.sbwt", "-q", d + "/r.fastq")
+    assert b"Running non-streaming queries" in p.stderr
+    assert open(d + "/ns.out", "rb").read() == want
+    # tiny batches force many GPU round trips; the output must not depend on the batching
+    p = run("search", "-o", d + "/st.out", "-i", d + "/st.sbwt", "-q", d + "/r.fastq", "--batch-bases", "1000")
+    assert b"Running streaming queries" in p.stderr
+    assert open(d + "/st.out", "rb").read() == want
+
+
+def test_cli_error_conventions(gpu, tmp_path):
+    d = str(tmp_path)
+    p = run("search", "-o", d + "/o.txt", "-i", d + "/missing.sbwt", "-q", d + "/q.fna", check=False)
+    assert p.returncode == 1 and p.stderr.strip().endswith(b"Runtime error: Error opening file: " + (d + "/missing.sbwt").encode())
+    p = run("frobnicate", check=False)
+    assert p.returncode == 1 and b"Runtime error: Invalid command: frobnicate" in p.stderr
+    p = run("search", check=False)
+    assert p.returncode == 1 and b"--index-file" in p.stderr          # help text, exit(1)
+    p = run(check=False)
+    assert p.returncode == 0 and b"Available commands" in p.stderr
+    # unknown variant string in the file
+    import struct
+    open(d + "/bad.sbwt", "wb").write(struct.pack("<q", 5) + b"bogus")
+    write_fasta(d + "/q.fna", [b"ACGTACGT"])
+    p = run("search", "-o", d + "/o.txt", "-i", d + "/bad.sbwt", "-q", d + "/q.fna", check=False)
+    assert p.returncode == 1 and b"unrecognized variant" in p.stderr
+    # list length mismatch (sbwt_search.cpp:111-115)
+    seqs = [b"ACTAGTGTAGCTACAAA"]
+    write_fasta(d + "/s.fna", seqs)
+    run("build", "-i", d + "/s.fna", "-o", d + "/s.sbwt", "-k", "6", "-p", "2")
+    open(d + "/ql.txt", "w").write(d + "/q.fna\n" + d + "/q.fna\n")
+    open(d + "/ol.txt", "w").write(d + "/o1.txt\n")
+    p = run("search", "-o", d + "/ol.txt", "-i", d + "/s.sbwt", "-q", d + "/ql.txt", check=False)
+    assert p.returncode == 1 and b"Number of input and output files does not match (2 vs 1)" in p.stderr

@@ -1,0 +1,183 @@
+"""CPU: host-side pieces either side of the hot path -- the sort-based builder (differentially
+against the oracle's literal restatement of NodeBOSSInMemoryConstructor, like the reference tests
+KMC vs in-memory construction, tests/test_small.hh:65-99), the index file format, the sequence
+reader."""
+import gzip
+import json
+import os
+import random
+import struct
+
+import numpy as np
+import pytest
+
+from oracle import OracleIndex
+from sbwt_amd import hostlib, synth
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+KATS = json.load(open(os.path.join(HERE, "golden", "ref_kats.json")))
+
+
+def same_bits(b, o):
+    return (b.n_nodes == o.n_nodes and b.n_kmers == o.n_kmers
+            and all(np.array_equal(x, y) for x, y in zip(b.cols, o.columns()))
+            and ((b.ssup is None and not o.has_streaming_support) or np.array_equal(b.ssup, o.ssup_words())))
+
+
+def test_builder_cli_kat_columns():
+    kat = KATS["cli_end_to_end"]
+    seqs = [s.encode() for s in kat["seqs"]]
+    b = hostlib.build_bits(seqs, kat["k"], True, True)
+    assert (b.n_nodes, b.n_kmers) == (87, 73)
+    assert same_bits(b, OracleIndex.build(seqs, kat["k"], True, True, 0))
+
+
+@pytest.mark.parametrize("case", KATS["small_cases"]["cases"], ids=lambda c: c["name"])
+def test_builder_small_cases(case):
+    seqs = [s.encode() for s in case["seqs"]]
+    for ssup in (True, False):
+        assert same_bits(hostlib.build_bits(seqs, case["k"], False, ssup), OracleIndex.build(seqs, case["k"], ssup))
+
+
+@pytest.mark.parametrize("k", [2, 3, 7, 30, 31, 32, 33, 63, 64])
+def test_builder_vs_oracle_random(k):
+    rnd = random.Random(k)
+    g0 = synth.random_genome(4000, k)
+    seqs = [g0.tobytes(), synth.mutate(g0, 0.05, k + 1).tobytes(), b"ACGTNNACGTTTGAnnACC" * 7,
+            bytes(rnd.choice(b"ACGT") for _ in range(k)), b"ACG"]
+    for rc in (False, True):
+        b = hostlib.build_bits(seqs, k, rc, True, n_threads=3)
+        assert same_bits(b, OracleIndex.build(seqs, k, True, rc, 0)), (k, rc)
+
+
+def test_builder_many_dummies_and_threads():
+    rnd = random.Random(3)
+    seqs = [bytes(rnd.choice(b"ACGT") for _ in range(12)) for _ in range(3000)]   # read-set like input
+    b1 = hostlib.build_bits(seqs, 11, False, True, n_threads=1)
+    b8 = hostlib.build_bits(seqs, 11, False, True, n_threads=8)
+    assert same_bits(b1, OracleIndex.build(seqs, 11, True, False, 0))
+    assert all(np.array_equal(x, y) for x, y in zip(b1.cols, b8.cols)) and np.array_equal(b1.ssup, b8.ssup)
+
+
+def test_index_file_roundtrip_and_layout(tmp_path):
+    kat = KATS["cli_end_to_end"]
+    seqs = [s.encode() for s in kat["seqs"]]
+    orc = OracleIndex.build(seqs, kat["k"], True, True, kat["precalc"])
+    path = str(tmp_path / "kat.sbwt")
+    hostlib.write_index_file(path, orc.columns(), orc.ssup_words(), orc.C, orc.precalc(), orc.precalc_k, orc.n_nodes,
+                             orc.n_kmers, orc.k)
+    f = hostlib.read_index_file(path)
+    assert (f.n_nodes, f.n_kmers, f.k, f.precalc_k, f.C) == (87, 73, 6, 4, [1, 25, 43, 59])
+    assert all(np.array_equal(x, y) for x, y in zip(f.cols, orc.columns()))
+    assert np.array_equal(f.ssup, orc.ssup_words()) and np.array_equal(f.precalc, orc.precalc())
+    # byte layout of SURVEY App. A
+    raw = open(path, "rb").read()
+    pos = 0
+
+    def take(n):
+        nonlocal pos
+        b = raw[pos:pos + n]
+        pos += n
+        return b
+    assert struct.unpack("<q", take(8))[0] == 12 and take(12) == b"plain-matrix"
+    assert struct.unpack("<q", take(8))[0] == 4 and take(4) == b"v0.1"
+    nw = (87 + 63) // 64
+    for c in range(4):
+        assert struct.unpack("<Q", take(8))[0] == 87
+        assert np.array_equal(np.frombuffer(take(8 * nw), dtype=np.uint64), orc.columns()[c])
+    for c in range(4):                                  # rank_support_v5: 2 * ((cap >> 11) + 1) words
+        bits = struct.unpack("<Q", take(8))[0]
+        assert bits == 64 * 2 * (((64 * nw) >> 11) + 1)
+        words = np.frombuffer(take(bits // 8), dtype=np.uint64)
+        col = orc.columns()[c]
+        assert words[0] == 0
+        ones6 = sum(bin(int(w)).count("1") for w in col[:6]) if nw >= 6 else None
+        if nw == 2:                                     # fewer than 6 words: no packed field is reached
+            assert words[1] == 0
+    assert struct.unpack("<Q", take(8))[0] == 87        # suffix_group_starts
+    take(8 * nw)
+    assert struct.unpack("<q", take(8))[0] == 32 and struct.unpack("<4q", take(32)) == (1, 25, 43, 59)
+    assert struct.unpack("<q", take(8))[0] == 16 * 4 ** 4
+    take(16 * 4 ** 4)
+    assert struct.unpack("<4q", take(32)) == (4, 87, 73, 6)
+    assert pos == len(raw)
+
+
+def test_index_file_v5_directory_values(tmp_path):
+    # a bigger vector so that superblocks and packed 12-bit fields are exercised
+    g = synth.random_genome(30_000, 9)
+    b = hostlib.build_bits([g.tobytes()], 20, False, True)
+    path = str(tmp_path / "big.sbwt")
+    hostlib.write_index_file(path, b.cols, b.ssup, [1, 2, 3, 4], None, 0, b.n_nodes, b.n_kmers, 20)
+    raw = open(path, "rb").read()
+    nw = (b.n_nodes + 63) // 64
+    pos = 8 + 12 + 8 + 4 + 4 * (8 + 8 * nw)
+    for c in range(4):
+        bits = struct.unpack_from("<Q", raw, pos)[0]
+        words = np.frombuffer(raw, dtype=np.uint64, count=bits // 64, offset=pos + 8)
+        pos += 8 + bits // 8
+        pc = np.array([bin(int(w)).count("1") for w in b.cols[c]], dtype=np.int64)
+        cum = np.concatenate([[0], np.cumsum(pc)])
+        for sb in range(len(words) // 2):
+            first = sb * 32
+            if first <= nw:
+                assert words[2 * sb] == cum[min(first, nw)]
+            for blk in range(1, 6):
+                w_end = first + 6 * blk
+                if w_end <= nw and first + 32 <= nw:    # a complete superblock: every field is defined
+                    field = (int(words[2 * sb + 1]) >> (60 - 12 * blk)) & 0x7FF
+                    assert field == cum[w_end] - cum[first]
+    f = hostlib.read_index_file(path)
+    assert not hasattr(f, "x") and f.precalc is None and f.n_nodes == b.n_nodes
+
+
+def test_index_file_without_streaming_support_and_errors(tmp_path):
+    seqs = [b"CCCGTGATGGCTA", b"TAATGCTGTAGC"]
+    orc = OracleIndex.build(seqs, 4, False, False, 2)
+    path = str(tmp_path / "nossup.sbwt")
+    hostlib.write_index_file(path, orc.columns(), None, orc.C, orc.precalc(), 2, orc.n_nodes, orc.n_kmers, 4)
+    f = hostlib.read_index_file(path)
+    assert f.ssup is None and f.precalc_k == 2
+    bad = str(tmp_path / "bad.sbwt")
+    raw = bytearray(open(path, "rb").read())
+    raw[8 + 12 + 8] = ord("x")                          # version string "v0.1" -> "x0.1"
+    open(bad, "wb").write(raw)
+    with pytest.raises(RuntimeError, match="incompatible version"):
+        hostlib.read_index_file(bad)
+    with pytest.raises(RuntimeError, match="Error opening file"):
+        hostlib.read_index_file(str(tmp_path / "missing.sbwt"))
+
+
+def test_sequence_reader_formats(tmp_path):
+    reads = [b"GGAGAACTAGTGTAGCTACAAAGAGAG", b"AGTGTGTAGCAAAATGTGCTGATGCTAGCAAAAAAAA", b"CTCTACACACTTC", b"acgtNNac"]
+    fq = b"".join(b"@r%d desc\n%s\n+\n%s\n" % (i, r, b"I" * len(r)) for i, r in enumerate(reads))
+    fa = b"".join(b">r%d\n%s\n%s\n" % (i, r[:10], r[10:]) for i, r in enumerate(reads))   # multi-line FASTA
+    files = {"q.fq": fq, "q.fna": fa, "q.fastq": fq, "q.fa": fa}
+    for name, data in list(files.items()):
+        (tmp_path / name).write_bytes(data)
+        with gzip.open(str(tmp_path / (name + ".gz")), "wb") as g:
+            g.write(data)
+        files[name + ".gz"] = data
+    want = b"".join(r.upper() for r in reads)
+    for name in files:
+        bases, off = hostlib.read_sequences(str(tmp_path / name))
+        assert bases.tobytes() == want, name
+        assert list(np.diff(off)) == [len(r) for r in reads], name
+    (tmp_path / "q.txt").write_bytes(fa)
+    with pytest.raises(RuntimeError, match="Unknown file format"):
+        hostlib.read_sequences(str(tmp_path / "q.txt"))
+
+
+def test_example_queries_fastq_shape():
+    # example_data/queries.fastq of the reference: 5000 reads x 100 bp with 21 N; the file is not
+    # shipped here, so a synthetic stand-in with the same shape goes through the reader
+    import tempfile
+    bases, off = synth.sample_reads([synth.random_genome(100_000, 1)], 5000, 100, 0.0, 42)
+    bases = synth.inject(bases, 21, ord("N"), 3)
+    with tempfile.TemporaryDirectory() as d:
+        p = os.path.join(d, "queries.fastq")
+        with open(p, "wb") as f:
+            for r in range(5000):
+                f.write(b"@q%d\n" % r + bases[off[r]:off[r + 1]].tobytes() + b"\n+\n" + b"F" * 100 + b"\n")
+        b2, o2 = hostlib.read_sequences(p)
+    assert np.array_equal(b2, bases) and np.array_equal(o2, off)
