@@ -74,6 +74,10 @@ typedef struct {
 const char *sbwtgpu_version(void);
 const char *sbwtgpu_last_error(void);
 int         sbwtgpu_device_count(int *count);
+/* Process-wide tuning knobs for experiments (results never depend on them):
+ *   "search_variant"  0 = k_search (the reference's order of searches), 1 = k_search_cert (default)
+ *   "probe_len"       length of the certificate probes (-1 = automatic, 0 = off) */
+int         sbwtgpu_set_tuning(const char *key, int64_t value);
 
 /* ---- index life cycle ---- */
 /* Replaces SBWT(A,C,G,T,ssup,k,n_kmers,precalc_k) ctor (SBWT.hh:335-353) and the tail of

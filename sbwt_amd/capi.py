@@ -28,7 +28,7 @@ ERR_READ_TOO_LONG = -9
 
 # every symbol include/sbwtgpu.h declares (checked by tests/test_abi.py)
 EXPORTED_SYMBOLS = [
-    "sbwtgpu_version", "sbwtgpu_last_error", "sbwtgpu_device_count",
+    "sbwtgpu_version", "sbwtgpu_last_error", "sbwtgpu_device_count", "sbwtgpu_set_tuning",
     "sbwtgpu_index_create", "sbwtgpu_index_destroy", "sbwtgpu_index_get_info", "sbwtgpu_index_get_precalc",
     "sbwtgpu_index_export_header", "sbwtgpu_index_blob", "sbwtgpu_index_copy_blob", "sbwtgpu_index_adopt", "sbwtgpu_index_bcast",
     "sbwtgpu_rank_batch", "sbwtgpu_streaming_search_batch", "sbwtgpu_search_batch",
@@ -81,6 +81,7 @@ def lib() -> C.CDLL:
     L.sbwtgpu_version.restype = C.c_char_p
     L.sbwtgpu_last_error.restype = C.c_char_p
     L.sbwtgpu_device_count.argtypes = [C.POINTER(ci)]
+    L.sbwtgpu_set_tuning.argtypes = [C.c_char_p, i64]
     L.sbwtgpu_index_create.argtypes = [C.POINTER(IndexDesc), ci, C.POINTER(vp)]
     L.sbwtgpu_index_destroy.argtypes = [vp]
     L.sbwtgpu_index_destroy.restype = None
@@ -112,6 +113,10 @@ def lib() -> C.CDLL:
 def _check(rc: int) -> None:
     if rc != OK:
         raise SbwtGpuError(rc, lib().sbwtgpu_last_error().decode(errors="replace"))
+
+
+def set_tuning(key: str, value: int) -> None:
+    _check(lib().sbwtgpu_set_tuning(key.encode(), value))
 
 
 def device_count() -> int:

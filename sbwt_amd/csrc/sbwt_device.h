@@ -37,6 +37,7 @@ struct SbwtIndexView {
     int p_dev;
     int n_mega;
     int has_ssup;
+    int probe_len;                  // length of the certificate probes of k_search_cert (0 = off)
 };
 
 // Position-independent description of a blob (what index_export_header hands out).
@@ -70,7 +71,7 @@ void sbwt_launch_encode(const char *d_bases, long long total_bases, uint4 *d_pac
                         hipStream_t stream);
 void sbwt_launch_search(const SbwtIndexView &ix, const uint4 *d_packed, const long long *d_read_off,
                         const long long *d_out_off, long long *d_out, long long n_reads, SbwtWorkHeader *ws,
-                        int streaming, hipStream_t stream);
+                        int streaming, hipStream_t stream, int variant);
 void sbwt_launch_rank(const SbwtIndexView &ix, const long long *d_pos, const char *d_sym, long long n,
                       long long *d_out, hipStream_t stream);
 void sbwt_launch_precalc(const SbwtIndexView &ix, int p, longlong2 *d_table, hipStream_t stream);

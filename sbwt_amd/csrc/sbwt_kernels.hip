@@ -108,6 +108,7 @@ __global__ void __launch_bounds__(256) k_encode(const unsigned char *__restrict_
 #define M_STREAM 1
 #define M_INIT 2
 #define M_STEP 3
+#define M_DEAD 4
 
 template <bool MEGA>
 __global__ void __launch_bounds__(256) k_search(SbwtIndexView ix, const uint4 *__restrict__ packed,
@@ -293,6 +294,280 @@ __global__ void __launch_bounds__(256) k_search(SbwtIndexView ix, const uint4 *_
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_search_cert: same results as k_search, far fewer gathers, one memory round trip per iteration.
+//
+// (1) Absent-substring certificates.  After a miss the reference runs a full search for every
+//     following k-mer; on a read with one substituted base that is ~k failing searches which all
+//     die at the same base.  A walk (prefix table + interval updates) that starts at read position
+//     s and becomes empty at position t proves that read[s..t] occurs nowhere in the index, hence
+//     EVERY k-mer that contains [s..t] is absent -- the reference would print -1 for each of them
+//     (a k-mer's result is SBWT::search(kmer) whenever the previous result is -1, SBWT.hh:557-559,
+//     and search() of an absent k-mer is -1).  So when the position b of the last failure lies
+//     inside the window of the next unresolved k-mer i, the walk is started close to b instead of
+//     at i (a short probe ending at b, then a probe starting at b): one short walk certifies the
+//     whole run [i..s] at once.  Walk starts are only a heuristic; a walk that stays alive to the
+//     end of k-mer i's window proves nothing for s > i and is followed by the reference's own walk
+//     from i, so results never depend on the heuristic.
+// (2) One gather slot per iteration.  Whatever a lane needs next -- a new read's offsets, the packed
+//     group holding its next base, the block of a streaming step, the block left of it when the
+//     suffix group starts there, a prefix-table entry, the two quads of an interval update -- is
+//     loaded in the single load/wait point of the loop, so a wave never serialises several memory
+//     round trips in one iteration because different lanes need different things
+//     (profiles/r01_v1_rocprof_summary.txt: the first kernel spent ~8 us per wave iteration).
+//     Reads are handed out from a per-wave pool refilled by one atomic per 64 reads.
+// (3) Results are staged per lane in LDS and written as runs of 8 (64 contiguous bytes), so the
+//     L2 merges them into whole-sector writes instead of one memory write per 8-byte result.
+// ---------------------------------------------------------------------------------------------
+#define M_FETCH 5
+#define M_BACK 6
+#define EV_NONE 0
+#define EV_EMIT1 1
+#define EV_FAIL 2
+#define EV_END 3
+#define K_NONE 0
+#define K_FETCH 1
+#define K_RELOAD 2
+#define K_MODE 3
+#define STAGE_DEPTH 8
+
+template <bool MEGA>
+__global__ void __launch_bounds__(256, 8) k_search_cert(SbwtIndexView ix, const uint4 *__restrict__ packed,
+                                                        const i64 *__restrict__ read_off,
+                                                        const i64 *__restrict__ out_off, i64 *__restrict__ out,
+                                                        i64 n_reads, SbwtWorkHeader *ws, int streaming) {
+    __shared__ u64 stage[STAGE_DEPTH][256];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int k = ix.k, p = ix.p_dev, L0 = ix.probe_len;
+    const i64 last_node = ix.n_nodes - 1;
+
+    int mode = M_IDLE;              // M_DEAD once the ticket counter has run past the last read
+    i64 P0 = 0, obase = 0;
+    int m = 0, i = 0, j = 0, b = -1, wstart = 0, cnt = 0;
+    i64 l = 0, r = 0;               // walk interval; M_STREAM: l = previous answer; M_BACK: r = block; M_FETCH: l = read
+    int tag = -1;                   // index of the cached packed group pair (g0 = group tag, g1 = tag + 1)
+    uint4 g0 = make_uint4(0, 0, 0, 0), g1 = make_uint4(0, 0, 0, 0);
+    u64 pool_next = 0, pool_end = 0;                              // wave-uniform pool of read tickets
+    unsigned c_stream = 0, c_search = 0, c_lf = 0, c_tab = 0;     // wave-uniform (scalar) work counters
+
+    // choose where the next walk starts (see header comment) and arm it
+    auto plan = [&](bool force_ref) {
+        int s0 = i;
+        if (!force_ref && L0 > 0 && b >= i && b <= i + k - 1) {
+            s0 = (b - i >= L0 - 1) ? (b - L0 + 1) : b;
+            if (s0 + p - 1 > i + k - 1) s0 = i;
+        }
+        wstart = s0;
+        j = 0;
+        if (p > 0) mode = M_INIT;
+        else { mode = M_STEP; l = 0; r = last_node; }
+    };
+    auto flush = [&]() {   // staged results are those of k-mers [i-cnt, i)
+#pragma unroll 1
+        for (int t = 0; t < cnt; t++) out[obase + (i - cnt + t)] = (i64)stage[t][tid];
+        cnt = 0;
+    };
+
+    for (;;) {
+        // ---- hand out reads to idle lanes from the wave's ticket pool ----
+        const u64 need = __ballot(mode == M_IDLE);
+        if (need) {
+            if (pool_next == pool_end) {
+                u64 t = 0;
+                if (lane == 0) t = atomicAdd(&ws->ticket, 64ull);
+                t = __shfl(t, 0);
+                pool_next = t;
+                pool_end = t + 64;
+            }
+            const unsigned avail = (unsigned)(pool_end - pool_next);
+            const unsigned n = (unsigned)__popcll(need);
+            const unsigned rank = (unsigned)__popcll(need & low_mask(lane));
+            if (mode == M_IDLE && rank < avail) {
+                const u64 rd = pool_next + rank;
+                if (rd < (u64)n_reads) { mode = M_FETCH; l = (i64)rd; }
+                else mode = M_DEAD;
+            }
+            pool_next += (n < avail) ? n : avail;
+        }
+        if (__ballot(mode != M_DEAD) == 0) break;
+
+        // ---- what does this lane gather this iteration? ----
+        int kind = K_NONE;
+        const uint4 *a1 = nullptr, *a2 = nullptr;
+        int ev = EV_NONE, tfail = 0, c = 0;
+        i64 res = -1;
+        if (mode == M_FETCH) {
+            kind = K_FETCH;
+        } else if (mode != M_IDLE && mode != M_DEAD) {
+            const int q = (mode == M_STREAM || mode == M_BACK) ? (i + k - 1) : (wstart + j);
+            const i64 P = P0 + q;
+            if ((int)(P >> 5) != tag) {
+                kind = K_RELOAD;                       // the packed group pair holding base q
+                a1 = packed + (P >> 5);
+                a2 = a1 + 1;
+            } else {
+                kind = K_MODE;
+                const int s = (int)(P & 31);
+                const u64 codes0 = quad_bits(g0);
+                c = (int)((codes0 >> (2 * s)) & 3ull);
+                if (mode == M_STREAM || mode == M_BACK) {
+                    if ((g0.z >> s) & 1u) {
+                        const i64 blk = (mode == M_BACK) ? r : (l >> 6);
+                        a1 = ix.blocks + ((blk << 2) + (c & 2));
+                        a2 = a1 + 1;
+                    } else {
+                        ev = EV_EMIT1;                 // non-ACGT after toupper -> -1 (SBWT.hh:568)
+                        b = i + k - 1;
+                    }
+                } else if (mode == M_INIT) {
+                    u64 w = codes0 >> (2 * s);
+                    if (s) w |= quad_bits(g1) << (64 - 2 * s);
+                    const u64 vr = (((u64)g1.w << 32) | (u64)g0.w) >> s;
+                    const u64 vm = low_mask(p);
+                    if ((vr & vm) == vm) {
+                        a1 = reinterpret_cast<const uint4 *>(ix.ptab + (w & low_mask(2 * p)));
+                    } else {
+                        ev = EV_FAIL;                  // a non-ACGT char inside the table window
+                        tfail = wstart + (__ffsll((i64)(~vr & vm)) - 1);
+                    }
+                } else {   // M_STEP
+                    if ((g0.w >> s) & 1u) {
+                        a1 = ix.blocks + (((l >> 6) << 2) + c);
+                        const uint4 *t = ix.blocks + ((((r + 1) >> 6) << 2) + c);
+                        if (t != a1) a2 = t;
+                    } else {
+                        ev = EV_FAIL;                  // SBWT.hh:427-428
+                        tfail = wstart + j;
+                    }
+                }
+            }
+        }
+        c_search += (unsigned)__popcll(__ballot(kind == K_MODE && (mode == M_INIT || (p == 0 && mode == M_STEP && j == 0))));
+        c_lf += (unsigned)__popcll(__ballot(kind == K_MODE && mode == M_STEP && a1 != nullptr));
+
+        // ---- the one memory round trip of this iteration ----
+        i64 f0 = 0, f1 = 0, f2 = 0;
+        uint4 v1 = make_uint4(0, 0, 0, 0), v2 = make_uint4(0, 0, 0, 0);
+        if (kind == K_FETCH) {
+            f0 = read_off[l];
+            f1 = read_off[l + 1];
+            f2 = out_off[l];
+        }
+        if (a1) v1 = *a1;
+        if (a2) v2 = *a2;
+
+        // ---- consume ----
+        bool tabhit = false;
+        if (kind == K_FETCH) {
+            P0 = f0;
+            obase = f2;
+            m = (int)(f1 - f0) - k + 1;
+            i = 0;
+            b = -1;
+            if (m > 0) plan(true);
+            else mode = M_IDLE;
+        } else if (kind == K_RELOAD) {
+            g0 = v1;
+            g1 = v2;
+            tag = (int)((P0 + ((mode == M_STREAM || mode == M_BACK) ? (i + k - 1) : (wstart + j))) >> 5);
+        } else if (a1) {
+            if (mode == M_STREAM || mode == M_BACK) {
+                const i64 blk = (mode == M_BACK) ? r : (l >> 6);
+                u64 msk = (u64)v1.w | ((u64)v2.w << 32);
+                if (mode == M_STREAM) msk &= (2ull << (int)(l & 63)) - 1ull;
+                if (msk == 0 && blk > 0) {
+                    mode = M_BACK;                     // the suffix group starts in an earlier block
+                    r = blk - 1;
+                } else {
+                    if (msk == 0) msk = 1;             // cannot happen: column 0 is always marked
+                    const uint4 mine = (c & 1) ? v2 : v1;
+                    const int gb = 63 - __clzll((i64)msk);
+                    const u64 bits = quad_bits(mine);
+                    u64 val = (u64)mine.z + (u64)__popcll(bits & low_mask(gb));
+                    if (MEGA) val += ix.mega[(i64)c * ix.n_mega + (((blk << 6) | gb) >> SBWT_MEGA_SHIFT)];
+                    // node_left == node_right <=> column c has its bit set at the group start (SBWT.hh:572-575)
+                    res = ((bits >> gb) & 1ull) ? (i64)val : -1;
+                    ev = EV_EMIT1;
+                    if (res == -1) b = i + k - 1;
+                }
+            } else if (mode == M_INIT) {
+                l = (i64)quad_bits(v1);
+                r = (i64)((u64)v1.z | ((u64)v1.w << 32));
+                tabhit = (l != -1);
+                if (l == -1) {
+                    ev = EV_FAIL;                      // read[wstart .. wstart+p-1] is not in the index
+                    tfail = wstart + p - 1;
+                } else {
+                    j = p;
+                    if (wstart + j == i + k) ev = EV_END;
+                    else mode = M_STEP;
+                }
+            } else {   // M_STEP
+                if (!a2) v2 = v1;
+                const u64 va = quad_rank<MEGA>(ix, v1, l, c);
+                const u64 vb = quad_rank<MEGA>(ix, v2, r + 1, c);
+                l = (i64)va;
+                r = (i64)vb - 1;
+                if (l > r) {
+                    ev = EV_FAIL;                      // SBWT.hh:433
+                    tfail = wstart + j;
+                } else if (wstart + (++j) == i + k) {
+                    ev = EV_END;
+                }
+            }
+        }
+        c_tab += (unsigned)__popcll(__ballot(tabhit));
+        c_stream += (unsigned)__popcll(__ballot(ev == EV_EMIT1 && (mode == M_STREAM || mode == M_BACK)));
+
+        // ---- events ----
+        if (ev == EV_END) {
+            if (wstart == i) {                         // k chars matched from i: the k-mer is there
+                res = l;
+                if (l != r) ws->status = SBWT_ERR_NOT_SINGLETON;   // SBWT.hh:410-413
+                ev = EV_EMIT1;
+                b = -1;
+            } else {
+                plan(true);                            // probe inconclusive: the reference's own walk
+            }
+        } else if (ev == EV_FAIL) {
+            // read[wstart..tfail] is not in the index: k-mers i..min(wstart, m-1) all contain it
+            const int hi = (wstart < m - 1) ? wstart : (m - 1);
+            b = tfail;
+            if (hi == i) {
+                ev = EV_EMIT1;                         // res == -1
+            } else {
+                flush();
+#pragma unroll 1
+                for (int t = i; t <= hi; t++) out[obase + t] = -1;
+                i = hi + 1;
+                if (i == m) mode = M_IDLE;
+                else plan(false);
+            }
+        }
+        if (ev == EV_EMIT1) {
+            stage[cnt][tid] = (u64)res;
+            cnt++;
+            i++;
+            if (cnt == STAGE_DEPTH || i == m) flush();
+            if (i == m) {
+                mode = M_IDLE;
+            } else if (res != -1 && streaming) {
+                mode = M_STREAM;                       // SBWT.hh:560-
+                l = res;
+            } else {
+                plan(false);                           // SBWT.hh:557-559 (with certificates)
+            }
+        }
+    }
+
+    if (lane == 0) {   // the counters are wave-uniform
+        atomicAdd(&ws->n_stream, (u64)c_stream);
+        atomicAdd(&ws->n_search, (u64)c_search);
+        atomicAdd(&ws->n_lf, (u64)c_lf);
+        atomicAdd(&ws->n_tab_hit, (u64)c_tab);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // k_rank: SubsetMatrixRank::rank(pos, c) for n independent (pos, sym) pairs
 // ---------------------------------------------------------------------------------------------
 template <bool MEGA>
@@ -404,8 +679,19 @@ void sbwt_launch_encode(const char *d_bases, long long total_bases, uint4 *d_pac
 
 void sbwt_launch_search(const SbwtIndexView &ix, const uint4 *d_packed, const long long *d_read_off,
                         const long long *d_out_off, long long *d_out, long long n_reads, SbwtWorkHeader *ws,
-                        int streaming, hipStream_t stream) {
+                        int streaming, hipStream_t stream, int variant) {
     if (n_reads <= 0) return;
+    if (variant == 1) {
+        i64 want1 = (n_reads + 255) / 256;
+        unsigned grid1 = (unsigned)(want1 < 2048 ? want1 : 2048);
+        if (ix.n_mega > 1)
+            hipLaunchKernelGGL(k_search_cert<true>, dim3(grid1), dim3(256), 0, stream, ix, d_packed, d_read_off,
+                               d_out_off, d_out, (i64)n_reads, ws, streaming);
+        else
+            hipLaunchKernelGGL(k_search_cert<false>, dim3(grid1), dim3(256), 0, stream, ix, d_packed, d_read_off,
+                               d_out_off, d_out, (i64)n_reads, ws, streaming);
+        return;
+    }
     // persistent-style grid: enough 256-thread workgroups to fill 256 CUs x 8 workgroups, never
     // more lanes than reads
     i64 want = (n_reads + 255) / 256;

@@ -57,11 +57,30 @@ struct DeviceGuard {
 
 }  // namespace
 
+// tuning knobs (A/B experiments; defaults are the shipped configuration)
+static int tuning_variant() {          // 0 = k_search (reference order), 1 = k_search_cert
+    static int v = [] { const char *e = getenv("SBWTGPU_SEARCH_VARIANT"); return e ? atoi(e) : 1; }();
+    return v;
+}
+static int g_variant_override = -1, g_probe_override = -1;
+
 struct sbwtgpu_index {
     SbwtBlobHeader h;
     int device = 0;
     char *blob = nullptr;       // device
     bool owns_blob = true;
+    // probe length of the certificate walks: long enough that a random string of that length is almost
+    // surely absent (log4(#k-mers) + 4), at least one char longer than the device prefix table
+    int probe_len() const {
+        if (g_probe_override >= 0) return g_probe_override < h.k ? g_probe_override : 0;
+        int64_t nk = h.n_kmers > 0 ? h.n_kmers : h.n_nodes;
+        int L = 4;
+        while (L < 40 && ((int64_t)1 << (2 * L)) < nk) L++;
+        L += 4;
+        if (L < h.p_dev + 2) L = (int)h.p_dev + 2;
+        if (L > h.k - 1) return 0;
+        return L;
+    }
     SbwtIndexView view() const {
         SbwtIndexView v;
         v.blocks = reinterpret_cast<const uint4 *>(blob + h.off_blocks);
@@ -73,6 +92,7 @@ struct sbwtgpu_index {
         v.p_dev = (int)h.p_dev;
         v.n_mega = (int)h.n_mega;
         v.has_ssup = h.has_ssup;
+        v.probe_len = probe_len();
         return v;
     }
 };
@@ -81,6 +101,13 @@ extern "C" {
 
 const char *sbwtgpu_version(void) { return "sbwtgpu 0.1 (gfx950)"; }
 const char *sbwtgpu_last_error(void) { return g_err; }
+
+int sbwtgpu_set_tuning(const char *key, int64_t value) {
+    if (!key) return fail(SBWTGPU_ERR_INVALID_ARG, "key is NULL");
+    if (!strcmp(key, "search_variant")) { g_variant_override = (int)value; return SBWTGPU_OK; }
+    if (!strcmp(key, "probe_len")) { g_probe_override = (int)value; return SBWTGPU_OK; }
+    return fail(SBWTGPU_ERR_INVALID_ARG, "unknown tuning key '%s'", key);
+}
 
 int sbwtgpu_device_count(int *count) {
     if (!count) return fail(SBWTGPU_ERR_INVALID_ARG, "count is NULL");
@@ -436,7 +463,7 @@ int sbwtgpu_search_encoded_dev(const sbwtgpu_index *idx, int64_t total_bases, co
     const uint4 *packed = reinterpret_cast<const uint4 *>(static_cast<char *>(d_ws) + sizeof(SbwtWorkHeader));
     sbwt_launch_search(idx->view(), packed, reinterpret_cast<const long long *>(d_read_off),
                        reinterpret_cast<const long long *>(d_out_off), reinterpret_cast<long long *>(d_out), n_reads,
-                       ws, streaming, st);
+                       ws, streaming, st, g_variant_override >= 0 ? g_variant_override : tuning_variant());
     e = hipGetLastError();
     if (e != hipSuccess) return fail(SBWTGPU_ERR_HIP, "kernel launch: %s", hipGetErrorString(e));
     return SBWTGPU_OK;

@@ -213,3 +213,27 @@ def test_streaming_equals_search_at_scale_properties(gpu, genome_case):
     # sample 2000 reads against the oracle
     want = oracle_batch(orc, bases[: 2000 * 150], off[:2001], True)
     assert np.array_equal(a[: len(want)], want)
+
+
+@pytest.mark.parametrize("variant,probe", [(0, -1), (1, -1), (1, 0), (1, 9), (1, 11), (1, 12), (1, 20), (1, 29)])
+def test_results_do_not_depend_on_search_variant_or_probe_length(gpu, genome_case, variant, probe):
+    # k_search (reference order) and k_search_cert (absent-substring certificates) must give the
+    # same bits for every probe length, including reads with N / lower case and all-miss reads
+    genomes, orc = genome_case
+    idx = gpu_index_from_oracle(orc)
+    capi.set_tuning("search_variant", variant)
+    capi.set_tuning("probe_len", probe)
+    try:
+        bases, off = synth.sample_reads(genomes, 3000, 150, 0.02, 77)
+        bases = synth.inject(bases, 80, ord("N"), 1)
+        bases = synth.inject(bases, 80, ord("g"), 2)
+        rb, ro = synth.random_reads(300, 150, 5)
+        bases = np.concatenate([bases, rb])
+        off = np.concatenate([off, ro[1:] + off[-1]])
+        got, _ = idx.streaming_search(bases, off)
+        assert np.array_equal(got, oracle_batch(orc, bases, off, True))
+        got, _ = idx.search(bases, off)
+        assert np.array_equal(got, oracle_batch(orc, bases, off, False))
+    finally:
+        capi.set_tuning("search_variant", -1)
+        capi.set_tuning("probe_len", -1)

@@ -1,0 +1,44 @@
+"""A/B timing of search-kernel variants in ONE process, interleaved rounds (guide rule 24)."""
+import os, sys, time, json
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from sbwt_amd import capi, hostlib, synth
+import bench as B
+
+n_reads = int(os.environ.get("NREADS", 4_000_000))
+glen = int(os.environ.get("GLEN", 5_000_000))
+configs = json.loads(os.environ.get("CONFIGS", '[[0,-1],[1,-1],[1,0]]'))   # [variant, probe_len]
+rounds = int(os.environ.get("ROUNDS", 3))
+dev = torch.device("cuda", 0)
+genomes = synth.coli3_like(glen)
+bits = hostlib.build_bits([g.tobytes() for g in genomes], 30, False, True, n_threads=os.cpu_count())
+idx = capi.Index.create(bits.cols[0], bits.cols[1], bits.cols[2], bits.cols[3], bits.ssup, bits.n_nodes, 30, bits.n_kmers, 8)
+print("n_nodes", idx.n_nodes, "p_dev", idx.device_precalc_k, "blob MB", idx.blob_bytes / 1e6, flush=True)
+d_bases = B.gpu_reads(genomes, n_reads, 42, dev)
+m = 121
+d_roff = torch.arange(n_reads + 1, dtype=torch.int64, device=dev) * 150
+d_ooff = torch.arange(n_reads + 1, dtype=torch.int64, device=dev) * m
+d_out = torch.empty(n_reads * m, dtype=torch.int64, device=dev)
+wsb = capi.search_workspace_bytes(d_bases.numel())
+d_ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+st = torch.cuda.current_stream().cuda_stream
+idx.encode_bases_dev(d_bases.data_ptr(), d_bases.numel(), d_ws.data_ptr(), wsb, st)
+ref = None
+times = {tuple(c): [] for c in configs}
+for rnd in range(rounds + 1):
+    for c in configs:
+        capi.set_tuning("search_variant", c[0]); capi.set_tuning("probe_len", c[1])
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        idx.search_encoded_dev(d_bases.numel(), d_roff.data_ptr(), n_reads, d_out.data_ptr(), d_ooff.data_ptr(), d_ws.data_ptr(), wsb, True, st)
+        e1.record(); torch.cuda.synchronize()
+        if rnd == 0:
+            chk = int((d_out * torch.arange(1, d_out.numel() + 1, device=dev)).sum().item())
+            if ref is None: ref = chk
+            print("config", c, "checksum", chk, "same" if chk == ref else "DIFFERENT", "stats", idx.workspace_stats(d_ws.data_ptr(), st), flush=True)
+        else:
+            times[tuple(c)].append(e0.elapsed_time(e1))
+for c, v in times.items():
+    print(f"variant={c[0]} probe={c[1]}: median {np.median(v):.2f} ms min {min(v):.2f} ms -> {n_reads * m / np.median(v) / 1e6:.2f} G kmers/s")
