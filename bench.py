@@ -40,10 +40,11 @@ PRECALC = 8
 READ_LEN = 150
 SUB_RATE = 0.01
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s peak
-# SURVEY 8d algorithmic bytes
-B_STREAM = 89                   # 1 base + 8 ssup word + (8 count + 64 block bits) + 8 out
-B_SEARCH_FIXED = K + 16 + 8     # k bases + 16 precalc entry + 8 out
-B_LF = 2 * 72                   # two ranks per interval update, (8 count + 64 block bits) each
+# SURVEY 8d algorithmic bytes, per operation
+B_STREAM = 89                   # streaming step: 1 base + 8 ssup word + (8 count + 64 block bits) + 8 out
+B_TABLE = 16                    # one prefix-table entry per walk (+ the bases of its window)
+B_LF = 2 * 72                   # interval update: two ranks, (8 count + 64 block bits) each
+B_OUT = 8                       # one int64 result
 
 
 def log(msg: str) -> None:
@@ -171,11 +172,15 @@ def main() -> int:
     status = index.workspace_status(d_ws.data_ptr(), stream)
     if status != 0:
         raise SystemExit(f"search kernel reported status {status}")
-    # reference algorithm's interval updates >= those executed past the device table + the levels the
-    # deeper device table (device_precalc_k) replaced for every non-empty lookup
-    lf_ref = n_lf + (index.device_precalc_k - PRECALC) * n_tab
-    alg_bytes = B_STREAM * n_stream + B_SEARCH_FIXED * n_search + B_LF * lf_ref
-    nominal_bytes = B_STREAM * n_stream + (B_SEARCH_FIXED + B_LF * (K - PRECALC)) * n_search
+    # Algorithmic bytes of the work the kernel EXECUTED, priced per operation at SURVEY 8d's figures:
+    # streaming steps, walks (prefix-table entry + its window of bases), interval updates, and the
+    # result of every k-mer that did not come from a streaming step.  (The reference's own order of
+    # searches would execute ~3.5x more interval updates for the same output; DESIGN.md.)
+    alg_bytes = (B_STREAM * n_stream + (B_TABLE + index.device_precalc_k) * n_search + B_LF * n_lf
+                 + B_OUT * (n_kmers - n_stream))
+    # SURVEY 8d's nominal formula (every full search priced at all k-p interval updates)
+    n_full = n_kmers - n_stream
+    nominal_bytes = B_STREAM * n_stream + (K + 16 + 8 + B_LF * (K - PRECALC)) * n_full
 
     total_kmers = n_kmers * world
     value = total_kmers * args.steps / elapsed
@@ -211,8 +216,8 @@ def main() -> int:
             "kernel_ms": kernel_ms,
             "algorithmic_bytes_per_launch": alg_bytes,
             "nominal_bytes_per_launch_survey_8d": nominal_bytes,
-            "work_per_launch": {"stream_steps": n_stream, "full_searches": n_search,
-                                "lf_steps_executed": n_lf, "lf_steps_reference_lower_bound": lf_ref},
+            "work_per_launch": {"stream_steps": n_stream, "walks": n_search, "interval_updates": n_lf,
+                                "table_hits": n_tab, "kmers_not_streamed": n_full},
             "kernel_only_kmers_per_s": n_kmers / (kernel_ms * 1e-3),
         },
     }
