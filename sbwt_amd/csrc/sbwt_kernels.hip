@@ -30,6 +30,7 @@ __device__ __forceinline__ u64 low_mask(int n) { return (1ull << n) - 1ull; }   
 
 // streaming (read-once / write-once) 16-byte accesses that should not displace the index in L2
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void st_stream(i64 *p, i64 v) { __builtin_nontemporal_store(v, p); }
 __device__ __forceinline__ uint4 ld_stream(const uint4 *p) {
     u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p));
     return make_uint4(v.x, v.y, v.z, v.w);
@@ -330,42 +331,46 @@ __global__ void __launch_bounds__(256) k_search(SbwtIndexView ix, const uint4 *_
 #define K_MODE 3
 #define STAGE_DEPTH 8
 
-template <bool MEGA>
-__global__ void __launch_bounds__(256, 8) k_search_cert(SbwtIndexView ix, const uint4 *__restrict__ packed,
+// WIDE = false: every column index fits 31 bits (n_nodes < 2^31 - 64): positions, results and the LDS
+// stage are 32-bit (16 staged results = one 128-byte line per flush).  WIDE = true: 64-bit
+// positions, mega-block counts, 8 staged 64-bit results.
+template <bool WIDE> struct SearchTypes;
+template <> struct SearchTypes<false> { typedef int pos_t; typedef unsigned stage_t; static constexpr int DEPTH = 16; };
+template <> struct SearchTypes<true> { typedef i64 pos_t; typedef u64 stage_t; static constexpr int DEPTH = 8; };
+
+template <bool WIDE>
+__device__ __forceinline__ typename SearchTypes<WIDE>::pos_t quad_rank_t(const SbwtIndexView &ix, const uint4 &q,
+                                                                        typename SearchTypes<WIDE>::pos_t pos, int c) {
+    typedef typename SearchTypes<WIDE>::pos_t pos_t;
+    pos_t v = (pos_t)q.z + (pos_t)__popcll(quad_bits(q) & low_mask((int)(pos & 63)));
+    if (WIDE) v += (pos_t)ix.mega[(i64)c * ix.n_mega + ((i64)pos >> SBWT_MEGA_SHIFT)];
+    return v;
+}
+
+template <bool WIDE, int WPS>
+__global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, const uint4 *__restrict__ packed,
                                                         const i64 *__restrict__ read_off,
                                                         const i64 *__restrict__ out_off, i64 *__restrict__ out,
                                                         i64 n_reads, SbwtWorkHeader *ws, int streaming) {
-    __shared__ u64 stage[STAGE_DEPTH][256];
+    typedef typename SearchTypes<WIDE>::pos_t pos_t;
+    typedef typename SearchTypes<WIDE>::stage_t stage_t;
+    constexpr int DEPTH = SearchTypes<WIDE>::DEPTH;
+    __shared__ stage_t stage[DEPTH][256];
     const int tid = threadIdx.x, lane = tid & 63;
     const int k = ix.k, p = ix.p_dev, L0 = ix.probe_len;
-    const i64 last_node = ix.n_nodes - 1;
+    const pos_t last_node = (pos_t)(ix.n_nodes - 1);
 
     int mode = M_IDLE;              // M_DEAD once the ticket counter has run past the last read
-    i64 P0 = 0, obase = 0;
+    i64 obase = 0;                  // first result slot of the current read
+    int pgrp = 0, poff = 0;         // the read starts at base poff of packed group pgrp
     int m = 0, i = 0, j = 0, b = -1, wstart = 0, cnt = 0;
-    i64 l = 0, r = 0;               // walk interval; M_STREAM: l = previous answer; M_BACK: r = block; M_FETCH: l = read
-    int tag = -1;                   // index of the cached packed group pair (g0 = group tag, g1 = tag + 1)
+    pos_t l = 0, r = 0;             // walk interval; M_STREAM: l = previous answer; M_BACK: r = block
+    i64 rd = 0;                     // M_FETCH: the read whose offsets are being fetched
+    int tag = -2;                   // g0 = packed group `tag`; g1 = group tag+1 if g1ok
+    bool g1ok = false;
     uint4 g0 = make_uint4(0, 0, 0, 0), g1 = make_uint4(0, 0, 0, 0);
     u64 pool_next = 0, pool_end = 0;                              // wave-uniform pool of read tickets
     unsigned c_stream = 0, c_search = 0, c_lf = 0, c_tab = 0;     // wave-uniform (scalar) work counters
-
-    // choose where the next walk starts (see header comment) and arm it
-    auto plan = [&](bool force_ref) {
-        int s0 = i;
-        if (!force_ref && L0 > 0 && b >= i && b <= i + k - 1) {
-            s0 = (b - i >= L0 - 1) ? (b - L0 + 1) : b;
-            if (s0 + p - 1 > i + k - 1) s0 = i;
-        }
-        wstart = s0;
-        j = 0;
-        if (p > 0) mode = M_INIT;
-        else { mode = M_STEP; l = 0; r = last_node; }
-    };
-    auto flush = [&]() {   // staged results are those of k-mers [i-cnt, i)
-#pragma unroll 1
-        for (int t = 0; t < cnt; t++) out[obase + (i - cnt + t)] = (i64)stage[t][tid];
-        cnt = 0;
-    };
 
     for (;;) {
         // ---- hand out reads to idle lanes from the wave's ticket pool ----
@@ -382,36 +387,44 @@ __global__ void __launch_bounds__(256, 8) k_search_cert(SbwtIndexView ix, const 
             const unsigned n = (unsigned)__popcll(need);
             const unsigned rank = (unsigned)__popcll(need & low_mask(lane));
             if (mode == M_IDLE && rank < avail) {
-                const u64 rd = pool_next + rank;
-                if (rd < (u64)n_reads) { mode = M_FETCH; l = (i64)rd; }
-                else mode = M_DEAD;
+                rd = (i64)(pool_next + rank);
+                mode = (rd < n_reads) ? M_FETCH : M_DEAD;
             }
             pool_next += (n < avail) ? n : avail;
         }
         if (__ballot(mode != M_DEAD) == 0) break;
 
-        // ---- what does this lane gather this iteration? ----
-        int kind = K_NONE;
-        const uint4 *a1 = nullptr, *a2 = nullptr;
-        int ev = EV_NONE, tfail = 0, c = 0;
-        i64 res = -1;
+        // ---- what does this lane gather this iteration?  Always two 16-byte loads; lanes that need
+        //      one (or none) load a duplicate (or the first block), so that the wave issues both
+        //      loads back to back and waits once. ----
+        int kind = K_NONE, ev = EV_NONE, tfail = 0, c = 0, grp = 0;
+        const uint4 *a1 = ix.blocks, *a2 = ix.blocks;
+        pos_t res = -1;
+        const bool strm = (mode == M_STREAM || mode == M_BACK);
         if (mode == M_FETCH) {
-            kind = K_FETCH;
+            kind = K_FETCH;                            // {read_off[rd], read_off[rd+1]}, {out_off[rd], ..}
+            a1 = reinterpret_cast<const uint4 *>(read_off + rd);
+            a2 = reinterpret_cast<const uint4 *>(out_off + rd);
         } else if (mode != M_IDLE && mode != M_DEAD) {
-            const int q = (mode == M_STREAM || mode == M_BACK) ? (i + k - 1) : (wstart + j);
-            const i64 P = P0 + q;
-            if ((int)(P >> 5) != tag) {
-                kind = K_RELOAD;                       // the packed group pair holding base q
-                a1 = packed + (P >> 5);
+            const int P = poff + (strm ? (i + k - 1) : (wstart + j));
+            const int s = P & 31;
+            grp = pgrp + (P >> 5);
+            if (grp == tag + 1 && g1ok && (mode != M_INIT || s + p <= 32)) {
+                g0 = g1;                               // crossed into the group that is already here
+                g1ok = false;
+                tag = grp;
+            }
+            if (grp != tag || (mode == M_INIT && s + p > 32 && !g1ok)) {
+                kind = K_RELOAD;                       // the packed group pair holding the next base(s)
+                a1 = packed + grp;
                 a2 = a1 + 1;
             } else {
                 kind = K_MODE;
-                const int s = (int)(P & 31);
                 const u64 codes0 = quad_bits(g0);
-                c = (int)((codes0 >> (2 * s)) & 3ull);
-                if (mode == M_STREAM || mode == M_BACK) {
+                c = (int)((unsigned)(codes0 >> (2 * s)) & 3u);
+                if (strm) {
                     if ((g0.z >> s) & 1u) {
-                        const i64 blk = (mode == M_BACK) ? r : (l >> 6);
+                        const i64 blk = (mode == M_BACK) ? (i64)r : ((i64)l >> 6);
                         a1 = ix.blocks + ((blk << 2) + (c & 2));
                         a2 = a1 + 1;
                     } else {
@@ -425,15 +438,15 @@ __global__ void __launch_bounds__(256, 8) k_search_cert(SbwtIndexView ix, const 
                     const u64 vm = low_mask(p);
                     if ((vr & vm) == vm) {
                         a1 = reinterpret_cast<const uint4 *>(ix.ptab + (w & low_mask(2 * p)));
+                        a2 = a1;
                     } else {
                         ev = EV_FAIL;                  // a non-ACGT char inside the table window
                         tfail = wstart + (__ffsll((i64)(~vr & vm)) - 1);
                     }
                 } else {   // M_STEP
                     if ((g0.w >> s) & 1u) {
-                        a1 = ix.blocks + (((l >> 6) << 2) + c);
-                        const uint4 *t = ix.blocks + ((((r + 1) >> 6) << 2) + c);
-                        if (t != a1) a2 = t;
+                        a1 = ix.blocks + ((((i64)l >> 6) << 2) + c);
+                        a2 = ix.blocks + (((((i64)r + 1) >> 6) << 2) + c);
                     } else {
                         ev = EV_FAIL;                  // SBWT.hh:427-428
                         tfail = wstart + j;
@@ -441,57 +454,54 @@ __global__ void __launch_bounds__(256, 8) k_search_cert(SbwtIndexView ix, const 
                 }
             }
         }
+        const bool have = (kind == K_MODE && ev == EV_NONE);
         c_search += (unsigned)__popcll(__ballot(kind == K_MODE && (mode == M_INIT || (p == 0 && mode == M_STEP && j == 0))));
-        c_lf += (unsigned)__popcll(__ballot(kind == K_MODE && mode == M_STEP && a1 != nullptr));
+        c_lf += (unsigned)__popcll(__ballot(have && mode == M_STEP));
 
         // ---- the one memory round trip of this iteration ----
-        i64 f0 = 0, f1 = 0, f2 = 0;
-        uint4 v1 = make_uint4(0, 0, 0, 0), v2 = make_uint4(0, 0, 0, 0);
-        if (kind == K_FETCH) {
-            f0 = read_off[l];
-            f1 = read_off[l + 1];
-            f2 = out_off[l];
-        }
-        if (a1) v1 = *a1;
-        if (a2) v2 = *a2;
+        const uint4 v1 = *a1;
+        const uint4 v2 = *a2;
 
         // ---- consume ----
-        bool tabhit = false;
+        bool tabhit = false, do_plan = false, force = false;
         if (kind == K_FETCH) {
-            P0 = f0;
-            obase = f2;
-            m = (int)(f1 - f0) - k + 1;
+            const i64 P0 = (i64)quad_bits(v1);
+            obase = (i64)quad_bits(v2);
+            pgrp = (int)(P0 >> 5);
+            poff = (int)(P0 & 31);
+            m = (int)((i64)((u64)v1.z | ((u64)v1.w << 32)) - P0) - k + 1;
             i = 0;
             b = -1;
-            if (m > 0) plan(true);
+            if (m > 0) { do_plan = true; force = true; }
             else mode = M_IDLE;
         } else if (kind == K_RELOAD) {
             g0 = v1;
             g1 = v2;
-            tag = (int)((P0 + ((mode == M_STREAM || mode == M_BACK) ? (i + k - 1) : (wstart + j))) >> 5);
-        } else if (a1) {
-            if (mode == M_STREAM || mode == M_BACK) {
-                const i64 blk = (mode == M_BACK) ? r : (l >> 6);
+            g1ok = true;
+            tag = grp;
+        } else if (have) {
+            if (strm) {
+                const i64 blk = (mode == M_BACK) ? (i64)r : ((i64)l >> 6);
                 u64 msk = (u64)v1.w | ((u64)v2.w << 32);
                 if (mode == M_STREAM) msk &= (2ull << (int)(l & 63)) - 1ull;
                 if (msk == 0 && blk > 0) {
                     mode = M_BACK;                     // the suffix group starts in an earlier block
-                    r = blk - 1;
+                    r = (pos_t)(blk - 1);
                 } else {
                     if (msk == 0) msk = 1;             // cannot happen: column 0 is always marked
                     const uint4 mine = (c & 1) ? v2 : v1;
                     const int gb = 63 - __clzll((i64)msk);
                     const u64 bits = quad_bits(mine);
-                    u64 val = (u64)mine.z + (u64)__popcll(bits & low_mask(gb));
-                    if (MEGA) val += ix.mega[(i64)c * ix.n_mega + (((blk << 6) | gb) >> SBWT_MEGA_SHIFT)];
+                    pos_t val = (pos_t)mine.z + (pos_t)__popcll(bits & low_mask(gb));
+                    if (WIDE) val += (pos_t)ix.mega[(i64)c * ix.n_mega + (((blk << 6) | gb) >> SBWT_MEGA_SHIFT)];
                     // node_left == node_right <=> column c has its bit set at the group start (SBWT.hh:572-575)
-                    res = ((bits >> gb) & 1ull) ? (i64)val : -1;
+                    res = ((bits >> gb) & 1ull) ? val : (pos_t)-1;
                     ev = EV_EMIT1;
                     if (res == -1) b = i + k - 1;
                 }
             } else if (mode == M_INIT) {
-                l = (i64)quad_bits(v1);
-                r = (i64)((u64)v1.z | ((u64)v1.w << 32));
+                l = (pos_t)(i64)quad_bits(v1);
+                r = (pos_t)(i64)((u64)v1.z | ((u64)v1.w << 32));
                 tabhit = (l != -1);
                 if (l == -1) {
                     ev = EV_FAIL;                      // read[wstart .. wstart+p-1] is not in the index
@@ -502,11 +512,8 @@ __global__ void __launch_bounds__(256, 8) k_search_cert(SbwtIndexView ix, const 
                     else mode = M_STEP;
                 }
             } else {   // M_STEP
-                if (!a2) v2 = v1;
-                const u64 va = quad_rank<MEGA>(ix, v1, l, c);
-                const u64 vb = quad_rank<MEGA>(ix, v2, r + 1, c);
-                l = (i64)va;
-                r = (i64)vb - 1;
+                l = quad_rank_t<WIDE>(ix, v1, l, c);
+                r = quad_rank_t<WIDE>(ix, v2, r + 1, c) - 1;
                 if (l > r) {
                     ev = EV_FAIL;                      // SBWT.hh:433
                     tfail = wstart + j;
@@ -516,9 +523,10 @@ __global__ void __launch_bounds__(256, 8) k_search_cert(SbwtIndexView ix, const 
             }
         }
         c_tab += (unsigned)__popcll(__ballot(tabhit));
-        c_stream += (unsigned)__popcll(__ballot(ev == EV_EMIT1 && (mode == M_STREAM || mode == M_BACK)));
+        c_stream += (unsigned)__popcll(__ballot(ev == EV_EMIT1 && strm));
 
-        // ---- events ----
+        // ---- events: results, certificates, next state ----
+        int burst_hi = -1;                             // >= i: k-mers i..burst_hi are certified absent
         if (ev == EV_END) {
             if (wstart == i) {                         // k chars matched from i: the k-mer is there
                 res = l;
@@ -526,40 +534,326 @@ __global__ void __launch_bounds__(256, 8) k_search_cert(SbwtIndexView ix, const 
                 ev = EV_EMIT1;
                 b = -1;
             } else {
-                plan(true);                            // probe inconclusive: the reference's own walk
+                do_plan = true;                        // probe inconclusive: the reference's own walk
+                force = true;
             }
         } else if (ev == EV_FAIL) {
             // read[wstart..tfail] is not in the index: k-mers i..min(wstart, m-1) all contain it
-            const int hi = (wstart < m - 1) ? wstart : (m - 1);
+            burst_hi = (wstart < m - 1) ? wstart : (m - 1);
             b = tfail;
-            if (hi == i) {
-                ev = EV_EMIT1;                         // res == -1
-            } else {
-                flush();
-#pragma unroll 1
-                for (int t = i; t <= hi; t++) out[obase + t] = -1;
-                i = hi + 1;
-                if (i == m) mode = M_IDLE;
-                else plan(false);
-            }
+            if (burst_hi == i) { ev = EV_EMIT1; burst_hi = -1; }   // a single -1 goes through the stage
         }
         if (ev == EV_EMIT1) {
-            stage[cnt][tid] = (u64)res;
+            stage[cnt][tid] = (stage_t)res;
             cnt++;
             i++;
-            if (cnt == STAGE_DEPTH || i == m) flush();
+        }
+        // ---- result writes, wave-cooperative ----
+        // Staged results are those of k-mers [i-cnt, i); they leave as one run that ends on a line
+        // boundary of `out` (DEPTH results = one 128-byte / 64-byte line), at a burst, or at the read's
+        // end.  A certified burst is a run of -1.  Each run is written by a group of DEPTH lanes with one
+        // coalesced store (64/DEPTH runs per store instruction) instead of a per-lane loop of 8-byte
+        // stores that would execute in almost every iteration for a handful of lanes.
+        {
+            const bool fl = (cnt > 0) && (burst_hi >= 0 || i == m || (((unsigned)obase + (unsigned)i) & (DEPTH - 1)) == 0);
+            i64 dst = obase + (i - cnt);               // run of staged results
+            int nrun = fl ? cnt : 0;
+            u64 fm = __ballot(fl);
+            const int sub = lane & (DEPTH - 1), grpl = lane / DEPTH;
+            constexpr int NG = 64 / DEPTH;
+            while (fm) {
+                int src = -1;
+#pragma unroll
+                for (int g = 0; g < NG; g++) {
+                    int f = fm ? (__ffsll((i64)fm) - 1) : -1;
+                    fm &= fm - 1;
+                    src = (grpl == g) ? f : src;
+                }
+                const int srcl = src < 0 ? 0 : src;
+                const i64 d = __shfl(dst, srcl);
+                const int nn = __shfl(nrun, srcl);
+                if (src >= 0 && sub < nn && !(ix.debug & 1)) {
+                    const i64 val = (i64)(pos_t)stage[sub][(tid & ~63) + src];
+                    if (ix.debug & 2) out[d + sub] = val;
+                    else st_stream(out + d + sub, val);
+                }
+            }
+            if (fl) cnt = 0;
+            // certified bursts: k-mers i..burst_hi are -1
+            dst = obase + i;
+            nrun = (burst_hi >= 0) ? (burst_hi - i + 1) : 0;
+            fm = __ballot(nrun > 0);
+            while (fm) {
+                int src = -1;
+                u64 served = 0;
+#pragma unroll
+                for (int g = 0; g < NG; g++) {
+                    int f = fm ? (__ffsll((i64)fm) - 1) : -1;
+                    if (f >= 0) served |= 1ull << f;
+                    fm &= fm - 1;
+                    src = (grpl == g) ? f : src;
+                }
+                const int srcl = src < 0 ? 0 : src;
+                const i64 d = __shfl(dst, srcl);
+                const int nn = __shfl(nrun, srcl);
+                if (src >= 0 && sub < nn && !(ix.debug & 1)) {
+                    if (ix.debug & 2) out[d + sub] = -1;
+                    else st_stream(out + d + sub, -1);
+                }
+                if ((served >> lane) & 1ull) { dst += DEPTH; nrun -= DEPTH; }
+                fm = __ballot(nrun > 0);
+            }
+            if (burst_hi >= 0) i = burst_hi + 1;
+        }
+        if (ev == EV_EMIT1 || burst_hi >= 0) {
             if (i == m) {
                 mode = M_IDLE;
-            } else if (res != -1 && streaming) {
+            } else if (ev == EV_EMIT1 && res != -1 && streaming) {
                 mode = M_STREAM;                       // SBWT.hh:560-
                 l = res;
             } else {
-                plan(false);                           // SBWT.hh:557-559 (with certificates)
+                do_plan = true;                        // SBWT.hh:557-559 (with certificates)
             }
+        }
+        if (do_plan) {
+            // where the next walk starts (see the header comment): at k-mer i itself, or close to
+            // the last failure position b when b lies inside k-mer i's window
+            int s0 = i;
+            if (!force && L0 > 0 && b >= i && b <= i + k - 1) {
+                s0 = (b - i >= L0 - 1) ? (b - L0 + 1) : b;
+                if (s0 + p - 1 > i + k - 1) s0 = i;
+            }
+            wstart = s0;
+            j = 0;
+            if (p > 0) mode = M_INIT;
+            else { mode = M_STEP; l = 0; r = last_node; }
         }
     }
 
     if (lane == 0) {   // the counters are wave-uniform
+        atomicAdd(&ws->n_stream, (u64)c_stream);
+        atomicAdd(&ws->n_search, (u64)c_search);
+        atomicAdd(&ws->n_lf, (u64)c_lf);
+        atomicAdd(&ws->n_tab_hit, (u64)c_tab);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_search_flat: the state machine of k_search_cert written as straight-line, select-based code.
+// In a wave every state is present in every iteration, so divergent branches buy nothing and cost
+// exec-mask bookkeeping and register copies (k_search_cert: 483 VALU of which 182 v_mov, 531 SALU
+// per iteration); here each iteration computes the candidates of all states once and selects.
+// Same states, same certificates, same results.
+// ---------------------------------------------------------------------------------------------
+template <bool WIDE>
+__global__ void __launch_bounds__(256, 4) k_search_flat(SbwtIndexView ix, const uint4 *__restrict__ packed,
+                                                        const i64 *__restrict__ read_off,
+                                                        const i64 *__restrict__ out_off, i64 *__restrict__ out,
+                                                        i64 n_reads, SbwtWorkHeader *ws, int streaming) {
+    typedef typename SearchTypes<WIDE>::pos_t pos_t;
+    typedef typename SearchTypes<WIDE>::stage_t stage_t;
+    constexpr int DEPTH = SearchTypes<WIDE>::DEPTH;
+    __shared__ stage_t stage[DEPTH][256];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int k = ix.k, p = ix.p_dev, L0 = ix.probe_len;
+    const pos_t last_node = (pos_t)(ix.n_nodes - 1);
+    const u64 vm = low_mask(p), tm = low_mask(2 * p);
+    // all gathers are addressed as byte offsets from the first block of the index image
+    const char *const base = reinterpret_cast<const char *>(ix.blocks);
+    const i64 d_ptab = reinterpret_cast<const char *>(ix.ptab) - base;
+    const i64 d_packed = reinterpret_cast<const char *>(packed) - base;
+    const i64 d_roff = reinterpret_cast<const char *>(read_off) - base;
+    const i64 d_ooff = reinterpret_cast<const char *>(out_off) - base;
+
+    int mode = M_IDLE;
+    i64 obase = 0;
+    int pgrp = 0, poff = 0;
+    int m = 0, i = 0, j = 0, b = -1, wstart = 0, cnt = 0;
+    pos_t l = 0, r = 0;
+    i64 rd = 0;
+    int tag = -2;
+    bool g1ok = false;
+    uint4 g0 = make_uint4(0, 0, 0, 0), g1 = make_uint4(0, 0, 0, 0);
+    u64 pool_next = 0, pool_end = 0;
+    unsigned c_stream = 0, c_search = 0, c_lf = 0, c_tab = 0;
+
+    for (;;) {
+        // ---- hand out reads to idle lanes from the wave's ticket pool ----
+        const u64 need = __ballot(mode == M_IDLE);
+        if (need) {
+            if (pool_next == pool_end) {
+                u64 t = 0;
+                if (lane == 0) t = atomicAdd(&ws->ticket, 64ull);
+                t = __shfl(t, 0);
+                pool_next = t;
+                pool_end = t + 64;
+            }
+            const unsigned avail = (unsigned)(pool_end - pool_next);
+            const unsigned n = (unsigned)__popcll(need);
+            const unsigned rank = (unsigned)__popcll(need & low_mask(lane));
+            if (mode == M_IDLE && rank < avail) {
+                rd = (i64)(pool_next + rank);
+                mode = (rd < n_reads) ? M_FETCH : M_DEAD;
+            }
+            pool_next += (n < avail) ? n : avail;
+        }
+        if (__ballot(mode != M_DEAD) == 0) break;
+
+        // ---- decode the lane's state ----
+        const bool mF = (mode == M_FETCH), mS = (mode == M_STREAM), mB = (mode == M_BACK);
+        const bool mI = (mode == M_INIT), mT = (mode == M_STEP);
+        const bool strm = mS | mB;
+        const bool active = strm | mI | mT;
+        const int q = strm ? (i + k - 1) : (wstart + j);
+        const int P = poff + q;
+        const int s = P & 31;
+        const int grp = pgrp + (P >> 5);
+        const bool span = mI & (s + p > 32);
+        const bool shift = active & (grp == tag + 1) & g1ok & !span;
+        g0.x = shift ? g1.x : g0.x; g0.y = shift ? g1.y : g0.y;
+        g0.z = shift ? g1.z : g0.z; g0.w = shift ? g1.w : g0.w;
+        tag = shift ? grp : tag;
+        g1ok = g1ok & !shift;
+        const bool reload = active & ((grp != tag) | (span & !g1ok));
+        const bool work = active & !reload;
+
+        const u64 codes0 = quad_bits(g0);
+        const u64 cw = codes0 >> (2 * s);
+        const int c = (int)((unsigned)cw & 3u);
+        const u64 hi = s ? (quad_bits(g1) << ((64 - 2 * s) & 63)) : 0ull;
+        const u64 widx = (cw | hi) & tm;
+        const u64 vr = ((((u64)g1.w << 32) | (u64)g0.w) >> s);
+        const u64 bad = ~vr & vm;
+        const bool okU = (g0.z >> s) & 1u, okR = (g0.w >> s) & 1u;
+        const bool inv_s = work & strm & !okU;          // SBWT.hh:568
+        const bool inv_i = work & mI & (bad != 0);      // SBWT.hh:398-399
+        const bool inv_t = work & mT & !okR;            // SBWT.hh:427-428
+        const bool have = work & !(inv_s | inv_i | inv_t);
+
+        // ---- the two gather addresses ----
+        const i64 blk1 = mB ? (i64)r : ((i64)l >> 6);
+        const i64 offA = (blk1 << 6) + ((strm ? (c & 2) : c) << 4);
+        const i64 offB = strm ? (offA + 16) : (((((i64)r + 1) >> 6) << 6) + (c << 4));
+        const i64 offT = d_ptab + (i64)(widx << 4);
+        const i64 offG = d_packed + ((i64)grp << 4);
+        i64 o1 = 0, o2 = 0;
+        o1 = have ? (mI ? offT : offA) : o1;
+        o2 = have ? (mI ? offT : offB) : o2;
+        o1 = reload ? offG : o1;
+        o2 = reload ? (offG + 16) : o2;
+        o1 = mF ? (d_roff + (rd << 3)) : o1;
+        o2 = mF ? (d_ooff + (rd << 3)) : o2;
+        c_search += (unsigned)__popcll(__ballot(work & (mI | ((p == 0) & mT & (j == 0)))));
+        c_lf += (unsigned)__popcll(__ballot(have & mT));
+
+        // ---- the one memory round trip of this iteration ----
+        const uint4 v1 = *reinterpret_cast<const uint4 *>(base + o1);
+        const uint4 v2 = *reinterpret_cast<const uint4 *>(base + o2);
+
+        // ---- candidates of every state ----
+        // packed group reload
+        g0.x = reload ? v1.x : g0.x; g0.y = reload ? v1.y : g0.y;
+        g0.z = reload ? v1.z : g0.z; g0.w = reload ? v1.w : g0.w;
+        g1.x = reload ? v2.x : g1.x; g1.y = reload ? v2.y : g1.y;
+        g1.z = reload ? v2.z : g1.z; g1.w = reload ? v2.w : g1.w;
+        g1ok = g1ok | reload;
+        tag = reload ? grp : tag;
+        // new read
+        const i64 P0 = (i64)quad_bits(v1);
+        const int m_new = (int)((i64)((u64)v1.z | ((u64)v1.w << 32)) - P0) - k + 1;
+        obase = mF ? (i64)quad_bits(v2) : obase;
+        pgrp = mF ? (int)(P0 >> 5) : pgrp;
+        poff = mF ? (int)(P0 & 31) : poff;
+        m = mF ? m_new : m;
+        i = mF ? 0 : i;
+        b = mF ? -1 : b;
+        // streaming step / walk-back
+        const u64 ssw = (u64)v1.w | ((u64)v2.w << 32);
+        const u64 msk = mB ? ssw : (ssw & ((2ull << (int)(l & 63)) - 1ull));
+        const bool goback = have & strm & (msk == 0) & (blk1 > 0);
+        const int gb = 63 - __clzll((i64)(msk ? msk : 1ull));
+        const bool odd = strm & (c & 1);
+        const unsigned qx = odd ? v2.x : v1.x, qy = odd ? v2.y : v1.y, qz = odd ? v2.z : v1.z;
+        const int oA = strm ? gb : (int)(l & 63);
+        const u64 bitsA = (u64)qx | ((u64)qy << 32);
+        pos_t rankA = (pos_t)qz + (pos_t)__popcll(bitsA & low_mask(oA));
+        const int oB = (int)((r + 1) & 63);
+        pos_t rankB = (pos_t)v2.z + (pos_t)__popcll(quad_bits(v2) & low_mask(oB));
+        if (WIDE) {
+            rankA += (pos_t)ix.mega[(i64)c * ix.n_mega + ((strm ? ((blk1 << 6) | gb) : (i64)l) >> SBWT_MEGA_SHIFT)];
+            rankB += (pos_t)ix.mega[(i64)c * ix.n_mega + (((i64)r + 1) >> SBWT_MEGA_SHIFT)];
+        }
+        rankB -= 1;
+        const bool hasbit = (bitsA >> oA) & 1ull;
+        const bool s_done = have & strm & !goback;
+        // prefix-table entry
+        const pos_t tl = (pos_t)(i64)quad_bits(v1), tr = (pos_t)(i64)((u64)v1.z | ((u64)v1.w << 32));
+        const bool i_ok = have & mI & (tl != -1);
+        const bool i_fail = have & mI & (tl == -1);
+        // interval update
+        const bool t_ok = have & mT & (rankA <= rankB);
+        const bool t_fail = have & mT & (rankA > rankB);
+        c_tab += (unsigned)__popcll(__ballot(i_ok));
+
+        // ---- merge: walk state ----
+        l = i_ok ? tl : (t_ok ? rankA : l);
+        r = i_ok ? tr : (t_ok ? rankB : (goback ? (pos_t)(blk1 - 1) : r));
+        j = i_ok ? p : (t_ok ? (j + 1) : j);
+        const bool w_end = (i_ok | t_ok) & (wstart + j == i + k);      // alive at the end of k-mer i's window
+        const bool found = w_end & (wstart == i);
+        const bool incon = w_end & !found;
+        if (found & (l != r)) ws->status = SBWT_ERR_NOT_SINGLETON;      // SBWT.hh:410-413
+        const bool fail = inv_i | inv_t | i_fail | t_fail;
+        const int tfail = inv_i ? (wstart + (__ffsll((i64)(bad | (1ull << 63))) - 1))
+                                : (i_fail ? (wstart + p - 1) : (wstart + j));
+        const int bh = (wstart < m - 1) ? wstart : (m - 1);
+        const bool single = fail & (bh == i);
+        const bool burst = fail & !single;
+        const pos_t s_res = hasbit ? rankA : (pos_t)-1;
+        const bool emit1 = s_done | inv_s | found | single;
+        const pos_t res = s_done ? s_res : (found ? l : (pos_t)-1);
+        c_stream += (unsigned)__popcll(__ballot(s_done | inv_s));
+        b = fail ? tfail : (((s_done | inv_s) & (res == -1)) ? (i + k - 1) : (found ? -1 : b));
+
+        // ---- results: LDS stage, line-aligned runs, certified bursts ----
+        if (emit1) stage[cnt][tid] = (stage_t)res;
+        cnt += emit1;
+        i += emit1;
+        if ((cnt > 0) & (burst | (i == m) | ((((unsigned)obase + (unsigned)i) & (DEPTH - 1)) == 0))) {
+#pragma unroll 1
+            for (int t = 0; t < cnt; t++) out[obase + (i - cnt + t)] = (i64)(pos_t)stage[t][tid];
+            cnt = 0;
+        }
+        if (burst) {
+#pragma unroll 1
+            for (int t = i; t <= bh; t++) out[obase + t] = -1;
+            i = bh + 1;
+        }
+
+        // ---- next state ----
+        const bool emitted = emit1 | burst;
+        const bool done = (emitted & (i == m)) | (mF & (m_new <= 0));
+        const bool gostream = emit1 & (res != -1) & (streaming != 0) & !done;
+        const bool do_plan = !done & ((mF & (m_new > 0)) | incon | (emitted & !gostream));
+        const bool force = mF | incon;
+        int s0 = i;
+        const bool near_b = !force & (L0 > 0) & (b >= i) & (b <= i + k - 1);
+        const int cand = (b - i >= L0 - 1) ? (b - L0 + 1) : b;
+        s0 = (near_b & (cand + p - 1 <= i + k - 1)) ? cand : s0;
+        wstart = do_plan ? s0 : wstart;
+        j = do_plan ? 0 : j;
+        l = gostream ? res : ((do_plan & (p == 0)) ? (pos_t)0 : l);
+        r = (do_plan & (p == 0)) ? last_node : r;
+        int nm = mode;
+        nm = goback ? M_BACK : nm;
+        nm = (i_ok & !w_end) ? M_STEP : nm;
+        nm = do_plan ? ((p > 0) ? M_INIT : M_STEP) : nm;
+        nm = gostream ? M_STREAM : nm;
+        nm = done ? M_IDLE : nm;
+        mode = nm;
+    }
+
+    if (lane == 0) {
         atomicAdd(&ws->n_stream, (u64)c_stream);
         atomicAdd(&ws->n_search, (u64)c_search);
         atomicAdd(&ws->n_lf, (u64)c_lf);
@@ -679,16 +973,33 @@ void sbwt_launch_encode(const char *d_bases, long long total_bases, uint4 *d_pac
 
 void sbwt_launch_search(const SbwtIndexView &ix, const uint4 *d_packed, const long long *d_read_off,
                         const long long *d_out_off, long long *d_out, long long n_reads, SbwtWorkHeader *ws,
-                        int streaming, hipStream_t stream, int variant) {
+                        int streaming, hipStream_t stream, int variant, long long total_groups) {
     if (n_reads <= 0) return;
+    if (variant == 2) {
+        i64 want2 = (n_reads + 255) / 256;
+        unsigned grid2 = (unsigned)(want2 < 1024 ? want2 : 1024);
+        const bool wide2 = ix.n_nodes >= ((1ll << 31) - 128) || total_groups >= (1ll << 27) - 4;
+        if (wide2)
+            hipLaunchKernelGGL(k_search_flat<true>, dim3(grid2), dim3(256), 0, stream, ix, d_packed, d_read_off,
+                               d_out_off, d_out, (i64)n_reads, ws, streaming);
+        else
+            hipLaunchKernelGGL(k_search_flat<false>, dim3(grid2), dim3(256), 0, stream, ix, d_packed, d_read_off,
+                               d_out_off, d_out, (i64)n_reads, ws, streaming);
+        return;
+    }
     if (variant == 1) {
         i64 want1 = (n_reads + 255) / 256;
         unsigned grid1 = (unsigned)(want1 < 2048 ? want1 : 2048);
-        if (ix.n_mega > 1)
-            hipLaunchKernelGGL(k_search_cert<true>, dim3(grid1), dim3(256), 0, stream, ix, d_packed, d_read_off,
+        // 32-bit positions need every column index (and n_nodes + 64) below 2^31 and < 2^31 packed groups
+        const bool wide = ix.n_nodes >= ((1ll << 31) - 128) || total_groups >= (1ll << 31) - 4;
+        // no-spill build: 72 VGPRs (7 waves/SIMD max); 4 workgroups per CU measured best (tools/ab_bench.py)
+        unsigned cap = (ix.debug >> 8) ? (unsigned)(ix.debug >> 8) : 1024u;
+        unsigned g = grid1 < cap ? grid1 : cap;
+        if (wide)
+            hipLaunchKernelGGL((k_search_cert<true, 4>), dim3(g), dim3(256), 0, stream, ix, d_packed, d_read_off,
                                d_out_off, d_out, (i64)n_reads, ws, streaming);
         else
-            hipLaunchKernelGGL(k_search_cert<false>, dim3(grid1), dim3(256), 0, stream, ix, d_packed, d_read_off,
+            hipLaunchKernelGGL((k_search_cert<false, 4>), dim3(g), dim3(256), 0, stream, ix, d_packed, d_read_off,
                                d_out_off, d_out, (i64)n_reads, ws, streaming);
         return;
     }

@@ -35,9 +35,19 @@ int fail(int code, const char *fmt, ...) {
                         "%s failed: %s", #expr, hipGetErrorString(e_));                        \
     } while (0)
 
-int default_device_precalc() {
+// Depth of the device-side prefix table: deep enough that most walks start with a nearly unique
+// interval (ceil(log4(n_nodes))), capped so that the table stays at 1 GiB (4^13 x 16 B) unless
+// SBWTGPU_DEVICE_PRECALC asks otherwise.  Measured on MI355X (tools/ab_bench.py, 12.8 M columns):
+// 8: 33, 10: 45, 11: 47, 12: 49 G k-mers/s.
+int default_device_precalc(int64_t n_nodes) {
     const char *e = getenv("SBWTGPU_DEVICE_PRECALC");
-    int v = e ? atoi(e) : 10;
+    int v;
+    if (e) {
+        v = atoi(e);
+    } else {
+        v = 1;
+        while (v < 13 && ((int64_t)1 << (2 * v)) < n_nodes) v++;
+    }
     if (v < 0) v = 0;
     if (v > 14) v = 14;
     return v;
@@ -62,7 +72,7 @@ static int tuning_variant() {          // 0 = k_search (reference order), 1 = k_
     static int v = [] { const char *e = getenv("SBWTGPU_SEARCH_VARIANT"); return e ? atoi(e) : 1; }();
     return v;
 }
-static int g_variant_override = -1, g_probe_override = -1;
+static int g_variant_override = -1, g_probe_override = -1, g_debug = 0;
 
 struct sbwtgpu_index {
     SbwtBlobHeader h;
@@ -93,6 +103,7 @@ struct sbwtgpu_index {
         v.n_mega = (int)h.n_mega;
         v.has_ssup = h.has_ssup;
         v.probe_len = probe_len();
+        v.debug = g_debug;
         return v;
     }
 };
@@ -106,6 +117,7 @@ int sbwtgpu_set_tuning(const char *key, int64_t value) {
     if (!key) return fail(SBWTGPU_ERR_INVALID_ARG, "key is NULL");
     if (!strcmp(key, "search_variant")) { g_variant_override = (int)value; return SBWTGPU_OK; }
     if (!strcmp(key, "probe_len")) { g_probe_override = (int)value; return SBWTGPU_OK; }
+    if (!strcmp(key, "debug")) { g_debug = (int)value; return SBWTGPU_OK; }
     return fail(SBWTGPU_ERR_INVALID_ARG, "unknown tuning key '%s'", key);
 }
 
@@ -147,7 +159,7 @@ int sbwtgpu_index_create(const sbwtgpu_index_desc *d, int device, sbwtgpu_index 
     const int64_t n_blocks = n / 64 + 1;
     const int64_t n_mega = (n >> SBWT_MEGA_SHIFT) + 1;
     int64_t p_file = d->precalc_k;
-    int64_t p_dev = default_device_precalc();
+    int64_t p_dev = default_device_precalc(n);
     if (p_dev < p_file) p_dev = p_file;
     if (p_dev > d->k) p_dev = d->k;
 
@@ -463,7 +475,8 @@ int sbwtgpu_search_encoded_dev(const sbwtgpu_index *idx, int64_t total_bases, co
     const uint4 *packed = reinterpret_cast<const uint4 *>(static_cast<char *>(d_ws) + sizeof(SbwtWorkHeader));
     sbwt_launch_search(idx->view(), packed, reinterpret_cast<const long long *>(d_read_off),
                        reinterpret_cast<const long long *>(d_out_off), reinterpret_cast<long long *>(d_out), n_reads,
-                       ws, streaming, st, g_variant_override >= 0 ? g_variant_override : tuning_variant());
+                       ws, streaming, st, g_variant_override >= 0 ? g_variant_override : tuning_variant(),
+                       total_bases / SBWT_GROUP_BASES + 2);
     e = hipGetLastError();
     if (e != hipSuccess) return fail(SBWTGPU_ERR_HIP, "kernel launch: %s", hipGetErrorString(e));
     return SBWTGPU_OK;

@@ -6,6 +6,7 @@ sys.path.insert(0, ROOT)
 import torch
 from sbwt_amd import capi, hostlib, synth
 import bench as B
+B.SUB_RATE = float(os.environ.get("SUB", B.SUB_RATE))
 
 n_reads = int(os.environ.get("NREADS", 4_000_000))
 glen = int(os.environ.get("GLEN", 5_000_000))
@@ -29,7 +30,7 @@ ref = None
 times = {tuple(c): [] for c in configs}
 for rnd in range(rounds + 1):
     for c in configs:
-        capi.set_tuning("search_variant", c[0]); capi.set_tuning("probe_len", c[1])
+        capi.set_tuning("search_variant", c[0]); capi.set_tuning("probe_len", c[1]); capi.set_tuning("debug", c[2] if len(c) > 2 else 0)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         idx.search_encoded_dev(d_bases.numel(), d_roff.data_ptr(), n_reads, d_out.data_ptr(), d_ooff.data_ptr(), d_ws.data_ptr(), wsb, True, st)
