@@ -243,16 +243,22 @@ def main() -> int:
         h_bases = d_bases[: probe * READ_LEN].cpu().numpy()
         roff = np.arange(probe + 1, dtype=np.int64) * READ_LEN
         ooff = np.arange(probe + 1, dtype=np.int64) * m
-        t1 = time.perf_counter()
-        orc.batch_search(h_bases, roff, ooff, 1)
-        per_read_1t = (time.perf_counter() - t1) / probe
-        sample = int(min(n_reads, max(probe, 20.0 / per_read_1t)))      # ~20 core-seconds of CPU work
+        _, secs1 = orc.batch_search(h_bases, roff, ooff, 1)
+        per_read_1t = secs1 / probe
+        # bounded sample: ~1 s of work per thread (about `cores` core-seconds), at most all reads
+        sample = int(min(n_reads, max(probe, cores * 1.0 / per_read_1t)))
         h_bases = d_bases[: sample * READ_LEN].cpu().numpy()
         roff = np.arange(sample + 1, dtype=np.int64) * READ_LEN
         ooff = np.arange(sample + 1, dtype=np.int64) * m
-        t1 = time.perf_counter()
-        cpu_out, _ = orc.batch_search(h_bases, roff, ooff, cores)
-        wall = time.perf_counter() - t1
+        cpu_out = np.full(sample * m, -3, dtype=np.int64)           # pre-faulted
+        best = None
+        for _ in range(2):                                           # second pass runs warm
+            t1 = time.perf_counter()
+            _, busy = orc.batch_search(h_bases, roff, ooff, cores, out=cpu_out)
+            wall_i = time.perf_counter() - t1
+            if best is None or busy < best[0]:
+                best = (busy, wall_i)
+        wall = best[0]      # the slowest thread's summed query time (sbwt_search.cpp:54-56 style)
         gpu_out = d_out[: sample * m].cpu().numpy()
         parity = bool(np.array_equal(cpu_out, gpu_out))
         result["cpu_baseline"] = {
@@ -261,7 +267,9 @@ def main() -> int:
             "cores": cores,
             "kind": "port",
             "sample": "first %d of the same reads (%d k-mers), oracle streaming_search, %d threads over "
-                      "contiguous read ranges, wall clock" % (sample, sample * m, cores),
+                      "contiguous read ranges; time = slowest thread's summed per-read query time "
+                      "(sbwt_search.cpp:54-56 style, best of 2 passes, output pre-faulted); wall clock of that "
+                      "pass %.3f s" % (sample, sample * m, cores, best[1]),
             "value_1thread": m / per_read_1t,
             "gpu_output_bit_identical_on_sample": parity,
         }

@@ -180,12 +180,16 @@ class OracleIndex:
         lib().orc_mark_suffix_groups(self._p, out.ctypes.data)
         return out
 
-    def batch_search(self, bases: np.ndarray, read_off: np.ndarray, out_off: np.ndarray, n_threads: int = 1):
-        """Returns (out, seconds): seconds = summed per-read query time like sbwt_search.cpp:54-56."""
+    def batch_search(self, bases: np.ndarray, read_off: np.ndarray, out_off: np.ndarray, n_threads: int = 1,
+                     out: Optional[np.ndarray] = None):
+        """Returns (out, seconds): seconds = the largest per-thread sum of per-read query times, timed
+        like sbwt_search.cpp:54-56 ("excluding I/O etc").  Pass a pre-faulted `out` to keep first-touch
+        page faults out of the timing."""
         bases = np.ascontiguousarray(bases, dtype=np.uint8)
         read_off = np.ascontiguousarray(read_off, dtype=np.int64)
         out_off = np.ascontiguousarray(out_off, dtype=np.int64)
-        out = np.zeros(int(out_off[-1]), dtype=np.int64)
+        if out is None:
+            out = np.full(int(out_off[-1]), -3, dtype=np.int64)
         secs = lib().orc_batch_search(self._p, bases.ctypes.data, read_off.ctypes.data, len(read_off) - 1,
                                       out.ctypes.data, out_off.ctypes.data, n_threads)
         return out, secs
