@@ -47,6 +47,24 @@ B_LF = 2 * 72                   # interval update: two ranks, (8 count + 64 bloc
 B_OUT = 8                       # one int64 result
 
 
+def effective_cores() -> int:
+    """CPUs this process may actually use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per) + 0.5)))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, int(q / per + 0.5)))
+        except Exception:
+            pass
+    return max(1, n)
+
+
 def log(msg: str) -> None:
     print(f"[bench] {msg}", file=sys.stderr, flush=True)
 
@@ -107,7 +125,7 @@ def main() -> int:
     genomes = synth.coli3_like(args.genome_len)
     bits = None
     if rank == 0:
-        bits = hostlib.build_bits([g.tobytes() for g in genomes], K, False, True, n_threads=os.cpu_count() or 1)
+        bits = hostlib.build_bits([g.tobytes() for g in genomes], K, False, True, n_threads=effective_cores())
         index = capi.Index.create(bits.cols[0], bits.cols[1], bits.cols[2], bits.cols[3], bits.ssup, bits.n_nodes, K,
                                   bits.n_kmers, PRECALC, None, device=local_rank)
         log(f"index: n_nodes={index.n_nodes} n_kmers={index.n_kmers} image={index.blob_bytes / 1e6:.1f} MB "
@@ -238,7 +256,7 @@ def main() -> int:
         from oracle import OracleIndex  # test infrastructure: used here only as baseline + checker
         orc = OracleIndex.from_bits(bits.cols[0], bits.cols[1], bits.cols[2], bits.cols[3], bits.ssup, bits.n_nodes,
                                     K, bits.n_kmers, PRECALC)
-        cores = os.cpu_count() or 1
+        cores = effective_cores()
         probe = min(n_reads, 20_000)
         h_bases = d_bases[: probe * READ_LEN].cpu().numpy()
         roff = np.arange(probe + 1, dtype=np.int64) * READ_LEN
@@ -271,6 +289,7 @@ def main() -> int:
                       "(sbwt_search.cpp:54-56 style, best of 2 passes, output pre-faulted); wall clock of that "
                       "pass %.3f s" % (sample, sample * m, cores, best[1]),
             "value_1thread": m / per_read_1t,
+            "host_logical_cpus": os.cpu_count(),
             "gpu_output_bit_identical_on_sample": parity,
         }
         result["gpu_vs_cpu"] = value / (sample * m / wall)

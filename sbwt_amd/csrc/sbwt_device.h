@@ -49,7 +49,7 @@ struct SbwtBlobHeader {
     int64_t n_blocks, n_mega;
     int64_t off_blocks, off_ptab, off_ftab, off_mega, blob_bytes;
     int32_t has_ssup;
-    int32_t reserved;
+    int32_t rank_only;              // the columns are not SBWT-consistent: only rank() is served
 };
 #define SBWT_BLOB_MAGIC 0x3155504754574253ull   // "SBWTGPU1" little endian
 

@@ -991,7 +991,7 @@ void sbwt_launch_search(const SbwtIndexView &ix, const uint4 *d_packed, const lo
         i64 want1 = (n_reads + 255) / 256;
         unsigned grid1 = (unsigned)(want1 < 2048 ? want1 : 2048);
         // 32-bit positions need every column index (and n_nodes + 64) below 2^31 and < 2^31 packed groups
-        const bool wide = ix.n_nodes >= ((1ll << 31) - 128) || total_groups >= (1ll << 31) - 4;
+        const bool wide = ix.n_nodes >= ((1ll << 31) - 128) || total_groups >= (1ll << 31) - 4 || (ix.debug & 16);
         // no-spill build: 72 VGPRs (7 waves/SIMD max); 4 workgroups per CU measured best (tools/ab_bench.py)
         unsigned cap = (ix.debug >> 8) ? (unsigned)(ix.debug >> 8) : 1024u;
         unsigned g = grid1 < cap ? grid1 : cap;

@@ -178,9 +178,10 @@ int sbwtgpu_index_create(const sbwtgpu_index_desc *d, int device, sbwtgpu_index 
     h.has_ssup = d->suffix_group_starts ? 1 : 0;
     h.off_blocks = 0;
     h.off_ptab = align256(n_blocks * 64);
-    int64_t ptab_bytes = p_dev > 0 ? (int64_t)16 << (2 * p_dev) : 0;
+    int64_t ptab_bytes = p_dev > 0 ? (int64_t)16 << (2 * p_dev) : 0;   // revised below for rank-only images
     h.off_ftab = align256(h.off_ptab + ptab_bytes);
     int64_t ftab_bytes = (p_file > 0 && p_file != p_dev) ? (int64_t)16 << (2 * p_file) : 0;
+    (void)ptab_bytes;
     if (ftab_bytes == 0) h.off_ftab = h.off_ptab;   // the same table serves both
     h.off_mega = align256(h.off_ftab + (ftab_bytes ? ftab_bytes : ptab_bytes));
     h.blob_bytes = align256(h.off_mega + 4 * n_mega * 8);
@@ -199,6 +200,35 @@ int sbwtgpu_index_create(const sbwtgpu_index_desc *d, int device, sbwtgpu_index 
         for (int64_t w = 0; w < nw; w++) tot[c] += __builtin_popcountll(word(cols[c], w));
     h.C[0] = 1;
     for (int c = 1; c < 4; c++) h.C[c] = h.C[c - 1] + tot[c - 1];
+    // In an SBWT every column except the root has exactly one incoming edge, so the matrix holds
+    // n_nodes - 1 set bits and every LF step stays inside [0, n_nodes).  Arbitrary bit vectors (the
+    // stand-alone SubsetMatrixRank use) are still served, but only by rank(): walking them would
+    // leave the image.
+    const bool consistent = (tot[0] + tot[1] + tot[2] + tot[3] == n - 1);
+    h.rank_only = consistent ? 0 : 1;
+    if (!consistent) {
+        if (p_file > 0) {
+            delete idx;
+            return fail(SBWTGPU_ERR_INVALID_ARG,
+                        "the four columns hold %lld set bits, an SBWT with %lld columns holds %lld: cannot "
+                        "compute a prefix table", (long long)(tot[0] + tot[1] + tot[2] + tot[3]), (long long)n,
+                        (long long)(n - 1));
+        }
+        p_dev = 0;
+        h.p_dev = 0;
+        h.has_ssup = 0;
+    }
+    if (d->precalc && p_file > 0) {
+        const int64_t np = (int64_t)1 << (2 * p_file);
+        for (int64_t e = 0; e < np; e++) {
+            int64_t l = d->precalc[2 * e], r = d->precalc[2 * e + 1];
+            if (!((l == -1 && r == -1) || (l >= 0 && l <= r && r < n))) {
+                delete idx;
+                return fail(SBWTGPU_ERR_INVALID_ARG, "prefix table entry %lld = (%lld, %lld) is outside the index",
+                            (long long)e, (long long)l, (long long)r);
+            }
+        }
+    }
 
     // interleaved blocks + mega table, built on the host in one pass, then uploaded
     std::vector<uint32_t> blocks;
@@ -236,6 +266,13 @@ int sbwtgpu_index_create(const sbwtgpu_index_desc *d, int device, sbwtgpu_index 
         }
     }
 
+    if (h.rank_only) {   // no tables in a rank-only image
+        ptab_bytes = 0;
+        ftab_bytes = 0;
+        h.off_ptab = h.off_ftab = align256(n_blocks * 64);
+        h.off_mega = h.off_ptab;
+        h.blob_bytes = align256(h.off_mega + 4 * n_mega * 8);
+    }
     hipError_t e = hipMalloc((void **)&idx->blob, (size_t)h.blob_bytes);
     if (e != hipSuccess) {
         delete idx;
@@ -431,9 +468,13 @@ int64_t sbwtgpu_search_workspace_bytes(int64_t total_bases) {
     return (int64_t)sizeof(SbwtWorkHeader) + groups * 16;
 }
 
+static const char *RANK_ONLY_MSG =
+    "the index columns are not a valid SBWT (set bits != n_nodes - 1): only rank() is available";
+
 static int search_dev_check(const sbwtgpu_index *idx, int64_t total_bases, int64_t n_reads, const void *d_ws,
                             int64_t ws_bytes, int streaming) {
     if (!idx) return fail(SBWTGPU_ERR_INVALID_ARG, "idx is NULL");
+    if (idx->h.rank_only) return fail(SBWTGPU_ERR_INVALID_ARG, "%s", RANK_ONLY_MSG);
     if (streaming && !idx->h.has_ssup)
         return fail(SBWTGPU_ERR_NO_STREAMING, "Error: streaming search support not built");
     if (n_reads < 0 || total_bases < 0) return fail(SBWTGPU_ERR_INVALID_ARG, "negative size");
@@ -658,6 +699,7 @@ int sbwtgpu_rank_batch(const sbwtgpu_index *idx, const int64_t *pos, const char 
 int sbwtgpu_update_interval_batch(const sbwtgpu_index *idx, const char *bases, const int64_t *off, int64_t n,
                                   int64_t *first, int64_t *second) {
     if (!idx) return fail(SBWTGPU_ERR_INVALID_ARG, "idx is NULL");
+    if (idx->h.rank_only) return fail(SBWTGPU_ERR_INVALID_ARG, "%s", RANK_ONLY_MSG);
     if (n < 0) return fail(SBWTGPU_ERR_INVALID_ARG, "negative n");
     if (n == 0) return SBWTGPU_OK;
     if (!off || !first || !second) return fail(SBWTGPU_ERR_INVALID_ARG, "NULL argument");
@@ -693,6 +735,7 @@ int sbwtgpu_update_interval_batch(const sbwtgpu_index *idx, const char *bases, c
 
 int sbwtgpu_forward_batch(const sbwtgpu_index *idx, const int64_t *node, const char *sym, int64_t n, int64_t *out) {
     if (!idx) return fail(SBWTGPU_ERR_INVALID_ARG, "idx is NULL");
+    if (idx->h.rank_only) return fail(SBWTGPU_ERR_INVALID_ARG, "%s", RANK_ONLY_MSG);
     if (!idx->h.has_ssup)
         return fail(SBWTGPU_ERR_NO_STREAMING, "Error: Streaming support required for SBWT::forward");
     if (n < 0) return fail(SBWTGPU_ERR_INVALID_ARG, "negative n");

@@ -237,3 +237,45 @@ def test_results_do_not_depend_on_search_variant_or_probe_length(gpu, genome_cas
     finally:
         capi.set_tuning("search_variant", -1)
         capi.set_tuning("probe_len", -1)
+
+
+def test_wide_kernel_instantiation_matches(gpu, genome_case):
+    # the 64-bit-position instantiation (used when n_nodes >= 2^31) forced onto a small index
+    genomes, orc = genome_case
+    idx = gpu_index_from_oracle(orc)
+    bases, off = synth.sample_reads(genomes, 3000, 150, 0.02, 91)
+    bases = synth.inject(bases, 40, ord("N"), 3)
+    capi.set_tuning("debug", 16)
+    try:
+        got, _ = idx.streaming_search(bases, off)
+        got2, _ = idx.search(bases, off)
+    finally:
+        capi.set_tuning("debug", 0)
+    assert np.array_equal(got, oracle_batch(orc, bases, off, True))
+    assert np.array_equal(got2, oracle_batch(orc, bases, off, False))
+
+
+def test_rank_beyond_2_pow_31_columns(gpu):
+    # mega-block path: more than 2^31 columns (random bit matrix; rank() is defined for any bits)
+    n = (1 << 31) + 1_000_003
+    nw = (n + 63) // 64
+    rng = np.random.default_rng(17)
+    cols = [rng.integers(0, 1 << 63, size=nw, dtype=np.int64).astype(np.uint64) for _ in range(4)]
+    idx = capi.Index.create(cols[0], cols[1], cols[2], cols[3], None, n, 31, 0, 0)
+    with pytest.raises(capi.SbwtGpuError, match="only rank"):      # random bits are not an SBWT
+        idx.search(np.frombuffer(b"A" * 40, dtype=np.uint8), np.array([0, 40]))
+    pos = np.concatenate([rng.integers(0, n + 1, size=4000),
+                          np.array([0, 1, (1 << 31) - 1, 1 << 31, (1 << 31) + 1, (1 << 31) + 64, n - 1, n])])
+    sym = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=len(pos))
+    got = idx.rank(pos, sym)
+    pc = [np.concatenate([[0], np.cumsum(np.bitwise_count(c).astype(np.int64))]) for c in cols]
+    code = {65: 0, 67: 1, 71: 2, 84: 3}
+    tail_mask = (np.uint64(1) << np.uint64(n & 63)) - np.uint64(1) if n & 63 else None
+    for p_, s_, g in zip(pos, sym, got):
+        c = code[int(s_)]
+        w, b = int(p_) >> 6, int(p_) & 63
+        want = int(pc[c][w])
+        if b:
+            want += bin(int(cols[c][w]) & ((1 << b) - 1)).count("1")
+        assert g == want, (p_, s_)
+    idx.close()
