@@ -35,7 +35,7 @@ import torch.distributed as dist  # noqa: E402
 from sbwt_amd import capi, hostlib, synth  # noqa: E402
 from sbwt_amd import dist as sdist  # noqa: E402
 
-K = 30
+K = 30                          # overridden by --config (3: k=31 pan-genome, 5: k=63 non-streaming)
 PRECALC = 8
 READ_LEN = 150
 SUB_RATE = 0.01
@@ -105,7 +105,20 @@ def main() -> int:
                     help="reads per GPU")
     ap.add_argument("--genome-len", type=int, default=int(os.environ.get("SBWT_BENCH_GENOME", 5_000_000)))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--config", type=int, default=2, choices=[2, 3, 5],
+                    help="BASELINE.json config: 2 = coli3-like k=30 (headline, default); 3 = pan-genome-like "
+                         "k=31 (65 genomes, 100 M reads unless --reads); 5 = k=63 without streaming support")
+    ap.add_argument("--derived", type=int, default=64, help="config 3: number of derived genomes")
     args = ap.parse_args()
+    global K
+    streaming = True
+    if args.config == 3:
+        K = 31
+        if "SBWT_BENCH_READS" not in os.environ and "--reads" not in sys.argv:
+            args.reads = 100_000_000
+    elif args.config == 5:
+        K = 63
+        streaming = False
 
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
@@ -122,10 +135,10 @@ def main() -> int:
 
     # ---- index: built once on rank 0 (host sort-based builder), replicated by one broadcast ----
     t0 = time.time()
-    genomes = synth.coli3_like(args.genome_len)
+    genomes = synth.pan_like(args.derived, args.genome_len) if args.config == 3 else synth.coli3_like(args.genome_len)
     bits = None
     if rank == 0:
-        bits = hostlib.build_bits([g.tobytes() for g in genomes], K, False, True, n_threads=effective_cores())
+        bits = hostlib.build_bits([g.tobytes() for g in genomes], K, False, streaming, n_threads=effective_cores())
         index = capi.Index.create(bits.cols[0], bits.cols[1], bits.cols[2], bits.cols[3], bits.ssup, bits.n_nodes, K,
                                   bits.n_kmers, PRECALC, None, device=local_rank)
         log(f"index: n_nodes={index.n_nodes} n_kmers={index.n_kmers} image={index.blob_bytes / 1e6:.1f} MB "
@@ -164,7 +177,7 @@ def main() -> int:
         if ev is not None:
             ev[0].record()
         index.search_encoded_dev(total_bases, d_roff.data_ptr(), n_reads, d_out.data_ptr(), d_ooff.data_ptr(),
-                                 d_ws.data_ptr(), ws_bytes, True, stream)
+                                 d_ws.data_ptr(), ws_bytes, streaming, stream)
         if ev is not None:
             ev[1].record()
 
@@ -199,11 +212,14 @@ def main() -> int:
     # SURVEY 8d's nominal formula (every full search priced at all k-p interval updates)
     n_full = n_kmers - n_stream
     nominal_bytes = B_STREAM * n_stream + (K + 16 + 8 + B_LF * (K - PRECALC)) * n_full
+    if not streaming:
+        n_full = n_kmers
 
     total_kmers = n_kmers * world
     value = total_kmers * args.steps / elapsed
     result = {
-        "metric": "k-mers/sec (whole node), plain-matrix k=30 streaming search",
+        "metric": "k-mers/sec (whole node), plain-matrix k=%d %s" % (K, "streaming search" if streaming else
+                                                                       "search (no streaming support)"),
         "value": value,
         "unit": "k-mers/s",
         "n_gpus": world,
@@ -216,9 +232,13 @@ def main() -> int:
         "dtype": "u64",
         "data": "synthetic",
         "config": {
-            "workload": "coli3-like synthetic genomes (3 x %d bp, 5%% divergence) k=30 plain-matrix precalc=8 "
-                        "streaming support; %d synthetic 150bp reads per GPU, 1%% substitutions; "
-                        "SBWT::streaming_search of every read" % (args.genome_len, n_reads),
+            "workload": ("config %d: " % args.config) + (
+                "pan-genome-like synthetic genomes (1 + %d x %d bp, 2%% divergence)" % (args.derived, args.genome_len)
+                if args.config == 3 else
+                "coli3-like synthetic genomes (3 x %d bp, 5%% divergence)" % args.genome_len) +
+                " k=%d plain-matrix precalc=8 %s; %d synthetic 150bp reads per GPU, 1%% substitutions; %s of every read"
+                % (K, "streaming support" if streaming else "NO streaming support", n_reads,
+                   "SBWT::streaming_search" if streaming else "SBWT::search of every k-mer"),
             "k": K, "precalc_k": PRECALC, "read_len": READ_LEN, "reads_per_gpu": n_reads,
             "kmers_per_gpu": n_kmers, "n_nodes": index.n_nodes, "index_image_bytes": index.blob_bytes,
             "parallelism": "reads sharded x%d, index replicated (one RCCL broadcast at load)" % world,
@@ -255,7 +275,7 @@ def main() -> int:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         from oracle import OracleIndex  # test infrastructure: used here only as baseline + checker
         orc = OracleIndex.from_bits(bits.cols[0], bits.cols[1], bits.cols[2], bits.cols[3], bits.ssup, bits.n_nodes,
-                                    K, bits.n_kmers, PRECALC)
+                                    K, bits.n_kmers, PRECALC)   # without ssup it runs the per-k-mer search loop
         cores = effective_cores()
         probe = min(n_reads, 20_000)
         h_bases = d_bases[: probe * READ_LEN].cpu().numpy()

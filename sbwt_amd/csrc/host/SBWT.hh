@@ -8,11 +8,13 @@
 // *_batch members for throughput.  There is no CPU query path here.
 #pragma once
 #include <cstdint>
+#include <algorithm>
 #include <cstring>
 #include <fstream>
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -197,19 +199,33 @@ public:
         return ans;
     }
     // Batched forms (new): read r = bases[read_off[r]..read_off[r+1]), results at out[out_off[r]..].
+    // With replicas (use_devices) the reads are split into contiguous ranges balanced by bases, one
+    // host thread per GPU; results land in place, so the output order never changes.
     void streaming_search_batch(const char *bases, const int64_t *read_off, int64_t n_reads, int64_t *out,
                                 const int64_t *out_off) const {
         if (suffix_group_starts.size() == 0) throw std::runtime_error("Error: streaming search support not built");
-        int rc = sbwtgpu_streaming_search_batch(need_device(), bases, read_off, n_reads, out, out_off);
-        bug_exit(rc);
-        detail::gpu_check(rc);
+        run_sharded(true, bases, read_off, n_reads, out, out_off);
     }
     void search_batch(const char *bases, const int64_t *read_off, int64_t n_reads, int64_t *out,
                       const int64_t *out_off) const {
-        int rc = sbwtgpu_search_batch(need_device(), bases, read_off, n_reads, out, out_off);
-        bug_exit(rc);
-        detail::gpu_check(rc);
+        run_sharded(false, bases, read_off, n_reads, out, out_off);
     }
+    // Replicates the device image onto the listed HIP devices (one RCCL broadcast over xGMI);
+    // the first entry should be the device the index was created on.  Listing a device twice is allowed
+    // (two host threads share it) and is how the sharding is tested on a single-GPU box.
+    void use_devices(const std::vector<int> &devices) {
+        need_device();
+        replicas_.clear();
+        if (devices.size() <= 1) return;
+        std::vector<sbwtgpu_index *> hs(devices.size(), nullptr);
+        detail::gpu_check(sbwtgpu_index_bcast(dev_->h, (int)devices.size(), devices.data(), hs.data()));
+        for (sbwtgpu_index *h : hs) {
+            auto p = std::make_shared<detail::DeviceIndex>();
+            if (h != dev_->h) p->h = h;   // owned replica; the root stays owned by dev_
+            replicas_.push_back({p, h});
+        }
+    }
+    int number_of_devices() const { return replicas_.empty() ? 1 : (int)replicas_.size(); }
     std::pair<int64_t, int64_t> update_sbwt_interval(const std::string &S, std::pair<int64_t, int64_t> I) const {
         return update_sbwt_interval(S.c_str(), (int64_t)S.size(), I);
     }
@@ -288,6 +304,52 @@ private:
     int64_t precalc_k = 0;
     int64_t n_nodes, n_kmers, k;
     std::shared_ptr<detail::DeviceIndex> dev_;
+    struct Replica { std::shared_ptr<detail::DeviceIndex> owner; sbwtgpu_index *h; };
+    std::vector<Replica> replicas_;
+
+    void run_one(bool streaming, const sbwtgpu_index *h, const char *bases, const int64_t *read_off, int64_t n_reads,
+                 int64_t *out, const int64_t *out_off, int *rc_out, std::string *err) const {
+        int rc = streaming ? sbwtgpu_streaming_search_batch(h, bases, read_off, n_reads, out, out_off)
+                           : sbwtgpu_search_batch(h, bases, read_off, n_reads, out, out_off);
+        *rc_out = rc;
+        if (rc != SBWTGPU_OK) *err = sbwtgpu_last_error();   // thread-local: capture it on this thread
+    }
+    void run_sharded(bool streaming, const char *bases, const int64_t *read_off, int64_t n_reads, int64_t *out,
+                     const int64_t *out_off) const {
+        const sbwtgpu_index *root = need_device();
+        const int G = number_of_devices();
+        std::vector<int> rcs((size_t)G, SBWTGPU_OK);
+        std::vector<std::string> errs((size_t)G);
+        if (G == 1 || n_reads < 2 * G) {
+            run_one(streaming, root, bases, read_off, n_reads, out, out_off, &rcs[0], &errs[0]);
+        } else {
+            // contiguous shards balanced by bases
+            std::vector<int64_t> cut((size_t)G + 1, 0);
+            const int64_t total = read_off[n_reads] - read_off[0];
+            for (int g = 1; g < G; g++) {
+                const int64_t target = read_off[0] + total * g / G;
+                cut[(size_t)g] = std::lower_bound(read_off, read_off + n_reads + 1, target) - read_off;
+                if (cut[(size_t)g] < cut[(size_t)g - 1]) cut[(size_t)g] = cut[(size_t)g - 1];
+            }
+            cut[(size_t)G] = n_reads;
+            std::vector<std::thread> th;
+            for (int g = 0; g < G; g++) {
+                const int64_t lo = cut[(size_t)g], hi = cut[(size_t)g + 1];
+                if (hi == lo) continue;
+                th.emplace_back([&, g, lo, hi] {
+                    run_one(streaming, replicas_[(size_t)g].h, bases, read_off + lo, hi - lo, out, out_off + lo,
+                            &rcs[(size_t)g], &errs[(size_t)g]);
+                });
+            }
+            for (auto &t : th) t.join();
+        }
+        for (int g = 0; g < G; g++) {
+            bug_exit(rcs[(size_t)g]);
+            if (rcs[(size_t)g] != SBWTGPU_OK)
+                throw std::runtime_error(errs[(size_t)g].empty() ? "sbwtgpu error " + std::to_string(rcs[(size_t)g])
+                                                                 : errs[(size_t)g]);
+        }
+    }
 
     void check_precalc(int64_t p) const {                 // SBWT.hh:619-624
         if (p > 20)

@@ -7,6 +7,8 @@
 //               [--no-streaming-support] [-t <threads>]      (subset of sbwt_build.cpp:40-55)
 // Extra, GPU-only flags of `search` (defaults keep the reference behaviour and output):
 //   --gpu <id>            HIP device to use (default 0)
+//   --gpus <n>            shard every batch over HIP devices 0..n-1 (index replicated by one RCCL broadcast)
+//   --gpu-list a,b,...    the same with an explicit device list (a device may be listed twice)
 //   --batch-bases <n>     bases sent to the GPU per batch (default 256 Mi)
 #include <algorithm>
 #include <cstdio>
@@ -169,6 +171,8 @@ int search_main(int argc, char **argv) {
         {"gzip-output", 'z', false,
          "Writes output in gzipped form. This can shrink the output files by an order of magnitude.", ""},
         {"gpu", 0, true, "HIP device to run on.", "0"},
+        {"gpus", 0, true, "Shard every batch over HIP devices 0..n-1.", "1"},
+        {"gpu-list", 0, true, "Explicit comma separated device list to shard over.", "-"},
         {"batch-bases", 0, true, "Bases sent to the GPU per batch.", "268435456"},
         {"help", 'h', false, "Print usage", ""},
     });
@@ -194,7 +198,21 @@ int search_main(int argc, char **argv) {
     else output_files = {outfile};
     for (const string &file : output_files) check_writable(file);
 
-    set_default_device(atoi(opts.get("gpu").c_str()));
+    vector<int> devices;
+    if (opts.get("gpu-list") != "-") {
+        string l = opts.get("gpu-list");
+        for (size_t pos = 0; pos <= l.size();) {
+            size_t e = l.find(',', pos);
+            if (e == string::npos) e = l.size();
+            devices.push_back(atoi(l.substr(pos, e - pos).c_str()));
+            pos = e + 1;
+        }
+    } else {
+        int n = atoi(opts.get("gpus").c_str());
+        if (n > 1) for (int g = 0; g < n; g++) devices.push_back(g);
+        else devices.push_back(atoi(opts.get("gpu").c_str()));
+    }
+    set_default_device(devices[0]);
     int64_t batch_bases = atoll(opts.get("batch-bases").c_str());
     if (batch_bases < 1) batch_bases = 1;
 
@@ -213,6 +231,10 @@ int search_main(int argc, char **argv) {
                                  variant + ")");
     plain_matrix_sbwt_t index;
     index.load(in);
+    if (devices.size() > 1) {
+        index.use_devices(devices);
+        write_log("Index replicated onto " + std::to_string(devices.size()) + " GPU contexts", LogLevel::MAJOR);
+    }
 
     if (input_files.size() != output_files.size())   // run_queries, sbwt_search.cpp:111-115
         throw std::runtime_error("Number of input and output files does not match (" +

@@ -92,6 +92,15 @@ def test_cli_non_streaming_index_and_batches(gpu, tmp_path):
     p = run("search", "-o", d + "/st.out", "-i", d + "/st.sbwt", "-q", d + "/r.fastq", "--batch-bases", "1000")
     assert b"Running streaming queries" in p.stderr
     assert open(d + "/st.out", "rb").read() == want
+    # sharded over three GPU contexts (the same device listed three times on a 1-GPU box): same bytes
+    p = run("search", "-o", d + "/sh.out", "-i", d + "/st.sbwt", "-q", d + "/r.fastq", "--gpu-list", "0,0,0",
+            "--batch-bases", "20000")
+    assert b"replicated onto 3 GPU contexts" in p.stderr
+    assert open(d + "/sh.out", "rb").read() == want
+    p = run("search", "-o", d + "/g1.out", "-i", d + "/ns.sbwt", "-q", d + "/r.fastq", "--gpus", "1")
+    assert open(d + "/g1.out", "rb").read() == want
+    p = run("search", "-o", d + "/g9.out", "-i", d + "/st.sbwt", "-q", d + "/r.fastq", "--gpus", "9", check=False)
+    assert p.returncode == 1 and b"Runtime error" in p.stderr        # more GPUs than the box has
 
 
 def test_cli_error_conventions(gpu, tmp_path):
