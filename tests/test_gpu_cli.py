@@ -127,3 +127,17 @@ def test_cli_error_conventions(gpu, tmp_path):
     open(d + "/ol.txt", "w").write(d + "/o1.txt\n")
     p = run("search", "-o", d + "/ol.txt", "-i", d + "/s.sbwt", "-q", d + "/ql.txt", check=False)
     assert p.returncode == 1 and b"Number of input and output files does not match (2 vs 1)" in p.stderr
+
+
+def test_cpp_api_mirror(gpu, tmp_path):
+    """Compiles tests/cpp/test_api.cpp against the host mirror headers (like api_examples/Makefile does
+    against the reference) and runs it: the reference's API tests, restated, on the GPU path."""
+    exe = str(tmp_path / "test_api")
+    lib = os.path.join(ROOT, "sbwt_amd", "lib")
+    cmd = ["g++", "-O1", "-std=c++17", "-pthread", "-I", os.path.join(ROOT, "sbwt_amd", "csrc", "host"),
+           os.path.join(ROOT, "tests", "cpp", "test_api.cpp"), "-o", exe, "-L" + lib, "-lsbwtgpu", "-lz",
+           "-Wl,-rpath," + lib, "-Wl,-rpath,/opt/rocm/lib"]
+    subprocess.run(cmd, check=True, timeout=300)
+    p = subprocess.run([exe], capture_output=True, timeout=600)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    assert p.stdout.startswith(b"OK ")
