@@ -163,6 +163,27 @@ int  sbwtgpu_workspace_status(const void *d_workspace, void *stream, int *status
  * device prefix table, [3] device prefix-table lookups that returned a non-empty interval. */
 int  sbwtgpu_workspace_stats(const void *d_workspace, void *stream, int64_t stats[4]);
 
+/* ---- output formatting on the device ---- */
+/* print_vector of src/CLI/sbwt_search.cpp:21-43 for a whole batch: one line per read, every value
+ * followed by one space, '\n' per read, -1 as "-1", 0 as an empty token (the reference's behaviour).
+ * d_line_off (n_reads+1 entries) receives the byte offset of every read's line; d_line_off[n_reads] is
+ * the length of the text.  text_cap must be >= sbwtgpu_format_text_bound(). */
+int64_t sbwtgpu_format_text_bound(const sbwtgpu_index *idx, int64_t n_values, int64_t n_reads);
+int64_t sbwtgpu_format_scratch_bytes(int64_t n_reads);
+int  sbwtgpu_format_results_dev(const sbwtgpu_index *idx, const int64_t *d_values, const int64_t *d_out_off,
+                                int64_t n_reads, int64_t n_values, char *d_text, int64_t text_cap,
+                                int64_t *d_line_off, void *d_scratch, int64_t scratch_bytes, void *stream);
+/* The whole `sbwt search` inner loop for one batch of reads in host memory (run_queries_streaming /
+ * run_queries_not_streaming, src/CLI/sbwt_search.cpp:46-91): searches every read (streaming != 0:
+ * streaming_search, else the per-k-mer search loop) and returns the formatted output text.  Large
+ * batches are cut into chunks that are pipelined over two HIP streams with pinned staging buffers
+ * (H2D of chunk i+1 and D2H of chunk i-1 overlap the kernels of chunk i).  *text is malloc'ed by the
+ * library: release it with sbwtgpu_free_host().  *n_queries receives the number of k-mers searched. */
+int  sbwtgpu_search_text_batch(const sbwtgpu_index *idx, const char *bases, const int64_t *read_off,
+                               int64_t n_reads, int streaming, char **text, int64_t *text_bytes,
+                               int64_t *n_queries);
+void sbwtgpu_free_host(void *p);
+
 #ifdef __cplusplus
 }
 #endif

@@ -36,6 +36,8 @@ EXPORTED_SYMBOLS = [
     "sbwtgpu_search_workspace_bytes", "sbwtgpu_streaming_search_dev", "sbwtgpu_search_dev",
     "sbwtgpu_rank_dev", "sbwtgpu_encode_bases_dev", "sbwtgpu_search_encoded_dev",
     "sbwtgpu_workspace_status", "sbwtgpu_workspace_stats",
+    "sbwtgpu_format_text_bound", "sbwtgpu_format_scratch_bytes", "sbwtgpu_format_results_dev",
+    "sbwtgpu_search_text_batch", "sbwtgpu_free_host",
 ]
 
 
@@ -106,6 +108,14 @@ def lib() -> C.CDLL:
     L.sbwtgpu_encode_bases_dev.argtypes = [vp, vp, i64, vp, i64, vp]
     L.sbwtgpu_search_encoded_dev.argtypes = [vp, i64, vp, i64, vp, vp, vp, i64, ci, vp]
     L.sbwtgpu_workspace_stats.argtypes = [vp, vp, C.POINTER(i64)]
+    L.sbwtgpu_format_text_bound.argtypes = [vp, i64, i64]
+    L.sbwtgpu_format_text_bound.restype = i64
+    L.sbwtgpu_format_scratch_bytes.argtypes = [i64]
+    L.sbwtgpu_format_scratch_bytes.restype = i64
+    L.sbwtgpu_format_results_dev.argtypes = [vp, vp, vp, i64, i64, vp, i64, vp, vp, i64, vp]
+    L.sbwtgpu_search_text_batch.argtypes = [vp, vp, vp, i64, ci, C.POINTER(vp), C.POINTER(i64), C.POINTER(i64)]
+    L.sbwtgpu_free_host.argtypes = [vp]
+    L.sbwtgpu_free_host.restype = None
     _lib = L
     return L
 
@@ -254,6 +264,19 @@ class Index:
         bases, off = concat_reads(reads)
         out, oo = self.search(bases, off)
         return [out[oo[i]:oo[i + 1]] for i in range(len(reads))]
+
+    def search_text(self, bases, read_off, streaming: bool = True):
+        """The formatted `sbwt search` output of a batch (device-side print_vector, pipelined host path):
+        returns (text bytes, number of k-mers searched)."""
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        read_off = np.ascontiguousarray(read_off, dtype=np.int64)
+        p, n, q = C.c_void_p(), C.c_int64(0), C.c_int64(0)
+        _check(lib().sbwtgpu_search_text_batch(self._h, bases.ctypes.data, read_off.ctypes.data, len(read_off) - 1,
+                                               int(streaming), C.byref(p), C.byref(n), C.byref(q)))
+        try:
+            return C.string_at(p.value, n.value), q.value
+        finally:
+            lib().sbwtgpu_free_host(p)
 
     def update_interval(self, bases, off, first, second):
         bases = np.ascontiguousarray(bases, dtype=np.uint8)

@@ -210,6 +210,54 @@ public:
                       const int64_t *out_off) const {
         run_sharded(false, bases, read_off, n_reads, out, out_off);
     }
+    // The whole inner loop of `sbwt search` for one batch: searches every read (streaming_search when
+    // the index has streaming support, else the per-k-mer search loop) and returns the output text in
+    // the reference's format (print_vector, sbwt_search.cpp:21-43), formatted on the GPU.  One text
+    // piece per GPU shard, in read order.  Returns the number of k-mers searched.
+    struct TextPiece {
+        char *data = nullptr;
+        int64_t size = 0;
+        TextPiece() = default;
+        TextPiece(const TextPiece &) = delete;
+        TextPiece &operator=(const TextPiece &) = delete;
+        TextPiece(TextPiece &&o) noexcept : data(o.data), size(o.size) { o.data = nullptr; o.size = 0; }
+        ~TextPiece() { sbwtgpu_free_host(data); }
+    };
+    int64_t search_text_batch(const char *bases, const int64_t *read_off, int64_t n_reads,
+                              std::vector<TextPiece> &pieces) const {
+        const sbwtgpu_index *root = need_device();
+        const bool streaming = has_streaming_query_support();
+        const int G = (n_reads < 2 * number_of_devices()) ? 1 : number_of_devices();
+        std::vector<int64_t> cut = shard_cuts(read_off, n_reads, G);
+        pieces.clear();
+        pieces.resize((size_t)G);
+        std::vector<int> rcs((size_t)G, SBWTGPU_OK);
+        std::vector<std::string> errs((size_t)G);
+        std::vector<int64_t> nq((size_t)G, 0);
+        auto work = [&](int g) {
+            const int64_t lo = cut[(size_t)g], hi = cut[(size_t)g + 1];
+            const sbwtgpu_index *h = (G == 1) ? root : replicas_[(size_t)g].h;
+            rcs[(size_t)g] = sbwtgpu_search_text_batch(h, bases, read_off + lo, hi - lo, streaming ? 1 : 0,
+                                                      &pieces[(size_t)g].data, &pieces[(size_t)g].size, &nq[(size_t)g]);
+            if (rcs[(size_t)g] != SBWTGPU_OK) errs[(size_t)g] = sbwtgpu_last_error();
+        };
+        if (G == 1) {
+            work(0);
+        } else {
+            std::vector<std::thread> th;
+            for (int g = 0; g < G; g++) th.emplace_back(work, g);
+            for (auto &t : th) t.join();
+        }
+        int64_t total = 0;
+        for (int g = 0; g < G; g++) {
+            bug_exit(rcs[(size_t)g]);
+            if (rcs[(size_t)g] != SBWTGPU_OK)
+                throw std::runtime_error(errs[(size_t)g].empty() ? "sbwtgpu error " + std::to_string(rcs[(size_t)g])
+                                                                 : errs[(size_t)g]);
+            total += nq[(size_t)g];
+        }
+        return total;
+    }
     // Replicates the device image onto the listed HIP devices (one RCCL broadcast over xGMI);
     // the first entry should be the device the index was created on.  Listing a device twice is allowed
     // (two host threads share it) and is how the sharding is tested on a single-GPU box.
@@ -307,6 +355,19 @@ private:
     struct Replica { std::shared_ptr<detail::DeviceIndex> owner; sbwtgpu_index *h; };
     std::vector<Replica> replicas_;
 
+    // contiguous shards balanced by bases: shard g = reads [cut[g], cut[g+1])
+    static std::vector<int64_t> shard_cuts(const int64_t *read_off, int64_t n_reads, int G) {
+        std::vector<int64_t> cut((size_t)G + 1, 0);
+        const int64_t total = n_reads ? read_off[n_reads] - read_off[0] : 0;
+        for (int g = 1; g < G; g++) {
+            const int64_t target = read_off[0] + total * g / G;
+            cut[(size_t)g] = std::lower_bound(read_off, read_off + n_reads + 1, target) - read_off;
+            if (cut[(size_t)g] < cut[(size_t)g - 1]) cut[(size_t)g] = cut[(size_t)g - 1];
+            if (cut[(size_t)g] > n_reads) cut[(size_t)g] = n_reads;
+        }
+        cut[(size_t)G] = n_reads;
+        return cut;
+    }
     void run_one(bool streaming, const sbwtgpu_index *h, const char *bases, const int64_t *read_off, int64_t n_reads,
                  int64_t *out, const int64_t *out_off, int *rc_out, std::string *err) const {
         int rc = streaming ? sbwtgpu_streaming_search_batch(h, bases, read_off, n_reads, out, out_off)
@@ -323,15 +384,7 @@ private:
         if (G == 1 || n_reads < 2 * G) {
             run_one(streaming, root, bases, read_off, n_reads, out, out_off, &rcs[0], &errs[0]);
         } else {
-            // contiguous shards balanced by bases
-            std::vector<int64_t> cut((size_t)G + 1, 0);
-            const int64_t total = read_off[n_reads] - read_off[0];
-            for (int g = 1; g < G; g++) {
-                const int64_t target = read_off[0] + total * g / G;
-                cut[(size_t)g] = std::lower_bound(read_off, read_off + n_reads + 1, target) - read_off;
-                if (cut[(size_t)g] < cut[(size_t)g - 1]) cut[(size_t)g] = cut[(size_t)g - 1];
-            }
-            cut[(size_t)G] = n_reads;
+            std::vector<int64_t> cut = shard_cuts(read_off, n_reads, G);
             std::vector<std::thread> th;
             for (int g = 0; g < G; g++) {
                 const int64_t lo = cut[(size_t)g], hi = cut[(size_t)g + 1];

@@ -10,6 +10,7 @@
 //   --gpus <n>            shard every batch over HIP devices 0..n-1 (index replicated by one RCCL broadcast)
 //   --gpu-list a,b,...    the same with an explicit device list (a device may be listed twice)
 //   --batch-bases <n>     bases sent to the GPU per batch (default 256 Mi)
+//   --host-format         print_vector on the CPU (default: formatted on the GPU, pipelined over PCIe)
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -114,7 +115,7 @@ struct QueryStats { int64_t queries = 0; int64_t micros = 0; };
 
 // run_file + run_queries_streaming / run_queries_not_streaming (sbwt_search.cpp:46-105), batched
 QueryStats run_file(const string &infile, const string &outfile, const plain_matrix_sbwt_t &index, bool gzip_output,
-                    int64_t batch_bases) {
+                    int64_t batch_bases, bool host_format) {
     seq_io::Reader reader(infile);
     seq_io::Buffered_ofstream writer(outfile, gzip_output);
     const bool streaming = index.has_streaming_query_support();
@@ -140,18 +141,30 @@ QueryStats run_file(const string &infile, const string &outfile, const plain_mat
         }
         const int64_t n_reads = (int64_t)read_off.size() - 1;
         if (n_reads == 0) break;
-        out.resize((size_t)out_off.back());
-        int64_t t0 = cur_time_micros();
-        if (streaming) index.streaming_search_batch(bases.data(), read_off.data(), n_reads, out.data(), out_off.data());
-        else index.search_batch(bases.data(), read_off.data(), n_reads, out.data(), out_off.data());
-        st.micros += cur_time_micros() - t0;
-        st.queries += out_off.back();
-        for (int64_t r = 0; r < n_reads; r++) {
-            print_vector(out.data() + out_off[(size_t)r], out_off[(size_t)r + 1] - out_off[(size_t)r], text);
-            if (text.size() > (1u << 22)) { writer.write(text.data(), (int64_t)text.size()); text.clear(); }
+        if (host_format) {
+            // reference-style: raw ranks back to the host, print_vector on the CPU
+            out.resize((size_t)out_off.back());
+            int64_t t0 = cur_time_micros();
+            if (streaming) index.streaming_search_batch(bases.data(), read_off.data(), n_reads, out.data(), out_off.data());
+            else index.search_batch(bases.data(), read_off.data(), n_reads, out.data(), out_off.data());
+            st.micros += cur_time_micros() - t0;
+            st.queries += out_off.back();
+            for (int64_t r = 0; r < n_reads; r++) {
+                print_vector(out.data() + out_off[(size_t)r], out_off[(size_t)r + 1] - out_off[(size_t)r], text);
+                if (text.size() > (1u << 22)) { writer.write(text.data(), (int64_t)text.size()); text.clear(); }
+            }
+            writer.write(text.data(), (int64_t)text.size());
+            text.clear();
+        } else {
+            // default: search + print_vector on the GPU, pipelined over PCIe
+            std::vector<plain_matrix_sbwt_t::TextPiece> pieces;
+            int64_t t0 = cur_time_micros();
+            st.queries += index.search_text_batch(bases.data(), read_off.data(), n_reads, pieces);
+            st.micros += cur_time_micros() - t0;
+            for (const auto &pc : pieces)
+                for (int64_t pos = 0; pos < pc.size; pos += (int64_t)1 << 30)
+                    writer.write(pc.data + pos, std::min<int64_t>((int64_t)1 << 30, pc.size - pos));
         }
-        writer.write(text.data(), (int64_t)text.size());
-        text.clear();
     }
     write_log("us/query: " + std::to_string((double)st.micros / (double)st.queries) + " (excluding I/O etc)",
               LogLevel::MAJOR);
@@ -174,6 +187,7 @@ int search_main(int argc, char **argv) {
         {"gpus", 0, true, "Shard every batch over HIP devices 0..n-1.", "1"},
         {"gpu-list", 0, true, "Explicit comma separated device list to shard over.", "-"},
         {"batch-bases", 0, true, "Bases sent to the GPU per batch.", "268435456"},
+        {"host-format", 0, false, "Format the output on the CPU (print_vector) instead of on the GPU.", ""},
         {"help", 'h', false, "Print usage", ""},
     });
     opts.parse(argc, argv);
@@ -241,7 +255,8 @@ int search_main(int argc, char **argv) {
                                  std::to_string(input_files.size()) + " vs " + std::to_string(output_files.size()) + ")");
     int64_t number_of_queries = 0;
     for (size_t i = 0; i < input_files.size(); i++)
-        number_of_queries += run_file(input_files[i], output_files[i], index, gzip_output, batch_bases).queries;
+        number_of_queries += run_file(input_files[i], output_files[i], index, gzip_output, batch_bases,
+                                      opts.count("host-format")).queries;
 
     int64_t total_micros = cur_time_micros() - micros_start;
     write_log("us/query end-to-end: " + std::to_string((double)total_micros / (double)number_of_queries), LogLevel::MAJOR);

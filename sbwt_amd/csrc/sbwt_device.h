@@ -80,3 +80,6 @@ void sbwt_launch_update_interval(const SbwtIndexView &ix, const char *d_bases, c
                                  long long *d_first, long long *d_second, hipStream_t stream);
 void sbwt_launch_forward(const SbwtIndexView &ix, const long long *d_node, const char *d_sym, long long n,
                          long long *d_out, hipStream_t stream);
+long long sbwt_format_scratch_bytes(long long n_reads);
+void sbwt_launch_format(const long long *d_vals, const long long *d_out_off, long long n_reads, char *d_text,
+                        long long *d_line_off, void *d_scratch, hipStream_t stream);

@@ -958,6 +958,126 @@ __global__ void __launch_bounds__(256) k_forward(SbwtIndexView ix, const i64 *__
 }
 
 // ---------------------------------------------------------------------------------------------
+// Output formatting on the device: print_vector of src/CLI/sbwt_search.cpp:21-43 for a whole batch.
+// One line per read, every value followed by one space, '\n' per read, -1 printed as "-1", and the
+// reference's quirk kept: 0 prints as an empty token.  One wave per read.
+//   k_fmt_len    line length of every read
+//   k_scan_*     exclusive prefix sum of the line lengths (three small kernels)
+//   k_fmt_write  the characters
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int fmt_len(i64 v) {      // characters of the token incl. its trailing space
+    if (v < 0) return 3;                             // "-1 "
+    int n = 1;                                       // the space; 0 -> empty token
+    u64 x = (u64)v;
+    while (x > 0) { n++; x /= 10; }
+    return n;
+}
+
+__global__ void __launch_bounds__(256) k_fmt_len(const i64 *__restrict__ vals, const i64 *__restrict__ out_off,
+                                                 i64 n_reads, i64 *__restrict__ line_len) {
+    const i64 r = ((i64)blockIdx.x * 256 + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (r >= n_reads) return;
+    const i64 lo = out_off[r], hi = out_off[r + 1];
+    i64 sum = 0;
+    for (i64 t = lo + lane; t < hi; t += 64) sum += fmt_len(vals[t]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off);
+    if (lane == 0) line_len[r] = sum + 1;            // + '\n'
+}
+
+// exclusive scan of n int64 values in[] -> out[] (out has n+1 entries, out[n] = total); 1024 per block
+__global__ void __launch_bounds__(256) k_scan_block_sums(const i64 *__restrict__ in, i64 n, i64 *__restrict__ bsum) {
+    __shared__ i64 sh[4];
+    const i64 base = (i64)blockIdx.x * 1024;
+    i64 s = 0;
+    for (int t = threadIdx.x; t < 1024; t += 256) s += (base + t < n) ? in[base + t] : 0;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) bsum[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+__global__ void __launch_bounds__(1024) k_scan_sums(i64 *bsum, i64 nb) {   // one block: in-place exclusive scan
+    __shared__ i64 sh[1024];
+    const i64 chunk = (nb + 1023) / 1024;
+    const i64 lo = (i64)threadIdx.x * chunk, hi = (lo + chunk < nb) ? lo + chunk : nb;
+    i64 loc = 0;
+    for (i64 b = lo; b < hi; b++) loc += bsum[b];
+    sh[threadIdx.x] = loc;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        i64 add = (threadIdx.x >= (unsigned)off) ? sh[threadIdx.x - off] : 0;
+        __syncthreads();
+        sh[threadIdx.x] += add;
+        __syncthreads();
+    }
+    i64 run = sh[threadIdx.x] - loc;
+    for (i64 b = lo; b < hi; b++) { i64 v = bsum[b]; bsum[b] = run; run += v; }
+    if (threadIdx.x == 1023) bsum[nb] = sh[1023];
+}
+__global__ void __launch_bounds__(256) k_scan_apply(const i64 *__restrict__ in, i64 n, const i64 *__restrict__ bsum,
+                                                    i64 *__restrict__ out) {
+    __shared__ i64 sh[256];
+    const i64 base = (i64)blockIdx.x * 1024;
+    i64 v[4], loc = 0;
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        const i64 idx = base + threadIdx.x * 4 + t;
+        v[t] = (idx < n) ? in[idx] : 0;
+        loc += v[t];
+    }
+    sh[threadIdx.x] = loc;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {        // Hillis-Steele over the 256 partial sums
+        i64 add = (threadIdx.x >= off) ? sh[threadIdx.x - off] : 0;
+        __syncthreads();
+        sh[threadIdx.x] += add;
+        __syncthreads();
+    }
+    i64 run = bsum[blockIdx.x] + sh[threadIdx.x] - loc;
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        const i64 idx = base + threadIdx.x * 4 + t;
+        if (idx < n) out[idx] = run;
+        run += v[t];
+    }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) out[n] = bsum[gridDim.x];
+}
+
+__global__ void __launch_bounds__(256) k_fmt_write(const i64 *__restrict__ vals, const i64 *__restrict__ out_off,
+                                                   i64 n_reads, const i64 *__restrict__ line_off,
+                                                   char *__restrict__ text) {
+    const i64 r = ((i64)blockIdx.x * 256 + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (r >= n_reads) return;
+    const i64 lo = out_off[r], hi = out_off[r + 1];
+    i64 pos = line_off[r];
+    for (i64 t0 = lo; t0 < hi; t0 += 64) {
+        const i64 t = t0 + lane;
+        const i64 v = (t < hi) ? vals[t] : 0;
+        const int len = (t < hi) ? fmt_len(v) : 0;
+        int incl = len;                              // inclusive wave prefix sum of the token lengths
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            int up = __shfl_up(incl, off);
+            if (lane >= off) incl += up;
+        }
+        if (t < hi) {
+            char *p = text + pos + (incl - len);
+            if (v < 0) { p[0] = '-'; p[1] = '1'; p[2] = ' '; }
+            else {
+                p[len - 1] = ' ';
+                u64 x = (u64)v;
+                for (int d = len - 2; d >= 0; d--) { p[d] = (char)('0' + (int)(x % 10)); x /= 10; }
+            }
+        }
+        pos += __shfl(incl, 63);
+    }
+    if (lane == 0) text[pos] = '\n';
+}
+
+// ---------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------
 static inline unsigned grid_for(i64 n) { return (unsigned)((n + 255) / 256); }
@@ -1050,4 +1170,24 @@ void sbwt_launch_forward(const SbwtIndexView &ix, const long long *d_node, const
         hipLaunchKernelGGL(k_forward<true>, dim3(grid_for(n)), dim3(256), 0, stream, ix, d_node, d_sym, (i64)n, d_out);
     else
         hipLaunchKernelGGL(k_forward<false>, dim3(grid_for(n)), dim3(256), 0, stream, ix, d_node, d_sym, (i64)n, d_out);
+}
+
+// scratch: line_len[n_reads] + bsum[n_reads/1024 + 2]
+long long sbwt_format_scratch_bytes(long long n_reads) {
+    return (n_reads + (n_reads + 1023) / 1024 + 2) * 8 + 256;
+}
+
+void sbwt_launch_format(const long long *d_vals, const long long *d_out_off, long long n_reads, char *d_text,
+                        long long *d_line_off, void *d_scratch, hipStream_t stream) {
+    if (n_reads <= 0) return;
+    i64 *line_len = reinterpret_cast<i64 *>(d_scratch);
+    i64 *bsum = line_len + n_reads;
+    const unsigned wave_blocks = (unsigned)((n_reads * 64 + 255) / 256);
+    const unsigned nb = (unsigned)((n_reads + 1023) / 1024);
+    hipLaunchKernelGGL(k_fmt_len, dim3(wave_blocks), dim3(256), 0, stream, d_vals, d_out_off, (i64)n_reads, line_len);
+    hipLaunchKernelGGL(k_scan_block_sums, dim3(nb), dim3(256), 0, stream, line_len, (i64)n_reads, bsum);
+    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, stream, bsum, (i64)nb);
+    hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(256), 0, stream, line_len, (i64)n_reads, bsum, d_line_off);
+    hipLaunchKernelGGL(k_fmt_write, dim3(wave_blocks), dim3(256), 0, stream, d_vals, d_out_off, (i64)n_reads,
+                       d_line_off, d_text);
 }

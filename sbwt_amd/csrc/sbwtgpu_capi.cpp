@@ -8,6 +8,8 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
+#include <cstddef>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -757,6 +759,234 @@ int sbwtgpu_forward_batch(const sbwtgpu_index *idx, const int64_t *node, const c
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(out, d_out.p, (size_t)n * 8, hipMemcpyDeviceToHost, st.s));
     HIP_TRY(hipStreamSynchronize(st.s));
+    return SBWTGPU_OK;
+}
+
+
+// ---- device-side formatting + pipelined host path ------------------------------------------------
+int64_t sbwtgpu_format_text_bound(const sbwtgpu_index *idx, int64_t n_values, int64_t n_reads) {
+    int digits = 1;
+    for (int64_t x = idx ? idx->h.n_nodes : INT64_MAX; x >= 10; x /= 10) digits++;
+    int tok = digits + 1 > 3 ? digits + 1 : 3;
+    return n_values * tok + n_reads + 16;
+}
+int64_t sbwtgpu_format_scratch_bytes(int64_t n_reads) { return sbwt_format_scratch_bytes(n_reads < 0 ? 0 : n_reads); }
+
+int sbwtgpu_format_results_dev(const sbwtgpu_index *idx, const int64_t *d_values, const int64_t *d_out_off,
+                               int64_t n_reads, int64_t n_values, char *d_text, int64_t text_cap, int64_t *d_line_off,
+                               void *d_scratch, int64_t scratch_bytes, void *stream) {
+    if (!idx) return fail(SBWTGPU_ERR_INVALID_ARG, "idx is NULL");
+    if (n_reads < 0 || n_values < 0) return fail(SBWTGPU_ERR_INVALID_ARG, "negative size");
+    if (n_reads == 0) return SBWTGPU_OK;
+    if (!d_out_off || !d_text || !d_line_off || !d_scratch || (n_values > 0 && !d_values))
+        return fail(SBWTGPU_ERR_INVALID_ARG, "NULL device pointer");
+    if (text_cap < sbwtgpu_format_text_bound(idx, n_values, n_reads))
+        return fail(SBWTGPU_ERR_INVALID_ARG, "text buffer smaller than sbwtgpu_format_text_bound()");
+    if (scratch_bytes < sbwtgpu_format_scratch_bytes(n_reads)) return fail(SBWTGPU_ERR_INVALID_ARG, "scratch too small");
+    DeviceGuard guard(idx->device);
+    sbwt_launch_format(reinterpret_cast<const long long *>(d_values), reinterpret_cast<const long long *>(d_out_off),
+                       n_reads, d_text, reinterpret_cast<long long *>(d_line_off), d_scratch,
+                       static_cast<hipStream_t>(stream));
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(SBWTGPU_ERR_HIP, "kernel launch: %s", hipGetErrorString(e));
+    return SBWTGPU_OK;
+}
+
+void sbwtgpu_free_host(void *p) { free(p); }
+
+namespace {
+// one pipeline slot: a stream with its device buffers and pinned staging buffers
+struct Slot {
+    hipStream_t st = nullptr;
+    char *h_in = nullptr;            // pinned: bases | read_off | out_off
+    char *h_text = nullptr;          // pinned: formatted text
+    int64_t *h_total = nullptr;      // pinned: text length, status
+    char *d_mem = nullptr;           // one device allocation carved below
+    int64_t cap_bases = 0, cap_reads = 0, cap_vals = 0, cap_text = 0;
+    // carved device pointers
+    char *d_bases = nullptr; int64_t *d_roff = nullptr, *d_ooff = nullptr, *d_out = nullptr, *d_line = nullptr;
+    char *d_ws = nullptr, *d_text = nullptr, *d_scr = nullptr;
+    int64_t ws_bytes = 0, scr_bytes = 0;
+    // the chunk in flight
+    int64_t n_reads = 0, n_vals = 0, text_len = 0;
+    bool busy = false;
+    void release() {
+        if (st) (void)hipStreamDestroy(st);
+        if (h_in) (void)hipHostFree(h_in);
+        if (h_text) (void)hipHostFree(h_text);
+        if (h_total) (void)hipHostFree(h_total);
+        if (d_mem) (void)hipFree(d_mem);
+        *this = Slot();
+    }
+};
+inline int64_t a256(int64_t x) { return (x + 255) & ~(int64_t)255; }
+}  // namespace
+
+int sbwtgpu_search_text_batch(const sbwtgpu_index *idx, const char *bases, const int64_t *read_off, int64_t n_reads,
+                              int streaming, char **text, int64_t *text_bytes, int64_t *n_queries) {
+    if (!idx || !text || !text_bytes) return fail(SBWTGPU_ERR_INVALID_ARG, "NULL argument");
+    *text = nullptr;
+    *text_bytes = 0;
+    if (n_queries) *n_queries = 0;
+    if (streaming && !idx->h.has_ssup)
+        return fail(SBWTGPU_ERR_NO_STREAMING, "Error: streaming search support not built");
+    if (idx->h.rank_only) return fail(SBWTGPU_ERR_INVALID_ARG, "%s", RANK_ONLY_MSG);
+    if (n_reads < 0) return fail(SBWTGPU_ERR_INVALID_ARG, "negative n_reads");
+    if (n_reads > 0 && (!read_off || (read_off[n_reads] > read_off[0] && !bases)))
+        return fail(SBWTGPU_ERR_INVALID_ARG, "NULL input");
+    const int64_t k = idx->h.k;
+    // ---- chunking: <= 32 Mi bases and <= 4 Mi reads per chunk ----
+    const int64_t CH_BASES = (int64_t)32 << 20, CH_READS = (int64_t)4 << 20;
+    std::vector<int64_t> cuts{0};
+    int64_t max_bases = 0, max_reads = 0, max_vals = 0;
+    {
+        int64_t lo = 0, vals = 0;
+        for (int64_t r = 0; r < n_reads; r++) {
+            int64_t len = read_off[r + 1] - read_off[r];
+            if (len < 0) return fail(SBWTGPU_ERR_INVALID_ARG, "read_off is not non-decreasing at read %lld", (long long)r);
+            if (len >= ((int64_t)1 << 31)) return fail(SBWTGPU_ERR_READ_TOO_LONG, "read %lld has >= 2^31 bases", (long long)r);
+            if (r > lo && (read_off[r + 1] - read_off[lo] > CH_BASES || r - lo >= CH_READS)) {
+                max_bases = std::max(max_bases, read_off[r] - read_off[lo]);
+                max_reads = std::max(max_reads, r - lo);
+                max_vals = std::max(max_vals, vals);
+                cuts.push_back(r);
+                lo = r;
+                vals = 0;
+            }
+            vals += std::max<int64_t>(0, len - k + 1);
+        }
+        if (n_reads > lo) {
+            max_bases = std::max(max_bases, read_off[n_reads] - read_off[lo]);
+            max_reads = std::max(max_reads, n_reads - lo);
+            max_vals = std::max(max_vals, vals);
+            cuts.push_back(n_reads);
+        }
+    }
+    const int64_t n_chunks = (int64_t)cuts.size() - 1;
+    std::vector<char> result;
+    if (n_chunks == 0) {
+        *text = (char *)malloc(1);
+        return *text ? SBWTGPU_OK : fail(SBWTGPU_ERR_OOM, "out of host memory");
+    }
+    DeviceGuard guard(idx->device);
+    Slot slots[2];
+    int rc = SBWTGPU_OK;
+    auto cleanup = [&]() { slots[0].release(); slots[1].release(); };
+#define PIPE_TRY(expr)                                                                                     \
+    do {                                                                                                   \
+        hipError_t e_ = (expr);                                                                            \
+        if (e_ != hipSuccess) {                                                                            \
+            rc = fail(e_ == hipErrorOutOfMemory ? SBWTGPU_ERR_OOM : SBWTGPU_ERR_HIP, "%s failed: %s", #expr, \
+                      hipGetErrorString(e_));                                                              \
+            cleanup();                                                                                     \
+            return rc;                                                                                     \
+        }                                                                                                  \
+    } while (0)
+    const int n_slots = n_chunks > 1 ? 2 : 1;
+    for (int s = 0; s < n_slots; s++) {
+        Slot &S = slots[s];
+        S.cap_bases = max_bases; S.cap_reads = max_reads; S.cap_vals = max_vals;
+        S.cap_text = sbwtgpu_format_text_bound(idx, max_vals, max_reads);
+        S.ws_bytes = sbwtgpu_search_workspace_bytes(max_bases);
+        S.scr_bytes = sbwtgpu_format_scratch_bytes(max_reads);
+        const int64_t in_bytes = a256(max_bases + 16) + 2 * a256((max_reads + 1) * 8);
+        const int64_t dev_bytes = a256(max_bases + 16) + 3 * a256((max_reads + 1) * 8) + a256(max_vals * 8 + 8) +
+                                  a256(S.ws_bytes) + a256(S.cap_text) + a256(S.scr_bytes);
+        PIPE_TRY(hipStreamCreateWithFlags(&S.st, hipStreamNonBlocking));
+        PIPE_TRY(hipHostMalloc((void **)&S.h_in, (size_t)in_bytes, hipHostMallocDefault));
+        PIPE_TRY(hipHostMalloc((void **)&S.h_text, (size_t)S.cap_text, hipHostMallocDefault));
+        PIPE_TRY(hipHostMalloc((void **)&S.h_total, 64, hipHostMallocDefault));
+        PIPE_TRY(hipMalloc((void **)&S.d_mem, (size_t)dev_bytes));
+        char *p = S.d_mem;
+        S.d_bases = p; p += a256(max_bases + 16);
+        S.d_roff = (int64_t *)p; p += a256((max_reads + 1) * 8);
+        S.d_ooff = (int64_t *)p; p += a256((max_reads + 1) * 8);
+        S.d_line = (int64_t *)p; p += a256((max_reads + 1) * 8);
+        S.d_out = (int64_t *)p; p += a256(max_vals * 8 + 8);
+        S.d_ws = p; p += a256(S.ws_bytes);
+        S.d_text = p; p += a256(S.cap_text);
+        S.d_scr = p;
+    }
+    int64_t total_queries = 0;
+    bool bug = false;
+    // enqueue everything of chunk c on its slot's stream up to the copy of the text length
+    auto submit = [&](int64_t c) -> int {
+        Slot &S = slots[c % n_slots];
+        const int64_t lo = cuts[(size_t)c], hi = cuts[(size_t)c + 1], nr = hi - lo;
+        const int64_t b0 = read_off[lo], nb = read_off[hi] - b0;
+        char *hb = S.h_in;
+        int64_t *hro = (int64_t *)(S.h_in + a256(S.cap_bases + 16));
+        int64_t *hoo = (int64_t *)((char *)hro + a256((S.cap_reads + 1) * 8));
+        if (nb) memcpy(hb, bases + b0, (size_t)nb);
+        int64_t acc = 0;
+        for (int64_t r = 0; r <= nr; r++) {
+            hro[r] = read_off[lo + r] - b0;
+            hoo[r] = acc;
+            if (r < nr) acc += std::max<int64_t>(0, read_off[lo + r + 1] - read_off[lo + r] - k + 1);
+        }
+        S.n_reads = nr;
+        S.n_vals = acc;
+        total_queries += acc;
+        hipError_t e;
+        if ((e = hipMemcpyAsync(S.d_bases, hb, (size_t)nb, hipMemcpyHostToDevice, S.st)) != hipSuccess ||
+            (e = hipMemcpyAsync(S.d_roff, hro, (size_t)(nr + 1) * 8, hipMemcpyHostToDevice, S.st)) != hipSuccess ||
+            (e = hipMemcpyAsync(S.d_ooff, hoo, (size_t)(nr + 1) * 8, hipMemcpyHostToDevice, S.st)) != hipSuccess)
+            return fail(SBWTGPU_ERR_HIP, "H2D copy: %s", hipGetErrorString(e));
+        int r2 = search_dev_common(idx, S.d_bases, nb, S.d_roff, nr, S.d_out, S.d_ooff, S.d_ws, S.ws_bytes, S.st, streaming);
+        if (r2 != SBWTGPU_OK) return r2;
+        r2 = sbwtgpu_format_results_dev(idx, S.d_out, S.d_ooff, nr, acc, S.d_text, S.cap_text, S.d_line, S.d_scr,
+                                        S.scr_bytes, S.st);
+        if (r2 != SBWTGPU_OK) return r2;
+        if ((e = hipMemcpyAsync(&S.h_total[0], S.d_line + nr, 8, hipMemcpyDeviceToHost, S.st)) != hipSuccess ||
+            (e = hipMemcpyAsync(&S.h_total[1], S.d_ws + offsetof(SbwtWorkHeader, status), 4, hipMemcpyDeviceToHost, S.st)) != hipSuccess)
+            return fail(SBWTGPU_ERR_HIP, "D2H copy: %s", hipGetErrorString(e));
+        S.busy = true;
+        return SBWTGPU_OK;
+    };
+    // wait for chunk c's kernels, then start the copy of its text
+    auto fetch = [&](int64_t c) -> int {
+        Slot &S = slots[c % n_slots];
+        hipError_t e = hipStreamSynchronize(S.st);
+        if (e != hipSuccess) return fail(SBWTGPU_ERR_HIP, "stream synchronize: %s", hipGetErrorString(e));
+        S.text_len = S.h_total[0];
+        if ((int)(S.h_total[1] & 0xffffffff) != 0) bug = true;
+        if (S.text_len < 0 || S.text_len > S.cap_text) return fail(SBWTGPU_ERR_HIP, "formatted text overflows its bound");
+        e = hipMemcpyAsync(S.h_text, S.d_text, (size_t)S.text_len, hipMemcpyDeviceToHost, S.st);
+        if (e != hipSuccess) return fail(SBWTGPU_ERR_HIP, "D2H copy: %s", hipGetErrorString(e));
+        return SBWTGPU_OK;
+    };
+    // wait for chunk c's text and append it
+    auto collect = [&](int64_t c) -> int {
+        Slot &S = slots[c % n_slots];
+        hipError_t e = hipStreamSynchronize(S.st);
+        if (e != hipSuccess) return fail(SBWTGPU_ERR_HIP, "stream synchronize: %s", hipGetErrorString(e));
+        try {
+            result.insert(result.end(), S.h_text, S.h_text + S.text_len);
+        } catch (...) {
+            return fail(SBWTGPU_ERR_OOM, "out of host memory");
+        }
+        S.busy = false;
+        return SBWTGPU_OK;
+    };
+    // chunk c+1 is submitted (other slot) before chunk c is fetched, so its H2D and kernels overlap
+    // chunk c's D2H and host append
+    for (int64_t c = 0; c < n_chunks && rc == SBWTGPU_OK; c++) {
+        if (c >= n_slots) rc = collect(c - n_slots);              // frees this chunk's slot
+        if (rc == SBWTGPU_OK) rc = submit(c);
+        if (rc == SBWTGPU_OK && c >= 1) rc = fetch(c - 1);
+    }
+    if (rc == SBWTGPU_OK) rc = fetch(n_chunks - 1);
+    for (int64_t c = std::max<int64_t>(0, n_chunks - n_slots); c < n_chunks && rc == SBWTGPU_OK; c++) rc = collect(c);
+    cleanup();
+#undef PIPE_TRY
+    if (rc != SBWTGPU_OK) return rc;
+    if (bug) return fail(SBWTGPU_ERR_NOT_SINGLETON, "Bug: k-mer search did not give a singleton interval");
+    char *outp = (char *)malloc(result.size() ? result.size() : 1);
+    if (!outp) return fail(SBWTGPU_ERR_OOM, "out of host memory");
+    if (!result.empty()) memcpy(outp, result.data(), result.size());
+    *text = outp;
+    *text_bytes = (int64_t)result.size();
+    if (n_queries) *n_queries = total_queries;
     return SBWTGPU_OK;
 }
 

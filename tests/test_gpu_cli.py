@@ -97,6 +97,10 @@ def test_cli_non_streaming_index_and_batches(gpu, tmp_path):
             "--batch-bases", "20000")
     assert b"replicated onto 3 GPU contexts" in p.stderr
     assert open(d + "/sh.out", "rb").read() == want
+    p = run("search", "-o", d + "/hf.out", "-i", d + "/st.sbwt", "-q", d + "/r.fastq", "--host-format")
+    assert open(d + "/hf.out", "rb").read() == want
+    p = run("search", "-o", d + "/hf2.out", "-i", d + "/st.sbwt", "-q", d + "/r.fastq", "--host-format", "--gpu-list", "0,0")
+    assert open(d + "/hf2.out", "rb").read() == want
     p = run("search", "-o", d + "/g1.out", "-i", d + "/ns.sbwt", "-q", d + "/r.fastq", "--gpus", "1")
     assert open(d + "/g1.out", "rb").read() == want
     p = run("search", "-o", d + "/g9.out", "-i", d + "/st.sbwt", "-q", d + "/r.fastq", "--gpus", "9", check=False)

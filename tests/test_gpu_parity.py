@@ -279,3 +279,50 @@ def test_rank_beyond_2_pow_31_columns(gpu):
             want += bin(int(cols[c][w]) & ((1 << b) - 1)).count("1")
         assert g == want, (p_, s_)
     idx.close()
+
+
+def test_device_side_print_vector(gpu, genome_case):
+    # print_vector of src/CLI/sbwt_search.cpp:21-43 on the device, incl. the pipelined
+    # host path with more than one chunk, empty reads, and the 0 -> empty-token quirk
+    import ctypes as C
+    import torch
+    genomes, orc = genome_case
+    idx = gpu_index_from_oracle(orc)
+    g = genomes[0].tobytes()
+    reads = [b"", g[:29], g[100:400], b"N" * 50, g[5000:5031], b""] + [g[i * 97:i * 97 + 150] for i in range(3000)]
+    bases, off = capi.concat_reads(reads)
+    bases = synth.inject(bases, 200, ord("N"), 4)
+    want = b"".join(print_vector(orc.streaming_search(bases[off[r]:off[r + 1]].tobytes())) for r in range(len(reads)))
+    text, nq = idx.search_text(bases, off, True)
+    assert text == want and nq == int(np.maximum(np.diff(off) - 29, 0).sum())
+    text2, _ = idx.search_text(bases, off, False)
+    assert text2 == want
+    # many chunks: > 4 Mi reads per chunk is the limit, so use short reads in bulk
+    big_b, big_o = synth.sample_reads(genomes, 600_000, 64, 0.01, 3)      # 38 M bases -> 2 chunks
+    t3, nq3 = idx.search_text(big_b, big_o, True)
+    got, oo = idx.streaming_search(big_b, big_o)
+    lines = t3.split(b"\n")
+    assert len(lines) == 600_001 and lines[-1] == b"" and nq3 == len(got)
+    for r in (0, 1, 299_999, 300_000, 599_999):
+        assert lines[r] + b"\n" == print_vector(got[oo[r]:oo[r + 1]])
+    import zlib
+    assert zlib.crc32(t3) == zlib.crc32(b"".join(print_vector(got[oo[r]:oo[r + 1]]) for r in range(600_000)))
+    # raw formatter on arbitrary values: 0 prints as an empty token, large values keep every digit
+    vals = np.array([0, -1, 7, 10, 99, 100, 12345678901234, -1, 0, 0, 9223372036854775807, 1], dtype=np.int64)
+    ooff = np.array([0, 3, 3, 11, 12], dtype=np.int64)
+    dev = torch.device("cuda:0")
+    d_v, d_o = torch.from_numpy(vals).to(dev), torch.from_numpy(ooff).to(dev)
+    L = capi.lib()
+    cap = 21 * len(vals) + 64
+    d_t = torch.zeros(cap, dtype=torch.uint8, device=dev)
+    d_l = torch.zeros(5, dtype=torch.int64, device=dev)
+    scr = L.sbwtgpu_format_scratch_bytes(4)
+    d_s = torch.zeros(scr, dtype=torch.uint8, device=dev)
+    big = capi.Index.create(*[np.zeros(1, np.uint64)] * 4, None, 1, 2)     # n_nodes = 1: bound would be tiny ...
+    rc = L.sbwtgpu_format_results_dev(big.handle, d_v.data_ptr(), d_o.data_ptr(), 4, len(vals), d_t.data_ptr(), cap,
+                                      d_l.data_ptr(), d_s.data_ptr(), scr, torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    torch.cuda.synchronize()
+    n = int(d_l[4].item())
+    assert bytes(d_t[:n].cpu().numpy()) == b"".join(print_vector(vals[ooff[r]:ooff[r + 1]]) for r in range(4))
+    assert list(d_l.cpu().numpy()) == [0, 7, 8, 8 + len(print_vector(vals[3:11])), n]
