@@ -183,6 +183,8 @@ int  sbwtgpu_search_text_batch(const sbwtgpu_index *idx, const char *bases, cons
                                int64_t n_reads, int streaming, char **text, int64_t *text_bytes,
                                int64_t *n_queries);
 void sbwtgpu_free_host(void *p);
+/* sbwtgpu_search_text_batch keeps its pinned staging and device buffers for the next call; this frees them. */
+void sbwtgpu_release_cached_buffers(void);
 
 #ifdef __cplusplus
 }

@@ -37,7 +37,7 @@ EXPORTED_SYMBOLS = [
     "sbwtgpu_rank_dev", "sbwtgpu_encode_bases_dev", "sbwtgpu_search_encoded_dev",
     "sbwtgpu_workspace_status", "sbwtgpu_workspace_stats",
     "sbwtgpu_format_text_bound", "sbwtgpu_format_scratch_bytes", "sbwtgpu_format_results_dev",
-    "sbwtgpu_search_text_batch", "sbwtgpu_free_host",
+    "sbwtgpu_search_text_batch", "sbwtgpu_free_host", "sbwtgpu_release_cached_buffers",
 ]
 
 
@@ -116,6 +116,7 @@ def lib() -> C.CDLL:
     L.sbwtgpu_search_text_batch.argtypes = [vp, vp, vp, i64, ci, C.POINTER(vp), C.POINTER(i64), C.POINTER(i64)]
     L.sbwtgpu_free_host.argtypes = [vp]
     L.sbwtgpu_free_host.restype = None
+    L.sbwtgpu_release_cached_buffers.restype = None
     _lib = L
     return L
 

@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <algorithm>
+#include <mutex>
 #include <cstddef>
 #include <cstring>
 #include <new>
@@ -820,7 +821,45 @@ struct Slot {
     }
 };
 inline int64_t a256(int64_t x) { return (x + 255) & ~(int64_t)255; }
+
+// Pinned + device buffers are expensive to create (page pinning), so finished calls park their slots
+// here and later calls on the same device reuse them when they are large enough.
+std::mutex g_slot_mutex;
+struct ParkedSlot { int device; Slot slot; };
+std::vector<ParkedSlot> g_parked;
+
+bool take_parked(int device, int64_t bases, int64_t reads, int64_t vals, int64_t text, Slot *out) {
+    std::lock_guard<std::mutex> lock(g_slot_mutex);
+    for (size_t i = 0; i < g_parked.size(); i++) {
+        Slot &S = g_parked[i].slot;
+        if (g_parked[i].device == device && S.cap_bases >= bases && S.cap_reads >= reads && S.cap_vals >= vals &&
+            S.cap_text >= text) {
+            *out = S;
+            g_parked.erase(g_parked.begin() + (long)i);
+            return true;
+        }
+    }
+    return false;
+}
+void park(int device, Slot &S) {
+    std::lock_guard<std::mutex> lock(g_slot_mutex);
+    if (g_parked.size() >= 8) { S.release(); return; }
+    g_parked.push_back(ParkedSlot{device, S});
+    S = Slot();
+}
 }  // namespace
+
+void sbwtgpu_release_cached_buffers(void) {
+    std::lock_guard<std::mutex> lock(g_slot_mutex);
+    for (auto &ps : g_parked) {
+        int prev = -1;
+        (void)hipGetDevice(&prev);
+        (void)hipSetDevice(ps.device);
+        ps.slot.release();
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+    g_parked.clear();
+}
 
 int sbwtgpu_search_text_batch(const sbwtgpu_index *idx, const char *bases, const int64_t *read_off, int64_t n_reads,
                               int streaming, char **text, int64_t *text_bytes, int64_t *n_queries) {
@@ -835,8 +874,8 @@ int sbwtgpu_search_text_batch(const sbwtgpu_index *idx, const char *bases, const
     if (n_reads > 0 && (!read_off || (read_off[n_reads] > read_off[0] && !bases)))
         return fail(SBWTGPU_ERR_INVALID_ARG, "NULL input");
     const int64_t k = idx->h.k;
-    // ---- chunking: <= 32 Mi bases and <= 4 Mi reads per chunk ----
-    const int64_t CH_BASES = (int64_t)32 << 20, CH_READS = (int64_t)4 << 20;
+    // ---- chunking: <= 8 Mi bases and <= 1 Mi reads per chunk (small pinned buffers, deep overlap) ----
+    const int64_t CH_BASES = (int64_t)8 << 20, CH_READS = (int64_t)1 << 20;
     std::vector<int64_t> cuts{0};
     int64_t max_bases = 0, max_reads = 0, max_vals = 0;
     {
@@ -863,7 +902,6 @@ int sbwtgpu_search_text_batch(const sbwtgpu_index *idx, const char *bases, const
         }
     }
     const int64_t n_chunks = (int64_t)cuts.size() - 1;
-    std::vector<char> result;
     if (n_chunks == 0) {
         *text = (char *)malloc(1);
         return *text ? SBWTGPU_OK : fail(SBWTGPU_ERR_OOM, "out of host memory");
@@ -872,6 +910,14 @@ int sbwtgpu_search_text_batch(const sbwtgpu_index *idx, const char *bases, const
     Slot slots[2];
     int rc = SBWTGPU_OK;
     auto cleanup = [&]() { slots[0].release(); slots[1].release(); };
+    // the output buffer is sized by the bound of the whole batch (untouched pages cost nothing) and
+    // shrunk at the end, so every chunk's text is copied exactly once
+    int64_t all_vals = 0;
+    for (int64_t r = 0; r < n_reads; r++) all_vals += std::max<int64_t>(0, read_off[r + 1] - read_off[r] - k + 1);
+    const int64_t result_cap = sbwtgpu_format_text_bound(idx, all_vals, n_reads);
+    char *result = (char *)malloc((size_t)result_cap);
+    if (!result) return fail(SBWTGPU_ERR_OOM, "out of host memory");
+    int64_t result_len = 0;
 #define PIPE_TRY(expr)                                                                                     \
     do {                                                                                                   \
         hipError_t e_ = (expr);                                                                            \
@@ -879,12 +925,15 @@ int sbwtgpu_search_text_batch(const sbwtgpu_index *idx, const char *bases, const
             rc = fail(e_ == hipErrorOutOfMemory ? SBWTGPU_ERR_OOM : SBWTGPU_ERR_HIP, "%s failed: %s", #expr, \
                       hipGetErrorString(e_));                                                              \
             cleanup();                                                                                     \
+            free(result);                                                                                  \
             return rc;                                                                                     \
         }                                                                                                  \
     } while (0)
     const int n_slots = n_chunks > 1 ? 2 : 1;
     for (int s = 0; s < n_slots; s++) {
         Slot &S = slots[s];
+        if (take_parked(idx->device, max_bases, max_reads, max_vals, sbwtgpu_format_text_bound(idx, max_vals, max_reads), &S))
+            continue;
         S.cap_bases = max_bases; S.cap_reads = max_reads; S.cap_vals = max_vals;
         S.cap_text = sbwtgpu_format_text_bound(idx, max_vals, max_reads);
         S.ws_bytes = sbwtgpu_search_workspace_bytes(max_bases);
@@ -960,11 +1009,9 @@ int sbwtgpu_search_text_batch(const sbwtgpu_index *idx, const char *bases, const
         Slot &S = slots[c % n_slots];
         hipError_t e = hipStreamSynchronize(S.st);
         if (e != hipSuccess) return fail(SBWTGPU_ERR_HIP, "stream synchronize: %s", hipGetErrorString(e));
-        try {
-            result.insert(result.end(), S.h_text, S.h_text + S.text_len);
-        } catch (...) {
-            return fail(SBWTGPU_ERR_OOM, "out of host memory");
-        }
+        if (result_len + S.text_len > result_cap) return fail(SBWTGPU_ERR_HIP, "formatted text overflows its bound");
+        memcpy(result + result_len, S.h_text, (size_t)S.text_len);
+        result_len += S.text_len;
         S.busy = false;
         return SBWTGPU_OK;
     };
@@ -977,15 +1024,21 @@ int sbwtgpu_search_text_batch(const sbwtgpu_index *idx, const char *bases, const
     }
     if (rc == SBWTGPU_OK) rc = fetch(n_chunks - 1);
     for (int64_t c = std::max<int64_t>(0, n_chunks - n_slots); c < n_chunks && rc == SBWTGPU_OK; c++) rc = collect(c);
-    cleanup();
 #undef PIPE_TRY
-    if (rc != SBWTGPU_OK) return rc;
-    if (bug) return fail(SBWTGPU_ERR_NOT_SINGLETON, "Bug: k-mer search did not give a singleton interval");
-    char *outp = (char *)malloc(result.size() ? result.size() : 1);
-    if (!outp) return fail(SBWTGPU_ERR_OOM, "out of host memory");
-    if (!result.empty()) memcpy(outp, result.data(), result.size());
-    *text = outp;
-    *text_bytes = (int64_t)result.size();
+    if (rc != SBWTGPU_OK) {
+        (void)hipDeviceSynchronize();
+        cleanup();
+        free(result);
+        return rc;
+    }
+    for (int s2 = 0; s2 < n_slots; s2++) park(idx->device, slots[s2]);
+    if (bug) {
+        free(result);
+        return fail(SBWTGPU_ERR_NOT_SINGLETON, "Bug: k-mer search did not give a singleton interval");
+    }
+    char *shrunk = (char *)realloc(result, (size_t)(result_len ? result_len : 1));
+    *text = shrunk ? shrunk : result;
+    *text_bytes = result_len;
     if (n_queries) *n_queries = total_queries;
     return SBWTGPU_OK;
 }
