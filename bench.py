@@ -127,11 +127,19 @@ def main() -> int:
         log(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the search path has no CPU fallback")
+    # test hooks: run several ranks on one GPU (SBWT_BENCH_FORCE_DEVICE) over gloo (SBWT_BENCH_BACKEND) to
+    # exercise the N>1 code path on a single-GPU box; the driver's multi-GPU run uses neither
+    if "SBWT_BENCH_FORCE_DEVICE" in os.environ:
+        local_rank = int(os.environ["SBWT_BENCH_FORCE_DEVICE"])
+    backend = os.environ.get("SBWT_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     # ---- index: built once on rank 0 (host sort-based builder), replicated by one broadcast ----
     t0 = time.time()
@@ -262,7 +270,7 @@ def main() -> int:
     if t_bcast is not None:
         result["index_broadcast_s"] = t_bcast
     traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(traffic_file):
+    if os.path.exists(traffic_file) and args.config == 2 and n_reads == 10_000_000:   # measured on this workload
         try:
             tj = json.load(open(traffic_file))
             result["roofline"]["traffic"] = tj.get("hbm_bytes_per_launch")
