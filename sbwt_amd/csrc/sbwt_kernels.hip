@@ -639,229 +639,6 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_search_flat: the state machine of k_search_cert written as straight-line, select-based code.
-// In a wave every state is present in every iteration, so divergent branches buy nothing and cost
-// exec-mask bookkeeping and register copies (k_search_cert: 483 VALU of which 182 v_mov, 531 SALU
-// per iteration); here each iteration computes the candidates of all states once and selects.
-// Same states, same certificates, same results.
-// ---------------------------------------------------------------------------------------------
-template <bool WIDE>
-__global__ void __launch_bounds__(256, 4) k_search_flat(SbwtIndexView ix, const uint4 *__restrict__ packed,
-                                                        const i64 *__restrict__ read_off,
-                                                        const i64 *__restrict__ out_off, i64 *__restrict__ out,
-                                                        i64 n_reads, SbwtWorkHeader *ws, int streaming) {
-    typedef typename SearchTypes<WIDE>::pos_t pos_t;
-    typedef typename SearchTypes<WIDE>::stage_t stage_t;
-    constexpr int DEPTH = SearchTypes<WIDE>::DEPTH;
-    __shared__ stage_t stage[DEPTH][256];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int k = ix.k, p = ix.p_dev, L0 = ix.probe_len;
-    const pos_t last_node = (pos_t)(ix.n_nodes - 1);
-    const u64 vm = low_mask(p), tm = low_mask(2 * p);
-    // all gathers are addressed as byte offsets from the first block of the index image
-    const char *const base = reinterpret_cast<const char *>(ix.blocks);
-    const i64 d_ptab = reinterpret_cast<const char *>(ix.ptab) - base;
-    const i64 d_packed = reinterpret_cast<const char *>(packed) - base;
-    const i64 d_roff = reinterpret_cast<const char *>(read_off) - base;
-    const i64 d_ooff = reinterpret_cast<const char *>(out_off) - base;
-
-    int mode = M_IDLE;
-    i64 obase = 0;
-    int pgrp = 0, poff = 0;
-    int m = 0, i = 0, j = 0, b = -1, wstart = 0, cnt = 0;
-    pos_t l = 0, r = 0;
-    i64 rd = 0;
-    int tag = -2;
-    bool g1ok = false;
-    uint4 g0 = make_uint4(0, 0, 0, 0), g1 = make_uint4(0, 0, 0, 0);
-    u64 pool_next = 0, pool_end = 0;
-    unsigned c_stream = 0, c_search = 0, c_lf = 0, c_tab = 0;
-
-    for (;;) {
-        // ---- hand out reads to idle lanes from the wave's ticket pool ----
-        const u64 need = __ballot(mode == M_IDLE);
-        if (need) {
-            if (pool_next == pool_end) {
-                u64 t = 0;
-                if (lane == 0) t = atomicAdd(&ws->ticket, 64ull);
-                t = __shfl(t, 0);
-                pool_next = t;
-                pool_end = t + 64;
-            }
-            const unsigned avail = (unsigned)(pool_end - pool_next);
-            const unsigned n = (unsigned)__popcll(need);
-            const unsigned rank = (unsigned)__popcll(need & low_mask(lane));
-            if (mode == M_IDLE && rank < avail) {
-                rd = (i64)(pool_next + rank);
-                mode = (rd < n_reads) ? M_FETCH : M_DEAD;
-            }
-            pool_next += (n < avail) ? n : avail;
-        }
-        if (__ballot(mode != M_DEAD) == 0) break;
-
-        // ---- decode the lane's state ----
-        const bool mF = (mode == M_FETCH), mS = (mode == M_STREAM), mB = (mode == M_BACK);
-        const bool mI = (mode == M_INIT), mT = (mode == M_STEP);
-        const bool strm = mS | mB;
-        const bool active = strm | mI | mT;
-        const int q = strm ? (i + k - 1) : (wstart + j);
-        const int P = poff + q;
-        const int s = P & 31;
-        const int grp = pgrp + (P >> 5);
-        const bool span = mI & (s + p > 32);
-        const bool shift = active & (grp == tag + 1) & g1ok & !span;
-        g0.x = shift ? g1.x : g0.x; g0.y = shift ? g1.y : g0.y;
-        g0.z = shift ? g1.z : g0.z; g0.w = shift ? g1.w : g0.w;
-        tag = shift ? grp : tag;
-        g1ok = g1ok & !shift;
-        const bool reload = active & ((grp != tag) | (span & !g1ok));
-        const bool work = active & !reload;
-
-        const u64 codes0 = quad_bits(g0);
-        const u64 cw = codes0 >> (2 * s);
-        const int c = (int)((unsigned)cw & 3u);
-        const u64 hi = s ? (quad_bits(g1) << ((64 - 2 * s) & 63)) : 0ull;
-        const u64 widx = (cw | hi) & tm;
-        const u64 vr = ((((u64)g1.w << 32) | (u64)g0.w) >> s);
-        const u64 bad = ~vr & vm;
-        const bool okU = (g0.z >> s) & 1u, okR = (g0.w >> s) & 1u;
-        const bool inv_s = work & strm & !okU;          // SBWT.hh:568
-        const bool inv_i = work & mI & (bad != 0);      // SBWT.hh:398-399
-        const bool inv_t = work & mT & !okR;            // SBWT.hh:427-428
-        const bool have = work & !(inv_s | inv_i | inv_t);
-
-        // ---- the two gather addresses ----
-        const i64 blk1 = mB ? (i64)r : ((i64)l >> 6);
-        const i64 offA = (blk1 << 6) + ((strm ? (c & 2) : c) << 4);
-        const i64 offB = strm ? (offA + 16) : (((((i64)r + 1) >> 6) << 6) + (c << 4));
-        const i64 offT = d_ptab + (i64)(widx << 4);
-        const i64 offG = d_packed + ((i64)grp << 4);
-        i64 o1 = 0, o2 = 0;
-        o1 = have ? (mI ? offT : offA) : o1;
-        o2 = have ? (mI ? offT : offB) : o2;
-        o1 = reload ? offG : o1;
-        o2 = reload ? (offG + 16) : o2;
-        o1 = mF ? (d_roff + (rd << 3)) : o1;
-        o2 = mF ? (d_ooff + (rd << 3)) : o2;
-        c_search += (unsigned)__popcll(__ballot(work & (mI | ((p == 0) & mT & (j == 0)))));
-        c_lf += (unsigned)__popcll(__ballot(have & mT));
-
-        // ---- the one memory round trip of this iteration ----
-        const uint4 v1 = *reinterpret_cast<const uint4 *>(base + o1);
-        const uint4 v2 = *reinterpret_cast<const uint4 *>(base + o2);
-
-        // ---- candidates of every state ----
-        // packed group reload
-        g0.x = reload ? v1.x : g0.x; g0.y = reload ? v1.y : g0.y;
-        g0.z = reload ? v1.z : g0.z; g0.w = reload ? v1.w : g0.w;
-        g1.x = reload ? v2.x : g1.x; g1.y = reload ? v2.y : g1.y;
-        g1.z = reload ? v2.z : g1.z; g1.w = reload ? v2.w : g1.w;
-        g1ok = g1ok | reload;
-        tag = reload ? grp : tag;
-        // new read
-        const i64 P0 = (i64)quad_bits(v1);
-        const int m_new = (int)((i64)((u64)v1.z | ((u64)v1.w << 32)) - P0) - k + 1;
-        obase = mF ? (i64)quad_bits(v2) : obase;
-        pgrp = mF ? (int)(P0 >> 5) : pgrp;
-        poff = mF ? (int)(P0 & 31) : poff;
-        m = mF ? m_new : m;
-        i = mF ? 0 : i;
-        b = mF ? -1 : b;
-        // streaming step / walk-back
-        const u64 ssw = (u64)v1.w | ((u64)v2.w << 32);
-        const u64 msk = mB ? ssw : (ssw & ((2ull << (int)(l & 63)) - 1ull));
-        const bool goback = have & strm & (msk == 0) & (blk1 > 0);
-        const int gb = 63 - __clzll((i64)(msk ? msk : 1ull));
-        const bool odd = strm & (c & 1);
-        const unsigned qx = odd ? v2.x : v1.x, qy = odd ? v2.y : v1.y, qz = odd ? v2.z : v1.z;
-        const int oA = strm ? gb : (int)(l & 63);
-        const u64 bitsA = (u64)qx | ((u64)qy << 32);
-        pos_t rankA = (pos_t)qz + (pos_t)__popcll(bitsA & low_mask(oA));
-        const int oB = (int)((r + 1) & 63);
-        pos_t rankB = (pos_t)v2.z + (pos_t)__popcll(quad_bits(v2) & low_mask(oB));
-        if (WIDE) {
-            rankA += (pos_t)ix.mega[(i64)c * ix.n_mega + ((strm ? ((blk1 << 6) | gb) : (i64)l) >> SBWT_MEGA_SHIFT)];
-            rankB += (pos_t)ix.mega[(i64)c * ix.n_mega + (((i64)r + 1) >> SBWT_MEGA_SHIFT)];
-        }
-        rankB -= 1;
-        const bool hasbit = (bitsA >> oA) & 1ull;
-        const bool s_done = have & strm & !goback;
-        // prefix-table entry
-        const pos_t tl = (pos_t)(i64)quad_bits(v1), tr = (pos_t)(i64)((u64)v1.z | ((u64)v1.w << 32));
-        const bool i_ok = have & mI & (tl != -1);
-        const bool i_fail = have & mI & (tl == -1);
-        // interval update
-        const bool t_ok = have & mT & (rankA <= rankB);
-        const bool t_fail = have & mT & (rankA > rankB);
-        c_tab += (unsigned)__popcll(__ballot(i_ok));
-
-        // ---- merge: walk state ----
-        l = i_ok ? tl : (t_ok ? rankA : l);
-        r = i_ok ? tr : (t_ok ? rankB : (goback ? (pos_t)(blk1 - 1) : r));
-        j = i_ok ? p : (t_ok ? (j + 1) : j);
-        const bool w_end = (i_ok | t_ok) & (wstart + j == i + k);      // alive at the end of k-mer i's window
-        const bool found = w_end & (wstart == i);
-        const bool incon = w_end & !found;
-        if (found & (l != r)) ws->status = SBWT_ERR_NOT_SINGLETON;      // SBWT.hh:410-413
-        const bool fail = inv_i | inv_t | i_fail | t_fail;
-        const int tfail = inv_i ? (wstart + (__ffsll((i64)(bad | (1ull << 63))) - 1))
-                                : (i_fail ? (wstart + p - 1) : (wstart + j));
-        const int bh = (wstart < m - 1) ? wstart : (m - 1);
-        const bool single = fail & (bh == i);
-        const bool burst = fail & !single;
-        const pos_t s_res = hasbit ? rankA : (pos_t)-1;
-        const bool emit1 = s_done | inv_s | found | single;
-        const pos_t res = s_done ? s_res : (found ? l : (pos_t)-1);
-        c_stream += (unsigned)__popcll(__ballot(s_done | inv_s));
-        b = fail ? tfail : (((s_done | inv_s) & (res == -1)) ? (i + k - 1) : (found ? -1 : b));
-
-        // ---- results: LDS stage, line-aligned runs, certified bursts ----
-        if (emit1) stage[cnt][tid] = (stage_t)res;
-        cnt += emit1;
-        i += emit1;
-        if ((cnt > 0) & (burst | (i == m) | ((((unsigned)obase + (unsigned)i) & (DEPTH - 1)) == 0))) {
-#pragma unroll 1
-            for (int t = 0; t < cnt; t++) out[obase + (i - cnt + t)] = (i64)(pos_t)stage[t][tid];
-            cnt = 0;
-        }
-        if (burst) {
-#pragma unroll 1
-            for (int t = i; t <= bh; t++) out[obase + t] = -1;
-            i = bh + 1;
-        }
-
-        // ---- next state ----
-        const bool emitted = emit1 | burst;
-        const bool done = (emitted & (i == m)) | (mF & (m_new <= 0));
-        const bool gostream = emit1 & (res != -1) & (streaming != 0) & !done;
-        const bool do_plan = !done & ((mF & (m_new > 0)) | incon | (emitted & !gostream));
-        const bool force = mF | incon;
-        int s0 = i;
-        const bool near_b = !force & (L0 > 0) & (b >= i) & (b <= i + k - 1);
-        const int cand = (b - i >= L0 - 1) ? (b - L0 + 1) : b;
-        s0 = (near_b & (cand + p - 1 <= i + k - 1)) ? cand : s0;
-        wstart = do_plan ? s0 : wstart;
-        j = do_plan ? 0 : j;
-        l = gostream ? res : ((do_plan & (p == 0)) ? (pos_t)0 : l);
-        r = (do_plan & (p == 0)) ? last_node : r;
-        int nm = mode;
-        nm = goback ? M_BACK : nm;
-        nm = (i_ok & !w_end) ? M_STEP : nm;
-        nm = do_plan ? ((p > 0) ? M_INIT : M_STEP) : nm;
-        nm = gostream ? M_STREAM : nm;
-        nm = done ? M_IDLE : nm;
-        mode = nm;
-    }
-
-    if (lane == 0) {
-        atomicAdd(&ws->n_stream, (u64)c_stream);
-        atomicAdd(&ws->n_search, (u64)c_search);
-        atomicAdd(&ws->n_lf, (u64)c_lf);
-        atomicAdd(&ws->n_tab_hit, (u64)c_tab);
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
 // k_rank: SubsetMatrixRank::rank(pos, c) for n independent (pos, sym) pairs
 // ---------------------------------------------------------------------------------------------
 template <bool MEGA>
@@ -1095,18 +872,6 @@ void sbwt_launch_search(const SbwtIndexView &ix, const uint4 *d_packed, const lo
                         const long long *d_out_off, long long *d_out, long long n_reads, SbwtWorkHeader *ws,
                         int streaming, hipStream_t stream, int variant, long long total_groups) {
     if (n_reads <= 0) return;
-    if (variant == 2) {
-        i64 want2 = (n_reads + 255) / 256;
-        unsigned grid2 = (unsigned)(want2 < 1024 ? want2 : 1024);
-        const bool wide2 = ix.n_nodes >= ((1ll << 31) - 128) || total_groups >= (1ll << 27) - 4;
-        if (wide2)
-            hipLaunchKernelGGL(k_search_flat<true>, dim3(grid2), dim3(256), 0, stream, ix, d_packed, d_read_off,
-                               d_out_off, d_out, (i64)n_reads, ws, streaming);
-        else
-            hipLaunchKernelGGL(k_search_flat<false>, dim3(grid2), dim3(256), 0, stream, ix, d_packed, d_read_off,
-                               d_out_off, d_out, (i64)n_reads, ws, streaming);
-        return;
-    }
     if (variant == 1) {
         i64 want1 = (n_reads + 255) / 256;
         unsigned grid1 = (unsigned)(want1 < 2048 ? want1 : 2048);

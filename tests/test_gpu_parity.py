@@ -215,7 +215,7 @@ def test_streaming_equals_search_at_scale_properties(gpu, genome_case):
     assert np.array_equal(a[: len(want)], want)
 
 
-@pytest.mark.parametrize("variant,probe", [(0, -1), (1, -1), (1, 0), (1, 9), (1, 12), (1, 29), (2, -1), (2, 0), (2, 9), (2, 11), (2, 12), (2, 20), (2, 29)])
+@pytest.mark.parametrize("variant,probe", [(0, -1), (1, -1), (1, 0), (1, 9), (1, 11), (1, 12), (1, 13), (1, 20), (1, 29)])
 def test_results_do_not_depend_on_search_variant_or_probe_length(gpu, genome_case, variant, probe):
     # k_search (reference order) and k_search_cert (absent-substring certificates) must give the
     # same bits for every probe length, including reads with N / lower case and all-miss reads
