@@ -220,8 +220,6 @@ def main() -> int:
     # SURVEY 8d's nominal formula (every full search priced at all k-p interval updates)
     n_full = n_kmers - n_stream
     nominal_bytes = B_STREAM * n_stream + (K + 16 + 8 + B_LF * (K - PRECALC)) * n_full
-    if not streaming:
-        n_full = n_kmers
 
     total_kmers = n_kmers * world
     value = total_kmers * args.steps / elapsed

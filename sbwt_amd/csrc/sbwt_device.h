@@ -50,6 +50,8 @@ struct SbwtBlobHeader {
     int64_t off_blocks, off_ptab, off_ftab, off_mega, blob_bytes;
     int32_t has_ssup;
     int32_t rank_only;              // the columns are not SBWT-consistent: only rank() is served
+    int32_t ssup_derived;           // no suffix_group_starts given: marks derived on the device (internal use)
+    int32_t reserved;
 };
 #define SBWT_BLOB_MAGIC 0x3155504754574253ull   // "SBWTGPU1" little endian
 
@@ -83,3 +85,5 @@ void sbwt_launch_forward(const SbwtIndexView &ix, const long long *d_node, const
 long long sbwt_format_scratch_bytes(long long n_reads);
 void sbwt_launch_format(const long long *d_vals, const long long *d_out_off, long long n_reads, char *d_text,
                         long long *d_line_off, void *d_scratch, hipStream_t stream);
+long long sbwt_derive_scratch_bytes(long long n_nodes);
+void sbwt_launch_derive_marks(const SbwtIndexView &ix, uint4 *d_blocks, void *d_scratch, hipStream_t stream);

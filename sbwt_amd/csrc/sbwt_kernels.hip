@@ -423,7 +423,10 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
                 const u64 codes0 = quad_bits(g0);
                 c = (int)((unsigned)(codes0 >> (2 * s)) & 3u);
                 if (strm) {
-                    if ((g0.z >> s) & 1u) {
+                    // streaming == 1: SBWT::streaming_search validates the upper-cased char (SBWT.hh:565-568);
+                    // streaming == 2: internal streaming inside the search loop keeps SBWT::search's raw-char
+                    // validation (SBWT.hh:398-399,427-428)
+                    if (((streaming == 2 ? g0.w : g0.z) >> s) & 1u) {
                         const i64 blk = (mode == M_BACK) ? (i64)r : ((i64)l >> 6);
                         a1 = ix.blocks + ((blk << 2) + (c & 2));
                         a2 = a1 + 1;
@@ -735,6 +738,51 @@ __global__ void __launch_bounds__(256) k_forward(SbwtIndexView ix, const i64 *__
 }
 
 // ---------------------------------------------------------------------------------------------
+// Suffix-group marks derived on the device (mark_suffix_groups, src/suffix_group_optimization.cpp:66-121)
+// for indexes saved with --no-streaming-support: the marks are a function of the four columns, so the
+// per-k-mer search loop can use streaming steps internally (with the raw-character validation of
+// SBWT::search) although the index carries no suffix_group_starts vector.  k-1 rounds of
+//   mark:       column i starts a group in this round iff its label differs from column i-1's
+//   propagate:  every edge (i --c--> C[c] + rank_c(i)) hands column i's label to its target
+// starting from label(v) = the symbol whose C-array range holds v ('$' for the root).
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_sg_init(SbwtIndexView ix, unsigned char *__restrict__ last) {
+    i64 v = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (v >= ix.n_nodes) return;
+    last[v] = (unsigned char)((v >= ix.C[0]) + (v >= ix.C[1]) + (v >= ix.C[2]) + (v >= ix.C[3]));
+}
+__global__ void __launch_bounds__(256) k_sg_mark(const unsigned char *__restrict__ last, i64 n, u64 *__restrict__ acc) {
+    i64 w = (i64)blockIdx.x * 256 + threadIdx.x;      // one 64-column word per thread
+    if (w * 64 >= n) return;
+    u64 m = 0;
+    for (int t = 0; t < 64; t++) {
+        i64 i = w * 64 + t;
+        if (i < n && (i == 0 || last[i] != last[i - 1])) m |= 1ull << t;
+    }
+    acc[w] |= m;
+}
+template <bool MEGA>
+__global__ void __launch_bounds__(256) k_sg_propagate(SbwtIndexView ix, const unsigned char *__restrict__ last,
+                                                      unsigned char *__restrict__ next) {
+    i64 i = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (i >= ix.n_nodes) return;
+    if (i == 0) next[0] = 0;                           // nothing points at the root: '$'
+    const unsigned char lab = last[i];
+    const uint4 *blk = ix.blocks + ((i >> 6) << 2);
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        const uint4 q = blk[c];
+        if ((quad_bits(q) >> (i & 63)) & 1ull) next[(i64)quad_rank<MEGA>(ix, q, i, c)] = lab;
+    }
+}
+__global__ void __launch_bounds__(256) k_sg_patch(uint4 *__restrict__ blocks, const u64 *__restrict__ acc, i64 n_blocks) {
+    i64 b = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (b >= n_blocks) return;
+    const u64 s = acc[b];
+    for (int c = 0; c < 4; c++) blocks[b * 4 + c].w = (c & 1) ? (unsigned)(s >> 32) : (unsigned)s;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Output formatting on the device: print_vector of src/CLI/sbwt_search.cpp:21-43 for a whole batch.
 // One line per read, every value followed by one space, '\n' per read, -1 printed as "-1", and the
 // reference's quirk kept: 0 prints as an empty token.  One wave per read.
@@ -894,10 +942,10 @@ void sbwt_launch_search(const SbwtIndexView &ix, const uint4 *d_packed, const lo
     unsigned grid = (unsigned)(want < 2048 ? want : 2048);
     if (ix.n_mega > 1)
         hipLaunchKernelGGL(k_search<true>, dim3(grid), dim3(256), 0, stream, ix, d_packed, d_read_off, d_out_off,
-                           d_out, (i64)n_reads, ws, streaming);
+                           d_out, (i64)n_reads, ws, streaming == 1 ? 1 : 0);
     else
         hipLaunchKernelGGL(k_search<false>, dim3(grid), dim3(256), 0, stream, ix, d_packed, d_read_off, d_out_off,
-                           d_out, (i64)n_reads, ws, streaming);
+                           d_out, (i64)n_reads, ws, streaming == 1 ? 1 : 0);
 }
 
 void sbwt_launch_rank(const SbwtIndexView &ix, const long long *d_pos, const char *d_sym, long long n,
@@ -955,4 +1003,25 @@ void sbwt_launch_format(const long long *d_vals, const long long *d_out_off, lon
     hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(256), 0, stream, line_len, (i64)n_reads, bsum, d_line_off);
     hipLaunchKernelGGL(k_fmt_write, dim3(wave_blocks), dim3(256), 0, stream, d_vals, d_out_off, (i64)n_reads,
                        d_line_off, d_text);
+}
+
+// scratch: last[n] + next[n] bytes + acc[n_blocks] words
+long long sbwt_derive_scratch_bytes(long long n_nodes) {
+    return 2 * ((n_nodes + 255) & ~255ll) + (n_nodes / 64 + 1) * 8 + 256;
+}
+void sbwt_launch_derive_marks(const SbwtIndexView &ix, uint4 *d_blocks, void *d_scratch, hipStream_t stream) {
+    const i64 n = ix.n_nodes, nb = n / 64 + 1, nal = (n + 255) & ~255ll;
+    unsigned char *last = reinterpret_cast<unsigned char *>(d_scratch), *next = last + nal;
+    u64 *acc = reinterpret_cast<u64 *>(next + nal);
+    (void)hipMemsetAsync(acc, 0, (size_t)nb * 8, stream);
+    hipLaunchKernelGGL(k_sg_init, dim3(grid_for(n)), dim3(256), 0, stream, ix, last);
+    for (int round = 0; round < ix.k - 1; round++) {
+        hipLaunchKernelGGL(k_sg_mark, dim3(grid_for(nb)), dim3(256), 0, stream, last, n, acc);
+        if (ix.n_mega > 1)
+            hipLaunchKernelGGL(k_sg_propagate<true>, dim3(grid_for(n)), dim3(256), 0, stream, ix, last, next);
+        else
+            hipLaunchKernelGGL(k_sg_propagate<false>, dim3(grid_for(n)), dim3(256), 0, stream, ix, last, next);
+        unsigned char *t = last; last = next; next = t;
+    }
+    hipLaunchKernelGGL(k_sg_patch, dim3(grid_for(nb)), dim3(256), 0, stream, d_blocks, acc, nb);
 }

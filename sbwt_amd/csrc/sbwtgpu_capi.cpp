@@ -75,7 +75,7 @@ static int tuning_variant() {          // 0 = k_search (reference order), 1 = k_
     static int v = [] { const char *e = getenv("SBWTGPU_SEARCH_VARIANT"); return e ? atoi(e) : 1; }();
     return v;
 }
-static int g_variant_override = -1, g_probe_override = -1, g_debug = 0;
+static int g_variant_override = -1, g_probe_override = -1, g_debug = 0, g_derive_ssup = 1;
 
 struct sbwtgpu_index {
     SbwtBlobHeader h;
@@ -121,6 +121,7 @@ int sbwtgpu_set_tuning(const char *key, int64_t value) {
     if (!strcmp(key, "search_variant")) { g_variant_override = (int)value; return SBWTGPU_OK; }
     if (!strcmp(key, "probe_len")) { g_probe_override = (int)value; return SBWTGPU_OK; }
     if (!strcmp(key, "debug")) { g_debug = (int)value; return SBWTGPU_OK; }
+    if (!strcmp(key, "derive_ssup")) { g_derive_ssup = (int)value; return SBWTGPU_OK; }
     return fail(SBWTGPU_ERR_INVALID_ARG, "unknown tuning key '%s'", key);
 }
 
@@ -292,6 +293,16 @@ int sbwtgpu_index_create(const sbwtgpu_index_desc *d, int device, sbwtgpu_index 
             hipSuccess)
             break;
         SbwtIndexView v = idx->view();
+        if (!d->suffix_group_starts && !h.rank_only && g_derive_ssup && d->k >= 2) {
+            // no streaming support in the file: derive the marks for internal use (has_ssup stays 0)
+            void *scr = nullptr;
+            if ((e = hipMalloc(&scr, (size_t)sbwt_derive_scratch_bytes(n))) != hipSuccess) break;
+            sbwt_launch_derive_marks(v, reinterpret_cast<uint4 *>(idx->blob + h.off_blocks), scr, 0);
+            e = hipDeviceSynchronize();
+            (void)hipFree(scr);
+            if (e != hipSuccess) break;
+            h.ssup_derived = 1;
+        }
         if (p_dev > 0) sbwt_launch_precalc(v, (int)p_dev, reinterpret_cast<longlong2 *>(idx->blob + h.off_ptab), 0);
         if (ftab_bytes) {
             if (d->precalc) {
@@ -519,7 +530,8 @@ int sbwtgpu_search_encoded_dev(const sbwtgpu_index *idx, int64_t total_bases, co
     const uint4 *packed = reinterpret_cast<const uint4 *>(static_cast<char *>(d_ws) + sizeof(SbwtWorkHeader));
     sbwt_launch_search(idx->view(), packed, reinterpret_cast<const long long *>(d_read_off),
                        reinterpret_cast<const long long *>(d_out_off), reinterpret_cast<long long *>(d_out), n_reads,
-                       ws, streaming, st, g_variant_override >= 0 ? g_variant_override : tuning_variant(),
+                       ws, (!streaming && idx->h.ssup_derived && g_derive_ssup) ? 2 : streaming, st,
+                       g_variant_override >= 0 ? g_variant_override : tuning_variant(),
                        total_bases / SBWT_GROUP_BASES + 2);
     e = hipGetLastError();
     if (e != hipSuccess) return fail(SBWTGPU_ERR_HIP, "kernel launch: %s", hipGetErrorString(e));

@@ -326,3 +326,34 @@ def test_device_side_print_vector(gpu, genome_case):
     n = int(d_l[4].item())
     assert bytes(d_t[:n].cpu().numpy()) == b"".join(print_vector(vals[ooff[r]:ooff[r + 1]]) for r in range(4))
     assert list(d_l.cpu().numpy()) == [0, 7, 8, 8 + len(print_vector(vals[3:11])), n]
+
+
+@pytest.mark.parametrize("derive", [1, 0])
+def test_internal_streaming_for_indexes_without_ssup(gpu, derive):
+    # An index created without suffix_group_starts gets the marks derived on the device
+    # (mark_suffix_groups, suffix_group_optimization.cpp:66-121) and the search loop streams internally
+    # with raw-char validation; results must equal SBWT::search of every k-mer, lower case included.
+    capi.set_tuning("derive_ssup", derive)
+    try:
+        for k, glen in ((63, 60_000), (30, 60_000), (6, 0)):
+            if k == 6:
+                kat = KATS["cli_end_to_end"]
+                seqs = [b(s) for s in kat["seqs"]]
+                orc = OracleIndex.build(seqs, 6, False, True, 4)
+                reads = [b(q) for q in kat["queries"]] + [b"ACTAGTGTAGCTACAAA", b"ACTAGtGTAGCTACAAA", b"NNNNNNNNN"]
+                bases, off = capi.concat_reads(reads)
+            else:
+                genomes = [synth.random_genome(glen, 5)]
+                genomes.append(synth.mutate(genomes[0], 0.03, 6))
+                orc = OracleIndex.build([g.tobytes() for g in genomes], k, False, False, 8)
+                bases, off = synth.sample_reads(genomes, 1500, 200, 0.005, 42)
+                bases = synth.inject(bases, 30, ord("N"), 7)
+                bases = synth.inject(bases, 30, ord("a"), 8)      # lower case must give -1 (raw validation)
+            idx = gpu_index_from_oracle(orc)
+            assert not idx.has_streaming_support
+            with pytest.raises(capi.SbwtGpuError):
+                idx.streaming_search(bases, off)                  # still "not built", like the reference
+            got, _ = idx.search(bases, off)
+            assert np.array_equal(got, oracle_batch(orc, bases, off, False)), (k, derive)
+    finally:
+        capi.set_tuning("derive_ssup", 1)
