@@ -10,7 +10,7 @@ from typing import List, Optional, Sequence
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libsbwthost.so")
+LIB_PATH = os.environ.get("SBWT_HOST_LIB", os.path.join(_HERE, "lib", "libsbwthost.so"))   # override: sanitizer build
 
 EXPORTED_SYMBOLS = [
     "sbwthost_last_error", "sbwthost_build", "sbwthost_bits_free", "sbwthost_bits_info", "sbwthost_bits_words",

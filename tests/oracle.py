@@ -14,7 +14,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
-LIB_PATH = os.path.join(ORACLE_DIR, "liboracle.so")
+LIB_PATH = os.environ.get("SBWT_ORACLE_LIB", os.path.join(ORACLE_DIR, "liboracle.so"))   # override: sanitizer build
 
 
 class _BitVec(C.Structure):

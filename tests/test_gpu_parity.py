@@ -357,3 +357,26 @@ def test_internal_streaming_for_indexes_without_ssup(gpu, derive):
             assert np.array_equal(got, oracle_batch(orc, bases, off, False)), (k, derive)
     finally:
         capi.set_tuning("derive_ssup", 1)
+
+
+@pytest.mark.parametrize("k", [65, 100, 255])
+def test_long_kmers_up_to_255(gpu, k):
+    # The reference supports k up to 255 (-DMAX_KMER_LENGTH, CMakeLists.txt:70-78); search itself is
+    # k-agnostic.  Columns come from the definition-level brute force (any k), truth from a set.
+    rnd = random.Random(k)
+    g = "".join(rnd.choice("ACGT") for _ in range(k + 300))
+    g2 = g[:150] + ("A" if g[150] != "A" else "C") + g[151:]
+    seqs = [g, g2]
+    brute = BruteSBWT(seqs, k)
+    cols, ssup = brute.columns()
+    n = len(brute.nodes)
+    from bruteforce import int_to_words
+    idx = capi.Index.create(*[int_to_words(c, n) for c in cols], int_to_words(ssup, n), n, k, len(brute.kmers), 8)
+    reads = [g.encode(), g2.encode(), (g[:k + 40] + "N" + g[k + 41:]).encode(), g[5:k + 4].encode(), g[7:k + 7].encode(),
+             ("".join(rnd.choice("ACGT") for _ in range(k + 20))).encode()]
+    got = idx.streaming_search_reads(reads)
+    got2 = idx.search_reads(reads)
+    for r, a, a2 in zip(reads, got, got2):
+        want = np.array(brute.search_all(r.decode()), dtype=np.int64)
+        assert np.array_equal(a, want) and np.array_equal(a2, want)
+    assert (got[0] >= 0).all() and (got[1] >= 0).all() and len(got[3]) == 0 and len(got[4]) == 1
