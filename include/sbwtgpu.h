@@ -133,7 +133,10 @@ int  sbwtgpu_update_interval_batch(const sbwtgpu_index *idx, const char *bases, 
 int  sbwtgpu_forward_batch(const sbwtgpu_index *idx, const int64_t *node, const char *sym, int64_t n,
                            int64_t *out);
 
-/* ---- queries, device buffers (asynchronous on `stream`) ---- */
+/* ---- queries, device buffers (asynchronous on `stream`) ----
+ * The device entry points cannot look at the offsets: the caller guarantees that read_off/out_off are
+ * non-decreasing, that out_off matches max(0, len-k+1) per read, that no read has 2^31 or more bases
+ * and that one call carries fewer than 2^36 bases. */
 /* Scratch the search kernels need: the 2-bit re-encoding of the bases (total_bases/2 + 64
  * bytes) plus a work-queue header.  The caller allocates it once and may reuse it across
  * calls on the same stream. */

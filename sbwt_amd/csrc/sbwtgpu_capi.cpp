@@ -391,6 +391,7 @@ int sbwtgpu_index_adopt(const void *header, int64_t header_bytes, void *dev_blob
     memcpy(&h, header, sizeof(h));
     if (h.magic != SBWT_BLOB_MAGIC) return fail(SBWTGPU_ERR_INVALID_ARG, "bad header magic");
     if (h.blob_bytes != blob_bytes) return fail(SBWTGPU_ERR_INVALID_ARG, "blob size does not match its header");
+    if (((uintptr_t)dev_blob & 255) != 0) return fail(SBWTGPU_ERR_INVALID_ARG, "the device image must be 256-byte aligned");
     sbwtgpu_index *idx = new (std::nothrow) sbwtgpu_index();
     if (!idx) return fail(SBWTGPU_ERR_OOM, "out of host memory");
     idx->h = h;
@@ -492,6 +493,8 @@ static int search_dev_check(const sbwtgpu_index *idx, int64_t total_bases, int64
     if (streaming && !idx->h.has_ssup)
         return fail(SBWTGPU_ERR_NO_STREAMING, "Error: streaming search support not built");
     if (n_reads < 0 || total_bases < 0) return fail(SBWTGPU_ERR_INVALID_ARG, "negative size");
+    if (total_bases >= ((int64_t)1 << 36))
+        return fail(SBWTGPU_ERR_INVALID_ARG, "more than 2^36 bases in one call: split the batch");
     if (!d_ws) return fail(SBWTGPU_ERR_INVALID_ARG, "NULL workspace");
     if (ws_bytes < sbwtgpu_search_workspace_bytes(total_bases))
         return fail(SBWTGPU_ERR_INVALID_ARG, "workspace too small (%lld < %lld)", (long long)ws_bytes,
