@@ -380,3 +380,31 @@ def test_long_kmers_up_to_255(gpu, k):
         want = np.array(brute.search_all(r.decode()), dtype=np.int64)
         assert np.array_equal(a, want) and np.array_equal(a2, want)
     assert (got[0] >= 0).all() and (got[1] >= 0).all() and len(got[3]) == 0 and len(got[4]) == 1
+
+
+@pytest.mark.parametrize("k,revcomp", [(30, True), (31, False), (12, True)])
+def test_reference_query_file(gpu, k, revcomp):
+    # the reference's own example_data/queries.fastq reads (tests/test_large.hh:104-115), indexed against
+    # themselves: overlapping real reads -> big suffix groups, branching, walk-backs across blocks
+    from test_oracle_golden import load_reference_queries
+    from sbwt_amd import hostlib
+    reads = load_reference_queries()
+    bits = hostlib.build_bits(reads[:3000], k, revcomp, True, n_threads=4)
+    orc = OracleIndex.from_bits(bits.cols[0], bits.cols[1], bits.cols[2], bits.cols[3], bits.ssup, bits.n_nodes, k,
+                                bits.n_kmers, 8)
+    idx = capi.Index.create(bits.cols[0], bits.cols[1], bits.cols[2], bits.cols[3], bits.ssup, bits.n_nodes, k,
+                            bits.n_kmers, 8)
+    bases, off = capi.concat_reads(reads)
+    got, oo = idx.streaming_search(bases, off)
+    want = oracle_batch(orc, bases, off, True)
+    assert np.array_equal(got, want)
+    assert (got >= 0).mean() > 0.5
+    got2, _ = idx.search(bases, off)
+    assert np.array_equal(got2, want)                      # streaming == per-k-mer search (upper-case input)
+    text, _ = idx.search_text(bases, off, True)
+    assert text == b"".join(print_vector(want[oo[r]:oo[r + 1]]) for r in range(len(reads)))
+    # the same index without streaming support: internal streaming must agree too
+    idx2 = capi.Index.create(bits.cols[0], bits.cols[1], bits.cols[2], bits.cols[3], None, bits.n_nodes, k,
+                             bits.n_kmers, 8)
+    got3, _ = idx2.search(bases, off)
+    assert np.array_equal(got3, want)

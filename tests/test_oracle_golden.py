@@ -127,22 +127,24 @@ def test_streaming_equals_search_and_forward_on_random_genome():
     for r in range(300):
         s = bases[off[r]:off[r + 1]].tobytes()
         assert np.array_equal(idx.streaming_search(s), idx.search_all(s))
-    truth = set()
+    all_kmers_set = set()
     for g in genomes:
         gb = g.tobytes()
-        for i in range(0, len(gb) - k + 1, 37):
-            truth.add(gb[i:i + k])
+        for i in range(len(gb) - k + 1):
+            all_kmers_set.add(gb[i:i + k])
+    truth = sorted(all_kmers_set)[::37]
     rnd = random.Random(12514)
-    for kmer in list(truth)[:400]:
+    for kmer in truth[:400]:
         col = idx.search(kmer)
         assert col >= 0
         for c in b"ACGT":
             nxt = kmer[1:] + bytes([c])
-            assert idx.forward(col, bytes([c])) == idx.search(nxt)
-    for _ in range(2000):                          # random absent k-mers -> -1
+            want = idx.search(nxt) if nxt in all_kmers_set else -1     # tests/test_large.hh:142-149
+            assert idx.forward(col, bytes([c])) == want
+    for _ in range(2000):                          # random absent k-mers -> -1 (tests/test_large.hh:157-168)
         kmer = bytes(rnd.choice(b"ACGT") for _ in range(k))
-        if kmer not in truth:
-            assert idx.search(kmer) in (-1,) or kmer in genomes[0].tobytes() or kmer in genomes[1].tobytes()
+        if kmer not in all_kmers_set:
+            assert idx.search(kmer) == -1
     assert np.array_equal(idx.mark_suffix_groups(), idx.ssup_words())
 
 
@@ -174,3 +176,26 @@ def test_precalc_limits():
     assert idx.do_precalc(5) == 0
     for kmer in all_kmers(5):
         pass
+
+
+def load_reference_queries():
+    import gzip
+    data = gzip.open(os.path.join(HERE, "golden", "queries_seqs.txt.gz"), "rb").read().split(b"\n")
+    return [s for s in data if s]
+
+
+def test_reference_query_file_streaming_equals_search():
+    # TEST_LARGE.streaming_queries (tests/test_large.hh:104-115) on the reference's own example_data/queries.fastq
+    # reads (5000 x 100 bp, 21 N).  coli3.fna is not in the checkout, so the index is built from the first
+    # 3000 reads (+ reverse complements): real, heavily overlapping reads give multi-member suffix groups
+    # and branching that random genomes do not.
+    reads = load_reference_queries()
+    assert len(reads) == 5000 and all(len(r) == 100 for r in reads) and sum(r.count(b"N") for r in reads) == 21
+    idx = OracleIndex.build(reads[:3000], 30, True, True, 8)
+    assert np.array_equal(idx.mark_suffix_groups(), idx.ssup_words())
+    hits = 0
+    for r in reads[::7]:
+        res = idx.streaming_search(r)
+        assert np.array_equal(res, idx.search_all(r))
+        hits += int((res >= 0).sum())
+    assert hits > 10000
