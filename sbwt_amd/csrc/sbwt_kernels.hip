@@ -28,6 +28,13 @@ __device__ __forceinline__ bool is_ACGT(unsigned b) { return b == 'A' || b == 'C
 __device__ __forceinline__ u64 quad_bits(const uint4 &q) { return (u64)q.x | ((u64)q.y << 32); }
 __device__ __forceinline__ u64 low_mask(int n) { return (1ull << n) - 1ull; }   // n in [0,63]
 
+// wave-uniform values the compiler cannot prove uniform: pin them to scalar registers
+__device__ __forceinline__ unsigned uniform32(unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ u64 uniform64(u64 v) {
+    return (u64)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v) |
+           ((u64)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32)) << 32);
+}
+
 // streaming (read-once / write-once) 16-byte accesses that should not displace the index in L2
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void st_stream(i64 *p, i64 v) { __builtin_nontemporal_store(v, p); }
@@ -379,9 +386,8 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
             if (pool_next == pool_end) {
                 u64 t = 0;
                 if (lane == 0) t = atomicAdd(&ws->ticket, 64ull);
-                t = __shfl(t, 0);
-                pool_next = t;
-                pool_end = t + 64;
+                pool_next = uniform64(t);              // lane 0's value, kept in scalar registers
+                pool_end = pool_next + 64;
             }
             const unsigned avail = (unsigned)(pool_end - pool_next);
             const unsigned n = (unsigned)__popcll(need);
@@ -390,7 +396,7 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
                 rd = (i64)(pool_next + rank);
                 mode = (rd < n_reads) ? M_FETCH : M_DEAD;
             }
-            pool_next += (n < avail) ? n : avail;
+            pool_next = uniform64(pool_next + ((n < avail) ? n : avail));
         }
         if (__ballot(mode != M_DEAD) == 0) break;
 
@@ -458,8 +464,8 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
             }
         }
         const bool have = (kind == K_MODE && ev == EV_NONE);
-        c_search += (unsigned)__popcll(__ballot(kind == K_MODE && (mode == M_INIT || (p == 0 && mode == M_STEP && j == 0))));
-        c_lf += (unsigned)__popcll(__ballot(have && mode == M_STEP));
+        c_search = uniform32(c_search + (unsigned)__popcll(__ballot(kind == K_MODE && (mode == M_INIT || (p == 0 && mode == M_STEP && j == 0)))));
+        c_lf = uniform32(c_lf + (unsigned)__popcll(__ballot(have && mode == M_STEP)));
 
         // ---- the one memory round trip of this iteration ----
         const uint4 v1 = *a1;
@@ -525,8 +531,8 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
                 }
             }
         }
-        c_tab += (unsigned)__popcll(__ballot(tabhit));
-        c_stream += (unsigned)__popcll(__ballot(ev == EV_EMIT1 && strm));
+        c_tab = uniform32(c_tab + (unsigned)__popcll(__ballot(tabhit)));
+        c_stream = uniform32(c_stream + (unsigned)__popcll(__ballot(ev == EV_EMIT1 && strm)));
 
         // ---- events: results, certificates, next state ----
         int burst_hi = -1;                             // >= i: k-mers i..burst_hi are certified absent

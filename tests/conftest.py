@@ -13,6 +13,14 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _native_code_is_built():
+    """The shared libraries and the CLI are built in-tree (they are git-ignored); make sure they are
+    there and current before any test loads them.  A no-op when __graft_entry__.build() already ran."""
+    from sbwt_amd import build
+    build.build_all(force=False)
+
+
 def _gpu_available() -> bool:
     try:
         from sbwt_amd import capi
