@@ -9,16 +9,21 @@
 //   --gpu <id>            HIP device to use (default 0)
 //   --gpus <n>            shard every batch over HIP devices 0..n-1 (index replicated by one RCCL broadcast)
 //   --gpu-list a,b,...    the same with an explicit device list (a device may be listed twice)
-//   --batch-bases <n>     bases sent to the GPU per batch (default 256 Mi)
+//   --batch-bases <n>     bases sent to the GPU per batch (default 64 Mi); the next batch is parsed and the
+//                         previous one written by their own threads meanwhile
 //   --host-format         print_vector on the CPU (default: formatted on the GPU, pipelined over PCIe)
 #include <algorithm>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <exception>
 #include <iostream>
+#include <deque>
 #include <map>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "SBWT.hh"
@@ -113,7 +118,52 @@ inline void print_vector(const int64_t *v, int64_t n, string &out) {
 
 struct QueryStats { int64_t queries = 0; int64_t micros = 0; };
 
-// run_file + run_queries_streaming / run_queries_not_streaming (sbwt_search.cpp:46-105), batched
+// A bounded hand-off between two threads (reader -> search -> writer).
+template <typename T>
+class Channel {
+public:
+    explicit Channel(size_t cap) : cap_(cap) {}
+    void push(T &&v) {
+        std::unique_lock<std::mutex> lk(m_);
+        cv_.wait(lk, [&] { return q_.size() < cap_; });
+        q_.push_back(std::move(v));
+        cv_.notify_all();
+    }
+    bool pop(T &out) {   // false when closed and drained
+        std::unique_lock<std::mutex> lk(m_);
+        cv_.wait(lk, [&] { return !q_.empty() || closed_; });
+        if (q_.empty()) return false;
+        out = std::move(q_.front());
+        q_.pop_front();
+        cv_.notify_all();
+        return true;
+    }
+    void close() {
+        std::lock_guard<std::mutex> lk(m_);
+        closed_ = true;
+        cv_.notify_all();
+    }
+
+private:
+    std::mutex m_;
+    std::condition_variable cv_;
+    std::deque<T> q_;
+    size_t cap_;
+    bool closed_ = false;
+};
+
+struct ReadBatch {
+    vector<char> bases;
+    vector<int64_t> read_off{0}, out_off{0};
+};
+struct TextBatch {
+    std::vector<plain_matrix_sbwt_t::TextPiece> pieces;   // GPU-formatted output
+    string host_text;                                      // --host-format output
+};
+
+// run_file + run_queries_streaming / run_queries_not_streaming (sbwt_search.cpp:46-105), batched and
+// pipelined: a reader thread parses the next batch and a writer thread writes the previous one while
+// the GPU searches the current one.  The output is written strictly in input order.
 QueryStats run_file(const string &infile, const string &outfile, const plain_matrix_sbwt_t &index, bool gzip_output,
                     int64_t batch_bases, bool host_format) {
     seq_io::Reader reader(infile);
@@ -124,48 +174,82 @@ QueryStats run_file(const string &infile, const string &outfile, const plain_mat
               LogLevel::MAJOR);
     const int64_t k = index.get_k();
     QueryStats st;
-    vector<char> bases;
-    vector<int64_t> read_off{0}, out_off{0}, out;
-    string text;
-    bool eof = false;
-    while (!eof) {
-        bases.clear();
-        read_off.assign(1, 0);
-        out_off.assign(1, 0);
-        while ((int64_t)bases.size() < batch_bases) {
-            int64_t len = reader.get_next_read_to_buffer();
-            if (len == 0) { eof = true; break; }
-            bases.insert(bases.end(), reader.read_buf, reader.read_buf + len);
-            read_off.push_back((int64_t)bases.size());
-            out_off.push_back(out_off.back() + std::max<int64_t>(0, len - k + 1));
-        }
-        const int64_t n_reads = (int64_t)read_off.size() - 1;
-        if (n_reads == 0) break;
-        if (host_format) {
-            // reference-style: raw ranks back to the host, print_vector on the CPU
-            out.resize((size_t)out_off.back());
-            int64_t t0 = cur_time_micros();
-            if (streaming) index.streaming_search_batch(bases.data(), read_off.data(), n_reads, out.data(), out_off.data());
-            else index.search_batch(bases.data(), read_off.data(), n_reads, out.data(), out_off.data());
-            st.micros += cur_time_micros() - t0;
-            st.queries += out_off.back();
-            for (int64_t r = 0; r < n_reads; r++) {
-                print_vector(out.data() + out_off[(size_t)r], out_off[(size_t)r + 1] - out_off[(size_t)r], text);
-                if (text.size() > (1u << 22)) { writer.write(text.data(), (int64_t)text.size()); text.clear(); }
+    Channel<ReadBatch> to_search(2);
+    Channel<TextBatch> to_write(2);
+    std::exception_ptr reader_err, writer_err;
+
+    std::thread reader_thread([&] {
+        try {
+            bool eof = false;
+            while (!eof) {
+                ReadBatch rb;
+                while ((int64_t)rb.bases.size() < batch_bases) {
+                    int64_t len = reader.get_next_read_to_buffer();
+                    if (len == 0) { eof = true; break; }
+                    rb.bases.insert(rb.bases.end(), reader.read_buf, reader.read_buf + len);
+                    rb.read_off.push_back((int64_t)rb.bases.size());
+                    rb.out_off.push_back(rb.out_off.back() + std::max<int64_t>(0, len - k + 1));
+                }
+                if (rb.read_off.size() > 1) to_search.push(std::move(rb));
             }
-            writer.write(text.data(), (int64_t)text.size());
-            text.clear();
-        } else {
-            // default: search + print_vector on the GPU, pipelined over PCIe
-            std::vector<plain_matrix_sbwt_t::TextPiece> pieces;
-            int64_t t0 = cur_time_micros();
-            st.queries += index.search_text_batch(bases.data(), read_off.data(), n_reads, pieces);
-            st.micros += cur_time_micros() - t0;
-            for (const auto &pc : pieces)
-                for (int64_t pos = 0; pos < pc.size; pos += (int64_t)1 << 30)
-                    writer.write(pc.data + pos, std::min<int64_t>((int64_t)1 << 30, pc.size - pos));
+        } catch (...) {
+            reader_err = std::current_exception();
         }
+        to_search.close();
+    });
+    std::thread writer_thread([&] {
+        try {
+            TextBatch tb;
+            while (to_write.pop(tb)) {
+                for (const auto &pc : tb.pieces)
+                    for (int64_t pos = 0; pos < pc.size; pos += (int64_t)1 << 30)
+                        writer.write(pc.data + pos, std::min<int64_t>((int64_t)1 << 30, pc.size - pos));
+                writer.write(tb.host_text.data(), (int64_t)tb.host_text.size());
+                tb = TextBatch();
+            }
+        } catch (...) {
+            writer_err = std::current_exception();
+            TextBatch drop;
+            while (to_write.pop(drop)) {}
+        }
+    });
+
+    std::exception_ptr search_err;
+    try {
+        ReadBatch rb;
+        vector<int64_t> out;
+        while (to_search.pop(rb)) {
+            const int64_t n_reads = (int64_t)rb.read_off.size() - 1;
+            TextBatch tb;
+            if (host_format) {
+                // reference-style: raw ranks back to the host, print_vector on the CPU
+                out.resize((size_t)rb.out_off.back());
+                int64_t t0 = cur_time_micros();
+                if (streaming) index.streaming_search_batch(rb.bases.data(), rb.read_off.data(), n_reads, out.data(), rb.out_off.data());
+                else index.search_batch(rb.bases.data(), rb.read_off.data(), n_reads, out.data(), rb.out_off.data());
+                st.micros += cur_time_micros() - t0;
+                st.queries += rb.out_off.back();
+                for (int64_t r = 0; r < n_reads; r++)
+                    print_vector(out.data() + rb.out_off[(size_t)r], rb.out_off[(size_t)r + 1] - rb.out_off[(size_t)r], tb.host_text);
+            } else {
+                // default: search + print_vector on the GPU, pipelined over PCIe
+                int64_t t0 = cur_time_micros();
+                st.queries += index.search_text_batch(rb.bases.data(), rb.read_off.data(), n_reads, tb.pieces);
+                st.micros += cur_time_micros() - t0;
+            }
+            to_write.push(std::move(tb));
+        }
+    } catch (...) {
+        search_err = std::current_exception();
+        ReadBatch drop;
+        while (to_search.pop(drop)) {}
     }
+    to_write.close();
+    reader_thread.join();
+    writer_thread.join();
+    if (search_err) std::rethrow_exception(search_err);
+    if (reader_err) std::rethrow_exception(reader_err);
+    if (writer_err) std::rethrow_exception(writer_err);
     write_log("us/query: " + std::to_string((double)st.micros / (double)st.queries) + " (excluding I/O etc)",
               LogLevel::MAJOR);
     return st;
@@ -186,7 +270,7 @@ int search_main(int argc, char **argv) {
         {"gpu", 0, true, "HIP device to run on.", "0"},
         {"gpus", 0, true, "Shard every batch over HIP devices 0..n-1.", "1"},
         {"gpu-list", 0, true, "Explicit comma separated device list to shard over.", "-"},
-        {"batch-bases", 0, true, "Bases sent to the GPU per batch.", "268435456"},
+        {"batch-bases", 0, true, "Bases sent to the GPU per batch.", "67108864"},
         {"host-format", 0, false, "Format the output on the CPU (print_vector) instead of on the GPU.", ""},
         {"help", 'h', false, "Print usage", ""},
     });
