@@ -17,7 +17,7 @@ const char *sbwthost_last_error(void);
 
 /* Sort-based in-memory builder (same columns as NodeBOSSInMemoryConstructor.hh:98-213 / the KMC
  * constructor of the reference).  seqs[i] has seq_lens[i] bytes; k-mers containing anything but
- * upper-case ACGT are skipped.  2 <= k <= 64. */
+ * upper-case ACGT are skipped.  2 <= k <= 255. */
 int  sbwthost_build(const char *const *seqs, const int64_t *seq_lens, int64_t n_seqs, int64_t k,
                     int add_revcomp, int build_streaming_support, int n_threads, sbwthost_bits **out);
 void sbwthost_bits_free(sbwthost_bits *b);

@@ -34,7 +34,7 @@ const char *sbwthost_last_error(void) { return g_err; }
 int sbwthost_build(const char *const *seqs, const int64_t *seq_lens, int64_t n_seqs, int64_t k, int add_revcomp,
                    int build_ssup, int n_threads, sbwthost_bits **out) {
     if (!out || n_seqs < 0 || (n_seqs > 0 && (!seqs || !seq_lens))) return fail("invalid argument");
-    if (k < 2 || k > 64) return fail("Error: this builder supports 2 <= k <= 64");
+    if (k < 2 || k > 255) return fail("Error: this builder supports 2 <= k <= 255");
     try {
         std::vector<std::string> v;
         v.reserve((size_t)n_seqs);

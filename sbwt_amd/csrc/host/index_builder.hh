@@ -27,6 +27,58 @@ struct PlainMatrixBits {
 
 namespace builder_detail {
 
+// Fixed-width unsigned integer of W 64-bit words (little endian) with just the operations the builder
+// needs, for k-mers longer than 64 bases (the reference supports k <= 255, CMakeLists.txt:70-78).
+template <int W>
+struct BigUInt {
+    uint64_t w[W];
+    BigUInt() { for (int i = 0; i < W; i++) w[i] = 0; }
+    BigUInt(uint64_t v) { w[0] = v; for (int i = 1; i < W; i++) w[i] = 0; }   // NOLINT (implicit on purpose)
+    BigUInt(int v) : BigUInt((uint64_t)v) {}                                   // NOLINT
+    explicit operator int() const { return (int)w[0]; }
+    bool operator==(const BigUInt &o) const { for (int i = 0; i < W; i++) if (w[i] != o.w[i]) return false; return true; }
+    bool operator!=(const BigUInt &o) const { return !(*this == o); }
+    bool operator<(const BigUInt &o) const {
+        for (int i = W - 1; i >= 0; i--) { if (w[i] != o.w[i]) return w[i] < o.w[i]; }
+        return false;
+    }
+    bool operator<=(const BigUInt &o) const { return !(o < *this); }
+    BigUInt operator|(const BigUInt &o) const { BigUInt r; for (int i = 0; i < W; i++) r.w[i] = w[i] | o.w[i]; return r; }
+    BigUInt operator&(const BigUInt &o) const { BigUInt r; for (int i = 0; i < W; i++) r.w[i] = w[i] & o.w[i]; return r; }
+    BigUInt operator<<(int n) const {
+        BigUInt r;
+        const int ws = n / 64, bs = n % 64;
+        for (int i = W - 1; i >= ws; i--) {
+            uint64_t v = w[i - ws] << bs;
+            if (bs && i - ws - 1 >= 0) v |= w[i - ws - 1] >> (64 - bs);
+            r.w[i] = v;
+        }
+        return r;
+    }
+    BigUInt operator<<(const BigUInt &n) const { return *this << (int)n.w[0]; }
+    BigUInt operator>>(int n) const {
+        BigUInt r;
+        const int ws = n / 64, bs = n % 64;
+        for (int i = 0; i + ws < W; i++) {
+            uint64_t v = w[i + ws] >> bs;
+            if (bs && i + ws + 1 < W) v |= w[i + ws + 1] << (64 - bs);
+            r.w[i] = v;
+        }
+        return r;
+    }
+    BigUInt operator>>(const BigUInt &n) const { return *this >> (int)n.w[0]; }
+    BigUInt operator-(const BigUInt &o) const {
+        BigUInt r;
+        unsigned __int128 borrow = 0;
+        for (int i = 0; i < W; i++) {
+            unsigned __int128 d = (unsigned __int128)w[i] - o.w[i] - borrow;
+            r.w[i] = (uint64_t)d;
+            borrow = (d >> 64) & 1;
+        }
+        return r;
+    }
+};
+
 inline int code_of(unsigned char ch) {
     switch (ch) {
         case 'A': return 0;
@@ -201,9 +253,11 @@ PlainMatrixBits build(const std::vector<std::string> &seqs, int k, bool add_revc
 // anything but upper-case ACGT are skipped, NodeBOSSInMemoryConstructor.hh:156-159).
 inline PlainMatrixBits build_plain_matrix_bits(const std::vector<std::string> &seqs, int k, bool add_revcomp,
                                                bool build_streaming_support, int n_threads = 1) {
-    if (k < 1 || k > 64) throw std::runtime_error("Error: this builder supports 1 <= k <= 64");
+    if (k < 2 || k > 255) throw std::runtime_error("Error: this builder supports 2 <= k <= 255");
     if (k <= 32) return builder_detail::build<uint64_t>(seqs, k, add_revcomp, build_streaming_support, n_threads);
-    return builder_detail::build<unsigned __int128>(seqs, k, add_revcomp, build_streaming_support, n_threads);
+    if (k <= 64) return builder_detail::build<unsigned __int128>(seqs, k, add_revcomp, build_streaming_support, n_threads);
+    if (k <= 128) return builder_detail::build<builder_detail::BigUInt<4>>(seqs, k, add_revcomp, build_streaming_support, n_threads);
+    return builder_detail::build<builder_detail::BigUInt<8>>(seqs, k, add_revcomp, build_streaming_support, n_threads);
 }
 
 }  // namespace sbwt

@@ -181,3 +181,21 @@ def test_example_queries_fastq_shape():
                 f.write(b"@q%d\n" % r + bases[off[r]:off[r + 1]].tobytes() + b"\n+\n" + b"F" * 100 + b"\n")
         b2, o2 = hostlib.read_sequences(p)
     assert np.array_equal(b2, bases) and np.array_equal(o2, off)
+
+
+@pytest.mark.parametrize("k", [65, 100, 128, 129, 200, 255])
+def test_builder_long_kmers_vs_bruteforce(k):
+    # k > 64 (the reference supports up to 255, CMakeLists.txt:70-78): multi-word keys in the builder,
+    # checked against the definition-level brute force (the oracle's own builder stops at 64)
+    from bruteforce import BruteSBWT, int_to_words
+    rnd = random.Random(1000 + k)
+    g = "".join(rnd.choice("ACGT") for _ in range(k + 120))
+    seqs = [g, g[:60] + ("A" if g[60] != "A" else "G") + g[61:], g[10:k + 9], "ACGTN" * 10]
+    for rc in (False, True):
+        b = hostlib.build_bits([s.encode() for s in seqs], k, rc, True, n_threads=2)
+        br = BruteSBWT(seqs, k, add_revcomp=rc)
+        cols, ssup = br.columns()
+        assert b.n_nodes == len(br.nodes) and b.n_kmers == len(br.kmers)
+        for x, y in zip(b.cols, cols):
+            assert np.array_equal(x, int_to_words(y, b.n_nodes))
+        assert np.array_equal(b.ssup, int_to_words(ssup, b.n_nodes))
