@@ -633,6 +633,56 @@ static int check_reads(const int64_t *read_off, const int64_t *out_off, int64_t 
     return SBWTGPU_OK;
 }
 
+
+// ---- long reads -----------------------------------------------------------------------------------
+// One lane walks one read, so a single very long query (a genome as one FASTA record) would keep one
+// lane busy for millions of steps.  The host entry points therefore cut reads longer than 2*PIECE
+// k-mers into pieces of about PIECE k-mers that overlap by k-1 bases and hand the pieces to the kernel
+// as reads of their own; their result ranges tile the read's range, so nothing else changes.  This is
+// exact: a piece starts at a k-mer whose window holds no lower-case acgt, and for such a k-mer the
+// reference's result does not depend on what came before (streaming step and full search agree,
+// tests/test_large.hh:104-115; only lower-case input makes the two differ).
+static const int64_t PIECE = 2048;
+
+static inline bool window_has_lower(const char *s, int64_t k) {
+    for (int64_t t = 0; t < k; t++) {
+        char ch = s[t];
+        if (ch == 'a' || ch == 'c' || ch == 'g' || ch == 't') return true;
+    }
+    return false;
+}
+// Appends the pieces of read `s` (len bases) to (dst bases, roff, ooff); dst may be NULL to count only.
+// Returns the number of bytes appended.
+static int64_t append_pieces(const char *s, int64_t len, int64_t k, char *dst, std::vector<int64_t> &roff,
+                             std::vector<int64_t> &ooff) {
+    const int64_t m = len - k + 1;
+    int64_t written = 0;
+    if (m <= 2 * PIECE) {
+        if (dst && len > 0) memcpy(dst, s, (size_t)len);
+        roff.push_back(roff.back() + len);
+        ooff.push_back(ooff.back() + (m > 0 ? m : 0));
+        return len;
+    }
+    int64_t start = 0;
+    while (start < m) {
+        int64_t next = start + PIECE;
+        if (m - next < PIECE) next = m;                              // no tiny tail piece
+        while (next < m && window_has_lower(s + next, k)) next++;    // a history-independent split point
+        const int64_t nb = (next - start) + k - 1;
+        if (dst) memcpy(dst + written, s + start, (size_t)nb);
+        written += nb;
+        roff.push_back(roff.back() + nb);
+        ooff.push_back(ooff.back() + (next - start));
+        start = next;
+    }
+    return written;
+}
+static inline int64_t pieces_bases_bound(int64_t len, int64_t k) {   // bytes append_pieces can write for a read
+    const int64_t m = len - k + 1;
+    if (m <= 2 * PIECE) return len > 0 ? len : 0;
+    return len + (m / PIECE + 2) * (k - 1);
+}
+
 static int search_host_common(const sbwtgpu_index *idx, const char *bases, const int64_t *read_off, int64_t n_reads,
                               int64_t *out, const int64_t *out_off, int streaming) {
     if (!idx) return fail(SBWTGPU_ERR_INVALID_ARG, "idx is NULL");
@@ -649,26 +699,52 @@ static int search_host_common(const sbwtgpu_index *idx, const char *bases, const
     if (n_out > 0 && !out) return fail(SBWTGPU_ERR_INVALID_ARG, "out is NULL");
     if (n_out == 0) return SBWTGPU_OK;
 
+    // offsets are rebased so that device buffers start at 0; long reads are cut into pieces (see above)
+    const int64_t kk = idx->h.k;
+    bool any_long = false;
+    for (int64_t r = 0; r < n_reads && !any_long; r++) any_long = (read_off[r + 1] - read_off[r] - kk + 1) > 2 * PIECE;
+    std::vector<int64_t> ro, oo;
+    std::vector<char> vbases;
+    const char *src_bases = bases + base0;
+    int64_t nv = n_reads, vtotal = total;
+    try {
+        if (!any_long) {
+            ro.resize((size_t)n_reads + 1);
+            oo.resize((size_t)n_reads + 1);
+            for (int64_t r = 0; r <= n_reads; r++) {
+                ro[(size_t)r] = read_off[r] - base0;
+                oo[(size_t)r] = out_off[r] - out0;
+            }
+        } else {
+            int64_t bound = 0;
+            for (int64_t r = 0; r < n_reads; r++) bound += pieces_bases_bound(read_off[r + 1] - read_off[r], kk);
+            vbases.resize((size_t)bound + 16);
+            ro.assign(1, 0);
+            oo.assign(1, 0);
+            int64_t w = 0;
+            for (int64_t r = 0; r < n_reads; r++)
+                w += append_pieces(bases + read_off[r], read_off[r + 1] - read_off[r], kk, vbases.data() + w, ro, oo);
+            src_bases = vbases.data();
+            vtotal = w;
+            nv = (int64_t)ro.size() - 1;
+        }
+    } catch (const std::bad_alloc &) {
+        return fail(SBWTGPU_ERR_OOM, "out of host memory");
+    }
     DeviceGuard guard(idx->device);
     Stream st;
     HIP_TRY(hipStreamCreateWithFlags(&st.s, hipStreamNonBlocking));
     DevBuf d_bases, d_roff, d_ooff, d_out, d_ws;
-    const int64_t ws_bytes = sbwtgpu_search_workspace_bytes(total);
-    HIP_TRY(d_bases.alloc((size_t)total + 16));
-    HIP_TRY(d_roff.alloc((size_t)(n_reads + 1) * 8));
-    HIP_TRY(d_ooff.alloc((size_t)(n_reads + 1) * 8));
+    const int64_t ws_bytes = sbwtgpu_search_workspace_bytes(vtotal);
+    HIP_TRY(d_bases.alloc((size_t)vtotal + 16));
+    HIP_TRY(d_roff.alloc((size_t)(nv + 1) * 8));
+    HIP_TRY(d_ooff.alloc((size_t)(nv + 1) * 8));
     HIP_TRY(d_out.alloc((size_t)n_out * 8));
     HIP_TRY(d_ws.alloc((size_t)ws_bytes));
-    // offsets are rebased so that device buffers start at 0
-    std::vector<int64_t> ro((size_t)n_reads + 1), oo((size_t)n_reads + 1);
-    for (int64_t r = 0; r <= n_reads; r++) {
-        ro[(size_t)r] = read_off[r] - base0;
-        oo[(size_t)r] = out_off[r] - out0;
-    }
-    HIP_TRY(hipMemcpyAsync(d_bases.p, bases + base0, (size_t)total, hipMemcpyHostToDevice, st.s));
-    HIP_TRY(hipMemcpyAsync(d_roff.p, ro.data(), (size_t)(n_reads + 1) * 8, hipMemcpyHostToDevice, st.s));
-    HIP_TRY(hipMemcpyAsync(d_ooff.p, oo.data(), (size_t)(n_reads + 1) * 8, hipMemcpyHostToDevice, st.s));
-    rc = search_dev_common(idx, (const char *)d_bases.p, total, (const int64_t *)d_roff.p, n_reads, (int64_t *)d_out.p,
+    HIP_TRY(hipMemcpyAsync(d_bases.p, src_bases, (size_t)vtotal, hipMemcpyHostToDevice, st.s));
+    HIP_TRY(hipMemcpyAsync(d_roff.p, ro.data(), (size_t)(nv + 1) * 8, hipMemcpyHostToDevice, st.s));
+    HIP_TRY(hipMemcpyAsync(d_ooff.p, oo.data(), (size_t)(nv + 1) * 8, hipMemcpyHostToDevice, st.s));
+    rc = search_dev_common(idx, (const char *)d_bases.p, vtotal, (const int64_t *)d_roff.p, nv, (int64_t *)d_out.p,
                            (const int64_t *)d_ooff.p, d_ws.p, ws_bytes, st.s, streaming);
     if (rc != SBWTGPU_OK) return rc;
     HIP_TRY(hipMemcpyAsync(out + out0, d_out.p, (size_t)n_out * 8, hipMemcpyDeviceToHost, st.s));
@@ -821,6 +897,8 @@ struct Slot {
     int64_t cap_bases = 0, cap_reads = 0, cap_vals = 0, cap_text = 0;
     // carved device pointers
     char *d_bases = nullptr; int64_t *d_roff = nullptr, *d_ooff = nullptr, *d_out = nullptr, *d_line = nullptr;
+    int64_t *d_vooff = nullptr;      // result offsets of the pieces (d_roff holds the pieces' base offsets)
+    int64_t cap_vreads = 0;          // pieces per chunk
     char *d_ws = nullptr, *d_text = nullptr, *d_scr = nullptr;
     int64_t ws_bytes = 0, scr_bytes = 0;
     // the chunk in flight
@@ -892,26 +970,32 @@ int sbwtgpu_search_text_batch(const sbwtgpu_index *idx, const char *bases, const
     // ---- chunking: <= 8 Mi bases and <= 1 Mi reads per chunk (small pinned buffers, deep overlap) ----
     const int64_t CH_BASES = (int64_t)8 << 20, CH_READS = (int64_t)1 << 20;
     std::vector<int64_t> cuts{0};
-    int64_t max_bases = 0, max_reads = 0, max_vals = 0;
+    int64_t max_bases = 0, max_reads = 0, max_vals = 0, max_vreads = 0;
     {
-        int64_t lo = 0, vals = 0;
+        // vb / vr: bases and reads of the chunk after long reads are cut into pieces
+        int64_t lo = 0, vals = 0, vb = 0, vr = 0;
         for (int64_t r = 0; r < n_reads; r++) {
             int64_t len = read_off[r + 1] - read_off[r];
             if (len < 0) return fail(SBWTGPU_ERR_INVALID_ARG, "read_off is not non-decreasing at read %lld", (long long)r);
             if (len >= ((int64_t)1 << 31)) return fail(SBWTGPU_ERR_READ_TOO_LONG, "read %lld has >= 2^31 bases", (long long)r);
             if (r > lo && (read_off[r + 1] - read_off[lo] > CH_BASES || r - lo >= CH_READS)) {
-                max_bases = std::max(max_bases, read_off[r] - read_off[lo]);
+                max_bases = std::max(max_bases, vb);
                 max_reads = std::max(max_reads, r - lo);
+                max_vreads = std::max(max_vreads, vr);
                 max_vals = std::max(max_vals, vals);
                 cuts.push_back(r);
                 lo = r;
-                vals = 0;
+                vals = vb = vr = 0;
             }
-            vals += std::max<int64_t>(0, len - k + 1);
+            const int64_t mm = std::max<int64_t>(0, len - k + 1);
+            vals += mm;
+            vb += pieces_bases_bound(len, k);
+            vr += (mm > 2 * PIECE) ? mm / PIECE + 2 : 1;
         }
         if (n_reads > lo) {
-            max_bases = std::max(max_bases, read_off[n_reads] - read_off[lo]);
+            max_bases = std::max(max_bases, vb);
             max_reads = std::max(max_reads, n_reads - lo);
+            max_vreads = std::max(max_vreads, vr);
             max_vals = std::max(max_vals, vals);
             cuts.push_back(n_reads);
         }
@@ -947,15 +1031,17 @@ int sbwtgpu_search_text_batch(const sbwtgpu_index *idx, const char *bases, const
     const int n_slots = n_chunks > 1 ? 2 : 1;
     for (int s = 0; s < n_slots; s++) {
         Slot &S = slots[s];
-        if (take_parked(idx->device, max_bases, max_reads, max_vals, sbwtgpu_format_text_bound(idx, max_vals, max_reads), &S))
+        if (take_parked(idx->device, max_bases, max_reads, max_vals, sbwtgpu_format_text_bound(idx, max_vals, max_reads), &S) &&
+            S.cap_vreads >= max_vreads)
             continue;
-        S.cap_bases = max_bases; S.cap_reads = max_reads; S.cap_vals = max_vals;
+        S.release();
+        S.cap_bases = max_bases; S.cap_reads = max_reads; S.cap_vals = max_vals; S.cap_vreads = max_vreads;
         S.cap_text = sbwtgpu_format_text_bound(idx, max_vals, max_reads);
         S.ws_bytes = sbwtgpu_search_workspace_bytes(max_bases);
         S.scr_bytes = sbwtgpu_format_scratch_bytes(max_reads);
-        const int64_t in_bytes = a256(max_bases + 16) + 2 * a256((max_reads + 1) * 8);
-        const int64_t dev_bytes = a256(max_bases + 16) + 3 * a256((max_reads + 1) * 8) + a256(max_vals * 8 + 8) +
-                                  a256(S.ws_bytes) + a256(S.cap_text) + a256(S.scr_bytes);
+        const int64_t in_bytes = a256(max_bases + 16) + 2 * a256((max_vreads + 1) * 8) + a256((max_reads + 1) * 8);
+        const int64_t dev_bytes = a256(max_bases + 16) + 2 * a256((max_vreads + 1) * 8) + 2 * a256((max_reads + 1) * 8) +
+                                  a256(max_vals * 8 + 8) + a256(S.ws_bytes) + a256(S.cap_text) + a256(S.scr_bytes);
         PIPE_TRY(hipStreamCreateWithFlags(&S.st, hipStreamNonBlocking));
         PIPE_TRY(hipHostMalloc((void **)&S.h_in, (size_t)in_bytes, hipHostMallocDefault));
         PIPE_TRY(hipHostMalloc((void **)&S.h_text, (size_t)S.cap_text, hipHostMallocDefault));
@@ -963,7 +1049,8 @@ int sbwtgpu_search_text_batch(const sbwtgpu_index *idx, const char *bases, const
         PIPE_TRY(hipMalloc((void **)&S.d_mem, (size_t)dev_bytes));
         char *p = S.d_mem;
         S.d_bases = p; p += a256(max_bases + 16);
-        S.d_roff = (int64_t *)p; p += a256((max_reads + 1) * 8);
+        S.d_roff = (int64_t *)p; p += a256((max_vreads + 1) * 8);
+        S.d_vooff = (int64_t *)p; p += a256((max_vreads + 1) * 8);
         S.d_ooff = (int64_t *)p; p += a256((max_reads + 1) * 8);
         S.d_line = (int64_t *)p; p += a256((max_reads + 1) * 8);
         S.d_out = (int64_t *)p; p += a256(max_vals * 8 + 8);
@@ -977,26 +1064,33 @@ int sbwtgpu_search_text_batch(const sbwtgpu_index *idx, const char *bases, const
     auto submit = [&](int64_t c) -> int {
         Slot &S = slots[c % n_slots];
         const int64_t lo = cuts[(size_t)c], hi = cuts[(size_t)c + 1], nr = hi - lo;
-        const int64_t b0 = read_off[lo], nb = read_off[hi] - b0;
         char *hb = S.h_in;
-        int64_t *hro = (int64_t *)(S.h_in + a256(S.cap_bases + 16));
-        int64_t *hoo = (int64_t *)((char *)hro + a256((S.cap_reads + 1) * 8));
-        if (nb) memcpy(hb, bases + b0, (size_t)nb);
-        int64_t acc = 0;
-        for (int64_t r = 0; r <= nr; r++) {
-            hro[r] = read_off[lo + r] - b0;
-            hoo[r] = acc;
-            if (r < nr) acc += std::max<int64_t>(0, read_off[lo + r + 1] - read_off[lo + r] - k + 1);
+        int64_t *hro = (int64_t *)(S.h_in + a256(S.cap_bases + 16));                    // pieces: base offsets
+        int64_t *hvo = (int64_t *)((char *)hro + a256((S.cap_vreads + 1) * 8));         // pieces: result offsets
+        int64_t *hoo = (int64_t *)((char *)hvo + a256((S.cap_vreads + 1) * 8));         // reads: result offsets
+        std::vector<int64_t> vro{0}, voo{0};
+        int64_t nb = 0, acc = 0;
+        hoo[0] = 0;
+        for (int64_t r = 0; r < nr; r++) {
+            const int64_t len = read_off[lo + r + 1] - read_off[lo + r];
+            nb += append_pieces(bases + read_off[lo + r], len, k, hb + nb, vro, voo);
+            acc += std::max<int64_t>(0, len - k + 1);
+            hoo[r + 1] = acc;
         }
+        const int64_t nv = (int64_t)vro.size() - 1;
+        if (nv > S.cap_vreads || nb > S.cap_bases) return fail(SBWTGPU_ERR_HIP, "internal: piece bound exceeded");
+        memcpy(hro, vro.data(), (size_t)(nv + 1) * 8);
+        memcpy(hvo, voo.data(), (size_t)(nv + 1) * 8);
         S.n_reads = nr;
         S.n_vals = acc;
         total_queries += acc;
         hipError_t e;
         if ((e = hipMemcpyAsync(S.d_bases, hb, (size_t)nb, hipMemcpyHostToDevice, S.st)) != hipSuccess ||
-            (e = hipMemcpyAsync(S.d_roff, hro, (size_t)(nr + 1) * 8, hipMemcpyHostToDevice, S.st)) != hipSuccess ||
+            (e = hipMemcpyAsync(S.d_roff, hro, (size_t)(nv + 1) * 8, hipMemcpyHostToDevice, S.st)) != hipSuccess ||
+            (e = hipMemcpyAsync(S.d_vooff, hvo, (size_t)(nv + 1) * 8, hipMemcpyHostToDevice, S.st)) != hipSuccess ||
             (e = hipMemcpyAsync(S.d_ooff, hoo, (size_t)(nr + 1) * 8, hipMemcpyHostToDevice, S.st)) != hipSuccess)
             return fail(SBWTGPU_ERR_HIP, "H2D copy: %s", hipGetErrorString(e));
-        int r2 = search_dev_common(idx, S.d_bases, nb, S.d_roff, nr, S.d_out, S.d_ooff, S.d_ws, S.ws_bytes, S.st, streaming);
+        int r2 = search_dev_common(idx, S.d_bases, nb, S.d_roff, nv, S.d_out, S.d_vooff, S.d_ws, S.ws_bytes, S.st, streaming);
         if (r2 != SBWTGPU_OK) return r2;
         r2 = sbwtgpu_format_results_dev(idx, S.d_out, S.d_ooff, nr, acc, S.d_text, S.cap_text, S.d_line, S.d_scr,
                                         S.scr_bytes, S.st);

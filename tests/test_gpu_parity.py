@@ -408,3 +408,29 @@ def test_reference_query_file(gpu, k, revcomp):
                              bits.n_kmers, 8)
     got3, _ = idx2.search(bases, off)
     assert np.array_equal(got3, want)
+
+
+def test_long_reads_are_split_exactly(gpu, genome_case):
+    # reads far longer than a lane should walk alone are cut into overlapping pieces by the host entry
+    # points; the cut points avoid windows with lower-case bases, so results stay bit-identical
+    genomes, orc = genome_case
+    idx = gpu_index_from_oracle(orc)
+    g0 = genomes[0].tobytes()
+    long1 = bytearray(g0[1000:151000])                      # 150 kbp
+    rnd = random.Random(5)
+    for _ in range(300):
+        long1[rnd.randrange(len(long1))] = ord(rnd.choice("ACGTNacgtn"))
+    lower_run = bytearray(g0[20000:60000])
+    lower_run[4090:4200] = bytes(lower_run[4090:4200]).lower()        # lower case exactly around a cut point
+    lower_run[8190:8200] = b"acgtacgtac"
+    all_lower = g0[500:20500].lower()
+    reads = [bytes(long1), g0[:100], bytes(lower_run), all_lower, g0[300:300 + 2 * 2048 + 29], g0[300:300 + 2 * 2048 + 30],
+             g0[7:7 + 3 * 2048 + 29 + 5], b"", genomes[1].tobytes()[:90000]]
+    bases, off = capi.concat_reads(reads)
+    want = oracle_batch(orc, bases, off, True)
+    got, oo = idx.streaming_search(bases, off)
+    assert np.array_equal(got, want)
+    got2, _ = idx.search(bases, off)
+    assert np.array_equal(got2, oracle_batch(orc, bases, off, False))
+    text, nq = idx.search_text(bases, off, True)
+    assert text == b"".join(print_vector(want[oo[r]:oo[r + 1]]) for r in range(len(reads))) and nq == len(want)
