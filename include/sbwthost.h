@@ -42,6 +42,9 @@ const int64_t  *sbwthost_file_precalc(const sbwthost_file *f);
  * *bases / *read_off are malloc'ed; free with sbwthost_free. */
 int  sbwthost_read_sequences(const char *path, char **bases, int64_t **read_off, int64_t *n_reads);
 void sbwthost_free(void *p);
+/* Writes n bytes through the CLI's buffered writer; gzip_output != 0 compresses 1 MiB blocks on n_threads
+ * threads (0 = automatic) into a multi-member gzip file (-z of `sbwt search`, sbwt_search.cpp:120). */
+int  sbwthost_write_file(const char *path, const char *data, int64_t n, int gzip_output, int n_threads);
 
 #ifdef __cplusplus
 }

@@ -170,4 +170,16 @@ int sbwthost_read_sequences(const char *path, char **bases, int64_t **read_off, 
 }
 void sbwthost_free(void *p) { free(p); }
 
+int sbwthost_write_file(const char *path, const char *data, int64_t n, int gzip_output, int n_threads) {
+    if (!path || n < 0 || (n > 0 && !data)) return fail("invalid argument");
+    try {
+        sbwt::seq_io::Buffered_ofstream out(path, gzip_output != 0, n_threads);
+        for (int64_t pos = 0; pos < n; pos += 3000000) out.write(data + pos, std::min<int64_t>(3000000, n - pos));
+        out.close();
+        return 0;
+    } catch (const std::exception &e) {
+        return fail("%s", e.what());
+    }
+}
+
 }  // extern "C"

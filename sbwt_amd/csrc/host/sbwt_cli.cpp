@@ -428,6 +428,8 @@ void print_help(char **argv) {
 }  // namespace
 
 int main(int argc, char **argv) {   // sbwt.cpp:19-57
+    // the reference logs its compile-time MAX_KMER_LENGTH here (sbwt.cpp:25); this build handles any k <= 255
+    write_log("Maximum k-mer length is set to 255", LogLevel::MAJOR);
     if (argc == 1) { print_help(argv); return 0; }
     string command = argv[1];
     if (command == "--help" || command == "-h") { print_help(argv); return 0; }

@@ -9,8 +9,11 @@
 #include <cctype>
 #include <cstdint>
 #include <cstring>
+#include <algorithm>
+#include <cstdio>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace sbwt {
@@ -150,37 +153,102 @@ private:
 };
 
 // Buffered output, optionally gzip-compressed (-z of `sbwt search`, sbwt_search.cpp:120,126-137).
+// Compression runs on several threads: the data is cut into 1 MiB blocks, every block becomes a gzip
+// member of its own, and the members are written in order -- a multi-member gzip file, which zcat,
+// zlib's gzread and Python's gzip module all read as one stream.
 class Buffered_ofstream {
 public:
-    Buffered_ofstream(const std::string &filename, bool gzip) : filename_(filename), gzip_(gzip) {
-        if (gzip_) {
-            gz_ = gzopen(filename.c_str(), "wb");
-            if (!gz_) throw std::runtime_error("Error opening file: " + filename);
-            gzbuffer(gz_, 1 << 20);
-        } else {
-            fp_ = fopen(filename.c_str(), "wb");
-            if (!fp_) throw std::runtime_error("Error opening file: " + filename);
-            setvbuf(fp_, nullptr, _IOFBF, 1 << 20);
+    Buffered_ofstream(const std::string &filename, bool gzip, int n_threads = 0) : filename_(filename), gzip_(gzip) {
+        fp_ = fopen(filename.c_str(), "wb");
+        if (!fp_) throw std::runtime_error("Error opening file: " + filename);
+        setvbuf(fp_, nullptr, _IOFBF, 1 << 20);
+        if (n_threads <= 0) {
+            n_threads = (int)std::thread::hardware_concurrency();
+            if (n_threads > 16) n_threads = 16;
+            if (n_threads < 1) n_threads = 1;
         }
+        n_threads_ = n_threads;
     }
-    ~Buffered_ofstream() { close(); }
+    ~Buffered_ofstream() {
+        try { close(); } catch (...) {}
+    }
     Buffered_ofstream(const Buffered_ofstream &) = delete;
     Buffered_ofstream &operator=(const Buffered_ofstream &) = delete;
     void write(const char *data, int64_t n) {
         if (n <= 0) return;
-        bool ok = gzip_ ? (gzwrite(gz_, data, (unsigned)n) == (int)n) : (fwrite(data, 1, (size_t)n, fp_) == (size_t)n);
-        if (!ok) throw std::runtime_error("Error writing to file " + filename_);
+        if (!gzip_) {
+            if (fwrite(data, 1, (size_t)n, fp_) != (size_t)n) throw std::runtime_error("Error writing to file " + filename_);
+            return;
+        }
+        pending_.insert(pending_.end(), data, data + n);
+        if (pending_.size() >= (size_t)n_threads_ * BLOCK) compress_pending(false);
     }
     void close() {
-        if (gz_) { gzclose(gz_); gz_ = nullptr; }
-        if (fp_) { fclose(fp_); fp_ = nullptr; }
+        if (!fp_) return;
+        if (gzip_) {
+            compress_pending(true);
+            if (!wrote_member_) {   // an empty gzip file still needs one (empty) member
+                std::vector<char> dummy;
+                std::vector<unsigned char> out;
+                deflate_block(dummy.data(), 0, out);
+                if (fwrite(out.data(), 1, out.size(), fp_) != out.size()) throw std::runtime_error("Error writing to file " + filename_);
+            }
+        }
+        FILE *f = fp_;
+        fp_ = nullptr;
+        if (fclose(f) != 0) throw std::runtime_error("Error writing to file " + filename_);
     }
 
 private:
+    static constexpr size_t BLOCK = 1 << 20;
+    static void deflate_block(const char *src, size_t n, std::vector<unsigned char> &out) {
+        z_stream zs;
+        memset(&zs, 0, sizeof(zs));
+        if (deflateInit2(&zs, Z_DEFAULT_COMPRESSION, Z_DEFLATED, 15 + 16, 8, Z_DEFAULT_STRATEGY) != Z_OK)
+            throw std::runtime_error("deflateInit2 failed");
+        out.resize(deflateBound(&zs, (uLong)n) + 64);
+        zs.next_in = (Bytef *)src;
+        zs.avail_in = (uInt)n;
+        zs.next_out = out.data();
+        zs.avail_out = (uInt)out.size();
+        int rc = deflate(&zs, Z_FINISH);
+        size_t produced = out.size() - zs.avail_out;
+        deflateEnd(&zs);
+        if (rc != Z_STREAM_END) throw std::runtime_error("deflate failed");
+        out.resize(produced);
+    }
+    void compress_pending(bool all) {
+        size_t n_blocks = all ? (pending_.size() + BLOCK - 1) / BLOCK : pending_.size() / BLOCK;
+        if (n_blocks == 0) return;
+        std::vector<std::vector<unsigned char>> outs(n_blocks);
+        std::vector<std::string> errs((size_t)n_threads_);
+        std::vector<std::thread> th;
+        for (int t = 0; t < n_threads_; t++)
+            th.emplace_back([&, t] {
+                try {
+                    for (size_t b = (size_t)t; b < n_blocks; b += (size_t)n_threads_) {
+                        size_t lo = b * BLOCK, hi = std::min(pending_.size(), lo + BLOCK);
+                        deflate_block(pending_.data() + lo, hi - lo, outs[b]);
+                    }
+                } catch (const std::exception &e) {
+                    errs[(size_t)t] = e.what();
+                }
+            });
+        for (auto &t : th) t.join();
+        for (auto &e : errs) if (!e.empty()) throw std::runtime_error("Error compressing " + filename_ + ": " + e);
+        for (auto &o : outs) {
+            if (fwrite(o.data(), 1, o.size(), fp_) != o.size()) throw std::runtime_error("Error writing to file " + filename_);
+            wrote_member_ = true;
+        }
+        size_t used = std::min(pending_.size(), n_blocks * BLOCK);
+        pending_.erase(pending_.begin(), pending_.begin() + (long)used);
+    }
     std::string filename_;
     bool gzip_;
-    gzFile gz_ = nullptr;
+    int n_threads_ = 1;
     FILE *fp_ = nullptr;
+    std::vector<char> pending_;
+    bool wrote_member_ = false;
 };
 
 // FASTA writer used by tests and `sbwt build --add-reverse-complements`

@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("SBWT_HOST_LIB", os.path.join(_HERE, "lib", "libsbwtho
 EXPORTED_SYMBOLS = [
     "sbwthost_last_error", "sbwthost_build", "sbwthost_bits_free", "sbwthost_bits_info", "sbwthost_bits_words",
     "sbwthost_file_write", "sbwthost_file_read", "sbwthost_file_free", "sbwthost_file_info",
-    "sbwthost_file_words", "sbwthost_file_precalc", "sbwthost_read_sequences", "sbwthost_free",
+    "sbwthost_file_words", "sbwthost_file_precalc", "sbwthost_read_sequences", "sbwthost_free", "sbwthost_write_file",
 ]
 
 _lib: Optional[C.CDLL] = None
@@ -49,6 +49,7 @@ def lib() -> C.CDLL:
     L.sbwthost_read_sequences.argtypes = [C.c_char_p, C.POINTER(vp), C.POINTER(vp), C.POINTER(i64)]
     L.sbwthost_free.argtypes = [vp]
     L.sbwthost_free.restype = None
+    L.sbwthost_write_file.argtypes = [C.c_char_p, C.c_char_p, i64, ci, ci]
     _lib = L
     return L
 
@@ -139,3 +140,9 @@ def read_sequences(path: str):
     finally:
         L.sbwthost_free(pb)
         L.sbwthost_free(po)
+
+
+def write_file(path: str, data: bytes, gzip_output: bool = False, n_threads: int = 0) -> None:
+    """Writes bytes through the CLI's buffered writer (parallel multi-member gzip when gzip_output)."""
+    if lib().sbwthost_write_file(path.encode(), data, len(data), int(gzip_output), n_threads) != 0:
+        raise RuntimeError(_err())

@@ -199,3 +199,22 @@ def test_builder_long_kmers_vs_bruteforce(k):
         for x, y in zip(b.cols, cols):
             assert np.array_equal(x, int_to_words(y, b.n_nodes))
         assert np.array_equal(b.ssup, int_to_words(ssup, b.n_nodes))
+
+
+
+def test_parallel_gzip_writer_roundtrip(tmp_path):
+    # Buffered_ofstream (the CLI's writer) compresses 1 MiB blocks on several threads into a multi-member
+    # gzip file: it must read back as one stream with Python's gzip and with the C++ reader (zlib gzread)
+    rng = np.random.default_rng(1)
+    for n in (0, 1, (1 << 20) - 1, 1 << 20, (1 << 20) + 1, 5 * (1 << 20) + 123):
+        seq = synth.ACGT[rng.integers(0, 4, size=n, dtype=np.uint8)].tobytes()
+        data = (b">x\n" + seq + b"\n") if n else b""
+        for threads in (1, 3):
+            p = str(tmp_path / ("w%d_%d.fna.gz" % (n, threads)))
+            hostlib.write_file(p, data, gzip_output=True, n_threads=threads)
+            assert gzip.open(p, "rb").read() == data
+            bases, off = hostlib.read_sequences(p)
+            assert bases.tobytes() == seq and len(off) == (2 if n else 1)
+    p = str(tmp_path / "plain.fna")
+    hostlib.write_file(p, b">y\nACGT\n", gzip_output=False)
+    assert open(p, "rb").read() == b">y\nACGT\n"
