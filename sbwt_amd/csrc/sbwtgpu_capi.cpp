@@ -39,9 +39,10 @@ int fail(int code, const char *fmt, ...) {
     } while (0)
 
 // Depth of the device-side prefix table: deep enough that most walks start with a nearly unique
-// interval (ceil(log4(n_nodes))), capped so that the table stays at 1 GiB (4^13 x 16 B) unless
-// SBWTGPU_DEVICE_PRECALC asks otherwise.  Measured on MI355X (tools/ab_bench.py, 12.8 M columns):
-// 8: 33, 10: 45, 11: 47, 12: 49 G k-mers/s.
+// interval (ceil(log4(n_nodes))), capped at 14 (4 GiB of the 288 GB of HBM) unless
+// SBWTGPU_DEVICE_PRECALC asks otherwise.  Measured on MI355X: 12.8 M columns (tools/ab_bench.py)
+// 8: 33, 10: 45, 11: 47, 12: 49 G k-mers/s; 142 M columns (bench.py --config 3) 11: 30.2, 12: 32.2,
+// 13: 34.1, 14: 36.1 G k-mers/s.
 int default_device_precalc(int64_t n_nodes) {
     const char *e = getenv("SBWTGPU_DEVICE_PRECALC");
     int v;
@@ -49,7 +50,7 @@ int default_device_precalc(int64_t n_nodes) {
         v = atoi(e);
     } else {
         v = 1;
-        while (v < 13 && ((int64_t)1 << (2 * v)) < n_nodes) v++;
+        while (v < 14 && ((int64_t)1 << (2 * v)) < n_nodes) v++;
     }
     if (v < 0) v = 0;
     if (v > 14) v = 14;
