@@ -39,7 +39,7 @@ int fail(int code, const char *fmt, ...) {
     } while (0)
 
 // Depth of the device-side prefix table: deep enough that most walks start with a nearly unique
-// interval (ceil(log4(n_nodes))), capped at 14 (4 GiB of the 288 GB of HBM) unless
+// interval (ceil(log4(n_nodes)) + 2), capped at 14 (4 GiB of the 288 GB of HBM) unless
 // SBWTGPU_DEVICE_PRECALC asks otherwise.  Measured on MI355X: 12.8 M columns (tools/ab_bench.py)
 // 8: 33, 10: 45, 11: 47, 12: 49 G k-mers/s; 142 M columns (bench.py --config 3) 11: 30.2, 12: 32.2,
 // 13: 34.1, 14: 36.1 G k-mers/s.
@@ -51,6 +51,7 @@ int default_device_precalc(int64_t n_nodes) {
     } else {
         v = 1;
         while (v < 14 && ((int64_t)1 << (2 * v)) < n_nodes) v++;
+        v = v + 2 > 14 ? 14 : v + 2;     // two levels past log4(n): most entries are empty and end a probe at once
     }
     if (v < 0) v = 0;
     if (v > 14) v = 14;
