@@ -6,6 +6,8 @@
 //   [ ptab     : 4^p_dev x 16 B  ]   device prefix table, (first,second) int64 pairs
 //   [ ftab     : 4^p_file x 16 B ]   the index file's own table (only if p_file != p_dev, p_file > 0)
 //   [ mega     : 4 x n_mega x 8 B]   absolute (C[c] + rank_c) at every 2^31-column boundary
+//   [ stab     : 2^log2b x 32 B  ]   sparse prefix table at depth p_sparse (only non-empty prefixes), hashed:
+//                                    bucket = two 16-byte entries { key | flags (u64), first (u32), second-first (u32) }
 //
 // One 64-byte block covers 64 consecutive columns and carries everything both query kinds need,
 // as four 16-byte quads, quad c for symbol c in {A,C,G,T}:
@@ -38,6 +40,9 @@ struct SbwtIndexView {
     int n_mega;
     int has_ssup;
     int probe_len;                  // length of the certificate probes of k_search_cert (0 = off)
+    const uint4 *stab;              // sparse prefix table (nullptr if p_sparse == 0)
+    int p_sparse;                   // its depth (0 = none)
+    int log2b;                      // log2 of its number of buckets
     int debug;                      // experiments only: bit0 = skip result stores
 };
 
@@ -51,9 +56,18 @@ struct SbwtBlobHeader {
     int32_t has_ssup;
     int32_t rank_only;              // the columns are not SBWT-consistent: only rank() is served
     int32_t ssup_derived;           // no suffix_group_starts given: marks derived on the device (internal use)
+    int32_t p_sparse;               // depth of the sparse prefix table (0 = none)
+    int64_t off_stab;
+    int32_t log2b;
     int32_t reserved;
 };
 #define SBWT_BLOB_MAGIC 0x3155504754574253ull   // "SBWTGPU1" little endian
+
+// Sparse prefix table entry words
+#define SBWT_SP_EMPTY (1ull << 63)              // the whole word of a free entry
+#define SBWT_SP_OVERFLOW (1ull << 62)           // set in entry 0 of a bucket some key had to skip
+#define SBWT_SP_MAX_DEPTH 31                    // keys are 2 bits per base in the low 62 bits
+#define SBWT_SP_HASH 0x9E3779B97F4A7C15ull
 
 // Workspace header (first 256 bytes of the search workspace).
 struct SbwtWorkHeader {
@@ -87,3 +101,6 @@ void sbwt_launch_format(const long long *d_vals, const long long *d_out_off, lon
                         long long *d_line_off, void *d_scratch, hipStream_t stream);
 long long sbwt_derive_scratch_bytes(long long n_nodes);
 void sbwt_launch_derive_marks(const SbwtIndexView &ix, uint4 *d_blocks, void *d_scratch, hipStream_t stream);
+long long sbwt_sparse_scratch_bytes(long long n_nodes);
+void sbwt_launch_build_sparse(const SbwtIndexView &ix, int p_dense, int p_sparse, int log2b, uint4 *d_table,
+                              void *d_scratch, hipStream_t stream);

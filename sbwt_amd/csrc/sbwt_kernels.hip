@@ -365,8 +365,10 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
     __shared__ stage_t stage[DEPTH][256];
     const int tid = threadIdx.x, lane = tid & 63;
     const int k = ix.k, p = ix.p_dev, L0 = ix.probe_len;
+    const int ps = WIDE ? 0 : ix.p_sparse;          // sparse table: 32-bit intervals only
     const pos_t last_node = (pos_t)(ix.n_nodes - 1);
 
+    bool spw = false;               // this walk starts with a sparse-table lookup (walks from k-mer i itself)
     int mode = M_IDLE;              // M_DEAD once the ticket counter has run past the last read
     i64 obase = 0;                  // first result slot of the current read
     int pgrp = 0, poff = 0;         // the read starts at base poff of packed group pgrp
@@ -412,15 +414,17 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
             a1 = reinterpret_cast<const uint4 *>(read_off + rd);
             a2 = reinterpret_cast<const uint4 *>(out_off + rd);
         } else if (mode != M_IDLE && mode != M_DEAD) {
-            const int P = poff + (strm ? (i + k - 1) : (wstart + j));
+            // M_INIT reads the window at wstart (j counts extra hash buckets there); M_STEP the base at wstart + j
+            const int P = poff + (strm ? (i + k - 1) : ((mode == M_INIT) ? wstart : (wstart + j)));
             const int s = P & 31;
+            const int wl = spw ? ps : p;               // bases the table window of this walk covers
             grp = pgrp + (P >> 5);
-            if (grp == tag + 1 && g1ok && (mode != M_INIT || s + p <= 32)) {
+            if (grp == tag + 1 && g1ok && (mode != M_INIT || s + wl <= 32)) {
                 g0 = g1;                               // crossed into the group that is already here
                 g1ok = false;
                 tag = grp;
             }
-            if (grp != tag || (mode == M_INIT && s + p > 32 && !g1ok)) {
+            if (grp != tag || (mode == M_INIT && s + wl > 32 && !g1ok)) {
                 kind = K_RELOAD;                       // the packed group pair holding the next base(s)
                 a1 = packed + grp;
                 a2 = a1 + 1;
@@ -444,10 +448,17 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
                     u64 w = codes0 >> (2 * s);
                     if (s) w |= quad_bits(g1) << (64 - 2 * s);
                     const u64 vr = (((u64)g1.w << 32) | (u64)g0.w) >> s;
-                    const u64 vm = low_mask(p);
+                    const u64 vm = low_mask(wl);
                     if ((vr & vm) == vm) {
-                        a1 = reinterpret_cast<const uint4 *>(ix.ptab + (w & low_mask(2 * p)));
-                        a2 = a1;
+                        if (spw) {                     // bucket (hash + j) of the sparse table: two entries
+                            const u64 key = w & low_mask(2 * ps);
+                            const u64 bkt = (((key * SBWT_SP_HASH) >> (64 - ix.log2b)) + (u64)j) & low_mask(ix.log2b);
+                            a1 = ix.stab + 2 * bkt;
+                            a2 = a1 + 1;
+                        } else {
+                            a1 = reinterpret_cast<const uint4 *>(ix.ptab + (w & low_mask(2 * p)));
+                            a2 = a1;
+                        }
                     } else {
                         ev = EV_FAIL;                  // a non-ACGT char inside the table window
                         tfail = wstart + (__ffsll((i64)(~vr & vm)) - 1);
@@ -509,16 +520,41 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
                     if (res == -1) b = i + k - 1;
                 }
             } else if (mode == M_INIT) {
-                l = (pos_t)(i64)quad_bits(v1);
-                r = (pos_t)(i64)((u64)v1.z | ((u64)v1.w << 32));
-                tabhit = (l != -1);
-                if (l == -1) {
-                    ev = EV_FAIL;                      // read[wstart .. wstart+p-1] is not in the index
-                    tfail = wstart + p - 1;
+                int wl = p;
+                bool again = false;
+                if (spw) {
+                    // the window's key, again (cheaper than keeping it across the load)
+                    const int Pw = poff + wstart, sw = Pw & 31;
+                    u64 w = quad_bits(g0) >> (2 * sw);
+                    if (sw) w |= quad_bits(g1) << (64 - 2 * sw);
+                    const u64 key = w & low_mask(2 * ps);
+                    const u64 w0 = quad_bits(v1), w1 = quad_bits(v2);
+                    const bool m0 = (w0 & ~SBWT_SP_OVERFLOW) == key, m1 = w1 == key;
+                    wl = ps;
+                    if (m0 | m1) {
+                        l = (pos_t)(m0 ? v1.z : v2.z);
+                        r = l + (pos_t)(m0 ? v1.w : v2.w);
+                    } else {
+                        // a later bucket may hold the key; otherwise the prefix is absent and the dense table
+                        // walks the same window to find WHERE it fails (the planner wants the exact position)
+                        again = true;
+                        if (w0 & SBWT_SP_OVERFLOW) j++;
+                        else { j = 0; spw = false; }
+                    }
                 } else {
-                    j = p;
-                    if (wstart + j == i + k) ev = EV_END;
-                    else mode = M_STEP;
+                    l = (pos_t)(i64)quad_bits(v1);
+                    r = (pos_t)(i64)((u64)v1.z | ((u64)v1.w << 32));
+                }
+                if (!again) {
+                    tabhit = (l != -1);
+                    if (l == -1) {
+                        ev = EV_FAIL;                  // read[wstart .. wstart+wl-1] is not in the index
+                        tfail = wstart + wl - 1;
+                    } else {
+                        j = wl;
+                        if (wstart + j == i + k) ev = EV_END;
+                        else mode = M_STEP;
+                    }
                 }
             } else {   // M_STEP
                 l = quad_rank_t<WIDE>(ix, v1, l, c);
@@ -549,7 +585,8 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
         } else if (ev == EV_FAIL) {
             // read[wstart..tfail] is not in the index: k-mers i..min(wstart, m-1) all contain it
             burst_hi = (wstart < m - 1) ? wstart : (m - 1);
-            b = tfail;
+            // a walk that started AT the known-bad position says nothing about where the next one is
+            b = (wstart == b) ? -1 : tfail;
             if (burst_hi == i) { ev = EV_EMIT1; burst_hi = -1; }   // a single -1 goes through the stage
         }
         if (ev == EV_EMIT1) {
@@ -634,6 +671,7 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
             }
             wstart = s0;
             j = 0;
+            spw = (ps > 0) && (s0 == i);               // probes keep the dense table: they need the exact failure position
             if (p > 0) mode = M_INIT;
             else { mode = M_STEP; l = 0; r = last_node; }
         }
@@ -786,6 +824,67 @@ __global__ void __launch_bounds__(256) k_sg_patch(uint4 *__restrict__ blocks, co
     if (b >= n_blocks) return;
     const u64 s = acc[b];
     for (int c = 0; c < 4; c++) blocks[b * 4 + c].w = (c & 1) ? (unsigned)(s >> 32) : (unsigned)s;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Sparse prefix table: kmer_prefix_precalc (SBWT.hh:40,616-645) at depth p_sparse (default 20, the
+// deepest the reference allows), holding only the prefixes whose interval is not empty -- at that depth
+// about one entry per k-mer instead of 4^20.  Built by expanding the non-empty entries of the dense
+// device table one character at a time (each expansion is the interval update of SBWT.hh:430-431) and
+// hashing the survivors into buckets of two entries; a bucket that a key had to skip carries an overflow
+// flag, so a lookup that meets a bucket without the flag knows the prefix is absent.
+// ---------------------------------------------------------------------------------------------
+struct SpItem { u64 key; i64 l; i64 r; };
+
+__global__ void __launch_bounds__(256) k_sp_collect(const longlong2 *__restrict__ ptab, u64 n_entries,
+                                                    SpItem *__restrict__ out, u64 *counter) {
+    u64 t = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n_entries) return;
+    longlong2 e = ptab[t];
+    if (e.x < 0) return;
+    u64 slot = atomicAdd(counter, 1ull);
+    out[slot] = SpItem{t, e.x, e.y};
+}
+__global__ void __launch_bounds__(256) k_sp_clear(uint4 *table, u64 n_entries) {
+    u64 t = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (t < n_entries) table[t] = make_uint4(0u, (unsigned)(SBWT_SP_EMPTY >> 32), 0u, 0u);
+}
+template <bool MEGA>
+__global__ void __launch_bounds__(256) k_sp_expand(SbwtIndexView ix, const SpItem *__restrict__ in, const u64 *n_in,
+                                                   int depth, SpItem *__restrict__ out, u64 *n_out) {
+    u64 t = (u64)blockIdx.x * 256 + threadIdx.x;
+    if ((t >> 2) >= *n_in) return;
+    const SpItem it = in[t >> 2];
+    const int c = (int)(t & 3);
+    uint4 q1 = ix.blocks[((it.l >> 6) << 2) + c];
+    uint4 q2 = ix.blocks[(((it.r + 1) >> 6) << 2) + c];
+    i64 l = (i64)quad_rank<MEGA>(ix, q1, it.l, c);
+    i64 r = (i64)quad_rank<MEGA>(ix, q2, it.r + 1, c) - 1;
+    if (l > r) return;
+    u64 slot = atomicAdd(n_out, 1ull);
+    out[slot] = SpItem{it.key | ((u64)c << (2 * depth)), l, r};   // char `depth` of the prefix is c
+}
+__global__ void __launch_bounds__(256) k_sp_insert(const SpItem *__restrict__ items, const u64 *n, uint4 *table,
+                                                   int log2b) {
+    u64 t = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (t >= *n) return;
+    const SpItem it = items[t];
+    const u64 mask = (1ull << log2b) - 1ull;
+    u64 bkt = (it.key * SBWT_SP_HASH) >> (64 - log2b);
+    for (;;) {
+        for (int e = 0; e < 2; e++) {
+            u64 *word = reinterpret_cast<u64 *>(&table[2 * bkt + e]);
+            u64 old = atomicCAS(word, SBWT_SP_EMPTY, it.key);
+            if (old == SBWT_SP_EMPTY) {
+                unsigned *pay = reinterpret_cast<unsigned *>(word) + 2;
+                pay[0] = (unsigned)it.l;
+                pay[1] = (unsigned)(it.r - it.l);
+                return;
+            }
+        }
+        atomicOr(reinterpret_cast<u64 *>(&table[2 * bkt]), SBWT_SP_OVERFLOW);   // both entries taken: mark and move on
+        bkt = (bkt + 1) & mask;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1030,4 +1129,35 @@ void sbwt_launch_derive_marks(const SbwtIndexView &ix, uint4 *d_blocks, void *d_
         unsigned char *t = last; last = next; next = t;
     }
     hipLaunchKernelGGL(k_sg_patch, dim3(grid_for(nb)), dim3(256), 0, stream, d_blocks, acc, nb);
+}
+
+// scratch of the sparse-table build: two item lists of n_nodes entries + two counters
+long long sbwt_sparse_scratch_bytes(long long n_nodes) { return 2 * (n_nodes + 64) * (long long)sizeof(SpItem) + 256; }
+
+void sbwt_launch_build_sparse(const SbwtIndexView &ix, int p_dense, int p_sparse, int log2b, uint4 *d_table,
+                              void *d_scratch, hipStream_t stream) {
+    u64 *counters = reinterpret_cast<u64 *>(d_scratch);                    // [0], [1]: list lengths
+    SpItem *listA = reinterpret_cast<SpItem *>(reinterpret_cast<char *>(d_scratch) + 256);
+    SpItem *listB = listA + (ix.n_nodes + 64);
+    (void)hipMemsetAsync(counters, 0, 256, stream);
+    hipLaunchKernelGGL(k_sp_clear, dim3(grid_for((i64)2 << log2b)), dim3(256), 0, stream, d_table, (u64)2 << log2b);
+    const u64 n_dense = 1ull << (2 * p_dense);
+    hipLaunchKernelGGL(k_sp_collect, dim3(grid_for((i64)n_dense)), dim3(256), 0, stream, ix.ptab, n_dense, listA,
+                       counters + 0);
+    SpItem *in = listA, *outl = listB;
+    int ci = 0;
+    for (int d = p_dense; d < p_sparse; d++) {
+        (void)hipMemsetAsync(counters + (ci ^ 1), 0, 8, stream);
+        const i64 threads = (ix.n_nodes + 64) * 4;
+        if (ix.n_mega > 1)
+            hipLaunchKernelGGL(k_sp_expand<true>, dim3(grid_for(threads)), dim3(256), 0, stream, ix, in, counters + ci, d,
+                               outl, counters + (ci ^ 1));
+        else
+            hipLaunchKernelGGL(k_sp_expand<false>, dim3(grid_for(threads)), dim3(256), 0, stream, ix, in, counters + ci, d,
+                               outl, counters + (ci ^ 1));
+        SpItem *t = in; in = outl; outl = t;
+        ci ^= 1;
+    }
+    hipLaunchKernelGGL(k_sp_insert, dim3(grid_for(ix.n_nodes + 64)), dim3(256), 0, stream, in, counters + ci, d_table,
+                       log2b);
 }

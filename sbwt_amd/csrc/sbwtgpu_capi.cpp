@@ -78,6 +78,8 @@ static int tuning_variant() {          // 0 = k_search (reference order), 1 = k_
     return v;
 }
 static int g_variant_override = -1, g_probe_override = -1, g_debug = 0, g_derive_ssup = 1;
+// depth of the sparse (hashed) prefix table built at index creation (capped at k and at 31 = one 62-bit key)
+static int g_sparse_depth = [] { const char *e = getenv("SBWTGPU_SPARSE_PRECALC"); return e ? atoi(e) : 31; }();
 
 struct sbwtgpu_index {
     SbwtBlobHeader h;
@@ -109,6 +111,9 @@ struct sbwtgpu_index {
         v.has_ssup = h.has_ssup;
         v.probe_len = probe_len();
         v.debug = g_debug;
+        v.p_sparse = (int)h.p_sparse;
+        v.log2b = (int)h.log2b;
+        v.stab = h.p_sparse > 0 ? reinterpret_cast<const uint4 *>(blob + h.off_stab) : nullptr;
         return v;
     }
 };
@@ -124,6 +129,11 @@ int sbwtgpu_set_tuning(const char *key, int64_t value) {
     if (!strcmp(key, "probe_len")) { g_probe_override = (int)value; return SBWTGPU_OK; }
     if (!strcmp(key, "debug")) { g_debug = (int)value; return SBWTGPU_OK; }
     if (!strcmp(key, "derive_ssup")) { g_derive_ssup = (int)value; return SBWTGPU_OK; }
+    if (!strcmp(key, "sparse_depth")) {      // takes effect for indexes created afterwards
+        if (value < 0 || value > 31) return fail(SBWTGPU_ERR_INVALID_ARG, "sparse_depth must be in [0,31]");
+        g_sparse_depth = (int)value;
+        return SBWTGPU_OK;
+    }
     return fail(SBWTGPU_ERR_INVALID_ARG, "unknown tuning key '%s'", key);
 }
 
@@ -191,6 +201,18 @@ int sbwtgpu_index_create(const sbwtgpu_index_desc *d, int device, sbwtgpu_index 
     if (ftab_bytes == 0) h.off_ftab = h.off_ptab;   // the same table serves both
     h.off_mega = align256(h.off_ftab + (ftab_bytes ? ftab_bytes : ptab_bytes));
     h.blob_bytes = align256(h.off_mega + 4 * n_mega * 8);
+    // sparse table one level above the dense one: 32-bit intervals only, one bucket per column on average
+    int64_t p_sparse = g_sparse_depth < d->k ? g_sparse_depth : d->k;
+    if (p_sparse > SBWT_SP_MAX_DEPTH) p_sparse = SBWT_SP_MAX_DEPTH;
+    if (p_sparse <= p_dev || p_dev <= 0 || n >= ((int64_t)1 << 32) || n_mega > 1) p_sparse = 0;
+    if (p_sparse > 0) {
+        int lb = 6;
+        while (((int64_t)1 << lb) < n) lb++;
+        h.p_sparse = (int32_t)p_sparse;
+        h.log2b = lb;
+        h.off_stab = h.blob_bytes;
+        h.blob_bytes = align256(h.off_stab + ((int64_t)32 << lb));
+    }
     idx->device = device;
 
     // C array (SBWT.hh:344-349): C[0] = 1 (ghost dollar into the root), C[i+1] = C[i] + rank(n, sigma_i)
@@ -223,6 +245,7 @@ int sbwtgpu_index_create(const sbwtgpu_index_desc *d, int device, sbwtgpu_index 
         p_dev = 0;
         h.p_dev = 0;
         h.has_ssup = 0;
+        h.p_sparse = 0;
     }
     if (d->precalc && p_file > 0) {
         const int64_t np = (int64_t)1 << (2 * p_file);
@@ -278,6 +301,8 @@ int sbwtgpu_index_create(const sbwtgpu_index_desc *d, int device, sbwtgpu_index 
         h.off_ptab = h.off_ftab = align256(n_blocks * 64);
         h.off_mega = h.off_ptab;
         h.blob_bytes = align256(h.off_mega + 4 * n_mega * 8);
+        h.off_stab = 0;
+        h.log2b = 0;
     }
     hipError_t e = hipMalloc((void **)&idx->blob, (size_t)h.blob_bytes);
     if (e != hipSuccess) {
@@ -314,6 +339,15 @@ int sbwtgpu_index_create(const sbwtgpu_index_desc *d, int device, sbwtgpu_index 
             } else {
                 sbwt_launch_precalc(v, (int)p_file, reinterpret_cast<longlong2 *>(idx->blob + h.off_ftab), 0);
             }
+        }
+        if (h.p_sparse > 0) {
+            void *scr = nullptr;
+            if ((e = hipMalloc(&scr, (size_t)sbwt_sparse_scratch_bytes(n))) != hipSuccess) break;
+            sbwt_launch_build_sparse(v, (int)p_dev, (int)h.p_sparse, (int)h.log2b,
+                                     reinterpret_cast<uint4 *>(idx->blob + h.off_stab), scr, 0);
+            e = hipDeviceSynchronize();
+            (void)hipFree(scr);
+            if (e != hipSuccess) break;
         }
         if ((e = hipGetLastError()) != hipSuccess) break;
         e = hipDeviceSynchronize();

@@ -15,8 +15,17 @@ rounds = int(os.environ.get("ROUNDS", 3))
 dev = torch.device("cuda", 0)
 genomes = synth.coli3_like(glen)
 bits = hostlib.build_bits([g.tobytes() for g in genomes], 30, False, True, n_threads=os.cpu_count())
-idx = capi.Index.create(bits.cols[0], bits.cols[1], bits.cols[2], bits.cols[3], bits.ssup, bits.n_nodes, 30, bits.n_kmers, 8)
-print("n_nodes", idx.n_nodes, "p_dev", idx.device_precalc_k, "blob MB", idx.blob_bytes / 1e6, flush=True)
+indexes = {}
+def index_for(sparse):      # configs may carry a 4th element: depth of the sparse prefix table (default 20, 0 = off)
+    if sparse not in indexes:
+        capi.set_tuning("sparse_depth", sparse)
+        t0 = time.time()
+        ix = capi.Index.create(bits.cols[0], bits.cols[1], bits.cols[2], bits.cols[3], bits.ssup, bits.n_nodes, 30, bits.n_kmers, 8)
+        print("sparse", sparse, "n_nodes", ix.n_nodes, "p_dev", ix.device_precalc_k, "blob MB", ix.blob_bytes / 1e6,
+              "create s", round(time.time() - t0, 2), flush=True)
+        indexes[sparse] = ix
+    return indexes[sparse]
+idx = index_for(20)
 d_bases = B.gpu_reads(genomes, n_reads, 42, dev)
 m = 121
 d_roff = torch.arange(n_reads + 1, dtype=torch.int64, device=dev) * 150
@@ -31,6 +40,7 @@ times = {tuple(c): [] for c in configs}
 for rnd in range(rounds + 1):
     for c in configs:
         capi.set_tuning("search_variant", c[0]); capi.set_tuning("probe_len", c[1]); capi.set_tuning("debug", c[2] if len(c) > 2 else 0)
+        idx = index_for(c[3] if len(c) > 3 else 20)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         idx.search_encoded_dev(d_bases.numel(), d_roff.data_ptr(), n_reads, d_out.data_ptr(), d_ooff.data_ptr(), d_ws.data_ptr(), wsb, True, st)
@@ -42,4 +52,4 @@ for rnd in range(rounds + 1):
         else:
             times[tuple(c)].append(e0.elapsed_time(e1))
 for c, v in times.items():
-    print(f"variant={c[0]} probe={c[1]}: median {np.median(v):.2f} ms min {min(v):.2f} ms -> {n_reads * m / np.median(v) / 1e6:.2f} G kmers/s")
+    print(f"variant={c[0]} probe={c[1]} rest={c[2:]}: median {np.median(v):.2f} ms min {min(v):.2f} ms -> {n_reads * m / np.median(v) / 1e6:.2f} G kmers/s")
