@@ -207,7 +207,7 @@ def main() -> int:
         elapsed = sdist.max_over_ranks(elapsed, dev)
 
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in events]))
-    n_stream, n_search, n_lf, n_tab = index.workspace_stats(d_ws.data_ptr(), stream)
+    n_stream, n_search, n_lf, n_tab, n_ext = index.workspace_stats(d_ws.data_ptr(), stream)
     status = index.workspace_status(d_ws.data_ptr(), stream)
     if status != 0:
         raise SystemExit(f"search kernel reported status {status}")

@@ -310,10 +310,10 @@ class Index:
                                                 ws_bytes, int(streaming), stream))
 
     def workspace_stats(self, d_ws: int, stream: int = 0):
-        """(n_stream, n_search, n_lf, n_tab_hit) of the last search on this workspace."""
-        st = (C.c_int64 * 4)()
+        """(n_stream, n_search, n_lf, n_tab_hit, n_ext) of the last search on this workspace."""
+        st = (C.c_int64 * 8)()
         _check(lib().sbwtgpu_workspace_stats(d_ws, stream, st))
-        return tuple(int(x) for x in st)
+        return tuple(int(x) for x in (st if os.environ.get('SBWT_ALL_STATS') else st[:5]))
 
     def workspace_status(self, d_ws: int, stream: int = 0) -> int:
         st = C.c_int(0)

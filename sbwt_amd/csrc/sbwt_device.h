@@ -6,6 +6,9 @@
 //   [ ptab     : 4^p_dev x 16 B  ]   device prefix table, (first,second) int64 pairs
 //   [ ftab     : 4^p_file x 16 B ]   the index file's own table (only if p_file != p_dev, p_file > 0)
 //   [ mega     : 4 x n_mega x 8 B]   absolute (C[c] + rank_c) at every 2^31-column boundary
+//   [ col, pos : n_nodes x 4 B each ]  path order (see k_path_* in sbwt_kernels.hip)
+//   [ pq       : (n/32+2) x 16 B ]   packed chars + go bits along the paths
+//   [ trans    : n_nodes x 32 B  ]   the four successors of every path position (columns, path positions)
 //   [ stab     : 2^log2b x 32 B  ]   sparse prefix table at depth p_sparse (only non-empty prefixes), hashed:
 //                                    bucket = two 16-byte entries { key | flags (u64), first (u32), second-first (u32) }
 //
@@ -43,6 +46,10 @@ struct SbwtIndexView {
     const uint4 *stab;              // sparse prefix table (nullptr if p_sparse == 0)
     int p_sparse;                   // its depth (0 = none)
     int log2b;                      // log2 of its number of buckets
+    const unsigned *col, *pos;      // path order: column at path position t, path position of column v (nullptr = none)
+    const uint4 *pq;                // packed path chars: quad t>>5 = { 32 chars (2 bits each), go mask, - }
+    const uint4 *trans;             // transition table: 2 quads per path position (successor columns, successor positions)
+    int stab_pos;                   // sparse entries are whole k-mers stored with their path position
     int debug;                      // experiments only: bit0 = skip result stores
 };
 
@@ -59,6 +66,9 @@ struct SbwtBlobHeader {
     int32_t p_sparse;               // depth of the sparse prefix table (0 = none)
     int64_t off_stab;
     int32_t log2b;
+    int32_t has_path;               // path order present (col, pos, pq)
+    int64_t off_col, off_pos, off_pq, off_trans;
+    int32_t stab_pos;
     int32_t reserved;
 };
 #define SBWT_BLOB_MAGIC 0x3155504754574253ull   // "SBWTGPU1" little endian
@@ -79,7 +89,8 @@ struct SbwtWorkHeader {
     unsigned long long n_search;    // full searches started (SBWT.hh:389-415)
     unsigned long long n_lf;        // interval updates executed past the device prefix table (SBWT.hh:430-431)
     unsigned long long n_tab_hit;   // prefix-table lookups that returned a non-empty interval
-    unsigned long long pad[26];
+    unsigned long long n_ext;       // k-mers answered along path runs (k_search_cert<PATH>), not counted in n_stream
+    unsigned long long pad[25];
 };
 static_assert(sizeof(SbwtWorkHeader) == 256, "workspace header is 256 bytes");
 
@@ -102,5 +113,9 @@ void sbwt_launch_format(const long long *d_vals, const long long *d_out_off, lon
 long long sbwt_derive_scratch_bytes(long long n_nodes);
 void sbwt_launch_derive_marks(const SbwtIndexView &ix, uint4 *d_blocks, void *d_scratch, hipStream_t stream);
 long long sbwt_sparse_scratch_bytes(long long n_nodes);
-void sbwt_launch_build_sparse(const SbwtIndexView &ix, int p_dense, int p_sparse, int log2b, uint4 *d_table,
-                              void *d_scratch, hipStream_t stream);
+long long sbwt_path_scratch_bytes(long long n_nodes);
+long long sbwt_path_quads(long long n_nodes);
+int sbwt_launch_build_path(const SbwtIndexView &ix, unsigned *d_col, unsigned *d_pos, uint4 *d_pq, uint4 *d_trans,
+                           void *d_scratch, hipStream_t stream);
+int sbwt_launch_build_sparse(const SbwtIndexView &ix, int p_dense, int p_sparse, int log2b, uint4 *d_table,
+                             void *d_scratch, const unsigned *d_pos, hipStream_t stream);

@@ -63,7 +63,7 @@ __global__ void __launch_bounds__(256) k_encode(const unsigned char *__restrict_
                                                 uint4 *__restrict__ packed, i64 n_groups,
                                                 SbwtWorkHeader *ws, int aligned16) {
     i64 g = (i64)blockIdx.x * 256 + threadIdx.x;
-    if (g == 0) { ws->ticket = 0; ws->status = 0; ws->n_stream = 0; ws->n_search = 0; ws->n_lf = 0; ws->n_tab_hit = 0; }
+    if (g == 0) { ws->ticket = 0; ws->status = 0; ws->n_stream = 0; ws->n_search = 0; ws->n_lf = 0; ws->n_tab_hit = 0; ws->n_ext = 0; }
     if (g >= n_groups) return;
     i64 base = g * SBWT_GROUP_BASES;
     u64 codes = 0;
@@ -328,6 +328,9 @@ __global__ void __launch_bounds__(256) k_search(SbwtIndexView ix, const uint4 *_
 // ---------------------------------------------------------------------------------------------
 #define M_FETCH 5
 #define M_BACK 6
+#define M_EXT 7                 // PATH: follow the path from position r while the read agrees with it
+#define M_TRANS 8               // PATH: the read left the path at position r: the streaming step, from the transition table
+#define M_POS 9                 // PATH: r = pos[l]  (a k-mer was found by a walk: onto its path)
 #define EV_NONE 0
 #define EV_EMIT1 1
 #define EV_FAIL 2
@@ -337,6 +340,9 @@ __global__ void __launch_bounds__(256) k_search(SbwtIndexView ix, const uint4 *_
 #define K_RELOAD 2
 #define K_MODE 3
 #define STAGE_DEPTH 8
+#ifndef SBWT_COPY_PIPE
+#define SBWT_COPY_PIPE 1
+#endif
 
 // WIDE = false: every column index fits 31 bits (n_nodes < 2^31 - 64): positions, results and the LDS
 // stage are 32-bit (16 staged results = one 128-byte line per flush).  WIDE = true: 64-bit
@@ -354,7 +360,14 @@ __device__ __forceinline__ typename SearchTypes<WIDE>::pos_t quad_rank_t(const S
     return v;
 }
 
-template <bool WIDE, int WPS>
+// (4) PATH = true (32-bit indexes with a path order, see k_path_*): after a k-mer is found at column l
+//     the lane moves to its path position and resolves up to 32 following k-mers per iteration by a
+//     2-bit compare of the read against the path's chars; their answers are the contiguous run
+//     col[t+1..], copied to `out` by the wave together.  Where the read leaves the path the streaming
+//     step is one 32-byte entry of the transition table (the four successors of position t, as columns
+//     and as path positions).  A third load per iteration prefetches the next packed group of the
+//     read, so that 32-base windows rarely wait for a reload.
+template <bool WIDE, int WPS, bool PATH>
 __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, const uint4 *__restrict__ packed,
                                                         const i64 *__restrict__ read_off,
                                                         const i64 *__restrict__ out_off, i64 *__restrict__ out,
@@ -377,6 +390,7 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
     i64 rd = 0;                     // M_FETCH: the read whose offsets are being fetched
     int tag = -2;                   // g0 = packed group `tag`; g1 = group tag+1 if g1ok
     bool g1ok = false;
+    unsigned c_ext = 0;             // PATH: k-mers answered along paths (per lane)
     uint4 g0 = make_uint4(0, 0, 0, 0), g1 = make_uint4(0, 0, 0, 0);
     u64 pool_next = 0, pool_end = 0;                              // wave-uniform pool of read tickets
     unsigned c_stream = 0, c_search = 0, c_lf = 0, c_tab = 0;     // wave-uniform (scalar) work counters
@@ -408,14 +422,24 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
         int kind = K_NONE, ev = EV_NONE, tfail = 0, c = 0, grp = 0;
         const uint4 *a1 = ix.blocks, *a2 = ix.blocks;
         pos_t res = -1;
-        const bool strm = (mode == M_STREAM || mode == M_BACK);
+        const bool strm = !PATH && (mode == M_STREAM || mode == M_BACK);
+        const bool ext = PATH && (mode == M_EXT);
+        const bool trn = PATH && (mode == M_TRANS);
+        bool rknown = false;                           // PATH: this iteration's answer came with its path position (in r)
+        pos_t tpos = -1;
+        int seg_n = 0;                                 // PATH: k-mers i .. i+seg_n-1 are col[seg_src ..]
+        unsigned seg_src = 0;
         if (mode == M_FETCH) {
             kind = K_FETCH;                            // {read_off[rd], read_off[rd+1]}, {out_off[rd], ..}
             a1 = reinterpret_cast<const uint4 *>(read_off + rd);
             a2 = reinterpret_cast<const uint4 *>(out_off + rd);
+        } else if (PATH && mode == M_POS) {
+            kind = K_MODE;                             // the aligned 16 bytes holding pos[l]
+            a1 = reinterpret_cast<const uint4 *>(ix.pos + ((unsigned)l & ~3u));
+            a2 = a1;
         } else if (mode != M_IDLE && mode != M_DEAD) {
             // M_INIT reads the window at wstart (j counts extra hash buckets there); M_STEP the base at wstart + j
-            const int P = poff + (strm ? (i + k - 1) : ((mode == M_INIT) ? wstart : (wstart + j)));
+            const int P = poff + ((strm || ext || trn) ? (i + k - 1) : ((mode == M_INIT) ? wstart : (wstart + j)));
             const int s = P & 31;
             const int wl = spw ? ps : p;               // bases the table window of this walk covers
             grp = pgrp + (P >> 5);
@@ -432,7 +456,18 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
                 kind = K_MODE;
                 const u64 codes0 = quad_bits(g0);
                 c = (int)((unsigned)(codes0 >> (2 * s)) & 3u);
-                if (strm) {
+                if (ext) {
+                    a1 = ix.pq + ((unsigned)r >> 5);   // the two quads holding path chars r .. r+31
+                    a2 = a1 + 1;
+                } else if (trn) {
+                    if (((streaming == 2 ? g0.w : g0.z) >> s) & 1u) {     // validity as in M_STREAM below
+                        a1 = ix.trans + 2 * (size_t)(unsigned)r;
+                        a2 = a1 + 1;
+                    } else {
+                        ev = EV_EMIT1;
+                        b = i + k - 1;
+                    }
+                } else if (strm) {
                     // streaming == 1: SBWT::streaming_search validates the upper-cased char (SBWT.hh:565-568);
                     // streaming == 2: internal streaming inside the search loop keeps SBWT::search's raw-char
                     // validation (SBWT.hh:398-399,427-428)
@@ -479,8 +514,15 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
         c_lf = uniform32(c_lf + (unsigned)__popcll(__ballot(have && mode == M_STEP)));
 
         // ---- the one memory round trip of this iteration ----
+        // PATH: the read's next packed group rides along when it is not here yet
+        const bool pf = PATH && !g1ok && kind == K_MODE;
+        const uint4 *a3 = pf ? (packed + (tag + 1)) : a1;
         const uint4 v1 = *a1;
         const uint4 v2 = *a2;
+        if (PATH) {
+            const uint4 v3 = *a3;
+            if (pf) { g1 = v3; g1ok = true; }
+        }
 
         // ---- consume ----
         bool tabhit = false, do_plan = false, force = false;
@@ -499,6 +541,44 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
             g1 = v2;
             g1ok = true;
             tag = grp;
+        } else if (PATH && have && mode == M_POS) {
+            const unsigned sel = (unsigned)l & 3u;
+            r = (pos_t)(sel == 0 ? v1.x : sel == 1 ? v1.y : sel == 2 ? v1.z : v1.w);
+            mode = M_EXT;
+        } else if (trn && have) {
+            // successors of path position r: v1 = their columns, v2 = their path positions (SBWT.hh:562-575)
+            const unsigned nc = (c == 0 ? v1.x : c == 1 ? v1.y : c == 2 ? v1.z : v1.w);
+            ev = EV_EMIT1;
+            if (nc == 0xFFFFFFFFu) {
+                b = i + k - 1;
+            } else {
+                res = (pos_t)nc;
+                r = (pos_t)(c == 0 ? v2.x : c == 1 ? v2.y : c == 2 ? v2.z : v2.w);
+                rknown = true;
+            }
+        } else if (ext && have) {
+            // k-mer i-1 sits at path position r.  Read bases i+k-1.. against path chars r..: while they agree
+            // (and the read's bases are valid and the path goes on), k-mer i+x sits at r+1+x.
+            const int P = poff + i + k - 1, s = P & 31, sp = (int)((unsigned)r & 31u);
+            u64 rw = quad_bits(g0) >> (2 * s), pw = quad_bits(v1) >> (2 * sp);
+            if (s) rw |= quad_bits(g1) << (64 - 2 * s);
+            if (sp) pw |= quad_bits(v2) << (64 - 2 * sp);
+            const u64 rv = ((streaming == 2) ? (((u64)g1.w << 32) | (u64)g0.w) : (((u64)g1.z << 32) | (u64)g0.z)) >> s;
+            const u64 pg = (((u64)v2.z << 32) | (u64)v1.z) >> sp;
+            const u64 x = rw ^ pw;
+            const u64 mm = (x | (x >> 1)) & 0x5555555555555555ull;
+            const int nm = mm ? ((__ffsll((i64)mm) - 1) >> 1) : 32;
+            const u64 bad = ~(rv & pg) | (1ull << 32);
+            const int nv = __ffsll((i64)bad) - 1;
+            int n = nm < nv ? nm : nv;
+            const bool stopped = n < 32;               // a mismatch, an invalid base or the end of the path
+            if (n > m - i) n = m - i;
+            seg_n = n;
+            seg_src = (unsigned)r + 1u;
+            r += (pos_t)n;
+            c_ext += (unsigned)n;
+            if (i + n == m) mode = M_IDLE;
+            else if (stopped) mode = M_TRANS;
         } else if (have) {
             if (strm) {
                 const i64 blk = (mode == M_BACK) ? (i64)r : ((i64)l >> 6);
@@ -533,7 +613,12 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
                     wl = ps;
                     if (m0 | m1) {
                         l = (pos_t)(m0 ? v1.z : v2.z);
-                        r = l + (pos_t)(m0 ? v1.w : v2.w);
+                        if (ix.stab_pos) {             // depth-k entries: one column, stored with its path position
+                            r = l;
+                            if (PATH) tpos = (pos_t)(m0 ? v1.w : v2.w);
+                        } else {
+                            r = l + (pos_t)(m0 ? v1.w : v2.w);
+                        }
                     } else {
                         // a later bucket may hold the key; otherwise the prefix is absent and the dense table
                         // walks the same window to find WHERE it fails (the planner wants the exact position)
@@ -568,7 +653,7 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
             }
         }
         c_tab = uniform32(c_tab + (unsigned)__popcll(__ballot(tabhit)));
-        c_stream = uniform32(c_stream + (unsigned)__popcll(__ballot(ev == EV_EMIT1 && strm)));
+        c_stream = uniform32(c_stream + (unsigned)__popcll(__ballot(ev == EV_EMIT1 && (strm || trn))));
 
         // ---- events: results, certificates, next state ----
         int burst_hi = -1;                             // >= i: k-mers i..burst_hi are certified absent
@@ -576,6 +661,7 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
             if (wstart == i) {                         // k chars matched from i: the k-mer is there
                 res = l;
                 if (l != r) ws->status = SBWT_ERR_NOT_SINGLETON;   // SBWT.hh:410-413
+                if (PATH && tpos >= 0) { r = tpos; rknown = true; }
                 ev = EV_EMIT1;
                 b = -1;
             } else {
@@ -601,7 +687,7 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
         // coalesced store (64/DEPTH runs per store instruction) instead of a per-lane loop of 8-byte
         // stores that would execute in almost every iteration for a handful of lanes.
         {
-            const bool fl = (cnt > 0) && (burst_hi >= 0 || i == m || (((unsigned)obase + (unsigned)i) & (DEPTH - 1)) == 0);
+            const bool fl = (cnt > 0) && (burst_hi >= 0 || seg_n > 0 || i == m || (((unsigned)obase + (unsigned)i) & (DEPTH - 1)) == 0);
             i64 dst = obase + (i - cnt);               // run of staged results
             int nrun = fl ? cnt : 0;
             u64 fm = __ballot(fl);
@@ -650,12 +736,61 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
                 fm = __ballot(nrun > 0);
             }
             if (burst_hi >= 0) i = burst_hi + 1;
+            if (PATH) {
+                // path runs: k-mers i .. i+seg_n-1 are col[seg_src ..], DEPTH of them per group and pass
+                dst = obase + i;
+                nrun = seg_n;
+                unsigned srcp = seg_src;
+                if (ix.debug & 128) {                  // debug: every lane copies its own run
+                    for (int x = 0; x < seg_n; x++) out[obase + i + x] = (i64)ix.col[seg_src + (unsigned)x];
+                    nrun = 0;
+                }
+                fm = __ballot(nrun > 0);
+                while (fm) {
+                    // PIPE passes per trip: their loads of col[] are in flight together
+                    constexpr int PIPE = SBWT_COPY_PIPE;
+                    i64 dd[PIPE];
+                    unsigned pp[PIPE];
+                    bool act[PIPE];
+#pragma unroll
+                    for (int u = 0; u < PIPE; u++) {
+                        int src = -1;
+                        u64 served = 0;
+#pragma unroll
+                        for (int g = 0; g < NG; g++) {
+                            int f = fm ? (__ffsll((i64)fm) - 1) : -1;
+                            if (f >= 0) served |= 1ull << f;
+                            fm &= fm - 1;
+                            src = (grpl == g) ? f : src;
+                        }
+                        const int srcl = src < 0 ? 0 : src;
+                        dd[u] = __shfl(dst, srcl) + sub;
+                        pp[u] = __shfl(srcp, srcl) + (unsigned)sub;
+                        const int nn = __shfl(nrun, srcl);   // every lane takes part: the holder may sit in an idle group
+                        act[u] = src >= 0 && sub < nn && !(ix.debug & 1);
+                        if ((served >> lane) & 1ull) { dst += DEPTH; nrun -= DEPTH; srcp += DEPTH; }
+                        fm = __ballot(nrun > 0);
+                    }
+                    unsigned vals[PIPE];
+#pragma unroll
+                    for (int u = 0; u < PIPE; u++) vals[u] = act[u] ? ix.col[pp[u]] : 0u;
+#pragma unroll
+                    for (int u = 0; u < PIPE; u++)
+                        if (act[u]) {
+                            if (ix.debug & 64) atomicAdd(&ws->pad[0], 1ull);
+                            if (ix.debug & 2) out[dd[u]] = (i64)vals[u];
+                            else st_stream(out + dd[u], (i64)vals[u]);
+                        }
+                }
+                if ((ix.debug & 64) && seg_n > 0) { atomicAdd(&ws->pad[1], (u64)seg_n); atomicAdd(&ws->pad[2], 1ull); }
+                i += seg_n;
+            }
         }
         if (ev == EV_EMIT1 || burst_hi >= 0) {
             if (i == m) {
                 mode = M_IDLE;
             } else if (ev == EV_EMIT1 && res != -1 && streaming) {
-                mode = M_STREAM;                       // SBWT.hh:560-
+                mode = PATH ? (rknown ? M_EXT : M_POS) : M_STREAM;   // SBWT.hh:560-
                 l = res;
             } else {
                 do_plan = true;                        // SBWT.hh:557-559 (with certificates)
@@ -677,6 +812,12 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
         }
     }
 
+    if (PATH) {
+        u64 e = c_ext;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) e += __shfl_down(e, off);
+        if (lane == 0) atomicAdd(&ws->n_ext, e);
+    }
     if (lane == 0) {   // the counters are wave-uniform
         atomicAdd(&ws->n_stream, (u64)c_stream);
         atomicAdd(&ws->n_search, (u64)c_search);
@@ -845,6 +986,10 @@ __global__ void __launch_bounds__(256) k_sp_collect(const longlong2 *__restrict_
     u64 slot = atomicAdd(counter, 1ull);
     out[slot] = SpItem{t, e.x, e.y};
 }
+__global__ void __launch_bounds__(256) k_sp_wide(const SpItem *__restrict__ items, const u64 *n, int *flag) {
+    u64 t = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (t < *n && items[t].l != items[t].r) *flag = 1;
+}
 __global__ void __launch_bounds__(256) k_sp_clear(uint4 *table, u64 n_entries) {
     u64 t = (u64)blockIdx.x * 256 + threadIdx.x;
     if (t < n_entries) table[t] = make_uint4(0u, (unsigned)(SBWT_SP_EMPTY >> 32), 0u, 0u);
@@ -864,8 +1009,9 @@ __global__ void __launch_bounds__(256) k_sp_expand(SbwtIndexView ix, const SpIte
     u64 slot = atomicAdd(n_out, 1ull);
     out[slot] = SpItem{it.key | ((u64)c << (2 * depth)), l, r};   // char `depth` of the prefix is c
 }
+// pos != nullptr: the items are whole k-mers (one column each); the second payload word is the column's path position
 __global__ void __launch_bounds__(256) k_sp_insert(const SpItem *__restrict__ items, const u64 *n, uint4 *table,
-                                                   int log2b) {
+                                                   int log2b, const unsigned *__restrict__ pos) {
     u64 t = (u64)blockIdx.x * 256 + threadIdx.x;
     if (t >= *n) return;
     const SpItem it = items[t];
@@ -878,13 +1024,161 @@ __global__ void __launch_bounds__(256) k_sp_insert(const SpItem *__restrict__ it
             if (old == SBWT_SP_EMPTY) {
                 unsigned *pay = reinterpret_cast<unsigned *>(word) + 2;
                 pay[0] = (unsigned)it.l;
-                pay[1] = (unsigned)(it.r - it.l);
+                pay[1] = pos ? pos[it.l] : (unsigned)(it.r - it.l);
                 return;
             }
         }
         atomicOr(reinterpret_cast<u64 *>(&table[2 * bkt]), SBWT_SP_OVERFLOW);   // both entries taken: mark and move on
         bkt = (bkt + 1) & mask;
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Path order: the streaming steps of SBWT::streaming_search (SBWT.hh:562-575), precomputed.
+//
+// A streaming step maps (column v, char c) to the column of the k-mer that follows, and that map does
+// not depend on the query.  Give every column ONE outgoing step (a char its suffix group offers) and
+// every column at most one incoming one: the columns fall apart into vertex-disjoint paths -- in a
+// genome, the unitigs strung together through their branch points.  Number the columns along the
+// paths: t = pos[v], v = col[t].  A query that sits on column col[t] and whose next base equals the
+// path's char at t sits on col[t+1] next, and so on: while the read follows the path, its answers are
+// the CONTIGUOUS run col[t+1], col[t+2], ... and checking that it does is a 2-bit compare against the
+// path's packed chars, 32 bases at a time.  The random 64-byte block gather per k-mer becomes
+// sequential 4-byte reads; the blocks are only touched where a read leaves its path (a branch taken
+// the other way, a substitution, the end of a path), by the generic step.
+//
+//   k_path_succ   per column: the group's start, the chars it offers, the char this member takes
+//                 (member r of a group with d chars takes the (r mod d)-th, so the members of a
+//                 bubble fan out), the target column; claims the target with atomicMin
+//   k_path_keep   a step survives if its source won the claim
+//   k_path_jump   pointer doubling over the predecessor links: head of the path + distance from it
+//                 (and the minimum column seen, which names a cycle's cut point)
+//   k_path_cut    columns that never reached a head lie on a cycle: cut it at its minimum
+//   k_path_len / scan / k_path_place   paths laid out head by head: pos, col and the packed chars
+// ---------------------------------------------------------------------------------------------
+#define PATH_NONE 0xFFFFFFFFu
+__global__ void __launch_bounds__(256) k_path_fill(unsigned *a, i64 n, unsigned v) {
+    i64 t = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (t < n) a[t] = v;
+}
+__global__ void __launch_bounds__(256) k_path_succ(SbwtIndexView ix, unsigned *__restrict__ succ,
+                                                   unsigned char *__restrict__ sch, unsigned *prv) {
+    const i64 v = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (v >= ix.n_nodes) return;
+    i64 blk = v >> 6;
+    u64 msk = ((u64)ix.blocks[blk * 4].w | ((u64)ix.blocks[blk * 4 + 1].w << 32)) & ((2ull << (int)(v & 63)) - 1ull);
+    while (msk == 0 && blk > 0) {
+        blk--;
+        msk = (u64)ix.blocks[blk * 4].w | ((u64)ix.blocks[blk * 4 + 1].w << 32);
+    }
+    if (msk == 0) msk = 1;
+    const int gb = 63 - __clzll((i64)msk);
+    const i64 g = (blk << 6) | gb;
+    uint4 q[4];
+    int deg = 0;
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        q[c] = ix.blocks[blk * 4 + c];
+        deg += (int)((quad_bits(q[c]) >> gb) & 1ull);
+    }
+    if (deg == 0) { succ[v] = PATH_NONE; sch[v] = 0; return; }
+    int want = (int)((v - g) % deg), pick = 0;
+    unsigned target = 0;
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        const u64 bits = quad_bits(q[c]);
+        if ((bits >> gb) & 1ull) {
+            if (want == 0) { pick = c; target = q[c].z + (unsigned)__popcll(bits & low_mask(gb)); }
+            want--;
+        }
+    }
+    succ[v] = target;
+    sch[v] = (unsigned char)pick;
+    atomicMin(&prv[target], (unsigned)v);
+}
+__global__ void __launch_bounds__(256) k_path_keep(i64 n, unsigned *__restrict__ succ, const unsigned *__restrict__ prv,
+                                                   unsigned *__restrict__ jump, unsigned *__restrict__ dist,
+                                                   unsigned *__restrict__ mn) {
+    const i64 v = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (v >= n) return;
+    const unsigned sv = succ[v];
+    if (sv != PATH_NONE && prv[sv] != (unsigned)v) succ[v] = PATH_NONE;
+    const unsigned pv = prv[v];
+    jump[v] = (pv == PATH_NONE) ? (unsigned)v : pv;     // heads point at themselves
+    dist[v] = (pv == PATH_NONE) ? 0u : 1u;
+    mn[v] = (unsigned)v;
+}
+__global__ void __launch_bounds__(256) k_path_jump(i64 n, const unsigned *__restrict__ jin, const unsigned *__restrict__ din,
+                                                   const unsigned *__restrict__ min_, unsigned *__restrict__ jout,
+                                                   unsigned *__restrict__ dout, unsigned *__restrict__ mout) {
+    const i64 v = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (v >= n) return;
+    const unsigned j = jin[v];
+    dout[v] = din[v] + din[j];
+    const unsigned a = min_[v], bq = min_[j];
+    mout[v] = a < bq ? a : bq;
+    jout[v] = jin[j];
+}
+__global__ void __launch_bounds__(256) k_path_cut(i64 n, const unsigned *__restrict__ jump, const unsigned *__restrict__ mn,
+                                                  unsigned *prv, unsigned *succ, int *flag) {
+    const i64 v = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (v >= n) return;
+    // reached a head?  (a cycle's cut point may be cut by its own thread while others look: they then
+    // return here, and the flag is raised by the cutting thread)
+    if (prv[jump[v]] == PATH_NONE) return;
+    if (mn[v] == (unsigned)v) {                         // the cycle's smallest column becomes a head
+        const unsigned pv = prv[v];
+        if (pv != PATH_NONE) { succ[pv] = PATH_NONE; prv[v] = PATH_NONE; }
+        *flag = 1;
+    }
+}
+__global__ void __launch_bounds__(256) k_path_len(i64 n, const unsigned *__restrict__ head, const unsigned *__restrict__ dist,
+                                                  unsigned long long *len) {
+    const i64 v = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (v >= n) return;
+    atomicMax(&len[head[v]], (unsigned long long)dist[v] + 1ull);
+}
+__global__ void __launch_bounds__(256) k_path_place(i64 n, const unsigned *__restrict__ head, const unsigned *__restrict__ dist,
+                                                    const i64 *__restrict__ base, const unsigned *__restrict__ succ,
+                                                    const unsigned char *__restrict__ sch, unsigned *__restrict__ pos,
+                                                    unsigned *__restrict__ col, unsigned *pq) {
+    const i64 v = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (v >= n) return;
+    const unsigned t = (unsigned)base[head[v]] + dist[v];
+    pos[v] = t;
+    col[t] = (unsigned)v;
+    if (succ[v] != PATH_NONE) {                         // quad t>>5 = { chars lo, chars hi, go mask, - }
+        unsigned *quad = pq + (size_t)(t >> 5) * 4;
+        const unsigned s = t & 31u;
+        if (sch[v]) atomicOr(&quad[s >> 4], (unsigned)sch[v] << (2 * (s & 15u)));
+        atomicOr(&quad[2], 1u << s);
+    }
+}
+
+// transition table: entry t = { columns of the four successors of col[t] } { their path positions }
+__global__ void __launch_bounds__(256) k_path_trans(SbwtIndexView ix, const unsigned *__restrict__ pos,
+                                                    uint4 *__restrict__ trans) {
+    const i64 v = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (v >= ix.n_nodes) return;
+    i64 blk = v >> 6;
+    u64 msk = ((u64)ix.blocks[blk * 4].w | ((u64)ix.blocks[blk * 4 + 1].w << 32)) & ((2ull << (int)(v & 63)) - 1ull);
+    while (msk == 0 && blk > 0) {
+        blk--;
+        msk = (u64)ix.blocks[blk * 4].w | ((u64)ix.blocks[blk * 4 + 1].w << 32);
+    }
+    if (msk == 0) msk = 1;
+    const int gb = 63 - __clzll((i64)msk);
+    unsigned nc[4], np[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        const uint4 q = ix.blocks[blk * 4 + c];
+        const u64 bits = quad_bits(q);
+        nc[c] = ((bits >> gb) & 1ull) ? (q.z + (unsigned)__popcll(bits & low_mask(gb))) : PATH_NONE;
+        np[c] = (nc[c] != PATH_NONE) ? pos[nc[c]] : PATH_NONE;
+    }
+    const size_t t = pos[v];
+    trans[2 * t] = make_uint4(nc[0], nc[1], nc[2], nc[3]);
+    trans[2 * t + 1] = make_uint4(np[0], np[1], np[2], np[3]);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1025,7 +1319,7 @@ void sbwt_launch_search(const SbwtIndexView &ix, const uint4 *d_packed, const lo
                         const long long *d_out_off, long long *d_out, long long n_reads, SbwtWorkHeader *ws,
                         int streaming, hipStream_t stream, int variant, long long total_groups) {
     if (n_reads <= 0) return;
-    if (variant == 1) {
+    if (variant >= 1) {
         i64 want1 = (n_reads + 255) / 256;
         unsigned grid1 = (unsigned)(want1 < 2048 ? want1 : 2048);
         // 32-bit positions need every column index (and n_nodes + 64) below 2^31 and < 2^31 packed groups
@@ -1034,10 +1328,13 @@ void sbwt_launch_search(const SbwtIndexView &ix, const uint4 *d_packed, const lo
         unsigned cap = (ix.debug >> 8) ? (unsigned)(ix.debug >> 8) : 1024u;
         unsigned g = grid1 < cap ? grid1 : cap;
         if (wide)
-            hipLaunchKernelGGL((k_search_cert<true, 4>), dim3(g), dim3(256), 0, stream, ix, d_packed, d_read_off,
+            hipLaunchKernelGGL((k_search_cert<true, 4, false>), dim3(g), dim3(256), 0, stream, ix, d_packed, d_read_off,
+                               d_out_off, d_out, (i64)n_reads, ws, streaming);
+        else if (variant >= 2 && ix.col && streaming)      // path order (the default when the index has one)
+            hipLaunchKernelGGL((k_search_cert<false, 4, true>), dim3(g), dim3(256), 0, stream, ix, d_packed, d_read_off,
                                d_out_off, d_out, (i64)n_reads, ws, streaming);
         else
-            hipLaunchKernelGGL((k_search_cert<false, 4>), dim3(g), dim3(256), 0, stream, ix, d_packed, d_read_off,
+            hipLaunchKernelGGL((k_search_cert<false, 4, false>), dim3(g), dim3(256), 0, stream, ix, d_packed, d_read_off,
                                d_out_off, d_out, (i64)n_reads, ws, streaming);
         return;
     }
@@ -1134,8 +1431,10 @@ void sbwt_launch_derive_marks(const SbwtIndexView &ix, uint4 *d_blocks, void *d_
 // scratch of the sparse-table build: two item lists of n_nodes entries + two counters
 long long sbwt_sparse_scratch_bytes(long long n_nodes) { return 2 * (n_nodes + 64) * (long long)sizeof(SpItem) + 256; }
 
-void sbwt_launch_build_sparse(const SbwtIndexView &ix, int p_dense, int p_sparse, int log2b, uint4 *d_table,
-                              void *d_scratch, hipStream_t stream) {
+// d_pos: path positions to store with depth-k entries (nullptr = none).  Returns 1 if they were stored,
+// 0 if not (no d_pos, p_sparse < k, or some k-mer's interval is wider than one column), < 0 on error.
+int sbwt_launch_build_sparse(const SbwtIndexView &ix, int p_dense, int p_sparse, int log2b, uint4 *d_table,
+                             void *d_scratch, const unsigned *d_pos, hipStream_t stream) {
     u64 *counters = reinterpret_cast<u64 *>(d_scratch);                    // [0], [1]: list lengths
     SpItem *listA = reinterpret_cast<SpItem *>(reinterpret_cast<char *>(d_scratch) + 256);
     SpItem *listB = listA + (ix.n_nodes + 64);
@@ -1158,6 +1457,79 @@ void sbwt_launch_build_sparse(const SbwtIndexView &ix, int p_dense, int p_sparse
         SpItem *t = in; in = outl; outl = t;
         ci ^= 1;
     }
+    int with_pos = 0;
+    if (d_pos && p_sparse == ix.k) {
+        int *flag = reinterpret_cast<int *>(counters + 8);
+        hipLaunchKernelGGL(k_sp_wide, dim3(grid_for(ix.n_nodes + 64)), dim3(256), 0, stream, in, counters + ci, flag);
+        int h_flag = 1;
+        if (hipMemcpyAsync(&h_flag, flag, 4, hipMemcpyDeviceToHost, stream) != hipSuccess) return -1;
+        if (hipStreamSynchronize(stream) != hipSuccess) return -1;
+        with_pos = h_flag ? 0 : 1;
+    }
     hipLaunchKernelGGL(k_sp_insert, dim3(grid_for(ix.n_nodes + 64)), dim3(256), 0, stream, in, counters + ci, d_table,
-                       log2b);
+                       log2b, with_pos ? d_pos : (const unsigned *)nullptr);
+    return with_pos;
+}
+
+// ---- path order (see k_path_*) ----
+static inline long long path_pad(long long n) { return (n + 64 + 255) & ~255ll; }
+long long sbwt_path_scratch_bytes(long long n_nodes) {
+    const long long np = path_pad(n_nodes);
+    const long long nb = (n_nodes + 1023) / 1024;
+    return np * 4 * 8 + np + np * 8 * 2 + (nb + 2) * 8 + 4096;
+}
+long long sbwt_path_quads(long long n_nodes) { return n_nodes / 32 + 2; }
+
+// d_col, d_pos: n_nodes (+4 padding) u32 each; d_pq: sbwt_path_quads() quads.  Synchronises the stream.
+int sbwt_launch_build_path(const SbwtIndexView &ix, unsigned *d_col, unsigned *d_pos, uint4 *d_pq, uint4 *d_trans,
+                           void *d_scratch, hipStream_t stream) {
+    const i64 n = ix.n_nodes;
+    const long long np = path_pad(n);
+    const i64 nb = (n + 1023) / 1024;
+    char *base = reinterpret_cast<char *>(d_scratch);
+    int *flag = reinterpret_cast<int *>(base);
+    base += 4096;
+    unsigned *succ = reinterpret_cast<unsigned *>(base); base += np * 4;
+    unsigned *prv = reinterpret_cast<unsigned *>(base); base += np * 4;
+    unsigned *buf[2][3];
+    for (int a = 0; a < 2; a++)
+        for (int f = 0; f < 3; f++) { buf[a][f] = reinterpret_cast<unsigned *>(base); base += np * 4; }
+    unsigned char *sch = reinterpret_cast<unsigned char *>(base); base += np;
+    unsigned long long *len = reinterpret_cast<unsigned long long *>(base); base += np * 8;
+    i64 *pbase = reinterpret_cast<i64 *>(base); base += np * 8;
+    i64 *bsum = reinterpret_cast<i64 *>(base);
+    const unsigned g = grid_for(n);
+    hipLaunchKernelGGL(k_path_fill, dim3(g), dim3(256), 0, stream, prv, n, PATH_NONE);
+    hipLaunchKernelGGL(k_path_succ, dim3(g), dim3(256), 0, stream, ix, succ, sch, prv);
+    int rounds = 1;
+    while (((i64)1 << rounds) < n) rounds++;
+    rounds++;
+    int cur = 0;
+    for (int attempt = 0; attempt < 3; attempt++) {
+        cur = 0;
+        hipLaunchKernelGGL(k_path_keep, dim3(g), dim3(256), 0, stream, n, succ, prv, buf[0][0], buf[0][1], buf[0][2]);
+        for (int r = 0; r < rounds; r++) {
+            hipLaunchKernelGGL(k_path_jump, dim3(g), dim3(256), 0, stream, n, buf[cur][0], buf[cur][1], buf[cur][2],
+                               buf[cur ^ 1][0], buf[cur ^ 1][1], buf[cur ^ 1][2]);
+            cur ^= 1;
+        }
+        (void)hipMemsetAsync(flag, 0, 4, stream);
+        hipLaunchKernelGGL(k_path_cut, dim3(g), dim3(256), 0, stream, n, buf[cur][0], buf[cur][2], prv, succ, flag);
+        int h_flag = 0;
+        if (hipMemcpyAsync(&h_flag, flag, 4, hipMemcpyDeviceToHost, stream) != hipSuccess) return -1;
+        if (hipStreamSynchronize(stream) != hipSuccess) return -1;
+        if (!h_flag) break;
+        if (attempt == 2) return -2;                    // cannot happen: one cut per cycle opens every cycle
+    }
+    (void)hipMemsetAsync(len, 0, (size_t)np * 8, stream);
+    hipLaunchKernelGGL(k_path_len, dim3(g), dim3(256), 0, stream, n, buf[cur][0], buf[cur][1], len);
+    hipLaunchKernelGGL(k_scan_block_sums, dim3((unsigned)nb), dim3(256), 0, stream, reinterpret_cast<const i64 *>(len), n, bsum);
+    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, stream, bsum, nb);
+    hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nb), dim3(256), 0, stream, reinterpret_cast<const i64 *>(len), n, bsum, pbase);
+    (void)hipMemsetAsync(d_pq, 0, (size_t)sbwt_path_quads(n) * 16, stream);
+    hipLaunchKernelGGL(k_path_place, dim3(g), dim3(256), 0, stream, n, buf[cur][0], buf[cur][1], pbase, succ, sch, d_pos,
+                       d_col, reinterpret_cast<unsigned *>(d_pq));
+    hipLaunchKernelGGL(k_path_trans, dim3(g), dim3(256), 0, stream, ix, d_pos, d_trans);
+    if (hipStreamSynchronize(stream) != hipSuccess) return -1;
+    return 0;
 }

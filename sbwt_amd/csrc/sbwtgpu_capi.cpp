@@ -73,12 +73,14 @@ struct DeviceGuard {
 }  // namespace
 
 // tuning knobs (A/B experiments; defaults are the shipped configuration)
-static int tuning_variant() {          // 0 = k_search (reference order), 1 = k_search_cert
-    static int v = [] { const char *e = getenv("SBWTGPU_SEARCH_VARIANT"); return e ? atoi(e) : 1; }();
+// 0 = k_search (reference order), 1 = k_search_cert, 2 = k_search_cert along the path order (when the index has one)
+static int tuning_variant() {
+    static int v = [] { const char *e = getenv("SBWTGPU_SEARCH_VARIANT"); return e ? atoi(e) : 2; }();
     return v;
 }
 static int g_variant_override = -1, g_probe_override = -1, g_debug = 0, g_derive_ssup = 1;
 // depth of the sparse (hashed) prefix table built at index creation (capped at k and at 31 = one 62-bit key)
+static int g_path_order = [] { const char *e = getenv("SBWTGPU_PATH_ORDER"); return e ? atoi(e) : 1; }();
 static int g_sparse_depth = [] { const char *e = getenv("SBWTGPU_SPARSE_PRECALC"); return e ? atoi(e) : 31; }();
 
 struct sbwtgpu_index {
@@ -114,6 +116,11 @@ struct sbwtgpu_index {
         v.p_sparse = (int)h.p_sparse;
         v.log2b = (int)h.log2b;
         v.stab = h.p_sparse > 0 ? reinterpret_cast<const uint4 *>(blob + h.off_stab) : nullptr;
+        v.col = h.has_path ? reinterpret_cast<const unsigned *>(blob + h.off_col) : nullptr;
+        v.pos = h.has_path ? reinterpret_cast<const unsigned *>(blob + h.off_pos) : nullptr;
+        v.pq = h.has_path ? reinterpret_cast<const uint4 *>(blob + h.off_pq) : nullptr;
+        v.trans = h.has_path ? reinterpret_cast<const uint4 *>(blob + h.off_trans) : nullptr;
+        v.stab_pos = h.stab_pos;
         return v;
     }
 };
@@ -129,6 +136,7 @@ int sbwtgpu_set_tuning(const char *key, int64_t value) {
     if (!strcmp(key, "probe_len")) { g_probe_override = (int)value; return SBWTGPU_OK; }
     if (!strcmp(key, "debug")) { g_debug = (int)value; return SBWTGPU_OK; }
     if (!strcmp(key, "derive_ssup")) { g_derive_ssup = (int)value; return SBWTGPU_OK; }
+    if (!strcmp(key, "path_order")) { g_path_order = (int)value; return SBWTGPU_OK; }   // indexes created afterwards
     if (!strcmp(key, "sparse_depth")) {      // takes effect for indexes created afterwards
         if (value < 0 || value > 31) return fail(SBWTGPU_ERR_INVALID_ARG, "sparse_depth must be in [0,31]");
         g_sparse_depth = (int)value;
@@ -213,6 +221,16 @@ int sbwtgpu_index_create(const sbwtgpu_index_desc *d, int device, sbwtgpu_index 
         h.off_stab = h.blob_bytes;
         h.blob_bytes = align256(h.off_stab + ((int64_t)32 << lb));
     }
+    // path order: needs suffix-group marks (given or derived) and 32-bit columns
+    const bool marks = d->suffix_group_starts || (g_derive_ssup && d->k >= 2);
+    if (g_path_order && marks && n < ((int64_t)1 << 31) - 64 && n_mega == 1) {
+        h.has_path = 1;
+        h.off_col = h.blob_bytes;
+        h.off_pos = align256(h.off_col + (n + 4) * 4);
+        h.off_pq = align256(h.off_pos + (n + 4) * 4);
+        h.off_trans = align256(h.off_pq + sbwt_path_quads(n) * 16);
+        h.blob_bytes = align256(h.off_trans + (n + 1) * 32);
+    }
     idx->device = device;
 
     // C array (SBWT.hh:344-349): C[0] = 1 (ghost dollar into the root), C[i+1] = C[i] + rank(n, sigma_i)
@@ -246,6 +264,7 @@ int sbwtgpu_index_create(const sbwtgpu_index_desc *d, int device, sbwtgpu_index 
         h.p_dev = 0;
         h.has_ssup = 0;
         h.p_sparse = 0;
+        h.has_path = 0;
     }
     if (d->precalc && p_file > 0) {
         const int64_t np = (int64_t)1 << (2 * p_file);
@@ -303,6 +322,7 @@ int sbwtgpu_index_create(const sbwtgpu_index_desc *d, int device, sbwtgpu_index 
         h.blob_bytes = align256(h.off_mega + 4 * n_mega * 8);
         h.off_stab = 0;
         h.log2b = 0;
+        h.off_col = h.off_pos = h.off_pq = h.off_trans = 0;
     }
     hipError_t e = hipMalloc((void **)&idx->blob, (size_t)h.blob_bytes);
     if (e != hipSuccess) {
@@ -340,14 +360,27 @@ int sbwtgpu_index_create(const sbwtgpu_index_desc *d, int device, sbwtgpu_index 
                 sbwt_launch_precalc(v, (int)p_file, reinterpret_cast<longlong2 *>(idx->blob + h.off_ftab), 0);
             }
         }
+        if (h.has_path) {
+            void *scr = nullptr;
+            if ((e = hipMalloc(&scr, (size_t)sbwt_path_scratch_bytes(n))) != hipSuccess) break;
+            int prc = sbwt_launch_build_path(v, reinterpret_cast<unsigned *>(idx->blob + h.off_col),
+                                             reinterpret_cast<unsigned *>(idx->blob + h.off_pos),
+                                             reinterpret_cast<uint4 *>(idx->blob + h.off_pq),
+                                             reinterpret_cast<uint4 *>(idx->blob + h.off_trans), scr, 0);
+            (void)hipFree(scr);
+            if (prc != 0) { e = hipErrorUnknown; break; }
+        }
         if (h.p_sparse > 0) {
             void *scr = nullptr;
             if ((e = hipMalloc(&scr, (size_t)sbwt_sparse_scratch_bytes(n))) != hipSuccess) break;
-            sbwt_launch_build_sparse(v, (int)p_dev, (int)h.p_sparse, (int)h.log2b,
-                                     reinterpret_cast<uint4 *>(idx->blob + h.off_stab), scr, 0);
+            int src = sbwt_launch_build_sparse(v, (int)p_dev, (int)h.p_sparse, (int)h.log2b,
+                                               reinterpret_cast<uint4 *>(idx->blob + h.off_stab), scr,
+                                               h.has_path ? reinterpret_cast<const unsigned *>(idx->blob + h.off_pos) : nullptr, 0);
             e = hipDeviceSynchronize();
             (void)hipFree(scr);
+            if (src < 0 && e == hipSuccess) e = hipErrorUnknown;
             if (e != hipSuccess) break;
+            h.stab_pos = src > 0 ? 1 : 0;
         }
         if ((e = hipGetLastError()) != hipSuccess) break;
         e = hipDeviceSynchronize();
@@ -626,7 +659,7 @@ int sbwtgpu_workspace_status(const void *d_ws, void *stream, int *status) {
     return SBWTGPU_OK;
 }
 
-int sbwtgpu_workspace_stats(const void *d_ws, void *stream, int64_t stats[4]) {
+int sbwtgpu_workspace_stats(const void *d_ws, void *stream, int64_t stats[8]) {
     if (!d_ws || !stats) return fail(SBWTGPU_ERR_INVALID_ARG, "NULL argument");
     SbwtWorkHeader hdr;
     HIP_TRY(hipMemcpyAsync(&hdr, d_ws, sizeof(hdr), hipMemcpyDeviceToHost, static_cast<hipStream_t>(stream)));
@@ -635,6 +668,8 @@ int sbwtgpu_workspace_stats(const void *d_ws, void *stream, int64_t stats[4]) {
     stats[1] = (int64_t)hdr.n_search;
     stats[2] = (int64_t)hdr.n_lf;
     stats[3] = (int64_t)hdr.n_tab_hit;
+    stats[4] = (int64_t)hdr.n_ext;
+    stats[5] = (int64_t)hdr.pad[0]; stats[6] = (int64_t)hdr.pad[1]; stats[7] = (int64_t)hdr.pad[2];
     return SBWTGPU_OK;
 }
 

@@ -41,6 +41,8 @@ for rnd in range(rounds + 1):
     for c in configs:
         capi.set_tuning("search_variant", c[0]); capi.set_tuning("probe_len", c[1]); capi.set_tuning("debug", c[2] if len(c) > 2 else 0)
         idx = index_for(c[3] if len(c) > 3 else 20)
+        if rnd == 0:
+            d_out.fill_(-7)        # never-written results must not inherit the previous config's values
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         idx.search_encoded_dev(d_bases.numel(), d_roff.data_ptr(), n_reads, d_out.data_ptr(), d_ooff.data_ptr(), d_ws.data_ptr(), wsb, True, st)
