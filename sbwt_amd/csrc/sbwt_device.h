@@ -9,6 +9,7 @@
 //   [ col, pos : n_nodes x 4 B each ]  path order (see k_path_* in sbwt_kernels.hip)
 //   [ pq       : (n/32+2) x 16 B ]   packed chars + go bits along the paths
 //   [ trans    : n_nodes x 32 B  ]   the four successors of every path position (columns, path positions)
+//   [ pfil     : 2^log2f x 16 B  ]   probe filter (see k_pf_insert)
 //   [ stab     : 2^log2b x 32 B  ]   sparse prefix table at depth p_sparse (only non-empty prefixes), hashed:
 //                                    bucket = two 16-byte entries { key | flags (u64), first (u32), second-first (u32) }
 //
@@ -48,6 +49,8 @@ struct SbwtIndexView {
     int log2b;                      // log2 of its number of buckets
     const unsigned *col, *pos;      // path order: column at path position t, path position of column v (nullptr = none)
     const uint4 *pq;                // packed path chars: quad t>>5 = { 32 chars (2 bits each), go mask, - }
+    const uint4 *pfil;              // probe filter: blocked Bloom filter over the p_filter-mers of the index (nullptr = none)
+    int p_filter, log2f;            // its depth and log2 of its number of 16-byte blocks
     const uint4 *trans;             // transition table: 2 quads per path position (successor columns, successor positions)
     int stab_pos;                   // sparse entries are whole k-mers stored with their path position
     int debug;                      // experiments only: bit0 = skip result stores
@@ -69,6 +72,9 @@ struct SbwtBlobHeader {
     int32_t has_path;               // path order present (col, pos, pq)
     int64_t off_col, off_pos, off_pq, off_trans;
     int32_t stab_pos;
+    int32_t p_filter;               // depth of the probe filter (0 = none)
+    int64_t off_pfil;
+    int32_t log2f;
     int32_t reserved;
 };
 #define SBWT_BLOB_MAGIC 0x3155504754574253ull   // "SBWTGPU1" little endian
@@ -78,6 +84,14 @@ struct SbwtBlobHeader {
 #define SBWT_SP_OVERFLOW (1ull << 62)           // set in entry 0 of a bucket some key had to skip
 #define SBWT_SP_MAX_DEPTH 31                    // keys are 2 bits per base in the low 62 bits
 #define SBWT_SP_HASH 0x9E3779B97F4A7C15ull
+// probe filter hash: block index in the top bits, two bit positions (7 bits each) in the low bits
+static __host__ __device__ inline unsigned long long sbwt_pf_hash(unsigned long long key) {
+    unsigned long long h = key * SBWT_SP_HASH;
+    h ^= h >> 32;
+    h *= 0xD6E8FEB86659FD93ull;
+    h ^= h >> 29;
+    return h;
+}
 
 // Workspace header (first 256 bytes of the search workspace).
 struct SbwtWorkHeader {
@@ -118,4 +132,5 @@ long long sbwt_path_quads(long long n_nodes);
 int sbwt_launch_build_path(const SbwtIndexView &ix, unsigned *d_col, unsigned *d_pos, uint4 *d_pq, uint4 *d_trans,
                            void *d_scratch, hipStream_t stream);
 int sbwt_launch_build_sparse(const SbwtIndexView &ix, int p_dense, int p_sparse, int log2b, uint4 *d_table,
-                             void *d_scratch, const unsigned *d_pos, hipStream_t stream);
+                             void *d_scratch, const unsigned *d_pos, int p_filter, int log2f, uint4 *d_filter,
+                             hipStream_t stream);

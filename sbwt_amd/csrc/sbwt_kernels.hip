@@ -335,6 +335,7 @@ __global__ void __launch_bounds__(256) k_search(SbwtIndexView ix, const uint4 *_
 #define EV_EMIT1 1
 #define EV_FAIL 2
 #define EV_END 3
+#define EV_PRES 4               // a range probe's window is in the index: the bad base is not inside it
 #define K_NONE 0
 #define K_FETCH 1
 #define K_RELOAD 2
@@ -379,9 +380,14 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
     const int tid = threadIdx.x, lane = tid & 63;
     const int k = ix.k, p = ix.p_dev, L0 = ix.probe_len;
     const int ps = WIDE ? 0 : ix.p_sparse;          // sparse table: 32-bit intervals only
+    const bool pfon = ix.pfil && ix.p_filter == L0 && L0 > p;
     const pos_t last_node = (pos_t)(ix.n_nodes - 1);
 
-    bool spw = false;               // this walk starts with a sparse-table lookup (walks from k-mer i itself)
+    int wtype = 0;                  // debug statistics: what kind of walk this is
+    int wk = 0;                     // how this walk starts: 0 dense prefix table, 1 sparse table (walks from k-mer i
+                                    // itself), 2 probe filter (certificate probes; a "maybe" falls back to 0),
+                                    // 3 range probe (dense table only: is the bad base inside this window?)
+    int blo = -1;                   // the last failure is known to lie in [blo, b] (blo >= b: exactly at b)
     int mode = M_IDLE;              // M_DEAD once the ticket counter has run past the last read
     i64 obase = 0;                  // first result slot of the current read
     int pgrp = 0, poff = 0;         // the read starts at base poff of packed group pgrp
@@ -441,7 +447,7 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
             // M_INIT reads the window at wstart (j counts extra hash buckets there); M_STEP the base at wstart + j
             const int P = poff + ((strm || ext || trn) ? (i + k - 1) : ((mode == M_INIT) ? wstart : (wstart + j)));
             const int s = P & 31;
-            const int wl = spw ? ps : p;               // bases the table window of this walk covers
+            const int wl = (wk == 1) ? ps : (wk == 2) ? L0 : p;   // bases the table window of this walk covers
             grp = pgrp + (P >> 5);
             if (grp == tag + 1 && g1ok && (mode != M_INIT || s + wl <= 32)) {
                 g0 = g1;                               // crossed into the group that is already here
@@ -465,7 +471,7 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
                         a2 = a1 + 1;
                     } else {
                         ev = EV_EMIT1;
-                        b = i + k - 1;
+                        b = blo = i + k - 1;
                     }
                 } else if (strm) {
                     // streaming == 1: SBWT::streaming_search validates the upper-cased char (SBWT.hh:565-568);
@@ -477,7 +483,7 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
                         a2 = a1 + 1;
                     } else {
                         ev = EV_EMIT1;                 // non-ACGT after toupper -> -1 (SBWT.hh:568)
-                        b = i + k - 1;
+                        b = blo = i + k - 1;
                     }
                 } else if (mode == M_INIT) {
                     u64 w = codes0 >> (2 * s);
@@ -485,11 +491,14 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
                     const u64 vr = (((u64)g1.w << 32) | (u64)g0.w) >> s;
                     const u64 vm = low_mask(wl);
                     if ((vr & vm) == vm) {
-                        if (spw) {                     // bucket (hash + j) of the sparse table: two entries
+                        if (wk == 1) {                 // bucket (hash + j) of the sparse table: two entries
                             const u64 key = w & low_mask(2 * ps);
                             const u64 bkt = (((key * SBWT_SP_HASH) >> (64 - ix.log2b)) + (u64)j) & low_mask(ix.log2b);
                             a1 = ix.stab + 2 * bkt;
                             a2 = a1 + 1;
+                        } else if (wk == 2) {          // the window's block of the probe filter
+                            a1 = ix.pfil + (sbwt_pf_hash(w & low_mask(2 * L0)) >> (64 - ix.log2f));
+                            a2 = a1;
                         } else {
                             a1 = reinterpret_cast<const uint4 *>(ix.ptab + (w & low_mask(2 * p)));
                             a2 = a1;
@@ -526,6 +535,7 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
 
         // ---- consume ----
         bool tabhit = false, do_plan = false, force = false;
+        bool imprecise = false;                        // this iteration's failure is a table-level miss
         if (kind == K_FETCH) {
             const i64 P0 = (i64)quad_bits(v1);
             obase = (i64)quad_bits(v2);
@@ -534,6 +544,7 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
             m = (int)((i64)((u64)v1.z | ((u64)v1.w << 32)) - P0) - k + 1;
             i = 0;
             b = -1;
+            blo = -1;
             if (m > 0) { do_plan = true; force = true; }
             else mode = M_IDLE;
         } else if (kind == K_RELOAD) {
@@ -550,7 +561,7 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
             const unsigned nc = (c == 0 ? v1.x : c == 1 ? v1.y : c == 2 ? v1.z : v1.w);
             ev = EV_EMIT1;
             if (nc == 0xFFFFFFFFu) {
-                b = i + k - 1;
+                b = blo = i + k - 1;
             } else {
                 res = (pos_t)nc;
                 r = (pos_t)(c == 0 ? v2.x : c == 1 ? v2.y : c == 2 ? v2.z : v2.w);
@@ -597,16 +608,30 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
                     // node_left == node_right <=> column c has its bit set at the group start (SBWT.hh:572-575)
                     res = ((bits >> gb) & 1ull) ? val : (pos_t)-1;
                     ev = EV_EMIT1;
-                    if (res == -1) b = i + k - 1;
+                    if (res == -1) b = blo = i + k - 1;
                 }
             } else if (mode == M_INIT) {
                 int wl = p;
                 bool again = false;
-                if (spw) {
+                if (wk == 1 || wk == 2) {
                     // the window's key, again (cheaper than keeping it across the load)
                     const int Pw = poff + wstart, sw = Pw & 31;
                     u64 w = quad_bits(g0) >> (2 * sw);
                     if (sw) w |= quad_bits(g1) << (64 - 2 * sw);
+                  if (wk == 2) {
+                    const u64 h = sbwt_pf_hash(w & low_mask(2 * L0));
+                    const unsigned b1 = (unsigned)h & 127u, b2 = (unsigned)(h >> 7) & 127u;
+                    const unsigned w1 = (b1 < 64) ? (b1 < 32 ? v1.x : v1.y) : (b1 < 96 ? v1.z : v1.w);
+                    const unsigned w2 = (b2 < 64) ? (b2 < 32 ? v1.x : v1.y) : (b2 < 96 ? v1.z : v1.w);
+                    wl = L0;
+                    if (((w1 >> (b1 & 31u)) & (w2 >> (b2 & 31u)) & 1u) != 0) {
+                        again = true;                  // perhaps present: the dense table walks the window exactly
+                        wk = 0;
+                        wtype = 2;
+                    } else {
+                        l = -1;                        // read[wstart .. wstart+L0-1] is not in the index
+                    }
+                  } else {
                     const u64 key = w & low_mask(2 * ps);
                     const u64 w0 = quad_bits(v1), w1 = quad_bits(v2);
                     const bool m0 = (w0 & ~SBWT_SP_OVERFLOW) == key, m1 = w1 == key;
@@ -619,13 +644,13 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
                         } else {
                             r = l + (pos_t)(m0 ? v1.w : v2.w);
                         }
+                    } else if (w0 & SBWT_SP_OVERFLOW) {
+                        again = true;                  // a later bucket may hold the key
+                        j++;
                     } else {
-                        // a later bucket may hold the key; otherwise the prefix is absent and the dense table
-                        // walks the same window to find WHERE it fails (the planner wants the exact position)
-                        again = true;
-                        if (w0 & SBWT_SP_OVERFLOW) j++;
-                        else { j = 0; spw = false; }
+                        l = -1;                        // read[wstart .. wstart+ps-1] is not in the index
                     }
+                  }
                 } else {
                     l = (pos_t)(i64)quad_bits(v1);
                     r = (pos_t)(i64)((u64)v1.z | ((u64)v1.w << 32));
@@ -635,6 +660,9 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
                     if (l == -1) {
                         ev = EV_FAIL;                  // read[wstart .. wstart+wl-1] is not in the index
                         tfail = wstart + wl - 1;
+                        imprecise = (wk != 2);         // ... but where inside the window it fails is not known
+                    } else if (wk == 3) {
+                        ev = EV_PRES;
                     } else {
                         j = wl;
                         if (wstart + j == i + k) ev = EV_END;
@@ -642,6 +670,7 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
                     }
                 }
             } else {   // M_STEP
+                if (ix.debug & 64) atomicAdd(&ws->pad[8 + wtype], 1ull);
                 l = quad_rank_t<WIDE>(ix, v1, l, c);
                 r = quad_rank_t<WIDE>(ix, v2, r + 1, c) - 1;
                 if (l > r) {
@@ -671,9 +700,25 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
         } else if (ev == EV_FAIL) {
             // read[wstart..tfail] is not in the index: k-mers i..min(wstart, m-1) all contain it
             burst_hi = (wstart < m - 1) ? wstart : (m - 1);
-            // a walk that started AT the known-bad position says nothing about where the next one is
-            b = (wstart == b) ? -1 : tfail;
+            if (wk == 3) {                             // range probe: the bad base is in [wstart, b]
+                if (wstart >= b) b = -1;
+                else if (blo < wstart + 1) blo = wstart + 1;
+            } else if (imprecise && !(wstart == b && blo >= b)) {
+                blo = wstart;                          // the bad base is somewhere in [wstart, tfail]
+                b = tfail;
+            } else {
+                // a walk that started AT the known-bad position says nothing about where the next one is
+                b = (wstart == b) ? -1 : tfail;
+                blo = b;
+            }
             if (burst_hi == i) { ev = EV_EMIT1; burst_hi = -1; }   // a single -1 goes through the stage
+        }
+        if (ev == EV_PRES) {                           // no bad base in [wstart, wstart+p-1]: shrink the range
+            const int lo = blo > i ? blo : i;
+            if (wstart > lo) b = wstart - 1;
+            else blo = wstart + p;
+            if (blo > b) b = -1;
+            do_plan = true;
         }
         if (ev == EV_EMIT1) {
             stage[cnt][tid] = (stage_t)res;
@@ -799,14 +844,30 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
         if (do_plan) {
             // where the next walk starts (see the header comment): at k-mer i itself, or close to
             // the last failure position b when b lies inside k-mer i's window
-            int s0 = i;
+            int s0 = i, nwk = (ps > 0) ? 1 : 0;
             if (!force && L0 > 0 && b >= i && b <= i + k - 1) {
-                s0 = (b - i >= L0 - 1) ? (b - L0 + 1) : b;
-                if (s0 + p - 1 > i + k - 1) s0 = i;
+                const int lo = blo > i ? blo : i;
+                if (lo < b && p > 0 && k - p >= 1) {
+                    // the bad base is somewhere in [lo, b]: halve the range with a window that starts inside it
+                    // (absent: k-mers i..x are certified; present: the bad base is left of x)
+                    int x = lo + ((b - lo + 1) >> 1);
+                    if (x > i + k - p) x = i + k - p;
+                    if (x <= i) x = i + 1;
+                    s0 = x;
+                    nwk = 3;
+                } else {
+                    s0 = (b - i >= L0 - 1) ? (b - L0 + 1) : b;
+                    if (s0 + p - 1 > i + k - 1) s0 = i;
+                    if (s0 != i) nwk = (pfon && s0 + L0 - 1 <= i + k - 1) ? 2 : 0;
+                }
             }
             wstart = s0;
             j = 0;
-            spw = (ps > 0) && (s0 == i);               // probes keep the dense table: they need the exact failure position
+            // walks from k-mer i itself: sparse table; certificate probes: the filter when the whole probe window
+            // lies inside k-mer i's window (a clear bit certifies; otherwise the dense table finds the exact position)
+            wk = nwk;
+            wtype = (s0 == i) ? 0 : (wk == 2 ? 4 : (wk == 3 ? 1 : (s0 == b ? 3 : 5)));
+            if (ix.debug & 64) atomicAdd(&ws->pad[16 + wtype], 1ull);
             if (p > 0) mode = M_INIT;
             else { mode = M_STEP; l = 0; r = last_node; }
         }
@@ -1008,6 +1069,19 @@ __global__ void __launch_bounds__(256) k_sp_expand(SbwtIndexView ix, const SpIte
     if (l > r) return;
     u64 slot = atomicAdd(n_out, 1ull);
     out[slot] = SpItem{it.key | ((u64)c << (2 * depth)), l, r};   // char `depth` of the prefix is c
+}
+// Probe filter: a blocked Bloom filter (128-bit blocks, two bits per key) over every p_filter-mer the index
+// holds.  A certificate probe asks "is this window absent?": a clear bit answers yes in one gather; two set bits
+// answer "perhaps not", and the exact walk through the dense table decides.
+__global__ void __launch_bounds__(256) k_pf_insert(const SpItem *__restrict__ items, const u64 *n, unsigned *filter,
+                                                   int log2f) {
+    u64 t = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (t >= *n) return;
+    const u64 h = sbwt_pf_hash(items[t].key);
+    unsigned *blk = filter + ((h >> (64 - log2f)) << 2);
+    const unsigned b1 = (unsigned)h & 127u, b2 = (unsigned)(h >> 7) & 127u;
+    atomicOr(&blk[b1 >> 5], 1u << (b1 & 31u));
+    atomicOr(&blk[b2 >> 5], 1u << (b2 & 31u));
 }
 // pos != nullptr: the items are whole k-mers (one column each); the second payload word is the column's path position
 __global__ void __launch_bounds__(256) k_sp_insert(const SpItem *__restrict__ items, const u64 *n, uint4 *table,
@@ -1434,7 +1508,8 @@ long long sbwt_sparse_scratch_bytes(long long n_nodes) { return 2 * (n_nodes + 6
 // d_pos: path positions to store with depth-k entries (nullptr = none).  Returns 1 if they were stored,
 // 0 if not (no d_pos, p_sparse < k, or some k-mer's interval is wider than one column), < 0 on error.
 int sbwt_launch_build_sparse(const SbwtIndexView &ix, int p_dense, int p_sparse, int log2b, uint4 *d_table,
-                             void *d_scratch, const unsigned *d_pos, hipStream_t stream) {
+                             void *d_scratch, const unsigned *d_pos, int p_filter, int log2f, uint4 *d_filter,
+                             hipStream_t stream) {
     u64 *counters = reinterpret_cast<u64 *>(d_scratch);                    // [0], [1]: list lengths
     SpItem *listA = reinterpret_cast<SpItem *>(reinterpret_cast<char *>(d_scratch) + 256);
     SpItem *listB = listA + (ix.n_nodes + 64);
@@ -1456,6 +1531,11 @@ int sbwt_launch_build_sparse(const SbwtIndexView &ix, int p_dense, int p_sparse,
                                outl, counters + (ci ^ 1));
         SpItem *t = in; in = outl; outl = t;
         ci ^= 1;
+        if (d_filter && d + 1 == p_filter) {
+            (void)hipMemsetAsync(d_filter, 0, (size_t)16 << log2f, stream);
+            hipLaunchKernelGGL(k_pf_insert, dim3(grid_for(ix.n_nodes + 64)), dim3(256), 0, stream, in, counters + ci,
+                               reinterpret_cast<unsigned *>(d_filter), log2f);
+        }
     }
     int with_pos = 0;
     if (d_pos && p_sparse == ix.k) {

@@ -80,6 +80,10 @@ static int tuning_variant() {
 }
 static int g_variant_override = -1, g_probe_override = -1, g_debug = 0, g_derive_ssup = 1;
 // depth of the sparse (hashed) prefix table built at index creation (capped at k and at 31 = one 62-bit key)
+// debug aid for the parity tests: fill the result range with a poison pattern before every search, so that a
+// result the kernel never writes cannot inherit a correct value from an earlier launch
+static int g_poison = [] { const char *e = getenv("SBWTGPU_POISON_RESULTS"); return e ? atoi(e) : 0; }();
+static int g_probe_filter = [] { const char *e = getenv("SBWTGPU_PROBE_FILTER"); return e ? atoi(e) : 1; }();
 static int g_path_order = [] { const char *e = getenv("SBWTGPU_PATH_ORDER"); return e ? atoi(e) : 1; }();
 static int g_sparse_depth = [] { const char *e = getenv("SBWTGPU_SPARSE_PRECALC"); return e ? atoi(e) : 31; }();
 
@@ -90,8 +94,8 @@ struct sbwtgpu_index {
     bool owns_blob = true;
     // probe length of the certificate walks: long enough that a random string of that length is almost
     // surely absent (log4(#k-mers) + 4), at least one char longer than the device prefix table
-    int probe_len() const {
-        if (g_probe_override >= 0) return g_probe_override < h.k ? g_probe_override : 0;
+    int probe_len(bool allow_override = true) const {
+        if (allow_override && g_probe_override >= 0) return g_probe_override < h.k ? g_probe_override : 0;
         int64_t nk = h.n_kmers > 0 ? h.n_kmers : h.n_nodes;
         int L = 4;
         while (L < 40 && ((int64_t)1 << (2 * L)) < nk) L++;
@@ -121,6 +125,9 @@ struct sbwtgpu_index {
         v.pq = h.has_path ? reinterpret_cast<const uint4 *>(blob + h.off_pq) : nullptr;
         v.trans = h.has_path ? reinterpret_cast<const uint4 *>(blob + h.off_trans) : nullptr;
         v.stab_pos = h.stab_pos;
+        v.pfil = h.p_filter > 0 ? reinterpret_cast<const uint4 *>(blob + h.off_pfil) : nullptr;
+        v.p_filter = (int)h.p_filter;
+        v.log2f = (int)h.log2f;
         return v;
     }
 };
@@ -136,6 +143,8 @@ int sbwtgpu_set_tuning(const char *key, int64_t value) {
     if (!strcmp(key, "probe_len")) { g_probe_override = (int)value; return SBWTGPU_OK; }
     if (!strcmp(key, "debug")) { g_debug = (int)value; return SBWTGPU_OK; }
     if (!strcmp(key, "derive_ssup")) { g_derive_ssup = (int)value; return SBWTGPU_OK; }
+    if (!strcmp(key, "poison_results")) { g_poison = (int)value; return SBWTGPU_OK; }
+    if (!strcmp(key, "probe_filter")) { g_probe_filter = (int)value; return SBWTGPU_OK; }   // indexes created afterwards
     if (!strcmp(key, "path_order")) { g_path_order = (int)value; return SBWTGPU_OK; }   // indexes created afterwards
     if (!strcmp(key, "sparse_depth")) {      // takes effect for indexes created afterwards
         if (value < 0 || value > 31) return fail(SBWTGPU_ERR_INVALID_ARG, "sparse_depth must be in [0,31]");
@@ -220,6 +229,16 @@ int sbwtgpu_index_create(const sbwtgpu_index_desc *d, int device, sbwtgpu_index 
         h.log2b = lb;
         h.off_stab = h.blob_bytes;
         h.blob_bytes = align256(h.off_stab + ((int64_t)32 << lb));
+        // probe filter at the certificate probes' length: 128-bit blocks, about 16 bits per column
+        const int L0 = idx->probe_len(false);
+        if (g_probe_filter && L0 > p_dev && L0 <= p_sparse) {
+            int lf = 4;
+            while (((int64_t)8 << lf) < n) lf++;
+            h.p_filter = L0;
+            h.log2f = lf;
+            h.off_pfil = h.blob_bytes;
+            h.blob_bytes = align256(h.off_pfil + ((int64_t)16 << lf));
+        }
     }
     // path order: needs suffix-group marks (given or derived) and 32-bit columns
     const bool marks = d->suffix_group_starts || (g_derive_ssup && d->k >= 2);
@@ -264,6 +283,7 @@ int sbwtgpu_index_create(const sbwtgpu_index_desc *d, int device, sbwtgpu_index 
         h.p_dev = 0;
         h.has_ssup = 0;
         h.p_sparse = 0;
+        h.p_filter = 0;
         h.has_path = 0;
     }
     if (d->precalc && p_file > 0) {
@@ -375,7 +395,9 @@ int sbwtgpu_index_create(const sbwtgpu_index_desc *d, int device, sbwtgpu_index 
             if ((e = hipMalloc(&scr, (size_t)sbwt_sparse_scratch_bytes(n))) != hipSuccess) break;
             int src = sbwt_launch_build_sparse(v, (int)p_dev, (int)h.p_sparse, (int)h.log2b,
                                                reinterpret_cast<uint4 *>(idx->blob + h.off_stab), scr,
-                                               h.has_path ? reinterpret_cast<const unsigned *>(idx->blob + h.off_pos) : nullptr, 0);
+                                               h.has_path ? reinterpret_cast<const unsigned *>(idx->blob + h.off_pos) : nullptr,
+                                               (int)h.p_filter, (int)h.log2f,
+                                               h.p_filter > 0 ? reinterpret_cast<uint4 *>(idx->blob + h.off_pfil) : nullptr, 0);
             e = hipDeviceSynchronize();
             (void)hipFree(scr);
             if (src < 0 && e == hipSuccess) e = hipErrorUnknown;
@@ -600,6 +622,13 @@ int sbwtgpu_search_encoded_dev(const sbwtgpu_index *idx, int64_t total_bases, co
     hipError_t e = hipMemsetAsync(ws, 0, sizeof(SbwtWorkHeader), st);
     if (e != hipSuccess) return fail(SBWTGPU_ERR_HIP, "hipMemsetAsync: %s", hipGetErrorString(e));
     const uint4 *packed = reinterpret_cast<const uint4 *>(static_cast<char *>(d_ws) + sizeof(SbwtWorkHeader));
+    if (g_poison && n_reads > 0) {
+        int64_t ends[2] = {0, 0};
+        HIP_TRY(hipMemcpyAsync(&ends[0], d_out_off, 8, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(&ends[1], d_out_off + n_reads, 8, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        if (ends[1] > ends[0]) HIP_TRY(hipMemsetAsync(d_out + ends[0], 0xA5, (size_t)(ends[1] - ends[0]) * 8, st));
+    }
     sbwt_launch_search(idx->view(), packed, reinterpret_cast<const long long *>(d_read_off),
                        reinterpret_cast<const long long *>(d_out_off), reinterpret_cast<long long *>(d_out), n_reads,
                        ws, (!streaming && idx->h.ssup_derived && g_derive_ssup) ? 2 : streaming, st,
@@ -650,6 +679,12 @@ int sbwtgpu_rank_dev(const sbwtgpu_index *idx, const int64_t *d_pos, const char 
     return SBWTGPU_OK;
 }
 
+// debug: the raw 256-byte workspace header (32 x u64)
+int sbwtgpu_workspace_raw(const void *d_ws, void *stream, uint64_t raw[32]) {
+    HIP_TRY(hipMemcpyAsync(raw, d_ws, 256, hipMemcpyDeviceToHost, static_cast<hipStream_t>(stream)));
+    HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+    return SBWTGPU_OK;
+}
 int sbwtgpu_workspace_status(const void *d_ws, void *stream, int *status) {
     if (!d_ws || !status) return fail(SBWTGPU_ERR_INVALID_ARG, "NULL argument");
     SbwtWorkHeader hdr;

@@ -37,4 +37,8 @@ def gpu():
     n = capi.device_count()
     if n <= 0:
         pytest.fail("no HIP device visible: -m gpu tests need a GPU (there is no CPU fallback)")
+    # every search first poisons its result range: a result the kernel forgets to write must not pass
+    # because an earlier launch left the right value in recycled device memory
+    capi.set_tuning("poison_results", 1)
+    os.environ["SBWTGPU_POISON_RESULTS"] = "1"      # the CLI subprocesses too
     return 0

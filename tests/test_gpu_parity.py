@@ -215,10 +215,11 @@ def test_streaming_equals_search_at_scale_properties(gpu, genome_case):
     assert np.array_equal(a[: len(want)], want)
 
 
-@pytest.mark.parametrize("variant,probe", [(0, -1), (1, -1), (1, 0), (1, 9), (1, 11), (1, 12), (1, 13), (1, 20), (1, 29)])
+@pytest.mark.parametrize("variant,probe", [(0, -1), (1, -1), (1, 0), (1, 9), (1, 11), (1, 12), (1, 13), (1, 20), (1, 29),
+                                           (2, -1), (2, 0), (2, 9), (2, 13), (2, 29)])
 def test_results_do_not_depend_on_search_variant_or_probe_length(gpu, genome_case, variant, probe):
-    # k_search (reference order) and k_search_cert (absent-substring certificates) must give the
-    # same bits for every probe length, including reads with N / lower case and all-miss reads
+    # k_search (reference order), k_search_cert (absent-substring certificates) and its path-order form
+    # must give the same bits for every probe length, including reads with N / lower case and all-miss reads
     genomes, orc = genome_case
     idx = gpu_index_from_oracle(orc)
     capi.set_tuning("search_variant", variant)
@@ -237,6 +238,29 @@ def test_results_do_not_depend_on_search_variant_or_probe_length(gpu, genome_cas
     finally:
         capi.set_tuning("search_variant", -1)
         capi.set_tuning("probe_len", -1)
+
+
+@pytest.mark.parametrize("sparse,path", [(0, 1), (20, 1), (31, 0), (0, 0), (16, 1)])
+def test_results_do_not_depend_on_acceleration_structures(gpu, genome_case, sparse, path):
+    # the sparse prefix table (any depth) and the path order are derived data: with or without them, same bits
+    genomes, orc = genome_case
+    capi.set_tuning("sparse_depth", sparse)
+    capi.set_tuning("path_order", path)
+    try:
+        idx = gpu_index_from_oracle(orc)
+    finally:
+        capi.set_tuning("sparse_depth", 31)
+        capi.set_tuning("path_order", 1)
+    bases, off = synth.sample_reads(genomes, 3000, 150, 0.02, 78)
+    bases = synth.inject(bases, 80, ord("N"), 1)
+    bases = synth.inject(bases, 80, ord("t"), 2)
+    rb, ro = synth.random_reads(200, 150, 6)
+    bases = np.concatenate([bases, rb])
+    off = np.concatenate([off, ro[1:] + off[-1]])
+    got, _ = idx.streaming_search(bases, off)
+    assert np.array_equal(got, oracle_batch(orc, bases, off, True))
+    got, _ = idx.search(bases, off)
+    assert np.array_equal(got, oracle_batch(orc, bases, off, False))
 
 
 def test_wide_kernel_instantiation_matches(gpu, genome_case):

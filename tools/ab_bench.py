@@ -16,16 +16,19 @@ dev = torch.device("cuda", 0)
 genomes = synth.coli3_like(glen)
 bits = hostlib.build_bits([g.tobytes() for g in genomes], 30, False, True, n_threads=os.cpu_count())
 indexes = {}
-def index_for(sparse):      # configs may carry a 4th element: depth of the sparse prefix table (default 20, 0 = off)
-    if sparse not in indexes:
+def index_for(sparse, pfilter=1, path=1):   # configs may carry: [3] sparse table depth (0 = off), [4] probe filter, [5] path order
+    key = (sparse, pfilter, path)
+    if key not in indexes:
         capi.set_tuning("sparse_depth", sparse)
+        capi.set_tuning("probe_filter", pfilter)
+        capi.set_tuning("path_order", path)
         t0 = time.time()
         ix = capi.Index.create(bits.cols[0], bits.cols[1], bits.cols[2], bits.cols[3], bits.ssup, bits.n_nodes, 30, bits.n_kmers, 8)
-        print("sparse", sparse, "n_nodes", ix.n_nodes, "p_dev", ix.device_precalc_k, "blob MB", ix.blob_bytes / 1e6,
+        print("sparse/filter/path", key, "n_nodes", ix.n_nodes, "p_dev", ix.device_precalc_k, "blob MB", ix.blob_bytes / 1e6,
               "create s", round(time.time() - t0, 2), flush=True)
-        indexes[sparse] = ix
-    return indexes[sparse]
-idx = index_for(20)
+        indexes[key] = ix
+    return indexes[key]
+idx = index_for(31)
 d_bases = B.gpu_reads(genomes, n_reads, 42, dev)
 m = 121
 d_roff = torch.arange(n_reads + 1, dtype=torch.int64, device=dev) * 150
@@ -40,7 +43,7 @@ times = {tuple(c): [] for c in configs}
 for rnd in range(rounds + 1):
     for c in configs:
         capi.set_tuning("search_variant", c[0]); capi.set_tuning("probe_len", c[1]); capi.set_tuning("debug", c[2] if len(c) > 2 else 0)
-        idx = index_for(c[3] if len(c) > 3 else 20)
+        idx = index_for(c[3] if len(c) > 3 else 31, c[4] if len(c) > 4 else 1, c[5] if len(c) > 5 else 1)
         if rnd == 0:
             d_out.fill_(-7)        # never-written results must not inherit the previous config's values
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -50,6 +53,13 @@ for rnd in range(rounds + 1):
         if rnd == 0:
             chk = int((d_out * torch.arange(1, d_out.numel() + 1, device=dev)).sum().item())
             if ref is None: ref = chk
+            if len(c) > 2 and (c[2] & 64):
+                import ctypes
+                raw = (ctypes.c_uint64 * 32)()
+                capi.lib().sbwtgpu_workspace_raw(ctypes.c_void_p(d_ws.data_ptr()), ctypes.c_void_p(st), raw)
+                r = list(raw)
+                print("   LF steps by walk type [ref, sparse-miss, filter-maybe, dense@b, -, dense-left]:", r[7 + 8:7 + 14])
+                print("   walks planned by type [ref, -, -, dense@b, filter, dense-left]:", r[7 + 16:7 + 22], flush=True)
             print("config", c, "checksum", chk, "same" if chk == ref else "DIFFERENT", "stats", idx.workspace_stats(d_ws.data_ptr(), st), flush=True)
         else:
             times[tuple(c)].append(e0.elapsed_time(e1))
