@@ -45,6 +45,9 @@ B_STREAM = 89                   # streaming step: 1 base + 8 ssup word + (8 coun
 B_TABLE = 16                    # one prefix-table entry per walk (+ the bases of its window)
 B_LF = 2 * 72                   # interval update: two ranks, (8 count + 64 block bits) each
 B_OUT = 8                       # one int64 result
+# the path-order kernel's own operations: what they must read and write
+B_RUN = 8 + 4 + 0.5 + 1         # k-mer answered along a path run: int64 out + col[t] + its share of the path quad + 1 base
+B_TRANS = 32 + 1 + 8            # streaming step at a branch point: one transition entry + 1 base + out
 
 
 def effective_cores() -> int:
@@ -215,11 +218,21 @@ def main() -> int:
     # streaming steps, walks (prefix-table entry + its window of bases), interval updates, and the
     # result of every k-mer that did not come from a streaming step.  (The reference's own order of
     # searches would execute ~3.5x more interval updates for the same output; DESIGN.md.)
-    alg_bytes = (B_STREAM * n_stream + (B_TABLE + index.device_precalc_k) * n_search + B_LF * n_lf
-                 + B_OUT * (n_kmers - n_stream))
+    n_streamed = n_stream + n_ext                # k-mers answered by streaming semantics (SBWT.hh:562-575)
+    if n_ext:
+        # path-order kernel: run k-mers and transition steps priced at what THIS algorithm must move;
+        # pricing them at the reference's 89 B/step would credit bytes the kernel never touches
+        alg_bytes = (B_RUN * n_ext + B_TRANS * n_stream + (B_TABLE + index.device_precalc_k) * n_search + B_LF * n_lf
+                     + B_OUT * (n_kmers - n_streamed))
+    else:
+        alg_bytes = (B_STREAM * n_stream + (B_TABLE + index.device_precalc_k) * n_search + B_LF * n_lf
+                     + B_OUT * (n_kmers - n_stream))
+    # the same work priced entirely at SURVEY 8d's per-operation figures (the reference's data structure)
+    survey_priced_bytes = (B_STREAM * n_streamed + (B_TABLE + index.device_precalc_k) * n_search + B_LF * n_lf
+                           + B_OUT * (n_kmers - n_streamed))
     # SURVEY 8d's nominal formula (every full search priced at all k-p interval updates)
-    n_full = n_kmers - n_stream
-    nominal_bytes = B_STREAM * n_stream + (K + 16 + 8 + B_LF * (K - PRECALC)) * n_full
+    n_full = n_kmers - n_streamed
+    nominal_bytes = B_STREAM * n_streamed + (K + 16 + 8 + B_LF * (K - PRECALC)) * n_full
 
     total_kmers = n_kmers * world
     value = total_kmers * args.steps / elapsed
@@ -251,7 +264,7 @@ def main() -> int:
         },
         "roofline": {
             "bound": "hbm",
-            "kernel": "k_search",
+            "kernel": "k_search_cert",
             "achieved": alg_bytes / (kernel_ms * 1e-3) / 1e9,
             "peak": HBM_PEAK_GBPS,
             "unit": "GB/s",
@@ -259,9 +272,11 @@ def main() -> int:
             "traffic": None,
             "kernel_ms": kernel_ms,
             "algorithmic_bytes_per_launch": alg_bytes,
+            "survey_8d_priced_bytes_per_launch": survey_priced_bytes,
+            "survey_8d_priced_GBps": survey_priced_bytes / (kernel_ms * 1e-3) / 1e9,
             "nominal_bytes_per_launch_survey_8d": nominal_bytes,
-            "work_per_launch": {"stream_steps": n_stream, "walks": n_search, "interval_updates": n_lf,
-                                "table_hits": n_tab, "kmers_not_streamed": n_full},
+            "work_per_launch": {"path_run_kmers": n_ext, "stream_steps": n_stream, "walks": n_search,
+                                "interval_updates": n_lf, "table_hits": n_tab, "kmers_not_streamed": n_full},
             "kernel_only_kmers_per_s": n_kmers / (kernel_ms * 1e-3),
         },
     }

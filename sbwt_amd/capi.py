@@ -13,7 +13,7 @@ from typing import Optional, Sequence
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libsbwtgpu.so")
+LIB_PATH = os.environ.get("SBWTGPU_LIB", os.path.join(_HERE, "lib", "libsbwtgpu.so"))   # override: A/B builds only
 
 OK = 0
 ERR_INVALID_ARG = -1
@@ -313,7 +313,7 @@ class Index:
         """(n_stream, n_search, n_lf, n_tab_hit, n_ext) of the last search on this workspace."""
         st = (C.c_int64 * 8)()
         _check(lib().sbwtgpu_workspace_stats(d_ws, stream, st))
-        return tuple(int(x) for x in (st if os.environ.get('SBWT_ALL_STATS') else st[:5]))
+        return tuple(int(x) for x in st[:5])
 
     def workspace_status(self, d_ws: int, stream: int = 0) -> int:
         st = C.c_int(0)

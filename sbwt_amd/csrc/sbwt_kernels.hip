@@ -38,6 +38,13 @@ __device__ __forceinline__ u64 uniform64(u64 v) {
 // streaming (read-once / write-once) 16-byte accesses that should not displace the index in L2
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void st_stream(i64 *p, i64 v) { __builtin_nontemporal_store(v, p); }
+// two consecutive results / columns at their natural (8-byte / 4-byte) alignment
+typedef i64 i64x2_a8 __attribute__((ext_vector_type(2), aligned(8)));
+typedef unsigned u32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));
+__device__ __forceinline__ void st_stream2(i64 *p, i64 a, i64 b) {
+    i64x2_a8 v = {a, b};
+    __builtin_nontemporal_store(v, reinterpret_cast<i64x2_a8 *>(p));
+}
 __device__ __forceinline__ uint4 ld_stream(const uint4 *p) {
     u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p));
     return make_uint4(v.x, v.y, v.z, v.w);
@@ -342,7 +349,7 @@ __global__ void __launch_bounds__(256) k_search(SbwtIndexView ix, const uint4 *_
 #define K_MODE 3
 #define STAGE_DEPTH 8
 #ifndef SBWT_COPY_PIPE
-#define SBWT_COPY_PIPE 1
+#define SBWT_COPY_PIPE 4
 #endif
 
 // WIDE = false: every column index fits 31 bits (n_nodes < 2^31 - 64): positions, results and the LDS
@@ -377,13 +384,13 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
     typedef typename SearchTypes<WIDE>::stage_t stage_t;
     constexpr int DEPTH = SearchTypes<WIDE>::DEPTH;
     __shared__ stage_t stage[DEPTH][256];
+    __shared__ uint4 desc[PATH ? 4 : 1][PATH ? 128 : 1];      // PATH: run descriptors, per wave
     const int tid = threadIdx.x, lane = tid & 63;
     const int k = ix.k, p = ix.p_dev, L0 = ix.probe_len;
     const int ps = WIDE ? 0 : ix.p_sparse;          // sparse table: 32-bit intervals only
     const bool pfon = ix.pfil && ix.p_filter == L0 && L0 > p;
     const pos_t last_node = (pos_t)(ix.n_nodes - 1);
 
-    int wtype = 0;                  // debug statistics: what kind of walk this is
     int wk = 0;                     // how this walk starts: 0 dense prefix table, 1 sparse table (walks from k-mer i
                                     // itself), 2 probe filter (certificate probes; a "maybe" falls back to 0),
                                     // 3 range probe (dense table only: is the bad base inside this window?)
@@ -582,8 +589,9 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
             const u64 bad = ~(rv & pg) | (1ull << 32);
             const int nv = __ffsll((i64)bad) - 1;
             int n = nm < nv ? nm : nv;
-            const bool stopped = n < 32;               // a mismatch, an invalid base or the end of the path
+            bool stopped = n < 32;                     // a mismatch, an invalid base or the end of the path
             if (n > m - i) n = m - i;
+            if (n > 32 - cnt) { n = 32 - cnt; stopped = false; }   // staged results + run travel in one descriptor
             seg_n = n;
             seg_src = (unsigned)r + 1u;
             r += (pos_t)n;
@@ -627,7 +635,6 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
                     if (((w1 >> (b1 & 31u)) & (w2 >> (b2 & 31u)) & 1u) != 0) {
                         again = true;                  // perhaps present: the dense table walks the window exactly
                         wk = 0;
-                        wtype = 2;
                     } else {
                         l = -1;                        // read[wstart .. wstart+L0-1] is not in the index
                     }
@@ -670,7 +677,6 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
                     }
                 }
             } else {   // M_STEP
-                if (ix.debug & 64) atomicAdd(&ws->pad[8 + wtype], 1ull);
                 l = quad_rank_t<WIDE>(ix, v1, l, c);
                 r = quad_rank_t<WIDE>(ix, v2, r + 1, c) - 1;
                 if (l > r) {
@@ -731,6 +737,81 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
         // end.  A certified burst is a run of -1.  Each run is written by a group of DEPTH lanes with one
         // coalesced store (64/DEPTH runs per store instruction) instead of a per-lane loop of 8-byte
         // stores that would execute in almost every iteration for a handful of lanes.
+        if (PATH) {
+            // One writer, whole lines.  The results of a read leave in order.  What a lane has not written yet --
+            // `cnt` results staged in LDS, always starting on a 64-byte line of `out` (or at the read's first
+            // result) -- is joined with this iteration's run (a certified burst of -1, or a path run out of col[]),
+            // and the part that ends on a line boundary is written; the tail goes (back) into the lane's stage.
+            // So every store covers whole 64-byte lines except at the two ends of a read.
+            // A lane with something to write posts a 16-byte descriptor in LDS at its rank among the posting
+            // lanes; group g of 16 lanes takes descriptors g, g+4, ... and handles two results per lane
+            // (stage + run <= 32 results), PIPE descriptors per trip with their loads in flight together.
+            int nleft = (burst_hi >= 0) ? (burst_hi - i + 1) : seg_n;
+            unsigned s2 = (burst_hi >= 0) ? 0xFFFFFFFFu : seg_src;
+            uint4 *mydesc = desc[tid >> 6];
+            const int sub = lane & 15, grpl = lane >> 4;
+            const u64 lt = low_mask(lane);
+            for (;;) {                                 // more than one round only for bursts longer than a descriptor
+                const i64 dst0 = obase + (i - cnt);
+                const int nn = nleft < 32 - cnt ? nleft : 32 - cnt;
+                const int total = cnt + nn;
+                const bool end = (i + nn == m);
+                const int over = (int)((unsigned)(dst0 + total) & 7u);   // results past the last line boundary
+                const bool post = nn > 0 || (cnt > 0 && (end || over == 0));
+                const int w = !post ? 0 : (end ? total : (over <= total ? total - over : 0));
+                const u64 pm = __ballot(post);
+                if (pm == 0) break;
+                const int ndesc = __popcll(pm);
+                if (post)
+                    mydesc[__popcll(pm & lt)] = make_uint4((unsigned)dst0, (unsigned)((u64)dst0 >> 32),
+                                                           (unsigned)cnt | ((unsigned)total << 8) | ((unsigned)w << 16) | ((unsigned)tid << 24), s2);
+                for (int base = 0; base < ndesc; base += 4 * SBWT_COPY_PIPE) {
+                    constexpr int PIPE = SBWT_COPY_PIPE;
+                    i64 dd[PIPE];
+                    int sa[PIPE], sb[PIPE], ca[PIPE], cb[PIPE], fa[PIPE], fb[PIPE], wl[PIPE], tl[PIPE], ht[PIPE];
+#pragma unroll
+                    for (int u = 0; u < PIPE; u++) {
+                        const int idx = base + 4 * u + grpl;
+                        const bool on = idx < ndesc && !(ix.debug & 1);
+                        const uint4 ds = mydesc[idx < ndesc ? idx : 0];
+                        const int dc = (int)(ds.z & 0xFFu), dt = (int)((ds.z >> 8) & 0xFFu);
+                        const int j0 = 2 * sub;
+                        ht[u] = (int)(ds.z >> 24);
+                        wl[u] = on ? (int)((ds.z >> 16) & 0xFFu) - j0 : 0;      // results of this lane's pair that go to `out`
+                        tl[u] = on ? dt - j0 : 0;                                 // ... that exist at all
+                        dd[u] = (i64)((u64)ds.x | ((u64)ds.y << 32)) + j0;
+                        if (ix.debug & 4) dd[u] &= 0xFFFE;            // timing experiment: all stores into one small region
+                        // both sources are read unconditionally (clamped addresses) and selected afterwards: loads
+                        // under divergent branches would be waited for one by one
+                        const bool isc = ds.w != 0xFFFFFFFFu && on;
+                        const int r0 = j0 < 15 ? j0 : 14;
+                        const unsigned c0 = (isc && j0 >= dc && tl[u] > 0) ? ds.w + (unsigned)(j0 - dc) : 0u;
+                        const unsigned c1 = (isc && j0 + 1 >= dc && tl[u] > 1) ? ds.w + (unsigned)(j0 + 1 - dc) : 0u;
+                        sa[u] = (int)stage[r0][ht[u]];
+                        sb[u] = (int)stage[r0 + 1][ht[u]];
+                        ca[u] = (int)ix.col[c0];
+                        cb[u] = (int)ix.col[c1];
+                        fa[u] = (j0 < dc) ? 0 : (isc ? 1 : 2);           // where the value comes from: stage, col, constant
+                        fb[u] = (j0 + 1 < dc) ? 0 : (isc ? 1 : 2);
+                    }
+#pragma unroll
+                    for (int u = 0; u < PIPE; u++) {
+                        const int va = fa[u] == 0 ? sa[u] : (fa[u] == 1 ? ca[u] : -1);
+                        const int vb = fb[u] == 0 ? sb[u] : (fb[u] == 1 ? cb[u] : -1);
+                        if (wl[u] >= 2) st_stream2(out + dd[u], (i64)va, (i64)vb);
+                        else if (wl[u] == 1) st_stream(out + dd[u], (i64)va);
+                        // the tail stays with the holder: stage slot = position past the written part
+                        if (tl[u] > 0 && wl[u] < 1) stage[-wl[u]][ht[u]] = (stage_t)va;
+                        if (tl[u] > 1 && wl[u] < 2) stage[1 - wl[u]][ht[u]] = (stage_t)vb;
+                    }
+                }
+                cnt = total - w;
+                i += nn;
+                nleft -= nn;
+                if (s2 != 0xFFFFFFFFu) s2 += (unsigned)nn;
+                if (__ballot(nleft > 0) == 0) break;
+            }
+        } else
         {
             const bool fl = (cnt > 0) && (burst_hi >= 0 || seg_n > 0 || i == m || (((unsigned)obase + (unsigned)i) & (DEPTH - 1)) == 0);
             i64 dst = obase + (i - cnt);               // run of staged results
@@ -781,55 +862,6 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
                 fm = __ballot(nrun > 0);
             }
             if (burst_hi >= 0) i = burst_hi + 1;
-            if (PATH) {
-                // path runs: k-mers i .. i+seg_n-1 are col[seg_src ..], DEPTH of them per group and pass
-                dst = obase + i;
-                nrun = seg_n;
-                unsigned srcp = seg_src;
-                if (ix.debug & 128) {                  // debug: every lane copies its own run
-                    for (int x = 0; x < seg_n; x++) out[obase + i + x] = (i64)ix.col[seg_src + (unsigned)x];
-                    nrun = 0;
-                }
-                fm = __ballot(nrun > 0);
-                while (fm) {
-                    // PIPE passes per trip: their loads of col[] are in flight together
-                    constexpr int PIPE = SBWT_COPY_PIPE;
-                    i64 dd[PIPE];
-                    unsigned pp[PIPE];
-                    bool act[PIPE];
-#pragma unroll
-                    for (int u = 0; u < PIPE; u++) {
-                        int src = -1;
-                        u64 served = 0;
-#pragma unroll
-                        for (int g = 0; g < NG; g++) {
-                            int f = fm ? (__ffsll((i64)fm) - 1) : -1;
-                            if (f >= 0) served |= 1ull << f;
-                            fm &= fm - 1;
-                            src = (grpl == g) ? f : src;
-                        }
-                        const int srcl = src < 0 ? 0 : src;
-                        dd[u] = __shfl(dst, srcl) + sub;
-                        pp[u] = __shfl(srcp, srcl) + (unsigned)sub;
-                        const int nn = __shfl(nrun, srcl);   // every lane takes part: the holder may sit in an idle group
-                        act[u] = src >= 0 && sub < nn && !(ix.debug & 1);
-                        if ((served >> lane) & 1ull) { dst += DEPTH; nrun -= DEPTH; srcp += DEPTH; }
-                        fm = __ballot(nrun > 0);
-                    }
-                    unsigned vals[PIPE];
-#pragma unroll
-                    for (int u = 0; u < PIPE; u++) vals[u] = act[u] ? ix.col[pp[u]] : 0u;
-#pragma unroll
-                    for (int u = 0; u < PIPE; u++)
-                        if (act[u]) {
-                            if (ix.debug & 64) atomicAdd(&ws->pad[0], 1ull);
-                            if (ix.debug & 2) out[dd[u]] = (i64)vals[u];
-                            else st_stream(out + dd[u], (i64)vals[u]);
-                        }
-                }
-                if ((ix.debug & 64) && seg_n > 0) { atomicAdd(&ws->pad[1], (u64)seg_n); atomicAdd(&ws->pad[2], 1ull); }
-                i += seg_n;
-            }
         }
         if (ev == EV_EMIT1 || burst_hi >= 0) {
             if (i == m) {
@@ -866,8 +898,6 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
             // walks from k-mer i itself: sparse table; certificate probes: the filter when the whole probe window
             // lies inside k-mer i's window (a clear bit certifies; otherwise the dense table finds the exact position)
             wk = nwk;
-            wtype = (s0 == i) ? 0 : (wk == 2 ? 4 : (wk == 3 ? 1 : (s0 == b ? 3 : 5)));
-            if (ix.debug & 64) atomicAdd(&ws->pad[16 + wtype], 1ull);
             if (p > 0) mode = M_INIT;
             else { mode = M_STEP; l = 0; r = last_node; }
         }

@@ -679,12 +679,6 @@ int sbwtgpu_rank_dev(const sbwtgpu_index *idx, const int64_t *d_pos, const char 
     return SBWTGPU_OK;
 }
 
-// debug: the raw 256-byte workspace header (32 x u64)
-int sbwtgpu_workspace_raw(const void *d_ws, void *stream, uint64_t raw[32]) {
-    HIP_TRY(hipMemcpyAsync(raw, d_ws, 256, hipMemcpyDeviceToHost, static_cast<hipStream_t>(stream)));
-    HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
-    return SBWTGPU_OK;
-}
 int sbwtgpu_workspace_status(const void *d_ws, void *stream, int *status) {
     if (!d_ws || !status) return fail(SBWTGPU_ERR_INVALID_ARG, "NULL argument");
     SbwtWorkHeader hdr;
@@ -704,7 +698,7 @@ int sbwtgpu_workspace_stats(const void *d_ws, void *stream, int64_t stats[8]) {
     stats[2] = (int64_t)hdr.n_lf;
     stats[3] = (int64_t)hdr.n_tab_hit;
     stats[4] = (int64_t)hdr.n_ext;
-    stats[5] = (int64_t)hdr.pad[0]; stats[6] = (int64_t)hdr.pad[1]; stats[7] = (int64_t)hdr.pad[2];
+    stats[5] = stats[6] = stats[7] = 0;
     return SBWTGPU_OK;
 }
 

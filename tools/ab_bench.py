@@ -53,13 +53,6 @@ for rnd in range(rounds + 1):
         if rnd == 0:
             chk = int((d_out * torch.arange(1, d_out.numel() + 1, device=dev)).sum().item())
             if ref is None: ref = chk
-            if len(c) > 2 and (c[2] & 64):
-                import ctypes
-                raw = (ctypes.c_uint64 * 32)()
-                capi.lib().sbwtgpu_workspace_raw(ctypes.c_void_p(d_ws.data_ptr()), ctypes.c_void_p(st), raw)
-                r = list(raw)
-                print("   LF steps by walk type [ref, sparse-miss, filter-maybe, dense@b, -, dense-left]:", r[7 + 8:7 + 14])
-                print("   walks planned by type [ref, -, -, dense@b, filter, dense-left]:", r[7 + 16:7 + 22], flush=True)
             print("config", c, "checksum", chk, "same" if chk == ref else "DIFFERENT", "stats", idx.workspace_stats(d_ws.data_ptr(), st), flush=True)
         else:
             times[tuple(c)].append(e0.elapsed_time(e1))

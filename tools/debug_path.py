@@ -28,7 +28,7 @@ idx.encode_bases_dev(d_bases.data_ptr(), len(bases), d_ws.data_ptr(), wsb, st)
 res = {}
 for v in (0, 1, 2):
     capi.set_tuning("search_variant", v)
-    capi.set_tuning("debug", int(os.environ.get("DEBUG", 64)))
+    capi.set_tuning("debug", int(os.environ.get("DEBUG", 0)))
     d_out = torch.full((int(ooff[-1]),), -7, dtype=torch.int64, device=dev)
     idx.search_encoded_dev(len(bases), d_roff.data_ptr(), nr, d_out.data_ptr(), d_ooff.data_ptr(), d_ws.data_ptr(), wsb, bool(ssup), st)
     torch.cuda.synchronize()
