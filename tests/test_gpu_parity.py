@@ -458,3 +458,34 @@ def test_long_reads_are_split_exactly(gpu, genome_case):
     assert np.array_equal(got2, oracle_batch(orc, bases, off, False))
     text, nq = idx.search_text(bases, off, True)
     assert text == b"".join(print_vector(want[oo[r]:oo[r + 1]]) for r in range(len(reads))) and nq == len(want)
+
+
+@pytest.mark.parametrize("k", [3, 4, 8, 16, 31])
+def test_periodic_sequences_cycles_in_the_path_order(gpu, k):
+    # Tandem repeats make cycles in the graph of streaming steps: the path order must cut every one of them
+    # (k_path_cut) and still answer exactly.  Homopolymers (a column that follows itself), short periods,
+    # a period longer than k, and the same with random flanks and branching variants.
+    rng = random.Random(1000 + k)
+    unit = "".join(rng.choice("ACGT") for _ in range(k + 5))
+    flank = lambda n: "".join(rng.choice("ACGT") for _ in range(n))
+    seqs = ["A" * 120, "AC" * 80, "ACG" * 60, "ACGT" * 50, "AACCGGTT" * 30, unit * 14,
+            flank(60) + "GATTACA" * 25 + flank(60), flank(40) + unit * 6 + flank(40),
+            flank(30) + ("ACGT" * 20) + "T" + ("ACGT" * 20) + flank(30)]
+    orc = OracleIndex.build([b(s) for s in seqs], k, True, False, min(k, 2))
+    idx = gpu_index_from_oracle(orc)
+    genomes = [np.frombuffer(b(s), dtype=np.uint8) for s in seqs]
+    bases, off = synth.sample_reads(genomes, 600, 100, 0.03, 5 + k)
+    bases = synth.inject(bases, 30, ord("N"), 2)
+    whole = np.concatenate(genomes)
+    woff = np.concatenate([[0], np.cumsum([len(g) for g in genomes])]).astype(np.int64)
+    bases = np.concatenate([bases, whole])
+    off = np.concatenate([off, woff[1:] + off[-1]])
+    for variant in (2, 1):
+        capi.set_tuning("search_variant", variant)
+        try:
+            got, _ = idx.streaming_search(bases, off)
+            got2, _ = idx.search(bases, off)
+        finally:
+            capi.set_tuning("search_variant", -1)
+        assert np.array_equal(got, oracle_batch(orc, bases, off, True))
+        assert np.array_equal(got2, oracle_batch(orc, bases, off, False))
