@@ -75,10 +75,18 @@ const char *sbwtgpu_version(void);
 const char *sbwtgpu_last_error(void);
 int         sbwtgpu_device_count(int *count);
 /* Process-wide tuning knobs for experiments (results never depend on them):
- *   "search_variant"  0 = k_search (the reference's order of searches), 1 = k_search_cert (default)
+ *   "search_variant"  0 = k_search (the reference's order of searches), 1 = k_search_cert on the blocks,
+ *                     2 = k_search_cert along the path order when the index has one (default)
  *   "probe_len"       length of the certificate probes (-1 = automatic, 0 = off)
  *   "derive_ssup"     1 (default): indexes created without suffix_group_starts get the marks derived on
- *                     the device so that the per-k-mer search loop can use streaming steps internally */
+ *                     the device so that the per-k-mer search loop can use streaming steps internally
+ *   "debug"           kernel experiment bits (0 = product behaviour)
+ *   "poison_results"  1: every search first fills its result range with 0xA5 (parity tests)
+ * Read when an index is CREATED (derived acceleration structures inside the device image; environment
+ * variables of the same meaning: SBWTGPU_SPARSE_PRECALC, SBWTGPU_PROBE_FILTER, SBWTGPU_PATH_ORDER):
+ *   "sparse_depth"    depth of the sparse (hashed) prefix table, 0 = none, default 31 (capped at k)
+ *   "probe_filter"    1 (default): Bloom filter over the probe_len-mers of the index for the certificate probes
+ *   "path_order"      1 (default): path order + transition table (32-bit indexes with suffix-group marks) */
 int         sbwtgpu_set_tuning(const char *key, int64_t value);
 
 /* ---- index life cycle ---- */

@@ -389,6 +389,7 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
     const int k = ix.k, p = ix.p_dev, L0 = ix.probe_len;
     const int ps = WIDE ? 0 : ix.p_sparse;          // sparse table: 32-bit intervals only
     const bool pfon = ix.pfil && ix.p_filter == L0 && L0 > p;
+    const int pw = pfon ? L0 : p;                   // window of a range probe: the filter's when there is one
     const pos_t last_node = (pos_t)(ix.n_nodes - 1);
 
     int wk = 0;                     // how this walk starts: 0 dense prefix table, 1 sparse table (walks from k-mer i
@@ -454,7 +455,7 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
             // M_INIT reads the window at wstart (j counts extra hash buckets there); M_STEP the base at wstart + j
             const int P = poff + ((strm || ext || trn) ? (i + k - 1) : ((mode == M_INIT) ? wstart : (wstart + j)));
             const int s = P & 31;
-            const int wl = (wk == 1) ? ps : (wk == 2) ? L0 : p;   // bases the table window of this walk covers
+            const int wl = (wk == 1) ? ps : (wk == 2) ? L0 : (wk == 3) ? pw : p;   // bases the table window of this walk covers
             grp = pgrp + (P >> 5);
             if (grp == tag + 1 && g1ok && (mode != M_INIT || s + wl <= 32)) {
                 g0 = g1;                               // crossed into the group that is already here
@@ -503,7 +504,7 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
                             const u64 bkt = (((key * SBWT_SP_HASH) >> (64 - ix.log2b)) + (u64)j) & low_mask(ix.log2b);
                             a1 = ix.stab + 2 * bkt;
                             a2 = a1 + 1;
-                        } else if (wk == 2) {          // the window's block of the probe filter
+                        } else if (wk == 2 || (wk == 3 && pfon)) {   // the window's block of the probe filter
                             a1 = ix.pfil + (sbwt_pf_hash(w & low_mask(2 * L0)) >> (64 - ix.log2f));
                             a2 = a1;
                         } else {
@@ -621,20 +622,25 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
             } else if (mode == M_INIT) {
                 int wl = p;
                 bool again = false;
-                if (wk == 1 || wk == 2) {
+                const bool viaf = (wk == 2) || (wk == 3 && pfon);
+                if (wk == 1 || viaf) {
                     // the window's key, again (cheaper than keeping it across the load)
                     const int Pw = poff + wstart, sw = Pw & 31;
                     u64 w = quad_bits(g0) >> (2 * sw);
                     if (sw) w |= quad_bits(g1) << (64 - 2 * sw);
-                  if (wk == 2) {
+                  if (viaf) {
                     const u64 h = sbwt_pf_hash(w & low_mask(2 * L0));
                     const unsigned b1 = (unsigned)h & 127u, b2 = (unsigned)(h >> 7) & 127u;
                     const unsigned w1 = (b1 < 64) ? (b1 < 32 ? v1.x : v1.y) : (b1 < 96 ? v1.z : v1.w);
                     const unsigned w2 = (b2 < 64) ? (b2 < 32 ? v1.x : v1.y) : (b2 < 96 ? v1.z : v1.w);
                     wl = L0;
                     if (((w1 >> (b1 & 31u)) & (w2 >> (b2 & 31u)) & 1u) != 0) {
-                        again = true;                  // perhaps present: the dense table walks the window exactly
-                        wk = 0;
+                        if (wk == 3) {
+                            l = 0;                     // range probe: "perhaps present" only moves the guess
+                        } else {
+                            again = true;              // perhaps present: the dense table walks the window exactly
+                            wk = 0;
+                        }
                     } else {
                         l = -1;                        // read[wstart .. wstart+L0-1] is not in the index
                     }
@@ -722,7 +728,7 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
         if (ev == EV_PRES) {                           // no bad base in [wstart, wstart+p-1]: shrink the range
             const int lo = blo > i ? blo : i;
             if (wstart > lo) b = wstart - 1;
-            else blo = wstart + p;
+            else blo = wstart + pw;
             if (blo > b) b = -1;
             do_plan = true;
         }
@@ -879,11 +885,11 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
             int s0 = i, nwk = (ps > 0) ? 1 : 0;
             if (!force && L0 > 0 && b >= i && b <= i + k - 1) {
                 const int lo = blo > i ? blo : i;
-                if (lo < b && p > 0 && k - p >= 1) {
+                if (lo < b && p > 0 && k - pw >= 1) {
                     // the bad base is somewhere in [lo, b]: halve the range with a window that starts inside it
                     // (absent: k-mers i..x are certified; present: the bad base is left of x)
                     int x = lo + ((b - lo + 1) >> 1);
-                    if (x > i + k - p) x = i + k - p;
+                    if (x > i + k - pw) x = i + k - pw;
                     if (x <= i) x = i + 1;
                     s0 = x;
                     nwk = 3;

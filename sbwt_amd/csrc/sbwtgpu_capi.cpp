@@ -43,7 +43,11 @@ int fail(int code, const char *fmt, ...) {
 // SBWTGPU_DEVICE_PRECALC asks otherwise.  Measured on MI355X: 12.8 M columns (tools/ab_bench.py)
 // 8: 33, 10: 45, 11: 47, 12: 49 G k-mers/s; 142 M columns (bench.py --config 3) 11: 30.2, 12: 32.2,
 // 13: 34.1, 14: 36.1 G k-mers/s.
-int default_device_precalc(int64_t n_nodes) {
+// Depth of the dense device prefix table.  Without the derived structures it is the only accelerator of the
+// walks: two levels past log4(n), where most entries are empty and end a probe at once.  With the sparse table
+// and the probe filter it only backs exact fall-back walks, and log4(n) does (measured: 12 and 14 give the
+// same 7.08 ms on config 2, and 4 GB less image).
+int default_device_precalc(int64_t n_nodes, bool derived) {
     const char *e = getenv("SBWTGPU_DEVICE_PRECALC");
     int v;
     if (e) {
@@ -51,7 +55,7 @@ int default_device_precalc(int64_t n_nodes) {
     } else {
         v = 1;
         while (v < 14 && ((int64_t)1 << (2 * v)) < n_nodes) v++;
-        v = v + 2 > 14 ? 14 : v + 2;     // two levels past log4(n): most entries are empty and end a probe at once
+        if (!derived) v = v + 2 > 14 ? 14 : v + 2;
     }
     if (v < 0) v = 0;
     if (v > 14) v = 14;
@@ -192,7 +196,9 @@ int sbwtgpu_index_create(const sbwtgpu_index_desc *d, int device, sbwtgpu_index 
     const int64_t n_blocks = n / 64 + 1;
     const int64_t n_mega = (n >> SBWT_MEGA_SHIFT) + 1;
     int64_t p_file = d->precalc_k;
-    int64_t p_dev = default_device_precalc(n);
+    const bool derived = g_sparse_depth > 0 && g_probe_filter && n < ((int64_t)1 << 31) - 64 && n_mega == 1 &&
+                         d->k > 16;
+    int64_t p_dev = default_device_precalc(n, derived);
     if (p_dev < p_file) p_dev = p_file;
     if (p_dev > d->k) p_dev = d->k;
 
