@@ -10,6 +10,8 @@
 //   [ pq       : (n/32+2) x 16 B ]   packed chars + go bits along the paths
 //   [ trans    : n_nodes x 32 B  ]   the four successors of every path position (columns, path positions)
 //   [ pfil     : 2^log2f x 16 B  ]   probe filter (see k_pf_insert)
+//   [ stab2    : 2^log2b2 x 32 B ]   second level for 31 < k <= 63: { rest key (8 B), first column of the 31-prefix's
+//                                    interval, flags } { column, path position, -, - }
 //   [ stab     : 2^log2b x 32 B  ]   sparse prefix table at depth p_sparse (only non-empty prefixes), hashed:
 //                                    bucket = two 16-byte entries { key | flags (u64), first (u32), second-first (u32) }
 //
@@ -49,6 +51,8 @@ struct SbwtIndexView {
     int log2b;                      // log2 of its number of buckets
     const unsigned *col, *pos;      // path order: column at path position t, path position of column v (nullptr = none)
     const uint4 *pq;                // packed path chars: quad t>>5 = { 32 chars (2 bits each), go mask, - }
+    const uint4 *stab2;             // second-level sparse table for 31 < k <= 63 (nullptr = none): key = (first column of the
+    int log2b2;                     // 31-prefix's interval, the remaining k-31 bases) -> the k-mer's column and path position
     const uint4 *pfil;              // probe filter: blocked Bloom filter over the p_filter-mers of the index (nullptr = none)
     int p_filter, log2f;            // its depth and log2 of its number of 16-byte blocks
     const uint4 *trans;             // transition table: 2 quads per path position (successor columns, successor positions)
@@ -75,7 +79,8 @@ struct SbwtBlobHeader {
     int32_t p_filter;               // depth of the probe filter (0 = none)
     int64_t off_pfil;
     int32_t log2f;
-    int32_t reserved;
+    int32_t log2b2;                 // second-level sparse table: log2 of its number of 32-byte entries (0 = none)
+    int64_t off_stab2;
 };
 #define SBWT_BLOB_MAGIC 0x3155504754574253ull   // "SBWTGPU1" little endian
 
@@ -84,6 +89,14 @@ struct SbwtBlobHeader {
 #define SBWT_SP_OVERFLOW (1ull << 62)           // set in entry 0 of a bucket some key had to skip
 #define SBWT_SP_MAX_DEPTH 31                    // keys are 2 bits per base in the low 62 bits
 #define SBWT_SP_HASH 0x9E3779B97F4A7C15ull
+// second-level sparse table hash: (first column of the prefix's interval, remaining bases)
+static __host__ __device__ inline unsigned long long sp2_hash(unsigned origin, unsigned long long key2) {
+    unsigned long long h = (key2 ^ ((unsigned long long)origin << 17)) * SBWT_SP_HASH;
+    h ^= h >> 31;
+    return (h + origin) * 0xD6E8FEB86659FD93ull;
+}
+#define SBWT_SP2_USED 1u                        // flags word of a second-level entry
+#define SBWT_SP2_OVERFLOW 2u
 // probe filter hash: block index in the top bits, two bit positions (7 bits each) in the low bits
 static __host__ __device__ inline unsigned long long sbwt_pf_hash(unsigned long long key) {
     unsigned long long h = key * SBWT_SP_HASH;
@@ -133,4 +146,4 @@ int sbwt_launch_build_path(const SbwtIndexView &ix, unsigned *d_col, unsigned *d
                            void *d_scratch, hipStream_t stream);
 int sbwt_launch_build_sparse(const SbwtIndexView &ix, int p_dense, int p_sparse, int log2b, uint4 *d_table,
                              void *d_scratch, const unsigned *d_pos, int p_filter, int log2f, uint4 *d_filter,
-                             hipStream_t stream);
+                             int log2b2, uint4 *d_table2, hipStream_t stream);

@@ -389,12 +389,14 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
     const int k = ix.k, p = ix.p_dev, L0 = ix.probe_len;
     const int ps = WIDE ? 0 : ix.p_sparse;          // sparse table: 32-bit intervals only
     const bool pfon = ix.pfil && ix.p_filter == L0 && L0 > p;
+    const u64 m2 = (k - ps >= 32) ? ~0ull : low_mask(2 * ((k - ps) & 31));   // key mask of the second-level window
     const int pw = pfon ? L0 : p;                   // window of a range probe: the filter's when there is one
     const pos_t last_node = (pos_t)(ix.n_nodes - 1);
 
     int wk = 0;                     // how this walk starts: 0 dense prefix table, 1 sparse table (walks from k-mer i
                                     // itself), 2 probe filter (certificate probes; a "maybe" falls back to 0),
-                                    // 3 range probe (dense table only: is the bad base inside this window?)
+                                    // 3 range probe (is the bad base inside this window?),
+                                    // 5 second-level sparse lookup (31 < k <= 63: l = the 31-prefix's first column)
     int blo = -1;                   // the last failure is known to lie in [blo, b] (blo >= b: exactly at b)
     int mode = M_IDLE;              // M_DEAD once the ticket counter has run past the last read
     i64 obase = 0;                  // first result slot of the current read
@@ -453,9 +455,11 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
             a2 = a1;
         } else if (mode != M_IDLE && mode != M_DEAD) {
             // M_INIT reads the window at wstart (j counts extra hash buckets there); M_STEP the base at wstart + j
-            const int P = poff + ((strm || ext || trn) ? (i + k - 1) : ((mode == M_INIT) ? wstart : (wstart + j)));
+            const int woff = (mode == M_INIT && wk == 5) ? ps : 0;   // the second-level window starts after the prefix
+            const int P = poff + ((strm || ext || trn) ? (i + k - 1) : ((mode == M_INIT) ? (wstart + woff) : (wstart + j)));
             const int s = P & 31;
-            const int wl = (wk == 1) ? ps : (wk == 2) ? L0 : (wk == 3) ? pw : p;   // bases the table window of this walk covers
+            // bases the table window of this walk covers
+            const int wl = (wk == 1) ? ps : (wk == 2) ? L0 : (wk == 3) ? pw : (wk == 5) ? k - ps : p;
             grp = pgrp + (P >> 5);
             if (grp == tag + 1 && g1ok && (mode != M_INIT || s + wl <= 32)) {
                 g0 = g1;                               // crossed into the group that is already here
@@ -504,6 +508,10 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
                             const u64 bkt = (((key * SBWT_SP_HASH) >> (64 - ix.log2b)) + (u64)j) & low_mask(ix.log2b);
                             a1 = ix.stab + 2 * bkt;
                             a2 = a1 + 1;
+                        } else if (wk == 5) {          // second level: (prefix interval, rest of the k-mer) -> one entry
+                            const u64 bkt = ((sp2_hash((unsigned)l, w & m2) >> (64 - ix.log2b2)) + (u64)j) & low_mask(ix.log2b2);
+                            a1 = ix.stab2 + 2 * bkt;
+                            a2 = a1 + 1;
                         } else if (wk == 2 || (wk == 3 && pfon)) {   // the window's block of the probe filter
                             a1 = ix.pfil + (sbwt_pf_hash(w & low_mask(2 * L0)) >> (64 - ix.log2f));
                             a2 = a1;
@@ -513,7 +521,7 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
                         }
                     } else {
                         ev = EV_FAIL;                  // a non-ACGT char inside the table window
-                        tfail = wstart + (__ffsll((i64)(~vr & vm)) - 1);
+                        tfail = wstart + woff + (__ffsll((i64)(~vr & vm)) - 1);
                     }
                 } else {   // M_STEP
                     if ((g0.w >> s) & 1u) {
@@ -623,9 +631,9 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
                 int wl = p;
                 bool again = false;
                 const bool viaf = (wk == 2) || (wk == 3 && pfon);
-                if (wk == 1 || viaf) {
+                if (wk == 1 || wk == 5 || viaf) {
                     // the window's key, again (cheaper than keeping it across the load)
-                    const int Pw = poff + wstart, sw = Pw & 31;
+                    const int Pw = poff + wstart + (wk == 5 ? ps : 0), sw = Pw & 31;
                     u64 w = quad_bits(g0) >> (2 * sw);
                     if (sw) w |= quad_bits(g1) << (64 - 2 * sw);
                   if (viaf) {
@@ -643,6 +651,18 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
                         }
                     } else {
                         l = -1;                        // read[wstart .. wstart+L0-1] is not in the index
+                    }
+                  } else if (wk == 5) {
+                    wl = k;                            // a hit completes the k-mer; a miss says read[wstart .. wstart+k-1] is absent
+                    if ((v1.w & SBWT_SP2_USED) && quad_bits(v1) == (w & m2) && v1.z == (unsigned)l) {
+                        l = (pos_t)v2.x;
+                        r = l;
+                        if (PATH) tpos = (pos_t)v2.y;
+                    } else if (v1.w & SBWT_SP2_OVERFLOW) {
+                        again = true;
+                        j++;
+                    } else {
+                        l = -1;
                     }
                   } else {
                     const u64 key = w & low_mask(2 * ps);
@@ -676,6 +696,9 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
                         imprecise = (wk != 2);         // ... but where inside the window it fails is not known
                     } else if (wk == 3) {
                         ev = EV_PRES;
+                    } else if (wk == 1 && ps < k && ix.stab2) {
+                        wk = 5;                        // the prefix is there (l = its first column): the rest in one more gather
+                        j = 0;
                     } else {
                         j = wl;
                         if (wstart + j == i + k) ev = EV_END;
@@ -1083,6 +1106,51 @@ __global__ void __launch_bounds__(256) k_sp_collect(const longlong2 *__restrict_
     u64 slot = atomicAdd(counter, 1ull);
     out[slot] = SpItem{t, e.x, e.y};
 }
+// ---- second level (31 < k <= 63): the 31-prefix's interval (named by its first column) + the remaining bases ----
+struct SpItem2 { u64 key2; unsigned origin, l, r, pad; };
+static_assert(sizeof(SpItem2) == sizeof(SpItem), "the two item lists share their buffers");
+__global__ void __launch_bounds__(256) k_sp2_seed(SpItem *items, const u64 *n) {     // in place: depth-31 items
+    u64 t = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (t >= *n) return;
+    const SpItem it = items[t];
+    reinterpret_cast<SpItem2 *>(items)[t] = SpItem2{0ull, (unsigned)it.l, (unsigned)it.l, (unsigned)it.r, 0u};
+}
+__global__ void __launch_bounds__(256) k_sp2_expand(SbwtIndexView ix, const SpItem2 *__restrict__ in, const u64 *n_in,
+                                                    int d2, SpItem2 *__restrict__ out, u64 *n_out) {
+    u64 t = (u64)blockIdx.x * 256 + threadIdx.x;
+    if ((t >> 2) >= *n_in) return;
+    const SpItem2 it = in[t >> 2];
+    const int c = (int)(t & 3);
+    uint4 q1 = ix.blocks[(((i64)it.l >> 6) << 2) + c];
+    uint4 q2 = ix.blocks[((((i64)it.r + 1) >> 6) << 2) + c];
+    i64 l = (i64)quad_rank<false>(ix, q1, (i64)it.l, c);
+    i64 r = (i64)quad_rank<false>(ix, q2, (i64)it.r + 1, c) - 1;
+    if (l > r) return;
+    u64 slot = atomicAdd(n_out, 1ull);
+    out[slot] = SpItem2{it.key2 | ((u64)c << (2 * d2)), it.origin, (unsigned)l, (unsigned)r, 0u};
+}
+__global__ void __launch_bounds__(256) k_sp2_insert(const SpItem2 *__restrict__ items, const u64 *n, uint4 *table,
+                                                    int log2b2, const unsigned *__restrict__ pos, int *wide_flag) {
+    u64 t = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (t >= *n) return;
+    const SpItem2 it = items[t];
+    if (it.l != it.r) *wide_flag = 1;                  // a k-mer's interval is one column in an SBWT
+    const u64 mask = (1ull << log2b2) - 1ull;
+    u64 bkt = sp2_hash(it.origin, it.key2) >> (64 - log2b2);
+    for (;;) {
+        unsigned *e = reinterpret_cast<unsigned *>(&table[2 * bkt]);
+        if (atomicCAS(&e[3], 0u, SBWT_SP2_USED) == 0u) {     // keys are distinct: an empty entry is simply taken
+            e[0] = (unsigned)it.key2;
+            e[1] = (unsigned)(it.key2 >> 32);
+            e[2] = it.origin;
+            e[4] = it.l;
+            e[5] = pos ? pos[it.l] : 0u;
+            return;
+        }
+        atomicOr(&e[3], SBWT_SP2_OVERFLOW);
+        bkt = (bkt + 1) & mask;
+    }
+}
 __global__ void __launch_bounds__(256) k_sp_wide(const SpItem *__restrict__ items, const u64 *n, int *flag) {
     u64 t = (u64)blockIdx.x * 256 + threadIdx.x;
     if (t < *n && items[t].l != items[t].r) *flag = 1;
@@ -1435,7 +1503,7 @@ void sbwt_launch_search(const SbwtIndexView &ix, const uint4 *d_packed, const lo
         // 32-bit positions need every column index (and n_nodes + 64) below 2^31 and < 2^31 packed groups
         const bool wide = ix.n_nodes >= ((1ll << 31) - 128) || total_groups >= (1ll << 31) - 4 || (ix.debug & 16);
         // no-spill build: 72 VGPRs (7 waves/SIMD max); 4 workgroups per CU measured best (tools/ab_bench.py)
-        unsigned cap = (ix.debug >> 8) ? (unsigned)(ix.debug >> 8) : 1024u;
+        unsigned cap = (ix.debug >> 8) ? (unsigned)(ix.debug >> 8) : (variant >= 2 ? 1280u : 1024u);
         unsigned g = grid1 < cap ? grid1 : cap;
         if (wide)
             hipLaunchKernelGGL((k_search_cert<true, 4, false>), dim3(g), dim3(256), 0, stream, ix, d_packed, d_read_off,
@@ -1545,7 +1613,7 @@ long long sbwt_sparse_scratch_bytes(long long n_nodes) { return 2 * (n_nodes + 6
 // 0 if not (no d_pos, p_sparse < k, or some k-mer's interval is wider than one column), < 0 on error.
 int sbwt_launch_build_sparse(const SbwtIndexView &ix, int p_dense, int p_sparse, int log2b, uint4 *d_table,
                              void *d_scratch, const unsigned *d_pos, int p_filter, int log2f, uint4 *d_filter,
-                             hipStream_t stream) {
+                             int log2b2, uint4 *d_table2, hipStream_t stream) {
     u64 *counters = reinterpret_cast<u64 *>(d_scratch);                    // [0], [1]: list lengths
     SpItem *listA = reinterpret_cast<SpItem *>(reinterpret_cast<char *>(d_scratch) + 256);
     SpItem *listB = listA + (ix.n_nodes + 64);
@@ -1584,6 +1652,26 @@ int sbwt_launch_build_sparse(const SbwtIndexView &ix, int p_dense, int p_sparse,
     }
     hipLaunchKernelGGL(k_sp_insert, dim3(grid_for(ix.n_nodes + 64)), dim3(256), 0, stream, in, counters + ci, d_table,
                        log2b, with_pos ? d_pos : (const unsigned *)nullptr);
+    if (d_table2 && ix.k > p_sparse) {
+        // second level: carry every depth-p_sparse prefix on to depth k, remembering where it started
+        (void)hipMemsetAsync(d_table2, 0, (size_t)32 << log2b2, stream);
+        hipLaunchKernelGGL(k_sp2_seed, dim3(grid_for(ix.n_nodes + 64)), dim3(256), 0, stream, in, counters + ci);
+        SpItem2 *in2 = reinterpret_cast<SpItem2 *>(in), *out2 = reinterpret_cast<SpItem2 *>(outl);
+        for (int d = p_sparse; d < ix.k; d++) {
+            (void)hipMemsetAsync(counters + (ci ^ 1), 0, 8, stream);
+            hipLaunchKernelGGL(k_sp2_expand, dim3(grid_for((ix.n_nodes + 64) * 4)), dim3(256), 0, stream, ix, in2,
+                               counters + ci, d - p_sparse, out2, counters + (ci ^ 1));
+            SpItem2 *t = in2; in2 = out2; out2 = t;
+            ci ^= 1;
+        }
+        int *flag = reinterpret_cast<int *>(counters + 9);
+        hipLaunchKernelGGL(k_sp2_insert, dim3(grid_for(ix.n_nodes + 64)), dim3(256), 0, stream, in2, counters + ci, d_table2,
+                           log2b2, d_pos, flag);
+        int h_flag = 1;
+        if (hipMemcpyAsync(&h_flag, flag, 4, hipMemcpyDeviceToHost, stream) != hipSuccess) return -1;
+        if (hipStreamSynchronize(stream) != hipSuccess) return -1;
+        if (h_flag) return -3;                          // not an SBWT: the caller drops the second level
+    }
     return with_pos;
 }
 

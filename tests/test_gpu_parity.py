@@ -489,3 +489,41 @@ def test_periodic_sequences_cycles_in_the_path_order(gpu, k):
             capi.set_tuning("search_variant", -1)
         assert np.array_equal(got, oracle_batch(orc, bases, off, True))
         assert np.array_equal(got2, oracle_batch(orc, bases, off, False))
+
+
+def test_exported_image_adopted_as_a_replica_gives_the_same_bits(gpu, genome_case):
+    # what multi-GPU replication does, on one device: header + image copied into a
+    # caller-owned buffer and adopted; the derived structures (sparse table, filter, path order) travel inside
+    import torch
+    genomes, orc = genome_case
+    idx = gpu_index_from_oracle(orc)
+    hdr = idx.export_header()
+    buf = torch.empty(idx.blob_bytes, dtype=torch.uint8, device="cuda:0")
+    idx.copy_blob(buf.data_ptr(), idx.blob_bytes, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    rep = capi.Index.adopt(hdr, buf.data_ptr(), idx.blob_bytes, 0, keepalive=buf)
+    del idx
+    bases, off = synth.sample_reads(genomes, 2000, 150, 0.02, 314)
+    bases = synth.inject(bases, 40, ord("N"), 4)
+    got, _ = rep.streaming_search(bases, off)
+    assert np.array_equal(got, oracle_batch(orc, bases, off, True))
+
+
+@pytest.mark.parametrize("k", [32, 33, 47, 62, 63])
+def test_second_level_sparse_table_for_k_up_to_63(gpu, k):
+    # 31 < k <= 63: the walk for a whole k-mer is the 31-base sparse lookup + one second-level lookup keyed by
+    # (the prefix's interval, the remaining k-31 bases); hits, misses in either level, N inside either window
+    genomes = [synth.random_genome(60_000, 21)]
+    genomes.append(synth.mutate(genomes[0], 0.03, 22))
+    orc = OracleIndex.build([g.tobytes() for g in genomes], k, True, False, 4)
+    idx = gpu_index_from_oracle(orc)
+    bases, off = synth.sample_reads(genomes, 1500, 150, 0.015, 23 + k)
+    bases = synth.inject(bases, 60, ord("N"), 3)
+    bases = synth.inject(bases, 30, ord("a"), 4)
+    rb, ro = synth.random_reads(100, 150, 9)
+    bases = np.concatenate([bases, rb])
+    off = np.concatenate([off, ro[1:] + off[-1]])
+    got, _ = idx.streaming_search(bases, off)
+    assert np.array_equal(got, oracle_batch(orc, bases, off, True))
+    got, _ = idx.search(bases, off)
+    assert np.array_equal(got, oracle_batch(orc, bases, off, False))
