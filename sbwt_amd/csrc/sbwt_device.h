@@ -97,14 +97,10 @@ static __host__ __device__ inline unsigned long long sp2_hash(unsigned origin, u
 }
 #define SBWT_SP2_USED 1u                        // flags word of a second-level entry
 #define SBWT_SP2_OVERFLOW 2u
-// probe filter hash: block index in the top bits, two bit positions (7 bits each) in the low bits
-static __host__ __device__ inline unsigned long long sbwt_pf_hash(unsigned long long key) {
-    unsigned long long h = key * SBWT_SP_HASH;
-    h ^= h >> 32;
-    h *= 0xD6E8FEB86659FD93ull;
-    h ^= h >> 29;
-    return h;
-}
+// probe filter hash (one multiply): block index in the top bits, two bit positions (7 bits each) from the
+// well-mixed middle of the product (returned in the low 14 bits of sbwt_pf_bits)
+static __host__ __device__ inline unsigned long long sbwt_pf_hash(unsigned long long key) { return key * SBWT_SP_HASH; }
+static __host__ __device__ inline unsigned sbwt_pf_bits(unsigned long long h) { return (unsigned)(h >> 24) ^ (unsigned)(h >> 41); }
 
 // Workspace header (first 256 bytes of the search workspace).
 struct SbwtWorkHeader {

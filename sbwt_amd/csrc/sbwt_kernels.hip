@@ -397,6 +397,7 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
                                     // itself), 2 probe filter (certificate probes; a "maybe" falls back to 0),
                                     // 3 range probe (is the bad base inside this window?),
                                     // 5 second-level sparse lookup (31 < k <= 63: l = the 31-prefix's first column)
+    u64 hk = 0;                     // M_INIT: the window's key (filter: the bit positions), kept across the gather
     int blo = -1;                   // the last failure is known to lie in [blo, b] (blo >= b: exactly at b)
     int mode = M_IDLE;              // M_DEAD once the ticket counter has run past the last read
     i64 obase = 0;                  // first result slot of the current read
@@ -505,15 +506,19 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
                     if ((vr & vm) == vm) {
                         if (wk == 1) {                 // bucket (hash + j) of the sparse table: two entries
                             const u64 key = w & low_mask(2 * ps);
+                            hk = key;
                             const u64 bkt = (((key * SBWT_SP_HASH) >> (64 - ix.log2b)) + (u64)j) & low_mask(ix.log2b);
                             a1 = ix.stab + 2 * bkt;
                             a2 = a1 + 1;
                         } else if (wk == 5) {          // second level: (prefix interval, rest of the k-mer) -> one entry
-                            const u64 bkt = ((sp2_hash((unsigned)l, w & m2) >> (64 - ix.log2b2)) + (u64)j) & low_mask(ix.log2b2);
+                            hk = w & m2;
+                            const u64 bkt = ((sp2_hash((unsigned)l, hk) >> (64 - ix.log2b2)) + (u64)j) & low_mask(ix.log2b2);
                             a1 = ix.stab2 + 2 * bkt;
                             a2 = a1 + 1;
                         } else if (wk == 2 || (wk == 3 && pfon)) {   // the window's block of the probe filter
-                            a1 = ix.pfil + (sbwt_pf_hash(w & low_mask(2 * L0)) >> (64 - ix.log2f));
+                            const u64 h = sbwt_pf_hash(w & low_mask(2 * L0));
+                            hk = (u64)sbwt_pf_bits(h);
+                            a1 = ix.pfil + (h >> (64 - ix.log2f));
                             a2 = a1;
                         } else {
                             a1 = reinterpret_cast<const uint4 *>(ix.ptab + (w & low_mask(2 * p)));
@@ -632,13 +637,8 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
                 bool again = false;
                 const bool viaf = (wk == 2) || (wk == 3 && pfon);
                 if (wk == 1 || wk == 5 || viaf) {
-                    // the window's key, again (cheaper than keeping it across the load)
-                    const int Pw = poff + wstart + (wk == 5 ? ps : 0), sw = Pw & 31;
-                    u64 w = quad_bits(g0) >> (2 * sw);
-                    if (sw) w |= quad_bits(g1) << (64 - 2 * sw);
                   if (viaf) {
-                    const u64 h = sbwt_pf_hash(w & low_mask(2 * L0));
-                    const unsigned b1 = (unsigned)h & 127u, b2 = (unsigned)(h >> 7) & 127u;
+                    const unsigned b1 = (unsigned)hk & 127u, b2 = ((unsigned)hk >> 7) & 127u;
                     const unsigned w1 = (b1 < 64) ? (b1 < 32 ? v1.x : v1.y) : (b1 < 96 ? v1.z : v1.w);
                     const unsigned w2 = (b2 < 64) ? (b2 < 32 ? v1.x : v1.y) : (b2 < 96 ? v1.z : v1.w);
                     wl = L0;
@@ -654,7 +654,7 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
                     }
                   } else if (wk == 5) {
                     wl = k;                            // a hit completes the k-mer; a miss says read[wstart .. wstart+k-1] is absent
-                    if ((v1.w & SBWT_SP2_USED) && quad_bits(v1) == (w & m2) && v1.z == (unsigned)l) {
+                    if ((v1.w & SBWT_SP2_USED) && quad_bits(v1) == hk && v1.z == (unsigned)l) {
                         l = (pos_t)v2.x;
                         r = l;
                         if (PATH) tpos = (pos_t)v2.y;
@@ -665,7 +665,7 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
                         l = -1;
                     }
                   } else {
-                    const u64 key = w & low_mask(2 * ps);
+                    const u64 key = hk;
                     const u64 w0 = quad_bits(v1), w1 = quad_bits(v2);
                     const bool m0 = (w0 & ~SBWT_SP_OVERFLOW) == key, m1 = w1 == key;
                     wl = ps;
@@ -1183,7 +1183,8 @@ __global__ void __launch_bounds__(256) k_pf_insert(const SpItem *__restrict__ it
     if (t >= *n) return;
     const u64 h = sbwt_pf_hash(items[t].key);
     unsigned *blk = filter + ((h >> (64 - log2f)) << 2);
-    const unsigned b1 = (unsigned)h & 127u, b2 = (unsigned)(h >> 7) & 127u;
+    const unsigned hb = sbwt_pf_bits(h);
+    const unsigned b1 = hb & 127u, b2 = (hb >> 7) & 127u;
     atomicOr(&blk[b1 >> 5], 1u << (b1 & 31u));
     atomicOr(&blk[b2 >> 5], 1u << (b2 & 31u));
 }
