@@ -540,6 +540,17 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
             }
         }
         const bool have = (kind == K_MODE && ev == EV_NONE);
+#ifdef SBWT_STATS
+        {   // lane-iterations by kind: pad[8..]: fetch, reload, init, step, trans, pos, ext, idle/dead, waves-iterations
+            const int cls = (kind == K_FETCH) ? 0 : (kind == K_RELOAD) ? 1 : (kind == K_NONE) ? 7 :
+                            (mode == M_INIT) ? 2 : (mode == M_STEP) ? 3 : (mode == M_TRANS) ? 4 : (mode == M_POS) ? 5 : (mode == M_EXT) ? 6 : 7;
+            for (int q = 0; q < 8; q++) {
+                const unsigned long long cq = __popcll(__ballot(cls == q));
+                if (lane == 0 && cq) atomicAdd(&ws->pad[8 + q], cq);
+            }
+            if (lane == 0) atomicAdd(&ws->pad[16], 1ull);
+        }
+#endif
         c_search = uniform32(c_search + (unsigned)__popcll(__ballot(kind == K_MODE && (mode == M_INIT || (p == 0 && mode == M_STEP && j == 0)))));
         c_lf = uniform32(c_lf + (unsigned)__popcll(__ballot(have && mode == M_STEP)));
 

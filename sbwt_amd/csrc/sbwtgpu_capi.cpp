@@ -651,7 +651,7 @@ int sbwtgpu_search_encoded_dev(const sbwtgpu_index *idx, int64_t total_bases, co
     }
     sbwt_launch_search(idx->view(), packed, reinterpret_cast<const long long *>(d_read_off),
                        reinterpret_cast<const long long *>(d_out_off), reinterpret_cast<long long *>(d_out), n_reads,
-                       ws, (!streaming && idx->h.ssup_derived && g_derive_ssup) ? 2 : streaming, st,
+                       ws, (!streaming && (idx->h.has_ssup || idx->h.ssup_derived) && g_derive_ssup) ? 2 : streaming, st,
                        g_variant_override >= 0 ? g_variant_override : tuning_variant(),
                        total_bases / SBWT_GROUP_BASES + 2);
     e = hipGetLastError();
