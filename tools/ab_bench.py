@@ -30,6 +30,27 @@ def index_for(sparse, pfilter=1, path=1):   # configs may carry: [3] sparse tabl
     return indexes[key]
 idx = index_for(31)
 d_bases = B.gpu_reads(genomes, n_reads, 42, dev)
+if os.environ.get("SORTED"):
+    # experiment: the same kind of reads, but in genome order (what a position-sorting pre-pass would produce)
+    gen = torch.Generator(device=dev); gen.manual_seed(42)
+    L = B.READ_LEN
+    cat = torch.from_numpy(np.concatenate(genomes)).to(dev)
+    lens = torch.tensor([len(g) for g in genomes], device=dev)
+    starts = torch.tensor(np.concatenate([[0], np.cumsum([len(g) for g in genomes])[:-1]]), device=dev)
+    which = torch.randint(0, len(genomes), (n_reads,), device=dev, generator=gen)
+    u = torch.rand(n_reads, device=dev, generator=gen, dtype=torch.float64)
+    off = ((u * (lens[which] - L + 1)).long() + starts[which]).sort().values
+    if os.environ.get("SORTED") == "block":      # sorted in blocks of 64K reads only (coarse bucket sort)
+        pass
+    acgt = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
+    code = torch.zeros(256, dtype=torch.uint8, device=dev); code[acgt.long()] = torch.arange(4, dtype=torch.uint8, device=dev)
+    ar = torch.arange(L, device=dev)
+    for lo in range(0, n_reads, 1 << 20):
+        n = min(1 << 20, n_reads - lo)
+        r = cat[(off[lo:lo + n, None] + ar[None, :]).reshape(-1)]
+        hit = torch.rand(n * L, device=dev, generator=gen) < B.SUB_RATE
+        shift = torch.randint(1, 4, (n * L,), device=dev, generator=gen, dtype=torch.uint8)
+        d_bases[lo * L:(lo + n) * L] = torch.where(hit, acgt[((code[r.long()] + shift) & 3).long()], r)
 m = 121
 d_roff = torch.arange(n_reads + 1, dtype=torch.int64, device=dev) * 150
 d_ooff = torch.arange(n_reads + 1, dtype=torch.int64, device=dev) * m
