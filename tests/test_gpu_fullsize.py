@@ -1,6 +1,6 @@
 """GPU, BASELINE.json config 2 at FULL size (10 M x 150 bp reads, 12.8 M-column index): size-independent
-properties through the device-buffer entry points -- the certificate kernel equals the reference-order
-kernel bit for bit (two independent code paths), streaming == per-k-mer search (tests/test_large.hh:104-115),
+properties through the device-buffer entry points -- the path-order kernel, the certificate kernel on the
+blocks and the reference-order kernel agree bit for bit (three independent code paths), streaming == per-k-mer search (tests/test_large.hh:104-115),
 hits are valid columns, misses are exactly the k-mers touching a mismatch or nothing else can explain,
 the run is deterministic, and a sample equals the oracle."""
 import os
@@ -46,8 +46,10 @@ def test_config2_full_size_properties(gpu):
             capi.set_tuning("search_variant", -1)
         return out
 
-    a = run(True, 1)                      # certificates + single gather slot
+    a = run(True, 2)                      # the product path: certificates along the path order
+    assert torch.equal(a, run(True, 1))   # certificates on the blocks only
     assert torch.equal(a, run(True, 0))   # the reference's order of searches
+    assert torch.equal(a, run(False, 2))  # per-k-mer search loop (internal streaming) == streaming (upper-case input)
     assert torch.equal(a, run(False, 1))  # per-k-mer search loop == streaming (upper-case input)
     assert torch.equal(a, run(True, 1))   # deterministic
     assert int(a.min()) == -1 and int(a.max()) < bits.n_nodes
