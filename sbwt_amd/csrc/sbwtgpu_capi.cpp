@@ -174,6 +174,9 @@ int sbwtgpu_device_count(int *count) {
 
 static inline int64_t align256(int64_t x) { return (x + 255) & ~(int64_t)255; }
 
+// set while sbwtgpu_index_create retries without the derived structures after running out of device memory
+static thread_local bool t_minimal_image = false;
+
 int sbwtgpu_index_create(const sbwtgpu_index_desc *d, int device, sbwtgpu_index **out) {
     if (!d || !out) return fail(SBWTGPU_ERR_INVALID_ARG, "desc/out is NULL");
     *out = nullptr;
@@ -198,8 +201,8 @@ int sbwtgpu_index_create(const sbwtgpu_index_desc *d, int device, sbwtgpu_index 
     const int64_t n_blocks = n / 64 + 1;
     const int64_t n_mega = (n >> SBWT_MEGA_SHIFT) + 1;
     int64_t p_file = d->precalc_k;
-    const bool derived = g_sparse_depth > 0 && g_probe_filter && n < ((int64_t)1 << 31) - 64 && n_mega == 1 &&
-                         d->k > 16;
+    const bool derived = !t_minimal_image && g_sparse_depth > 0 && g_probe_filter && n < ((int64_t)1 << 31) - 64 &&
+                         n_mega == 1 && d->k > 16;
     int64_t p_dev = default_device_precalc(n, derived);
     if (p_dev < p_file) p_dev = p_file;
     if (p_dev > d->k) p_dev = d->k;
@@ -228,6 +231,7 @@ int sbwtgpu_index_create(const sbwtgpu_index_desc *d, int device, sbwtgpu_index 
     h.blob_bytes = align256(h.off_mega + 4 * n_mega * 8);
     // sparse table one level above the dense one: 32-bit intervals only, one bucket per column on average
     int64_t p_sparse = g_sparse_depth < d->k ? g_sparse_depth : d->k;
+    if (t_minimal_image) p_sparse = 0;
     if (p_sparse > SBWT_SP_MAX_DEPTH) p_sparse = SBWT_SP_MAX_DEPTH;
     if (p_sparse <= p_dev || p_dev <= 0 || n >= ((int64_t)1 << 32) || n_mega > 1) p_sparse = 0;
     if (p_sparse > 0) {
@@ -258,7 +262,7 @@ int sbwtgpu_index_create(const sbwtgpu_index_desc *d, int device, sbwtgpu_index 
     }
     // path order: needs suffix-group marks (given or derived) and 32-bit columns
     const bool marks = d->suffix_group_starts || (g_derive_ssup && d->k >= 2);
-    if (g_path_order && marks && n < ((int64_t)1 << 31) - 64 && n_mega == 1) {
+    if (g_path_order && !t_minimal_image && marks && n < ((int64_t)1 << 31) - 64 && n_mega == 1) {
         h.has_path = 1;
         h.off_col = h.blob_bytes;
         h.off_pos = align256(h.off_col + (n + 4) * 4);
@@ -362,6 +366,15 @@ int sbwtgpu_index_create(const sbwtgpu_index_desc *d, int device, sbwtgpu_index 
         h.off_col = h.off_pos = h.off_pq = h.off_trans = 0;
     }
     hipError_t e = hipMalloc((void **)&idx->blob, (size_t)h.blob_bytes);
+    if (e != hipSuccess && !t_minimal_image && (h.has_path || h.p_sparse > 0)) {
+        // the derived structures are optional (about 100 bytes per column): without them the blocks-only kernel serves
+        (void)hipGetLastError();
+        delete idx;
+        t_minimal_image = true;
+        const int rc2 = sbwtgpu_index_create(d, device, out);
+        t_minimal_image = false;
+        return rc2;
+    }
     if (e != hipSuccess) {
         delete idx;
         return fail(SBWTGPU_ERR_OOM, "hipMalloc(%lld bytes) for the index image: %s", (long long)h.blob_bytes,
@@ -427,6 +440,15 @@ int sbwtgpu_index_create(const sbwtgpu_index_desc *d, int device, sbwtgpu_index 
         if ((e = hipGetLastError()) != hipSuccess) break;
         e = hipDeviceSynchronize();
     } while (0);
+    if (e == hipErrorOutOfMemory && !t_minimal_image && (h.has_path || h.p_sparse > 0)) {
+        (void)hipGetLastError();                       // scratch of a derived structure did not fit: build without them
+        (void)hipFree(idx->blob);
+        delete idx;
+        t_minimal_image = true;
+        const int rc2 = sbwtgpu_index_create(d, device, out);
+        t_minimal_image = false;
+        return rc2;
+    }
     if (e != hipSuccess) {
         rc = fail(SBWTGPU_ERR_HIP, "building the index image: %s", hipGetErrorString(e));
         (void)hipFree(idx->blob);
