@@ -1,8 +1,20 @@
 // sbwt_kernels.hip -- hand-written HIP kernels (gfx950 / CDNA4) for the plain-matrix SBWT
-// k-mer search path.  Integer / bit-manipulation only; the bound is random 64-byte-line
-// gathers from the index image (HBM / Infinity Cache), so the design rules are: one dependent
-// memory round trip per query step, 16-byte vector loads, all 64 lanes of a wave kept busy by
-// a work queue, no MFMA.
+// k-mer search path.  Integer / bit-manipulation only; the bound is the rate of 64-byte fabric
+// requests (random gathers from the index image, result lines), so the design rules are: one dependent
+// memory round trip per query step, 16-byte vector loads issued unconditionally and back to back, as
+// few requests per k-mer as the data structure allows, all 64 lanes of a wave kept busy by a work
+// queue, whole-line result writes, no MFMA.
+//
+// Contents, in file order:
+//   k_encode                     ASCII bases -> packed groups of 32 bases
+//   k_search                     lane-per-read search in the reference's order of searches (variant 0, cross-check)
+//   k_search_cert<WIDE,WPS,PATH> the product kernel: certificates; PATH = along the path order
+//   k_rank, k_precalc, k_update_interval, k_forward    the batched API neighbours
+//   k_sg_*                       suffix-group marks derived on the device (indexes without streaming support)
+//   k_sp_*, k_sp2_*, k_pf_insert sparse prefix table (+ second level for 31 < k <= 63), probe filter
+//   k_path_*                     path order, packed path chars, transition table
+//   k_fmt_*, k_scan_*            print_vector on the device
+//   sbwt_launch_*                host launchers
 //
 // Reference semantics restated here (paths relative to the reference repo):
 //   SBWT::streaming_search      include/sbwt/SBWT.hh:544-581
@@ -330,8 +342,8 @@ __global__ void __launch_bounds__(256) k_search(SbwtIndexView ix, const uint4 *_
 //     round trips in one iteration because different lanes need different things
 //     (profiles/r01_v1_rocprof_summary.txt: the first kernel spent ~8 us per wave iteration).
 //     Reads are handed out from a per-wave pool refilled by one atomic per 64 reads.
-// (3) Results are staged per lane in LDS and written as runs of 8 (64 contiguous bytes), so the
-//     L2 merges them into whole-sector writes instead of one memory write per 8-byte result.
+// (3) Results are staged per lane in LDS and leave as line-aligned runs written by groups of lanes, so
+//     that a result costs a share of a whole-line write instead of one memory write per 8 bytes.
 // ---------------------------------------------------------------------------------------------
 #define M_FETCH 5
 #define M_BACK 6
