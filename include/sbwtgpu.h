@@ -86,7 +86,8 @@ int         sbwtgpu_device_count(int *count);
  * variables of the same meaning: SBWTGPU_SPARSE_PRECALC, SBWTGPU_PROBE_FILTER, SBWTGPU_PATH_ORDER):
  *   "sparse_depth"    depth of the sparse (hashed) prefix table, 0 = none, default 31 (capped at k)
  *   "probe_filter"    1 (default): Bloom filter over the probe_len-mers of the index for the certificate probes
- *   "path_order"      1 (default): path order + transition table (32-bit indexes with suffix-group marks) */
+ *   "path_order"      1 (default): path order + transition table (32-bit indexes with suffix-group marks)
+ *   "path_safe"       1 (default): substitution-safe bits along the paths (k <= 31; SBWTGPU_PATH_SAFE) */
 int         sbwtgpu_set_tuning(const char *key, int64_t value);
 
 /* ---- index life cycle ---- */

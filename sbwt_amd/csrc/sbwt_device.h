@@ -50,7 +50,8 @@ struct SbwtIndexView {
     int p_sparse;                   // its depth (0 = none)
     int log2b;                      // log2 of its number of buckets
     const unsigned *col, *pos;      // path order: column at path position t, path position of column v (nullptr = none)
-    const uint4 *pq;                // packed path chars: quad t>>5 = { 32 chars (2 bits each), go mask, - }
+    const uint4 *pq;                // packed path chars: quad t>>5 = { 32 chars (2 bits each), go mask, safe mask }
+    int has_safe;                   // the safe masks are filled in (k_path_safe)
     const uint4 *stab2;             // second-level sparse table for 31 < k <= 63 (nullptr = none): key = (first column of the
     int log2b2;                     // 31-prefix's interval, the remaining k-31 bases) -> the k-mer's column and path position
     const uint4 *pfil;              // probe filter: blocked Bloom filter over the p_filter-mers of the index (nullptr = none)
@@ -79,6 +80,8 @@ struct SbwtBlobHeader {
     int32_t p_filter;               // depth of the probe filter (0 = none)
     int64_t off_pfil;
     int32_t log2f;
+    int32_t has_safe;               // pq carries the substitution-safe bits
+    int32_t reserved2;
     int32_t log2b2;                 // second-level sparse table: log2 of its number of 32-byte entries (0 = none)
     int64_t off_stab2;
 };
@@ -113,7 +116,8 @@ struct SbwtWorkHeader {
     unsigned long long n_lf;        // interval updates executed past the device prefix table (SBWT.hh:430-431)
     unsigned long long n_tab_hit;   // prefix-table lookups that returned a non-empty interval
     unsigned long long n_ext;       // k-mers answered along path runs (k_search_cert<PATH>), not counted in n_stream
-    unsigned long long pad[25];
+    unsigned long long n_bridge;    // substitutions bridged by the path's safe bits (no probes)
+    unsigned long long pad[24];
 };
 static_assert(sizeof(SbwtWorkHeader) == 256, "workspace header is 256 bytes");
 
@@ -138,6 +142,7 @@ void sbwt_launch_derive_marks(const SbwtIndexView &ix, uint4 *d_blocks, void *d_
 long long sbwt_sparse_scratch_bytes(long long n_nodes);
 long long sbwt_path_scratch_bytes(long long n_nodes);
 long long sbwt_path_quads(long long n_nodes);
+void sbwt_launch_path_safe(const SbwtIndexView &ix, uint4 *d_pq, hipStream_t stream);
 int sbwt_launch_build_path(const SbwtIndexView &ix, unsigned *d_col, unsigned *d_pos, uint4 *d_pq, uint4 *d_trans,
                            void *d_scratch, hipStream_t stream);
 int sbwt_launch_build_sparse(const SbwtIndexView &ix, int p_dense, int p_sparse, int log2b, uint4 *d_table,

@@ -82,7 +82,7 @@ __global__ void __launch_bounds__(256) k_encode(const unsigned char *__restrict_
                                                 uint4 *__restrict__ packed, i64 n_groups,
                                                 SbwtWorkHeader *ws, int aligned16) {
     i64 g = (i64)blockIdx.x * 256 + threadIdx.x;
-    if (g == 0) { ws->ticket = 0; ws->status = 0; ws->n_stream = 0; ws->n_search = 0; ws->n_lf = 0; ws->n_tab_hit = 0; ws->n_ext = 0; }
+    if (g == 0) { ws->ticket = 0; ws->status = 0; ws->n_stream = 0; ws->n_search = 0; ws->n_lf = 0; ws->n_tab_hit = 0; ws->n_ext = 0; ws->n_bridge = 0; }
     if (g >= n_groups) return;
     i64 base = g * SBWT_GROUP_BASES;
     u64 codes = 0;
@@ -350,6 +350,7 @@ __global__ void __launch_bounds__(256) k_search(SbwtIndexView ix, const uint4 *_
 #define M_EXT 7                 // PATH: follow the path from position r while the read agrees with it
 #define M_TRANS 8               // PATH: the read left the path at position r: the streaming step, from the transition table
 #define M_POS 9                 // PATH: r = pos[l]  (a k-mer was found by a walk: onto its path)
+#define M_BRIDGE 10             // PATH: the read differs from the path at a substitution-safe base: do the next k-1 agree?
 #define EV_NONE 0
 #define EV_EMIT1 1
 #define EV_FAIL 2
@@ -420,6 +421,7 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
     int tag = -2;                   // g0 = packed group `tag`; g1 = group tag+1 if g1ok
     bool g1ok = false;
     unsigned c_ext = 0;             // PATH: k-mers answered along paths (per lane)
+    unsigned c_brg = 0;             // PATH: substitutions bridged (per lane)
     uint4 g0 = make_uint4(0, 0, 0, 0), g1 = make_uint4(0, 0, 0, 0);
     u64 pool_next = 0, pool_end = 0;                              // wave-uniform pool of read tickets
     unsigned c_stream = 0, c_search = 0, c_lf = 0, c_tab = 0;     // wave-uniform (scalar) work counters
@@ -454,6 +456,7 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
         const bool strm = !PATH && (mode == M_STREAM || mode == M_BACK);
         const bool ext = PATH && (mode == M_EXT);
         const bool trn = PATH && (mode == M_TRANS);
+        const bool brg = PATH && (mode == M_BRIDGE);
         bool rknown = false;                           // PATH: this iteration's answer came with its path position (in r)
         pos_t tpos = -1;
         int seg_n = 0;                                 // PATH: k-mers i .. i+seg_n-1 are col[seg_src ..]
@@ -469,7 +472,7 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
         } else if (mode != M_IDLE && mode != M_DEAD) {
             // M_INIT reads the window at wstart (j counts extra hash buckets there); M_STEP the base at wstart + j
             const int woff = (mode == M_INIT && wk == 5) ? ps : 0;   // the second-level window starts after the prefix
-            const int P = poff + ((strm || ext || trn) ? (i + k - 1) : ((mode == M_INIT) ? (wstart + woff) : (wstart + j)));
+            const int P = poff + ((strm || ext || trn) ? (i + k - 1) : brg ? (i + k) : ((mode == M_INIT) ? (wstart + woff) : (wstart + j)));
             const int s = P & 31;
             // bases the table window of this walk covers
             const int wl = (wk == 1) ? ps : (wk == 2) ? L0 : (wk == 3) ? pw : (wk == 5) ? k - ps : p;
@@ -487,8 +490,8 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
                 kind = K_MODE;
                 const u64 codes0 = quad_bits(g0);
                 c = (int)((unsigned)(codes0 >> (2 * s)) & 3u);
-                if (ext) {
-                    a1 = ix.pq + ((unsigned)r >> 5);   // the two quads holding path chars r .. r+31
+                if (ext || brg) {
+                    a1 = ix.pq + (((unsigned)r + (brg ? 1u : 0u)) >> 5);   // the two quads holding path chars r (+1) .. +31
                     a2 = a1 + 1;
                 } else if (trn) {
                     if (((streaming == 2 ? g0.w : g0.z) >> s) & 1u) {     // validity as in M_STREAM below
@@ -580,6 +583,7 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
         // ---- consume ----
         bool tabhit = false, do_plan = false, force = false;
         bool imprecise = false;                        // this iteration's failure is a table-level miss
+        int burst_to = -1;                             // M_BRIDGE: k-mers i .. burst_to are certified absent
         if (kind == K_FETCH) {
             const i64 P0 = (i64)quad_bits(v1);
             obase = (i64)quad_bits(v2);
@@ -611,6 +615,24 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
                 r = (pos_t)(c == 0 ? v2.x : c == 1 ? v2.y : c == 2 ? v2.z : v2.w);
                 rknown = true;
             }
+        } else if (brg && have) {
+            // k-mer i (ending at the mismatching base) .. : if the bases after it agree with the path again, every
+            // k-mer that contains the mismatching base is a one-base variant of a path k-mer, absent by the safe bit
+            const int P = poff + i + k, s = P & 31, sp = (int)(((unsigned)r + 1u) & 31u);
+            u64 rw = quad_bits(g0) >> (2 * s), pw = quad_bits(v1) >> (2 * sp);
+            if (s) rw |= quad_bits(g1) << (64 - 2 * s);
+            if (sp) pw |= quad_bits(v2) << (64 - 2 * sp);
+            const u64 x = rw ^ pw;
+            const u64 mm = (x | (x >> 1)) & 0x5555555555555555ull;
+            const int nm = mm ? ((__ffsll((i64)mm) - 1) >> 1) : 32;
+            const int need = (k - 1 < m - 1 - i) ? (k - 1) : (m - 1 - i);
+            if (nm >= need) {
+                ev = EV_FAIL;
+                burst_to = i + need;
+                c_brg++;
+            } else {
+                mode = M_TRANS;
+            }
         } else if (ext && have) {
             // k-mer i-1 sits at path position r.  Read bases i+k-1.. against path chars r..: while they agree
             // (and the read's bases are valid and the path goes on), k-mer i+x sits at r+1+x.
@@ -633,8 +655,10 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
             seg_src = (unsigned)r + 1u;
             r += (pos_t)n;
             c_ext += (unsigned)n;
+            bool sbit = false;                         // stopped at a char mismatch whose path step is substitution-safe?
+            if (ix.has_safe && stopped && nm < nv) sbit = ((((((u64)v2.w << 32) | (u64)v1.w) >> sp) >> nm) & 1ull) != 0;
             if (i + n == m) mode = M_IDLE;
-            else if (stopped) mode = M_TRANS;
+            else if (stopped) mode = sbit ? M_BRIDGE : M_TRANS;
         } else if (have) {
             if (strm) {
                 const i64 blk = (mode == M_BACK) ? (i64)r : ((i64)l >> 6);
@@ -758,7 +782,10 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
         } else if (ev == EV_FAIL) {
             // read[wstart..tfail] is not in the index: k-mers i..min(wstart, m-1) all contain it
             burst_hi = (wstart < m - 1) ? wstart : (m - 1);
-            if (wk == 3) {                             // range probe: the bad base is in [wstart, b]
+            if (burst_to >= 0) {                       // bridged substitution: nothing is known about the next one
+                burst_hi = burst_to;
+                b = -1;
+            } else if (wk == 3) {                             // range probe: the bad base is in [wstart, b]
                 if (wstart >= b) b = -1;
                 else if (blo < wstart + 1) blo = wstart + 1;
             } else if (imprecise && !(wstart == b && blo >= b)) {
@@ -956,10 +983,10 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
     }
 
     if (PATH) {
-        u64 e = c_ext;
+        u64 e = c_ext, eb = c_brg;
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) e += __shfl_down(e, off);
-        if (lane == 0) atomicAdd(&ws->n_ext, e);
+        for (int off = 32; off > 0; off >>= 1) { e += __shfl_down(e, off); eb += __shfl_down(eb, off); }
+        if (lane == 0) { atomicAdd(&ws->n_ext, e); atomicAdd(&ws->n_bridge, eb); }
     }
     if (lane == 0) {   // the counters are wave-uniform
         atomicAdd(&ws->n_stream, (u64)c_stream);
@@ -1357,6 +1384,46 @@ __global__ void __launch_bounds__(256) k_path_place(i64 n, const unsigned *__res
     }
 }
 
+// Substitution-safe bits.  Path index u carries the char ch[u] of the step from position u to u+1.  Bit u says:
+// the 2k steps around u lie on one path, and replacing ch[u] by any other base gives, in each of the k windows
+// of k chars that contain it, a k-mer that is NOT in the index (3k exact lookups in the depth-k sparse table).
+// A read that follows the path, differs from it in exactly the base at u and agrees again on the next k-1 bases
+// therefore has -1 for all k k-mers that contain that base -- no probe needed (M_BRIDGE).
+__device__ __forceinline__ bool sp_present(const SbwtIndexView &ix, u64 key) {
+    u64 bkt = (key * SBWT_SP_HASH) >> (64 - ix.log2b);
+    for (;;) {
+        const uint4 e0 = ix.stab[2 * bkt], e1 = ix.stab[2 * bkt + 1];
+        const u64 w0 = quad_bits(e0), w1 = quad_bits(e1);
+        if ((w0 & ~SBWT_SP_OVERFLOW) == key || w1 == key) return true;
+        if (!(w0 & SBWT_SP_OVERFLOW)) return false;
+        bkt = (bkt + 1) & low_mask(ix.log2b);
+    }
+}
+__global__ void __launch_bounds__(256) k_path_safe(SbwtIndexView ix, unsigned *pq_words) {
+    const i64 u = (i64)blockIdx.x * 256 + threadIdx.x;
+    const int k = ix.k;
+    if (u < k || u + k > ix.n_nodes) return;
+    const i64 lo = u - k;                               // steps lo .. lo+2k-1 must all be kept
+    const uint4 *q = ix.pq + (lo >> 5);
+    const uint4 a = q[0], b = q[1], c = q[2];
+    const int s = (int)(lo & 31);
+    const u64 A = quad_bits(a), B = quad_bits(b), C = quad_bits(c);
+    const u64 w0 = s ? ((A >> (2 * s)) | (B << (64 - 2 * s))) : A;       // chars lo .. lo+31
+    const u64 w1 = s ? ((B >> (2 * s)) | (C << (64 - 2 * s))) : B;       // chars lo+32 .. lo+63
+    const u64 ga = ((u64)b.z << 32) | (u64)a.z, gb = ((u64)c.z << 32) | (u64)b.z;
+    const u64 g = (ga >> s) | (s ? ((gb >> 32) << (64 - s)) : 0ull);      // go bits lo .. lo+63
+    if ((g & low_mask(2 * k)) != low_mask(2 * k)) return;
+    const u64 km = low_mask(2 * k);
+    for (int w = 0; w < k; w++) {
+        const int st = k - w;                           // the window starts st steps after lo; ch[u] is its char w
+        u64 key = (st < 32) ? ((w0 >> (2 * st)) | (st ? (w1 << (64 - 2 * st)) : 0ull)) : (w1 >> (2 * (st - 32)));
+        key &= km;
+        for (u64 alt = 1; alt < 4; alt++)
+            if (sp_present(ix, key ^ (alt << (2 * w)))) return;
+    }
+    atomicOr(&pq_words[(size_t)(u >> 5) * 4 + 3], 1u << (int)(u & 31));
+}
+
 // transition table: entry t = { columns of the four successors of col[t] } { their path positions }
 __global__ void __launch_bounds__(256) k_path_trans(SbwtIndexView ix, const unsigned *__restrict__ pos,
                                                     uint4 *__restrict__ trans) {
@@ -1706,7 +1773,10 @@ long long sbwt_path_scratch_bytes(long long n_nodes) {
     const long long nb = (n_nodes + 1023) / 1024;
     return np * 4 * 8 + np + np * 8 * 2 + (nb + 2) * 8 + 4096;
 }
-long long sbwt_path_quads(long long n_nodes) { return n_nodes / 32 + 2; }
+long long sbwt_path_quads(long long n_nodes) { return n_nodes / 32 + 4; }
+void sbwt_launch_path_safe(const SbwtIndexView &ix, uint4 *d_pq, hipStream_t stream) {
+    hipLaunchKernelGGL(k_path_safe, dim3(grid_for(ix.n_nodes)), dim3(256), 0, stream, ix, reinterpret_cast<unsigned *>(d_pq));
+}
 
 // d_col, d_pos: n_nodes (+4 padding) u32 each; d_pq: sbwt_path_quads() quads.  Synchronises the stream.
 int sbwt_launch_build_path(const SbwtIndexView &ix, unsigned *d_col, unsigned *d_pos, uint4 *d_pq, uint4 *d_trans,

@@ -88,6 +88,7 @@ static int g_variant_override = -1, g_probe_override = -1, g_debug = 0, g_derive
 // result the kernel never writes cannot inherit a correct value from an earlier launch
 static int g_poison = [] { const char *e = getenv("SBWTGPU_POISON_RESULTS"); return e ? atoi(e) : 0; }();
 static int g_probe_filter = [] { const char *e = getenv("SBWTGPU_PROBE_FILTER"); return e ? atoi(e) : 1; }();
+static int g_path_safe = [] { const char *e = getenv("SBWTGPU_PATH_SAFE"); return e ? atoi(e) : 1; }();
 static int g_path_order = [] { const char *e = getenv("SBWTGPU_PATH_ORDER"); return e ? atoi(e) : 1; }();
 static int g_sparse_depth = [] { const char *e = getenv("SBWTGPU_SPARSE_PRECALC"); return e ? atoi(e) : 31; }();
 
@@ -129,6 +130,7 @@ struct sbwtgpu_index {
         v.pq = h.has_path ? reinterpret_cast<const uint4 *>(blob + h.off_pq) : nullptr;
         v.trans = h.has_path ? reinterpret_cast<const uint4 *>(blob + h.off_trans) : nullptr;
         v.stab_pos = h.stab_pos;
+        v.has_safe = h.has_safe;
         v.stab2 = h.log2b2 > 0 ? reinterpret_cast<const uint4 *>(blob + h.off_stab2) : nullptr;
         v.log2b2 = (int)h.log2b2;
         v.pfil = h.p_filter > 0 ? reinterpret_cast<const uint4 *>(blob + h.off_pfil) : nullptr;
@@ -151,6 +153,7 @@ int sbwtgpu_set_tuning(const char *key, int64_t value) {
     if (!strcmp(key, "derive_ssup")) { g_derive_ssup = (int)value; return SBWTGPU_OK; }
     if (!strcmp(key, "poison_results")) { g_poison = (int)value; return SBWTGPU_OK; }
     if (!strcmp(key, "probe_filter")) { g_probe_filter = (int)value; return SBWTGPU_OK; }   // indexes created afterwards
+    if (!strcmp(key, "path_safe")) { g_path_safe = (int)value; return SBWTGPU_OK; }   // indexes created afterwards
     if (!strcmp(key, "path_order")) { g_path_order = (int)value; return SBWTGPU_OK; }   // indexes created afterwards
     if (!strcmp(key, "sparse_depth")) {      // takes effect for indexes created afterwards
         if (value < 0 || value > 31) return fail(SBWTGPU_ERR_INVALID_ARG, "sparse_depth must be in [0,31]");
@@ -436,6 +439,13 @@ int sbwtgpu_index_create(const sbwtgpu_index_desc *d, int device, sbwtgpu_index 
             if (src < 0 && e == hipSuccess) e = hipErrorUnknown;
             if (e != hipSuccess) break;
             h.stab_pos = src > 0 ? 1 : 0;
+            // substitution-safe bits of the path: need the whole k-mers in the sparse table
+            if (h.has_path && h.p_sparse == d->k && g_path_safe) {
+                SbwtIndexView v2 = idx->view();
+                sbwt_launch_path_safe(v2, reinterpret_cast<uint4 *>(idx->blob + h.off_pq), 0);
+                if ((e = hipDeviceSynchronize()) != hipSuccess) break;
+                h.has_safe = 1;
+            }
         }
         if ((e = hipGetLastError()) != hipSuccess) break;
         e = hipDeviceSynchronize();
@@ -740,7 +750,8 @@ int sbwtgpu_workspace_stats(const void *d_ws, void *stream, int64_t stats[8]) {
     stats[2] = (int64_t)hdr.n_lf;
     stats[3] = (int64_t)hdr.n_tab_hit;
     stats[4] = (int64_t)hdr.n_ext;
-    stats[5] = stats[6] = stats[7] = 0;
+    stats[5] = (int64_t)hdr.n_bridge;
+    stats[6] = stats[7] = 0;
     return SBWTGPU_OK;
 }
 

@@ -240,17 +240,20 @@ def test_results_do_not_depend_on_search_variant_or_probe_length(gpu, genome_cas
         capi.set_tuning("probe_len", -1)
 
 
-@pytest.mark.parametrize("sparse,path", [(0, 1), (20, 1), (31, 0), (0, 0), (16, 1)])
-def test_results_do_not_depend_on_acceleration_structures(gpu, genome_case, sparse, path):
-    # the sparse prefix table (any depth) and the path order are derived data: with or without them, same bits
+@pytest.mark.parametrize("sparse,path,safe", [(0, 1, 1), (20, 1, 1), (31, 0, 1), (0, 0, 1), (16, 1, 1), (31, 1, 0)])
+def test_results_do_not_depend_on_acceleration_structures(gpu, genome_case, sparse, path, safe):
+    # the sparse prefix table (any depth), the path order and its substitution-safe bits are derived data:
+    # with or without them, same bits
     genomes, orc = genome_case
     capi.set_tuning("sparse_depth", sparse)
     capi.set_tuning("path_order", path)
+    capi.set_tuning("path_safe", safe)
     try:
         idx = gpu_index_from_oracle(orc)
     finally:
         capi.set_tuning("sparse_depth", 31)
         capi.set_tuning("path_order", 1)
+        capi.set_tuning("path_safe", 1)
     bases, off = synth.sample_reads(genomes, 3000, 150, 0.02, 78)
     bases = synth.inject(bases, 80, ord("N"), 1)
     bases = synth.inject(bases, 80, ord("t"), 2)
