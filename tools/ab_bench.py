@@ -14,6 +14,8 @@ configs = json.loads(os.environ.get("CONFIGS", '[[0,-1],[1,-1],[1,0]]'))   # [va
 rounds = int(os.environ.get("ROUNDS", 3))
 dev = torch.device("cuda", 0)
 genomes = synth.coli3_like(glen)
+if os.environ.get("SINGLE"):            # one strain only: long unbranched paths
+    genomes = genomes[:1]
 bits = hostlib.build_bits([g.tobytes() for g in genomes], 30, False, True, n_threads=os.cpu_count())
 indexes = {}
 def index_for(sparse, pfilter=1, path=1):   # configs may carry: [3] sparse table depth (0 = off), [4] probe filter, [5] path order
