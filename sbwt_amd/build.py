@@ -43,8 +43,10 @@ def _glob(d, exts):
 def build_gpu(force=False) -> str:
     os.makedirs(LIB, exist_ok=True)
     out = os.path.join(LIB, "libsbwtgpu.so")
-    srcs = [os.path.join(CSRC, "sbwt_kernels.hip"), os.path.join(CSRC, "sbwtgpu_capi.cpp")]
-    deps = srcs + [os.path.join(CSRC, "sbwt_device.h"), os.path.join(INC, "sbwtgpu.h")]
+    srcs = [os.path.join(CSRC, f) for f in ("sbwt_search.hip", "sbwt_api_kernels.hip", "sbwt_derived.hip",
+                                            "sbwt_format.hip", "sbwtgpu_capi.cpp")]
+    deps = srcs + [os.path.join(CSRC, f) for f in ("sbwt_device.h", "sbwt_kernels_common.h", "sbwt_scan.h")] + \
+        [os.path.join(INC, "sbwtgpu.h")]
     if force or _newer(out, deps):
         _run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", out] + srcs + ["-ldl"])
     return out

@@ -1,0 +1,522 @@
+// sbwt_derived.hip -- structures derived from the index on the device when the image is created: suffix-group
+// marks for indexes without streaming support, the sparse prefix table (+ second level), the probe filter, the
+// path order with its packed chars, substitution-safe bits and transition table (DESIGN.md sections 2-3).
+#include "sbwt_kernels_common.h"
+#include "sbwt_scan.h"
+
+// ---------------------------------------------------------------------------------------------
+// Suffix-group marks derived on the device (mark_suffix_groups, src/suffix_group_optimization.cpp:66-121)
+// for indexes saved with --no-streaming-support: the marks are a function of the four columns, so the
+// per-k-mer search loop can use streaming steps internally (with the raw-character validation of
+// SBWT::search) although the index carries no suffix_group_starts vector.  k-1 rounds of
+//   mark:       column i starts a group in this round iff its label differs from column i-1's
+//   propagate:  every edge (i --c--> C[c] + rank_c(i)) hands column i's label to its target
+// starting from label(v) = the symbol whose C-array range holds v ('$' for the root).
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_sg_init(SbwtIndexView ix, unsigned char *__restrict__ last) {
+    i64 v = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (v >= ix.n_nodes) return;
+    last[v] = (unsigned char)((v >= ix.C[0]) + (v >= ix.C[1]) + (v >= ix.C[2]) + (v >= ix.C[3]));
+}
+__global__ void __launch_bounds__(256) k_sg_mark(const unsigned char *__restrict__ last, i64 n, u64 *__restrict__ acc) {
+    i64 w = (i64)blockIdx.x * 256 + threadIdx.x;      // one 64-column word per thread
+    if (w * 64 >= n) return;
+    u64 m = 0;
+    for (int t = 0; t < 64; t++) {
+        i64 i = w * 64 + t;
+        if (i < n && (i == 0 || last[i] != last[i - 1])) m |= 1ull << t;
+    }
+    acc[w] |= m;
+}
+template <bool MEGA>
+__global__ void __launch_bounds__(256) k_sg_propagate(SbwtIndexView ix, const unsigned char *__restrict__ last,
+                                                      unsigned char *__restrict__ next) {
+    i64 i = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (i >= ix.n_nodes) return;
+    if (i == 0) next[0] = 0;                           // nothing points at the root: '$'
+    const unsigned char lab = last[i];
+    const uint4 *blk = ix.blocks + ((i >> 6) << 2);
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        const uint4 q = blk[c];
+        if ((quad_bits(q) >> (i & 63)) & 1ull) next[(i64)quad_rank<MEGA>(ix, q, i, c)] = lab;
+    }
+}
+__global__ void __launch_bounds__(256) k_sg_patch(uint4 *__restrict__ blocks, const u64 *__restrict__ acc, i64 n_blocks) {
+    i64 b = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (b >= n_blocks) return;
+    const u64 s = acc[b];
+    for (int c = 0; c < 4; c++) blocks[b * 4 + c].w = (c & 1) ? (unsigned)(s >> 32) : (unsigned)s;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Sparse prefix table: kmer_prefix_precalc (SBWT.hh:40,616-645) at depth p_sparse (default 20, the
+// deepest the reference allows), holding only the prefixes whose interval is not empty -- at that depth
+// about one entry per k-mer instead of 4^20.  Built by expanding the non-empty entries of the dense
+// device table one character at a time (each expansion is the interval update of SBWT.hh:430-431) and
+// hashing the survivors into buckets of two entries; a bucket that a key had to skip carries an overflow
+// flag, so a lookup that meets a bucket without the flag knows the prefix is absent.
+// ---------------------------------------------------------------------------------------------
+struct SpItem { u64 key; i64 l; i64 r; };
+
+__global__ void __launch_bounds__(256) k_sp_collect(const longlong2 *__restrict__ ptab, u64 n_entries,
+                                                    SpItem *__restrict__ out, u64 *counter) {
+    u64 t = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n_entries) return;
+    longlong2 e = ptab[t];
+    if (e.x < 0) return;
+    u64 slot = atomicAdd(counter, 1ull);
+    out[slot] = SpItem{t, e.x, e.y};
+}
+// ---- second level (31 < k <= 63): the 31-prefix's interval (named by its first column) + the remaining bases ----
+struct SpItem2 { u64 key2; unsigned origin, l, r, pad; };
+static_assert(sizeof(SpItem2) == sizeof(SpItem), "the two item lists share their buffers");
+__global__ void __launch_bounds__(256) k_sp2_seed(SpItem *items, const u64 *n) {     // in place: depth-31 items
+    u64 t = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (t >= *n) return;
+    const SpItem it = items[t];
+    reinterpret_cast<SpItem2 *>(items)[t] = SpItem2{0ull, (unsigned)it.l, (unsigned)it.l, (unsigned)it.r, 0u};
+}
+__global__ void __launch_bounds__(256) k_sp2_expand(SbwtIndexView ix, const SpItem2 *__restrict__ in, const u64 *n_in,
+                                                    int d2, SpItem2 *__restrict__ out, u64 *n_out) {
+    u64 t = (u64)blockIdx.x * 256 + threadIdx.x;
+    if ((t >> 2) >= *n_in) return;
+    const SpItem2 it = in[t >> 2];
+    const int c = (int)(t & 3);
+    uint4 q1 = ix.blocks[(((i64)it.l >> 6) << 2) + c];
+    uint4 q2 = ix.blocks[((((i64)it.r + 1) >> 6) << 2) + c];
+    i64 l = (i64)quad_rank<false>(ix, q1, (i64)it.l, c);
+    i64 r = (i64)quad_rank<false>(ix, q2, (i64)it.r + 1, c) - 1;
+    if (l > r) return;
+    u64 slot = atomicAdd(n_out, 1ull);
+    out[slot] = SpItem2{it.key2 | ((u64)c << (2 * d2)), it.origin, (unsigned)l, (unsigned)r, 0u};
+}
+__global__ void __launch_bounds__(256) k_sp2_insert(const SpItem2 *__restrict__ items, const u64 *n, uint4 *table,
+                                                    int log2b2, const unsigned *__restrict__ pos, int *wide_flag) {
+    u64 t = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (t >= *n) return;
+    const SpItem2 it = items[t];
+    if (it.l != it.r) *wide_flag = 1;                  // a k-mer's interval is one column in an SBWT
+    const u64 mask = (1ull << log2b2) - 1ull;
+    u64 bkt = sp2_hash(it.origin, it.key2) >> (64 - log2b2);
+    for (;;) {
+        unsigned *e = reinterpret_cast<unsigned *>(&table[2 * bkt]);
+        if (atomicCAS(&e[3], 0u, SBWT_SP2_USED) == 0u) {     // keys are distinct: an empty entry is simply taken
+            e[0] = (unsigned)it.key2;
+            e[1] = (unsigned)(it.key2 >> 32);
+            e[2] = it.origin;
+            e[4] = it.l;
+            e[5] = pos ? pos[it.l] : 0u;
+            return;
+        }
+        atomicOr(&e[3], SBWT_SP2_OVERFLOW);
+        bkt = (bkt + 1) & mask;
+    }
+}
+__global__ void __launch_bounds__(256) k_sp_wide(const SpItem *__restrict__ items, const u64 *n, int *flag) {
+    u64 t = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (t < *n && items[t].l != items[t].r) *flag = 1;
+}
+__global__ void __launch_bounds__(256) k_sp_clear(uint4 *table, u64 n_entries) {
+    u64 t = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (t < n_entries) table[t] = make_uint4(0u, (unsigned)(SBWT_SP_EMPTY >> 32), 0u, 0u);
+}
+template <bool MEGA>
+__global__ void __launch_bounds__(256) k_sp_expand(SbwtIndexView ix, const SpItem *__restrict__ in, const u64 *n_in,
+                                                   int depth, SpItem *__restrict__ out, u64 *n_out) {
+    u64 t = (u64)blockIdx.x * 256 + threadIdx.x;
+    if ((t >> 2) >= *n_in) return;
+    const SpItem it = in[t >> 2];
+    const int c = (int)(t & 3);
+    uint4 q1 = ix.blocks[((it.l >> 6) << 2) + c];
+    uint4 q2 = ix.blocks[(((it.r + 1) >> 6) << 2) + c];
+    i64 l = (i64)quad_rank<MEGA>(ix, q1, it.l, c);
+    i64 r = (i64)quad_rank<MEGA>(ix, q2, it.r + 1, c) - 1;
+    if (l > r) return;
+    u64 slot = atomicAdd(n_out, 1ull);
+    out[slot] = SpItem{it.key | ((u64)c << (2 * depth)), l, r};   // char `depth` of the prefix is c
+}
+// Probe filter: a blocked Bloom filter (128-bit blocks, two bits per key) over every p_filter-mer the index
+// holds.  A certificate probe asks "is this window absent?": a clear bit answers yes in one gather; two set bits
+// answer "perhaps not", and the exact walk through the dense table decides.
+__global__ void __launch_bounds__(256) k_pf_insert(const SpItem *__restrict__ items, const u64 *n, unsigned *filter,
+                                                   int log2f) {
+    u64 t = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (t >= *n) return;
+    const u64 h = sbwt_pf_hash(items[t].key);
+    unsigned *blk = filter + ((h >> (64 - log2f)) << 2);
+    const unsigned hb = sbwt_pf_bits(h);
+    const unsigned b1 = hb & 127u, b2 = (hb >> 7) & 127u;
+    atomicOr(&blk[b1 >> 5], 1u << (b1 & 31u));
+    atomicOr(&blk[b2 >> 5], 1u << (b2 & 31u));
+}
+// pos != nullptr: the items are whole k-mers (one column each); the second payload word is the column's path position
+__global__ void __launch_bounds__(256) k_sp_insert(const SpItem *__restrict__ items, const u64 *n, uint4 *table,
+                                                   int log2b, const unsigned *__restrict__ pos) {
+    u64 t = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (t >= *n) return;
+    const SpItem it = items[t];
+    const u64 mask = (1ull << log2b) - 1ull;
+    u64 bkt = (it.key * SBWT_SP_HASH) >> (64 - log2b);
+    for (;;) {
+        for (int e = 0; e < 2; e++) {
+            u64 *word = reinterpret_cast<u64 *>(&table[2 * bkt + e]);
+            u64 old = atomicCAS(word, SBWT_SP_EMPTY, it.key);
+            if (old == SBWT_SP_EMPTY) {
+                unsigned *pay = reinterpret_cast<unsigned *>(word) + 2;
+                pay[0] = (unsigned)it.l;
+                pay[1] = pos ? pos[it.l] : (unsigned)(it.r - it.l);
+                return;
+            }
+        }
+        atomicOr(reinterpret_cast<u64 *>(&table[2 * bkt]), SBWT_SP_OVERFLOW);   // both entries taken: mark and move on
+        bkt = (bkt + 1) & mask;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Path order: the streaming steps of SBWT::streaming_search (SBWT.hh:562-575), precomputed.
+//
+// A streaming step maps (column v, char c) to the column of the k-mer that follows, and that map does
+// not depend on the query.  Give every column ONE outgoing step (a char its suffix group offers) and
+// every column at most one incoming one: the columns fall apart into vertex-disjoint paths -- in a
+// genome, the unitigs strung together through their branch points.  Number the columns along the
+// paths: t = pos[v], v = col[t].  A query that sits on column col[t] and whose next base equals the
+// path's char at t sits on col[t+1] next, and so on: while the read follows the path, its answers are
+// the CONTIGUOUS run col[t+1], col[t+2], ... and checking that it does is a 2-bit compare against the
+// path's packed chars, 32 bases at a time.  The random 64-byte block gather per k-mer becomes
+// sequential 4-byte reads; the blocks are only touched where a read leaves its path (a branch taken
+// the other way, a substitution, the end of a path), by the generic step.
+//
+//   k_path_succ   per column: the group's start, the chars it offers, the char this member takes
+//                 (member r of a group with d chars takes the (r mod d)-th, so the members of a
+//                 bubble fan out), the target column; claims the target with atomicMin
+//   k_path_keep   a step survives if its source won the claim
+//   k_path_jump   pointer doubling over the predecessor links: head of the path + distance from it
+//                 (and the minimum column seen, which names a cycle's cut point)
+//   k_path_cut    columns that never reached a head lie on a cycle: cut it at its minimum
+//   k_path_len / scan / k_path_place   paths laid out head by head: pos, col and the packed chars
+// ---------------------------------------------------------------------------------------------
+#define PATH_NONE 0xFFFFFFFFu
+__global__ void __launch_bounds__(256) k_path_fill(unsigned *a, i64 n, unsigned v) {
+    i64 t = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (t < n) a[t] = v;
+}
+__global__ void __launch_bounds__(256) k_path_succ(SbwtIndexView ix, unsigned *__restrict__ succ,
+                                                   unsigned char *__restrict__ sch, unsigned *prv) {
+    const i64 v = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (v >= ix.n_nodes) return;
+    i64 blk = v >> 6;
+    u64 msk = ((u64)ix.blocks[blk * 4].w | ((u64)ix.blocks[blk * 4 + 1].w << 32)) & ((2ull << (int)(v & 63)) - 1ull);
+    while (msk == 0 && blk > 0) {
+        blk--;
+        msk = (u64)ix.blocks[blk * 4].w | ((u64)ix.blocks[blk * 4 + 1].w << 32);
+    }
+    if (msk == 0) msk = 1;
+    const int gb = 63 - __clzll((i64)msk);
+    const i64 g = (blk << 6) | gb;
+    uint4 q[4];
+    int deg = 0;
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        q[c] = ix.blocks[blk * 4 + c];
+        deg += (int)((quad_bits(q[c]) >> gb) & 1ull);
+    }
+    if (deg == 0) { succ[v] = PATH_NONE; sch[v] = 0; return; }
+    int want = (int)((v - g) % deg), pick = 0;
+    unsigned target = 0;
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        const u64 bits = quad_bits(q[c]);
+        if ((bits >> gb) & 1ull) {
+            if (want == 0) { pick = c; target = q[c].z + (unsigned)__popcll(bits & low_mask(gb)); }
+            want--;
+        }
+    }
+    succ[v] = target;
+    sch[v] = (unsigned char)pick;
+    atomicMin(&prv[target], (unsigned)v);
+}
+__global__ void __launch_bounds__(256) k_path_keep(i64 n, unsigned *__restrict__ succ, const unsigned *__restrict__ prv,
+                                                   unsigned *__restrict__ jump, unsigned *__restrict__ dist,
+                                                   unsigned *__restrict__ mn) {
+    const i64 v = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (v >= n) return;
+    const unsigned sv = succ[v];
+    if (sv != PATH_NONE && prv[sv] != (unsigned)v) succ[v] = PATH_NONE;
+    const unsigned pv = prv[v];
+    jump[v] = (pv == PATH_NONE) ? (unsigned)v : pv;     // heads point at themselves
+    dist[v] = (pv == PATH_NONE) ? 0u : 1u;
+    mn[v] = (unsigned)v;
+}
+__global__ void __launch_bounds__(256) k_path_jump(i64 n, const unsigned *__restrict__ jin, const unsigned *__restrict__ din,
+                                                   const unsigned *__restrict__ min_, unsigned *__restrict__ jout,
+                                                   unsigned *__restrict__ dout, unsigned *__restrict__ mout) {
+    const i64 v = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (v >= n) return;
+    const unsigned j = jin[v];
+    dout[v] = din[v] + din[j];
+    const unsigned a = min_[v], bq = min_[j];
+    mout[v] = a < bq ? a : bq;
+    jout[v] = jin[j];
+}
+__global__ void __launch_bounds__(256) k_path_cut(i64 n, const unsigned *__restrict__ jump, const unsigned *__restrict__ mn,
+                                                  unsigned *prv, unsigned *succ, int *flag) {
+    const i64 v = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (v >= n) return;
+    // reached a head?  (a cycle's cut point may be cut by its own thread while others look: they then
+    // return here, and the flag is raised by the cutting thread)
+    if (prv[jump[v]] == PATH_NONE) return;
+    if (mn[v] == (unsigned)v) {                         // the cycle's smallest column becomes a head
+        const unsigned pv = prv[v];
+        if (pv != PATH_NONE) { succ[pv] = PATH_NONE; prv[v] = PATH_NONE; }
+        *flag = 1;
+    }
+}
+__global__ void __launch_bounds__(256) k_path_len(i64 n, const unsigned *__restrict__ head, const unsigned *__restrict__ dist,
+                                                  unsigned long long *len) {
+    const i64 v = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (v >= n) return;
+    atomicMax(&len[head[v]], (unsigned long long)dist[v] + 1ull);
+}
+__global__ void __launch_bounds__(256) k_path_place(i64 n, const unsigned *__restrict__ head, const unsigned *__restrict__ dist,
+                                                    const i64 *__restrict__ base, const unsigned *__restrict__ succ,
+                                                    const unsigned char *__restrict__ sch, unsigned *__restrict__ pos,
+                                                    unsigned *__restrict__ col, unsigned *pq) {
+    const i64 v = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (v >= n) return;
+    const unsigned t = (unsigned)base[head[v]] + dist[v];
+    pos[v] = t;
+    col[t] = (unsigned)v;
+    if (succ[v] != PATH_NONE) {                         // quad t>>5 = { chars lo, chars hi, go mask, - }
+        unsigned *quad = pq + (size_t)(t >> 5) * 4;
+        const unsigned s = t & 31u;
+        if (sch[v]) atomicOr(&quad[s >> 4], (unsigned)sch[v] << (2 * (s & 15u)));
+        atomicOr(&quad[2], 1u << s);
+    }
+}
+
+// Substitution-safe bits.  Path index u carries the char ch[u] of the step from position u to u+1.  Bit u says:
+// the 2k steps around u lie on one path, and replacing ch[u] by any other base gives, in each of the k windows
+// of k chars that contain it, a k-mer that is NOT in the index (3k exact lookups in the depth-k sparse table).
+// A read that follows the path, differs from it in exactly the base at u and agrees again on the next k-1 bases
+// therefore has -1 for all k k-mers that contain that base -- no probe needed (M_BRIDGE).
+__device__ __forceinline__ bool sp_present(const SbwtIndexView &ix, u64 key) {
+    u64 bkt = (key * SBWT_SP_HASH) >> (64 - ix.log2b);
+    for (;;) {
+        const uint4 e0 = ix.stab[2 * bkt], e1 = ix.stab[2 * bkt + 1];
+        const u64 w0 = quad_bits(e0), w1 = quad_bits(e1);
+        if ((w0 & ~SBWT_SP_OVERFLOW) == key || w1 == key) return true;
+        if (!(w0 & SBWT_SP_OVERFLOW)) return false;
+        bkt = (bkt + 1) & low_mask(ix.log2b);
+    }
+}
+__global__ void __launch_bounds__(256) k_path_safe(SbwtIndexView ix, unsigned *pq_words) {
+    const i64 u = (i64)blockIdx.x * 256 + threadIdx.x;
+    const int k = ix.k;
+    if (u < k || u + k > ix.n_nodes) return;
+    const i64 lo = u - k;                               // steps lo .. lo+2k-1 must all be kept
+    const uint4 *q = ix.pq + (lo >> 5);
+    const uint4 a = q[0], b = q[1], c = q[2];
+    const int s = (int)(lo & 31);
+    const u64 A = quad_bits(a), B = quad_bits(b), C = quad_bits(c);
+    const u64 w0 = s ? ((A >> (2 * s)) | (B << (64 - 2 * s))) : A;       // chars lo .. lo+31
+    const u64 w1 = s ? ((B >> (2 * s)) | (C << (64 - 2 * s))) : B;       // chars lo+32 .. lo+63
+    const u64 ga = ((u64)b.z << 32) | (u64)a.z, gb = ((u64)c.z << 32) | (u64)b.z;
+    const u64 g = (ga >> s) | (s ? ((gb >> 32) << (64 - s)) : 0ull);      // go bits lo .. lo+63
+    if ((g & low_mask(2 * k)) != low_mask(2 * k)) return;
+    const u64 km = low_mask(2 * k);
+    for (int w = 0; w < k; w++) {
+        const int st = k - w;                           // the window starts st steps after lo; ch[u] is its char w
+        u64 key = (st < 32) ? ((w0 >> (2 * st)) | (st ? (w1 << (64 - 2 * st)) : 0ull)) : (w1 >> (2 * (st - 32)));
+        key &= km;
+        for (u64 alt = 1; alt < 4; alt++)
+            if (sp_present(ix, key ^ (alt << (2 * w)))) return;
+    }
+    atomicOr(&pq_words[(size_t)(u >> 5) * 4 + 3], 1u << (int)(u & 31));
+}
+
+// transition table: entry t = { columns of the four successors of col[t] } { their path positions }
+__global__ void __launch_bounds__(256) k_path_trans(SbwtIndexView ix, const unsigned *__restrict__ pos,
+                                                    uint4 *__restrict__ trans) {
+    const i64 v = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (v >= ix.n_nodes) return;
+    i64 blk = v >> 6;
+    u64 msk = ((u64)ix.blocks[blk * 4].w | ((u64)ix.blocks[blk * 4 + 1].w << 32)) & ((2ull << (int)(v & 63)) - 1ull);
+    while (msk == 0 && blk > 0) {
+        blk--;
+        msk = (u64)ix.blocks[blk * 4].w | ((u64)ix.blocks[blk * 4 + 1].w << 32);
+    }
+    if (msk == 0) msk = 1;
+    const int gb = 63 - __clzll((i64)msk);
+    unsigned nc[4], np[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        const uint4 q = ix.blocks[blk * 4 + c];
+        const u64 bits = quad_bits(q);
+        nc[c] = ((bits >> gb) & 1ull) ? (q.z + (unsigned)__popcll(bits & low_mask(gb))) : PATH_NONE;
+        np[c] = (nc[c] != PATH_NONE) ? pos[nc[c]] : PATH_NONE;
+    }
+    const size_t t = pos[v];
+    trans[2 * t] = make_uint4(nc[0], nc[1], nc[2], nc[3]);
+    trans[2 * t + 1] = make_uint4(np[0], np[1], np[2], np[3]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------------
+long long sbwt_derive_scratch_bytes(long long n_nodes) {
+    return 2 * ((n_nodes + 255) & ~255ll) + (n_nodes / 64 + 1) * 8 + 256;
+}
+void sbwt_launch_derive_marks(const SbwtIndexView &ix, uint4 *d_blocks, void *d_scratch, hipStream_t stream) {
+    const i64 n = ix.n_nodes, nb = n / 64 + 1, nal = (n + 255) & ~255ll;
+    unsigned char *last = reinterpret_cast<unsigned char *>(d_scratch), *next = last + nal;
+    u64 *acc = reinterpret_cast<u64 *>(next + nal);
+    (void)hipMemsetAsync(acc, 0, (size_t)nb * 8, stream);
+    hipLaunchKernelGGL(k_sg_init, dim3(grid_for(n)), dim3(256), 0, stream, ix, last);
+    for (int round = 0; round < ix.k - 1; round++) {
+        hipLaunchKernelGGL(k_sg_mark, dim3(grid_for(nb)), dim3(256), 0, stream, last, n, acc);
+        if (ix.n_mega > 1)
+            hipLaunchKernelGGL(k_sg_propagate<true>, dim3(grid_for(n)), dim3(256), 0, stream, ix, last, next);
+        else
+            hipLaunchKernelGGL(k_sg_propagate<false>, dim3(grid_for(n)), dim3(256), 0, stream, ix, last, next);
+        unsigned char *t = last; last = next; next = t;
+    }
+    hipLaunchKernelGGL(k_sg_patch, dim3(grid_for(nb)), dim3(256), 0, stream, d_blocks, acc, nb);
+}
+
+// scratch of the sparse-table build: two item lists of n_nodes entries + two counters
+long long sbwt_sparse_scratch_bytes(long long n_nodes) { return 2 * (n_nodes + 64) * (long long)sizeof(SpItem) + 256; }
+
+// d_pos: path positions to store with depth-k entries (nullptr = none).  Returns 1 if they were stored,
+// 0 if not (no d_pos, p_sparse < k, or some k-mer's interval is wider than one column), < 0 on error.
+int sbwt_launch_build_sparse(const SbwtIndexView &ix, int p_dense, int p_sparse, int log2b, uint4 *d_table,
+                             void *d_scratch, const unsigned *d_pos, int p_filter, int log2f, uint4 *d_filter,
+                             int log2b2, uint4 *d_table2, hipStream_t stream) {
+    u64 *counters = reinterpret_cast<u64 *>(d_scratch);                    // [0], [1]: list lengths
+    SpItem *listA = reinterpret_cast<SpItem *>(reinterpret_cast<char *>(d_scratch) + 256);
+    SpItem *listB = listA + (ix.n_nodes + 64);
+    (void)hipMemsetAsync(counters, 0, 256, stream);
+    hipLaunchKernelGGL(k_sp_clear, dim3(grid_for((i64)2 << log2b)), dim3(256), 0, stream, d_table, (u64)2 << log2b);
+    const u64 n_dense = 1ull << (2 * p_dense);
+    hipLaunchKernelGGL(k_sp_collect, dim3(grid_for((i64)n_dense)), dim3(256), 0, stream, ix.ptab, n_dense, listA,
+                       counters + 0);
+    SpItem *in = listA, *outl = listB;
+    int ci = 0;
+    for (int d = p_dense; d < p_sparse; d++) {
+        (void)hipMemsetAsync(counters + (ci ^ 1), 0, 8, stream);
+        const i64 threads = (ix.n_nodes + 64) * 4;
+        if (ix.n_mega > 1)
+            hipLaunchKernelGGL(k_sp_expand<true>, dim3(grid_for(threads)), dim3(256), 0, stream, ix, in, counters + ci, d,
+                               outl, counters + (ci ^ 1));
+        else
+            hipLaunchKernelGGL(k_sp_expand<false>, dim3(grid_for(threads)), dim3(256), 0, stream, ix, in, counters + ci, d,
+                               outl, counters + (ci ^ 1));
+        SpItem *t = in; in = outl; outl = t;
+        ci ^= 1;
+        if (d_filter && d + 1 == p_filter) {
+            (void)hipMemsetAsync(d_filter, 0, (size_t)16 << log2f, stream);
+            hipLaunchKernelGGL(k_pf_insert, dim3(grid_for(ix.n_nodes + 64)), dim3(256), 0, stream, in, counters + ci,
+                               reinterpret_cast<unsigned *>(d_filter), log2f);
+        }
+    }
+    int with_pos = 0;
+    if (d_pos && p_sparse == ix.k) {
+        int *flag = reinterpret_cast<int *>(counters + 8);
+        hipLaunchKernelGGL(k_sp_wide, dim3(grid_for(ix.n_nodes + 64)), dim3(256), 0, stream, in, counters + ci, flag);
+        int h_flag = 1;
+        if (hipMemcpyAsync(&h_flag, flag, 4, hipMemcpyDeviceToHost, stream) != hipSuccess) return -1;
+        if (hipStreamSynchronize(stream) != hipSuccess) return -1;
+        with_pos = h_flag ? 0 : 1;
+    }
+    hipLaunchKernelGGL(k_sp_insert, dim3(grid_for(ix.n_nodes + 64)), dim3(256), 0, stream, in, counters + ci, d_table,
+                       log2b, with_pos ? d_pos : (const unsigned *)nullptr);
+    if (d_table2 && ix.k > p_sparse) {
+        // second level: carry every depth-p_sparse prefix on to depth k, remembering where it started
+        (void)hipMemsetAsync(d_table2, 0, (size_t)32 << log2b2, stream);
+        hipLaunchKernelGGL(k_sp2_seed, dim3(grid_for(ix.n_nodes + 64)), dim3(256), 0, stream, in, counters + ci);
+        SpItem2 *in2 = reinterpret_cast<SpItem2 *>(in), *out2 = reinterpret_cast<SpItem2 *>(outl);
+        for (int d = p_sparse; d < ix.k; d++) {
+            (void)hipMemsetAsync(counters + (ci ^ 1), 0, 8, stream);
+            hipLaunchKernelGGL(k_sp2_expand, dim3(grid_for((ix.n_nodes + 64) * 4)), dim3(256), 0, stream, ix, in2,
+                               counters + ci, d - p_sparse, out2, counters + (ci ^ 1));
+            SpItem2 *t = in2; in2 = out2; out2 = t;
+            ci ^= 1;
+        }
+        int *flag = reinterpret_cast<int *>(counters + 9);
+        hipLaunchKernelGGL(k_sp2_insert, dim3(grid_for(ix.n_nodes + 64)), dim3(256), 0, stream, in2, counters + ci, d_table2,
+                           log2b2, d_pos, flag);
+        int h_flag = 1;
+        if (hipMemcpyAsync(&h_flag, flag, 4, hipMemcpyDeviceToHost, stream) != hipSuccess) return -1;
+        if (hipStreamSynchronize(stream) != hipSuccess) return -1;
+        if (h_flag) return -3;                          // not an SBWT: the caller drops the second level
+    }
+    return with_pos;
+}
+
+// ---- path order (see k_path_*) ----
+static inline long long path_pad(long long n) { return (n + 64 + 255) & ~255ll; }
+long long sbwt_path_scratch_bytes(long long n_nodes) {
+    const long long np = path_pad(n_nodes);
+    const long long nb = (n_nodes + 1023) / 1024;
+    return np * 4 * 8 + np + np * 8 * 2 + (nb + 2) * 8 + 4096;
+}
+long long sbwt_path_quads(long long n_nodes) { return n_nodes / 32 + 4; }
+void sbwt_launch_path_safe(const SbwtIndexView &ix, uint4 *d_pq, hipStream_t stream) {
+    hipLaunchKernelGGL(k_path_safe, dim3(grid_for(ix.n_nodes)), dim3(256), 0, stream, ix, reinterpret_cast<unsigned *>(d_pq));
+}
+
+// d_col, d_pos: n_nodes (+4 padding) u32 each; d_pq: sbwt_path_quads() quads.  Synchronises the stream.
+int sbwt_launch_build_path(const SbwtIndexView &ix, unsigned *d_col, unsigned *d_pos, uint4 *d_pq, uint4 *d_trans,
+                           void *d_scratch, hipStream_t stream) {
+    const i64 n = ix.n_nodes;
+    const long long np = path_pad(n);
+    const i64 nb = (n + 1023) / 1024;
+    char *base = reinterpret_cast<char *>(d_scratch);
+    int *flag = reinterpret_cast<int *>(base);
+    base += 4096;
+    unsigned *succ = reinterpret_cast<unsigned *>(base); base += np * 4;
+    unsigned *prv = reinterpret_cast<unsigned *>(base); base += np * 4;
+    unsigned *buf[2][3];
+    for (int a = 0; a < 2; a++)
+        for (int f = 0; f < 3; f++) { buf[a][f] = reinterpret_cast<unsigned *>(base); base += np * 4; }
+    unsigned char *sch = reinterpret_cast<unsigned char *>(base); base += np;
+    unsigned long long *len = reinterpret_cast<unsigned long long *>(base); base += np * 8;
+    i64 *pbase = reinterpret_cast<i64 *>(base); base += np * 8;
+    i64 *bsum = reinterpret_cast<i64 *>(base);
+    const unsigned g = grid_for(n);
+    hipLaunchKernelGGL(k_path_fill, dim3(g), dim3(256), 0, stream, prv, n, PATH_NONE);
+    hipLaunchKernelGGL(k_path_succ, dim3(g), dim3(256), 0, stream, ix, succ, sch, prv);
+    int rounds = 1;
+    while (((i64)1 << rounds) < n) rounds++;
+    rounds++;
+    int cur = 0;
+    for (int attempt = 0; attempt < 3; attempt++) {
+        cur = 0;
+        hipLaunchKernelGGL(k_path_keep, dim3(g), dim3(256), 0, stream, n, succ, prv, buf[0][0], buf[0][1], buf[0][2]);
+        for (int r = 0; r < rounds; r++) {
+            hipLaunchKernelGGL(k_path_jump, dim3(g), dim3(256), 0, stream, n, buf[cur][0], buf[cur][1], buf[cur][2],
+                               buf[cur ^ 1][0], buf[cur ^ 1][1], buf[cur ^ 1][2]);
+            cur ^= 1;
+        }
+        (void)hipMemsetAsync(flag, 0, 4, stream);
+        hipLaunchKernelGGL(k_path_cut, dim3(g), dim3(256), 0, stream, n, buf[cur][0], buf[cur][2], prv, succ, flag);
+        int h_flag = 0;
+        if (hipMemcpyAsync(&h_flag, flag, 4, hipMemcpyDeviceToHost, stream) != hipSuccess) return -1;
+        if (hipStreamSynchronize(stream) != hipSuccess) return -1;
+        if (!h_flag) break;
+        if (attempt == 2) return -2;                    // cannot happen: one cut per cycle opens every cycle
+    }
+    (void)hipMemsetAsync(len, 0, (size_t)np * 8, stream);
+    hipLaunchKernelGGL(k_path_len, dim3(g), dim3(256), 0, stream, n, buf[cur][0], buf[cur][1], len);
+    hipLaunchKernelGGL(k_scan_block_sums, dim3((unsigned)nb), dim3(256), 0, stream, reinterpret_cast<const i64 *>(len), n, bsum);
+    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, stream, bsum, nb);
+    hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nb), dim3(256), 0, stream, reinterpret_cast<const i64 *>(len), n, bsum, pbase);
+    (void)hipMemsetAsync(d_pq, 0, (size_t)sbwt_path_quads(n) * 16, stream);
+    hipLaunchKernelGGL(k_path_place, dim3(g), dim3(256), 0, stream, n, buf[cur][0], buf[cur][1], pbase, succ, sch, d_pos,
+                       d_col, reinterpret_cast<unsigned *>(d_pq));
+    hipLaunchKernelGGL(k_path_trans, dim3(g), dim3(256), 0, stream, ix, d_pos, d_trans);
+    if (hipStreamSynchronize(stream) != hipSuccess) return -1;
+    return 0;
+}
+

@@ -6,7 +6,7 @@
 //   [ ptab     : 4^p_dev x 16 B  ]   device prefix table, (first,second) int64 pairs
 //   [ ftab     : 4^p_file x 16 B ]   the index file's own table (only if p_file != p_dev, p_file > 0)
 //   [ mega     : 4 x n_mega x 8 B]   absolute (C[c] + rank_c) at every 2^31-column boundary
-//   [ col, pos : n_nodes x 4 B each ]  path order (see k_path_* in sbwt_kernels.hip)
+//   [ col, pos : n_nodes x 4 B each ]  path order (see k_path_* in sbwt_derived.hip)
 //   [ pq       : (n/32+2) x 16 B ]   packed chars + go bits along the paths
 //   [ trans    : n_nodes x 32 B  ]   the four successors of every path position (columns, path positions)
 //   [ pfil     : 2^log2f x 16 B  ]   probe filter (see k_pf_insert)
@@ -121,7 +121,7 @@ struct SbwtWorkHeader {
 };
 static_assert(sizeof(SbwtWorkHeader) == 256, "workspace header is 256 bytes");
 
-// launchers implemented in sbwt_kernels.hip (all asynchronous on `stream`)
+// launchers implemented in sbwt_search.hip, sbwt_api_kernels.hip, sbwt_derived.hip, sbwt_format.hip (all asynchronous on `stream`)
 void sbwt_launch_encode(const char *d_bases, long long total_bases, uint4 *d_packed, SbwtWorkHeader *ws,
                         hipStream_t stream);
 void sbwt_launch_search(const SbwtIndexView &ix, const uint4 *d_packed, const long long *d_read_off,

@@ -1,0 +1,52 @@
+// sbwt_kernels_common.h -- device helpers shared by the HIP translation units of libsbwtgpu
+// (sbwt_search.hip, sbwt_api_kernels.hip, sbwt_derived.hip, sbwt_format.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "sbwt_device.h"
+
+typedef unsigned long long u64;
+typedef long long i64;
+
+#define SBWT_ERR_NOT_SINGLETON (-7)
+
+// ---------------------------------------------------------------------------------------------
+// small helpers
+// ---------------------------------------------------------------------------------------------
+// ASCII -> 0..3 for A,C,G,T (globals.hh:38-47); only meaningful when the validity bit is set.
+__device__ __forceinline__ unsigned dna_code(unsigned b) { return ((b >> 1) & 3u) ^ ((b >> 2) & 1u); }
+__device__ __forceinline__ bool is_ACGT(unsigned b) { return b == 'A' || b == 'C' || b == 'G' || b == 'T'; }
+__device__ __forceinline__ u64 quad_bits(const uint4 &q) { return (u64)q.x | ((u64)q.y << 32); }
+__device__ __forceinline__ u64 low_mask(int n) { return (1ull << n) - 1ull; }   // n in [0,63]
+
+// wave-uniform values the compiler cannot prove uniform: pin them to scalar registers
+__device__ __forceinline__ unsigned uniform32(unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ u64 uniform64(u64 v) {
+    return (u64)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v) |
+           ((u64)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32)) << 32);
+}
+
+// streaming (read-once / write-once) 16-byte accesses that should not displace the index in L2
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void st_stream(i64 *p, i64 v) { __builtin_nontemporal_store(v, p); }
+// two consecutive results / columns at their natural (8-byte / 4-byte) alignment
+typedef i64 i64x2_a8 __attribute__((ext_vector_type(2), aligned(8)));
+typedef unsigned u32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));
+__device__ __forceinline__ void st_stream2(i64 *p, i64 a, i64 b) {
+    i64x2_a8 v = {a, b};
+    __builtin_nontemporal_store(v, reinterpret_cast<i64x2_a8 *>(p));
+}
+__device__ __forceinline__ uint4 ld_stream(const uint4 *p) {
+    u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p));
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+
+// value of (C[c] + rank_c(pos)) from the quad of pos's block
+template <bool MEGA>
+__device__ __forceinline__ u64 quad_rank(const SbwtIndexView &ix, const uint4 &q, i64 pos, int c) {
+    u64 v = (u64)q.z + (u64)__popcll(quad_bits(q) & low_mask((int)(pos & 63)));
+    if (MEGA) v += ix.mega[(i64)c * ix.n_mega + (pos >> SBWT_MEGA_SHIFT)];
+    return v;
+}
+
+
+static inline unsigned grid_for(i64 n) { return (unsigned)((n + 255) / 256); }

@@ -1,6 +1,6 @@
 // sbwtgpu_capi.cpp -- implementation of the C ABI declared in include/sbwtgpu.h.
 // Host-side glue only: builds the device image of an index, owns device memory, and enqueues
-// the kernels of sbwt_kernels.hip.  There is deliberately no CPU query path in this library:
+// the kernels of sbwt_search.hip and its siblings.  There is deliberately no CPU query path in this library:
 // every query entry point runs on the GPU or fails with an error code.
 #include <hip/hip_runtime.h>
 

@@ -1,6 +1,6 @@
 """Lane-iterations of the search kernel by kind (fetch / reload / walk start / interval update / transition / path run).
 Needs a library built with -DSBWT_STATS:
-  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -DSBWT_STATS -o /tmp/lib_stats.so sbwt_amd/csrc/sbwt_kernels.hip sbwt_amd/csrc/sbwtgpu_capi.cpp -ldl
+  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -DSBWT_STATS -o /tmp/lib_stats.so sbwt_amd/csrc/sbwt_search.hip sbwt_amd/csrc/sbwt_api_kernels.hip sbwt_amd/csrc/sbwt_derived.hip sbwt_amd/csrc/sbwt_format.hip sbwt_amd/csrc/sbwtgpu_capi.cpp -ldl
   SBWTGPU_LIB=/tmp/lib_stats.so python tools/lane_stats.py"""
 import os, sys, ctypes
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
