@@ -175,7 +175,8 @@ int  sbwtgpu_workspace_status(const void *d_workspace, void *stream, int *status
 /* Synchronises `stream`, then reports the work the last search on this workspace performed:
  * stats[0] streaming one-step extensions, [1] full searches, [2] interval updates executed past the
  * device prefix table, [3] device prefix-table lookups that returned a non-empty interval, [4] k-mers
- * answered along path runs (streaming steps that needed no block access), [5..7] reserved (0). */
+ * answered along path runs (streaming steps that needed no block access), [5] substitutions bridged by the
+ * path's safe bits, [6..7] reserved (0). */
 int  sbwtgpu_workspace_stats(const void *d_workspace, void *stream, int64_t stats[8]);
 
 /* ---- output formatting on the device ---- */
