@@ -43,17 +43,21 @@ __global__ void __launch_bounds__(256) k_encode(const unsigned char *__restrict_
         const uint4 *src = reinterpret_cast<const uint4 *>(bases + base);
         uint4 x0 = ld_stream(src), x1 = ld_stream(src + 1);
         unsigned w[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+        // four bases per 32-bit operation: upper-case, 2-bit codes, and "byte equals A/C/G/T" by exact per-byte
+        // zero detection; the per-byte bits are gathered with one multiply each
 #pragma unroll
         for (int d = 0; d < 8; d++) {
-#pragma unroll
-            for (int t = 0; t < 4; t++) {
-                unsigned b = (w[d] >> (8 * t)) & 0xFFu;
-                unsigned up = b & 0xDFu;
-                int pos = d * 4 + t;
-                codes |= (u64)dna_code(up) << (2 * pos);
-                vu |= (unsigned)is_ACGT(up) << pos;
-                vr |= (unsigned)is_ACGT(b) << pos;
-            }
+            const unsigned up = w[d] & 0xDFDFDFDFu;
+            const unsigned t = ((up >> 1) & 0x03030303u) ^ ((up >> 2) & 0x01010101u);        // dna_code of every byte
+            const unsigned c8 = (t * 0x01041040u) >> 24;                                     // 4 x 2 bits -> one byte
+            auto nz = [](unsigned v) { return ((v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | v; };       // bit 7 of a byte set <=> byte != 0
+            const unsigned none = nz(up ^ 0x41414141u) & nz(up ^ 0x43434343u) & nz(up ^ 0x47474747u) & nz(up ^ 0x54545454u);
+            const unsigned isl = (~none >> 7) & 0x01010101u;                                 // 1 per byte that is ACGT after toupper
+            const unsigned u4 = (isl * 0x10204080u) >> 28;
+            const unsigned low4 = (((w[d] >> 5) & 0x01010101u) * 0x10204080u) >> 28;          // bit 5 set: lower case
+            codes |= (u64)c8 << (8 * d);
+            vu |= u4 << (4 * d);
+            vr |= (u4 & ~low4) << (4 * d);
         }
     } else {
         for (int pos = 0; pos < SBWT_GROUP_BASES; pos++) {

@@ -530,3 +530,20 @@ def test_second_level_sparse_table_for_k_up_to_63(gpu, k):
     assert np.array_equal(got, oracle_batch(orc, bases, off, True))
     got, _ = idx.search(bases, off)
     assert np.array_equal(got, oracle_batch(orc, bases, off, False))
+
+
+def test_arbitrary_bytes_in_reads(gpu, genome_case):
+    # every byte value 1..255 somewhere in the reads: only upper-case ACGT is valid for a full search, ACGT after
+    # toupper for a streaming step (the encode kernel classifies four bases per 32-bit operation)
+    genomes, orc = genome_case
+    idx = gpu_index_from_oracle(orc)
+    bases, off = synth.sample_reads(genomes, 3000, 150, 0.005, 99)
+    rng = np.random.default_rng(17)
+    where = rng.choice(len(bases), size=6000, replace=False)
+    bases = bases.copy()
+    bases[where] = rng.integers(1, 256, size=len(where), dtype=np.uint8)
+    bases[where[:256]] = np.arange(256, dtype=np.uint8).clip(1)      # each value at least once
+    got, _ = idx.streaming_search(bases, off)
+    assert np.array_equal(got, oracle_batch(orc, bases, off, True))
+    got, _ = idx.search(bases, off)
+    assert np.array_equal(got, oracle_batch(orc, bases, off, False))
