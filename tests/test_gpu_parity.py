@@ -547,3 +547,26 @@ def test_arbitrary_bytes_in_reads(gpu, genome_case):
     assert np.array_equal(got, oracle_batch(orc, bases, off, True))
     got, _ = idx.search(bases, off)
     assert np.array_equal(got, oracle_batch(orc, bases, off, False))
+
+
+def test_many_short_reads_of_mixed_lengths(gpu, genome_case):
+    # reads of k-2 .. k+12 bases (0 .. 13 k-mers each): every alignment of a read's results to the 64-byte lines of
+    # `out`, reads without results between reads with results, runs that end after one or two results
+    genomes, orc = genome_case
+    idx = gpu_index_from_oracle(orc)
+    k = orc.k
+    rng = np.random.default_rng(5)
+    cat = np.concatenate(genomes)
+    n = 60_000
+    lens = rng.integers(k - 2, k + 13, size=n)
+    starts = rng.integers(0, len(cat) - 64, size=n)
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    bases = np.empty(int(off[-1]), dtype=np.uint8)
+    for r in range(n):
+        bases[off[r]:off[r + 1]] = cat[starts[r]:starts[r] + lens[r]]
+    flip = rng.choice(len(bases), size=len(bases) // 60, replace=False)
+    bases[flip] = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=len(flip))]
+    got, oo = idx.streaming_search(bases, off)
+    assert np.array_equal(got, oracle_batch(orc, bases, off, True))
+    got2, _ = idx.search(bases, off)
+    assert np.array_equal(got2, oracle_batch(orc, bases, off, False))
