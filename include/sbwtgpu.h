@@ -82,6 +82,8 @@ int         sbwtgpu_device_count(int *count);
  *                     the device so that the per-k-mer search loop can use streaming steps internally
  *   "debug"           kernel experiment bits (0 = product behaviour)
  *   "poison_results"  1: every search first fills its result range with 0xA5 (parity tests)
+ *   "trans_ext"       -1 (default): the kernel decides per wave whether a transition step runs on along the 8 path
+ *                     steps quoted in its table entry (pays on pan-genomes); 0 never, 1 always
  * Read when an index is CREATED (derived acceleration structures inside the device image; environment
  * variables of the same meaning: SBWTGPU_SPARSE_PRECALC, SBWTGPU_PROBE_FILTER, SBWTGPU_PATH_ORDER):
  *   "sparse_depth"    depth of the sparse (hashed) prefix table, 0 = none, default 31 (capped at k)

@@ -336,7 +336,9 @@ __global__ void __launch_bounds__(256) k_path_safe(SbwtIndexView ix, unsigned *p
     atomicOr(&pq_words[(size_t)(u >> 5) * 4 + 3], 1u << (int)(u & 31));
 }
 
-// transition table: entry t = { columns of the four successors of col[t] } { their path positions }
+// transition table: entry t = four 16-byte quads, one per char c: { column of the successor of col[t] by c (or none),
+// its path position p, the next 8 steps of its path: chars p..p+7 (16 bits) | go bits (8) | safe bits (8), - }
+// (built last: the path's chars and safe bits must be final)
 __global__ void __launch_bounds__(256) k_path_trans(SbwtIndexView ix, const unsigned *__restrict__ pos,
                                                     uint4 *__restrict__ trans) {
     const i64 v = (i64)blockIdx.x * 256 + threadIdx.x;
@@ -358,8 +360,19 @@ __global__ void __launch_bounds__(256) k_path_trans(SbwtIndexView ix, const unsi
         np[c] = (nc[c] != PATH_NONE) ? pos[nc[c]] : PATH_NONE;
     }
     const size_t t = pos[v];
-    trans[2 * t] = make_uint4(nc[0], nc[1], nc[2], nc[3]);
-    trans[2 * t + 1] = make_uint4(np[0], np[1], np[2], np[3]);
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        unsigned ext = 0;
+        if (nc[c] != PATH_NONE) {
+            const uint4 *q = ix.pq + (np[c] >> 5);
+            const uint4 a = q[0], b = q[1];
+            const int s = (int)(np[c] & 31u);
+            const u64 ch = (quad_bits(a) >> (2 * s)) | (s ? (quad_bits(b) << (64 - 2 * s)) : 0ull);
+            const u64 go = ((((u64)b.z << 32) | (u64)a.z) >> s), sf = ((((u64)b.w << 32) | (u64)a.w) >> s);
+            ext = (unsigned)(ch & 0xFFFFull) | ((unsigned)(go & 0xFFull) << 16) | ((unsigned)(sf & 0xFFull) << 24);
+        }
+        trans[4 * t + c] = make_uint4(nc[c], np[c], ext, 0u);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -515,8 +528,11 @@ int sbwt_launch_build_path(const SbwtIndexView &ix, unsigned *d_col, unsigned *d
     (void)hipMemsetAsync(d_pq, 0, (size_t)sbwt_path_quads(n) * 16, stream);
     hipLaunchKernelGGL(k_path_place, dim3(g), dim3(256), 0, stream, n, buf[cur][0], buf[cur][1], pbase, succ, sch, d_pos,
                        d_col, reinterpret_cast<unsigned *>(d_pq));
-    hipLaunchKernelGGL(k_path_trans, dim3(g), dim3(256), 0, stream, ix, d_pos, d_trans);
     if (hipStreamSynchronize(stream) != hipSuccess) return -1;
+    (void)d_trans;                                      // filled by sbwt_launch_path_trans once the safe bits are final
     return 0;
+}
+void sbwt_launch_path_trans(const SbwtIndexView &ix, uint4 *d_trans, hipStream_t stream) {
+    hipLaunchKernelGGL(k_path_trans, dim3(grid_for(ix.n_nodes)), dim3(256), 0, stream, ix, ix.pos, d_trans);
 }
 

@@ -8,7 +8,7 @@
 //   [ mega     : 4 x n_mega x 8 B]   absolute (C[c] + rank_c) at every 2^31-column boundary
 //   [ col, pos : n_nodes x 4 B each ]  path order (see k_path_* in sbwt_derived.hip)
 //   [ pq       : (n/32+2) x 16 B ]   packed chars + go bits along the paths
-//   [ trans    : n_nodes x 32 B  ]   the four successors of every path position (columns, path positions)
+//   [ trans    : n_nodes x 64 B  ]   the four successors of every path position (column, path position, next 8 steps)
 //   [ pfil     : 2^log2f x 16 B  ]   probe filter (see k_pf_insert)
 //   [ stab2    : 2^log2b2 x 32 B ]   second level for 31 < k <= 63: { rest key (8 B), first column of the 31-prefix's
 //                                    interval, flags } { column, path position, -, - }
@@ -52,11 +52,14 @@ struct SbwtIndexView {
     const unsigned *col, *pos;      // path order: column at path position t, path position of column v (nullptr = none)
     const uint4 *pq;                // packed path chars: quad t>>5 = { 32 chars (2 bits each), go mask, safe mask }
     int has_safe;                   // the safe masks are filled in (k_path_safe)
+    int trans_ext;                  // run on from a transition along the 8 steps its entry quotes: 1 always, 0 never,
+                                    // -1 (default) while most runs after a transition are shorter than that (per wave)
     const uint4 *stab2;             // second-level sparse table for 31 < k <= 63 (nullptr = none): key = (first column of the
     int log2b2;                     // 31-prefix's interval, the remaining k-31 bases) -> the k-mer's column and path position
     const uint4 *pfil;              // probe filter: blocked Bloom filter over the p_filter-mers of the index (nullptr = none)
     int p_filter, log2f;            // its depth and log2 of its number of 16-byte blocks
-    const uint4 *trans;             // transition table: 2 quads per path position (successor columns, successor positions)
+    const uint4 *trans;             // transition table: 4 quads per path position, one per char: { successor column, its path
+                                    // position, its path's next 8 steps (chars | go << 16 | safe << 24), - }
     int stab_pos;                   // sparse entries are whole k-mers stored with their path position
     int debug;                      // experiments only: bit0 = skip result stores
 };
@@ -143,6 +146,7 @@ long long sbwt_sparse_scratch_bytes(long long n_nodes);
 long long sbwt_path_scratch_bytes(long long n_nodes);
 long long sbwt_path_quads(long long n_nodes);
 void sbwt_launch_path_safe(const SbwtIndexView &ix, uint4 *d_pq, hipStream_t stream);
+void sbwt_launch_path_trans(const SbwtIndexView &ix, uint4 *d_trans, hipStream_t stream);
 int sbwt_launch_build_path(const SbwtIndexView &ix, unsigned *d_col, unsigned *d_pos, uint4 *d_pq, uint4 *d_trans,
                            void *d_scratch, hipStream_t stream);
 int sbwt_launch_build_sparse(const SbwtIndexView &ix, int p_dense, int p_sparse, int log2b, uint4 *d_table,

@@ -341,8 +341,8 @@ __device__ __forceinline__ typename SearchTypes<WIDE>::pos_t quad_rank_t(const S
 //     the lane moves to its path position and resolves up to 32 following k-mers per iteration by a
 //     2-bit compare of the read against the path's chars; their answers are the contiguous run
 //     col[t+1..], copied to `out` by the wave together.  Where the read leaves the path the streaming
-//     step is one 32-byte entry of the transition table (the four successors of position t, as columns
-//     and as path positions).  A third load per iteration prefetches the next packed group of the
+//     step is one 16-byte quad of the transition table (the successor of position t by that char: column,
+//     path position and the next 8 steps of its path, so that short runs end in the same iteration).  A third load per iteration prefetches the next packed group of the
 //     read, so that 32-base windows rarely wait for a reload.
 template <bool WIDE, int WPS, bool PATH>
 __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, const uint4 *__restrict__ packed,
@@ -381,6 +381,7 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
     uint4 g0 = make_uint4(0, 0, 0, 0), g1 = make_uint4(0, 0, 0, 0);
     u64 pool_next = 0, pool_end = 0;                              // wave-uniform pool of read tickets
     unsigned c_stream = 0, c_search = 0, c_lf = 0, c_tab = 0;     // wave-uniform (scalar) work counters
+    unsigned c_iter = 0, c_short = 0;                             // PATH: iterations of this wave; runs shorter than 8 k-mers
 
     for (;;) {
         // ---- hand out reads to idle lanes from the wave's ticket pool ----
@@ -414,6 +415,12 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
         const bool trn = PATH && (mode == M_TRANS);
         const bool brg = PATH && (mode == M_BRIDGE);
         bool rknown = false;                           // PATH: this iteration's answer came with its path position (in r)
+        bool qshort = false;                           // PATH: a run of fewer than 8 k-mers ended in this iteration
+        // run on from transitions while short runs are a sizeable part of this wave's work (one lane-iteration in
+        // eight: pan-genomes; on a few strains the saved iterations do not pay for the extra instructions)
+        const bool use_q = PATH && (ix.trans_ext > 0 || (ix.trans_ext < 0 && c_short >= 8u * c_iter));
+        c_iter++;
+        int tnext = M_EXT;                             // PATH: where a transition's quoted steps already end the run
         pos_t tpos = -1;
         int seg_n = 0;                                 // PATH: k-mers i .. i+seg_n-1 are col[seg_src ..]
         unsigned seg_src = 0;
@@ -451,8 +458,8 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
                     a2 = a1 + 1;
                 } else if (trn) {
                     if (((streaming == 2 ? g0.w : g0.z) >> s) & 1u) {     // validity as in M_STREAM below
-                        a1 = ix.trans + 2 * (size_t)(unsigned)r;
-                        a2 = a1 + 1;
+                        a1 = ix.trans + (4 * (size_t)(unsigned)r + (unsigned)c);   // the quad of this char's successor
+                        a2 = a1;
                     } else {
                         ev = EV_EMIT1;
                         b = blo = i + k - 1;
@@ -561,15 +568,44 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
             r = (pos_t)(sel == 0 ? v1.x : sel == 1 ? v1.y : sel == 2 ? v1.z : v1.w);
             mode = M_EXT;
         } else if (trn && have) {
-            // successors of path position r: v1 = their columns, v2 = their path positions (SBWT.hh:562-575)
-            const unsigned nc = (c == 0 ? v1.x : c == 1 ? v1.y : c == 2 ? v1.z : v1.w);
+            // v1 = { successor column (SBWT.hh:562-575) or none, its path position, its path's next 8 steps, - }
             ev = EV_EMIT1;
-            if (nc == 0xFFFFFFFFu) {
+            if (v1.x == 0xFFFFFFFFu) {
                 b = blo = i + k - 1;
             } else {
-                res = (pos_t)nc;
-                r = (pos_t)(c == 0 ? v2.x : c == 1 ? v2.y : c == 2 ? v2.z : v2.w);
+                res = (pos_t)v1.x;
+                r = (pos_t)v1.y;
                 rknown = true;
+                // the read's next bases against the 8 steps quoted in the entry: short runs (pan-genomes branch every
+                // few k-mers) end here without a separate M_EXT iteration
+                const int P1 = poff + i + k, s1 = P1 & 31;
+                if (use_q && ((s1 != 0 && (s1 <= 24 || g1ok)) || (s1 == 0 && g1ok))) {
+                    u64 rw, rv;
+                    const u64 va = (streaming == 2) ? (((u64)g1.w << 32) | (u64)g0.w) : (((u64)g1.z << 32) | (u64)g0.z);
+                    if (s1 != 0) {
+                        rw = (quad_bits(g0) >> (2 * s1)) | (quad_bits(g1) << (64 - 2 * s1));
+                        rv = va >> s1;
+                    } else {                           // the base after P starts the next group
+                        rw = quad_bits(g1);
+                        rv = va >> 32;
+                    }
+                    const unsigned x = ((unsigned)rw ^ v1.z) & 0xFFFFu;
+                    const unsigned mm = (x | (x >> 1)) & 0x5555u;
+                    const int nm = mm ? ((__ffs((int)mm) - 1) >> 1) : 8;
+                    const unsigned okb = (unsigned)rv & (v1.z >> 16) & 0xFFu;
+                    const int nv = __ffs((int)(~okb | 0x100u)) - 1;
+                    int n2 = nm < nv ? nm : nv;
+                    bool stop2 = n2 < 8;
+                    if (n2 > m - 1 - i) { n2 = m - 1 - i; stop2 = false; }
+                    if (n2 > 31 - cnt) { n2 = 31 - cnt; stop2 = false; }
+                    if (n2 < 0) n2 = 0;
+                    seg_n = n2;
+                    seg_src = (unsigned)r + 1u;
+                    r += (pos_t)n2;
+                    c_ext += (unsigned)n2;
+                    if (stop2) tnext = (ix.has_safe && nm < nv && ((v1.z >> 24 >> nm) & 1u)) ? M_BRIDGE : M_TRANS;
+                    qshort = stop2;
+                }
             }
         } else if (brg && have) {
             // k-mer i (ending at the mismatching base) .. : if the bases after it agree with the path again, every
@@ -613,6 +649,7 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
             c_ext += (unsigned)n;
             bool sbit = false;                         // stopped at a char mismatch whose path step is substitution-safe?
             if (ix.has_safe && stopped && nm < nv) sbit = ((((((u64)v2.w << 32) | (u64)v1.w) >> sp) >> nm) & 1ull) != 0;
+            qshort = stopped && n < 8;
             if (i + n == m) mode = M_IDLE;
             else if (stopped) mode = sbit ? M_BRIDGE : M_TRANS;
         } else if (have) {
@@ -721,6 +758,9 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
         }
         c_tab = uniform32(c_tab + (unsigned)__popcll(__ballot(tabhit)));
         c_stream = uniform32(c_stream + (unsigned)__popcll(__ballot(ev == EV_EMIT1 && (strm || trn))));
+        if (PATH) {
+            c_short = uniform32(c_short + (unsigned)__popcll(__ballot(qshort)));
+        }
 
         // ---- events: results, certificates, next state ----
         int burst_hi = -1;                             // >= i: k-mers i..burst_hi are certified absent
@@ -902,7 +942,7 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
             if (i == m) {
                 mode = M_IDLE;
             } else if (ev == EV_EMIT1 && res != -1 && streaming) {
-                mode = PATH ? (rknown ? M_EXT : M_POS) : M_STREAM;   // SBWT.hh:560-
+                mode = PATH ? (rknown ? tnext : M_POS) : M_STREAM;   // SBWT.hh:560-
                 l = res;
             } else {
                 do_plan = true;                        // SBWT.hh:557-559 (with certificates)

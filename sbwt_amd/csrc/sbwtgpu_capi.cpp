@@ -88,6 +88,7 @@ static int g_variant_override = -1, g_probe_override = -1, g_debug = 0, g_derive
 // result the kernel never writes cannot inherit a correct value from an earlier launch
 static int g_poison = [] { const char *e = getenv("SBWTGPU_POISON_RESULTS"); return e ? atoi(e) : 0; }();
 static int g_probe_filter = [] { const char *e = getenv("SBWTGPU_PROBE_FILTER"); return e ? atoi(e) : 1; }();
+static int g_trans_ext = -1;    // -1: adaptive per wave, 0/1: force
 static int g_path_safe = [] { const char *e = getenv("SBWTGPU_PATH_SAFE"); return e ? atoi(e) : 1; }();
 static int g_path_order = [] { const char *e = getenv("SBWTGPU_PATH_ORDER"); return e ? atoi(e) : 1; }();
 static int g_sparse_depth = [] { const char *e = getenv("SBWTGPU_SPARSE_PRECALC"); return e ? atoi(e) : 31; }();
@@ -131,6 +132,7 @@ struct sbwtgpu_index {
         v.trans = h.has_path ? reinterpret_cast<const uint4 *>(blob + h.off_trans) : nullptr;
         v.stab_pos = h.stab_pos;
         v.has_safe = h.has_safe;
+        v.trans_ext = g_trans_ext;
         v.stab2 = h.log2b2 > 0 ? reinterpret_cast<const uint4 *>(blob + h.off_stab2) : nullptr;
         v.log2b2 = (int)h.log2b2;
         v.pfil = h.p_filter > 0 ? reinterpret_cast<const uint4 *>(blob + h.off_pfil) : nullptr;
@@ -153,6 +155,7 @@ int sbwtgpu_set_tuning(const char *key, int64_t value) {
     if (!strcmp(key, "derive_ssup")) { g_derive_ssup = (int)value; return SBWTGPU_OK; }
     if (!strcmp(key, "poison_results")) { g_poison = (int)value; return SBWTGPU_OK; }
     if (!strcmp(key, "probe_filter")) { g_probe_filter = (int)value; return SBWTGPU_OK; }   // indexes created afterwards
+    if (!strcmp(key, "trans_ext")) { g_trans_ext = (int)value; return SBWTGPU_OK; }
     if (!strcmp(key, "path_safe")) { g_path_safe = (int)value; return SBWTGPU_OK; }   // indexes created afterwards
     if (!strcmp(key, "path_order")) { g_path_order = (int)value; return SBWTGPU_OK; }   // indexes created afterwards
     if (!strcmp(key, "sparse_depth")) {      // takes effect for indexes created afterwards
@@ -271,7 +274,7 @@ int sbwtgpu_index_create(const sbwtgpu_index_desc *d, int device, sbwtgpu_index 
         h.off_pos = align256(h.off_col + (n + 4) * 4);
         h.off_pq = align256(h.off_pos + (n + 4) * 4);
         h.off_trans = align256(h.off_pq + sbwt_path_quads(n) * 16);
-        h.blob_bytes = align256(h.off_trans + (n + 1) * 32);
+        h.blob_bytes = align256(h.off_trans + (n + 1) * 64);
     }
     idx->device = device;
 
@@ -446,6 +449,10 @@ int sbwtgpu_index_create(const sbwtgpu_index_desc *d, int device, sbwtgpu_index 
                 if ((e = hipDeviceSynchronize()) != hipSuccess) break;
                 h.has_safe = 1;
             }
+        }
+        if (h.has_path) {                               // last: the transition entries quote the final path chars / safe bits
+            SbwtIndexView v3 = idx->view();
+            sbwt_launch_path_trans(v3, reinterpret_cast<uint4 *>(idx->blob + h.off_trans), 0);
         }
         if ((e = hipGetLastError()) != hipSuccess) break;
         e = hipDeviceSynchronize();

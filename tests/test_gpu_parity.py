@@ -570,3 +570,22 @@ def test_many_short_reads_of_mixed_lengths(gpu, genome_case):
     assert np.array_equal(got, oracle_batch(orc, bases, off, True))
     got2, _ = idx.search(bases, off)
     assert np.array_equal(got2, oracle_batch(orc, bases, off, False))
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_transition_quoted_steps_on_and_off(gpu, genome_case, mode):
+    # the 8 path steps quoted in a transition entry let short runs end in the transition's own iteration; the
+    # kernel decides per wave, here both settings are forced
+    genomes, orc = genome_case
+    idx = gpu_index_from_oracle(orc)
+    bases, off = synth.sample_reads(genomes, 3000, 150, 0.02, 123)
+    bases = synth.inject(bases, 50, ord("N"), 6)
+    bases = synth.inject(bases, 50, ord("c"), 7)
+    capi.set_tuning("trans_ext", mode)
+    try:
+        got, _ = idx.streaming_search(bases, off)
+        got2, _ = idx.search(bases, off)
+    finally:
+        capi.set_tuning("trans_ext", -1)
+    assert np.array_equal(got, oracle_batch(orc, bases, off, True))
+    assert np.array_equal(got2, oracle_batch(orc, bases, off, False))

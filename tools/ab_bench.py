@@ -66,6 +66,7 @@ times = {tuple(c): [] for c in configs}
 for rnd in range(rounds + 1):
     for c in configs:
         capi.set_tuning("search_variant", c[0]); capi.set_tuning("probe_len", c[1]); capi.set_tuning("debug", c[2] if len(c) > 2 else 0)
+        capi.set_tuning("trans_ext", c[6] if len(c) > 6 else -1)      # [6]: run on from transitions (-1 = as the index says)
         idx = index_for(c[3] if len(c) > 3 else 31, c[4] if len(c) > 4 else 1, c[5] if len(c) > 5 else 1)
         if rnd == 0:
             d_out.fill_(-7)        # never-written results must not inherit the previous config's values
