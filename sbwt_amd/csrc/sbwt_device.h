@@ -120,7 +120,11 @@ struct SbwtWorkHeader {
     unsigned long long n_tab_hit;   // prefix-table lookups that returned a non-empty interval
     unsigned long long n_ext;       // k-mers answered along path runs (k_search_cert<PATH>), not counted in n_stream
     unsigned long long n_bridge;    // substitutions bridged by the path's safe bits (no probes)
-    unsigned long long pad[24];
+    // set by k_check_uniform before the search: all reads have one length and the result ranges one stride
+    // (u_bad == 0): read r starts at u_read0 + r*u_len, its results at u_out0 + r*u_stride -- no offset fetch needed
+    unsigned long long u_bad;
+    long long u_read0, u_len, u_out0, u_stride;
+    unsigned long long pad[19];
 };
 static_assert(sizeof(SbwtWorkHeader) == 256, "workspace header is 256 bytes");
 
