@@ -1,0 +1,85 @@
+"""GPU fuzz: random indexes (k, genome shapes with repeats / related strains / tiny alphabets) and random reads
+(substitutions, N, lower case, ragged lengths); the product kernel (variant 2, and 1) must equal the reference-order
+kernel (variant 0) bit for bit, and a sample must equal the oracle.  Usage: python tools/fuzz_gpu.py [seconds]"""
+import os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+from sbwt_amd import capi, hostlib, synth
+from oracle import OracleIndex
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+capi.set_tuning("poison_results", 1)
+t_end = time.time() + budget
+case = 0
+rng = np.random.default_rng(int(os.environ.get("SEED", 1)))
+while time.time() < t_end:
+    case += 1
+    k = int(rng.choice([4, 7, 12, 16, 21, 30, 31, 32, 33, 40, 63]))
+    shape = int(rng.integers(0, 5))
+    glen = int(rng.integers(2_000, 120_000))
+    g0 = synth.random_genome(glen, int(rng.integers(1, 1 << 30)))
+    if shape == 0:
+        genomes = [g0]
+    elif shape == 1:
+        genomes = [g0, synth.mutate(g0, float(rng.choice([0.001, 0.01, 0.05])), int(rng.integers(1, 1 << 30)))]
+    elif shape == 2:      # tandem repeats and a low-complexity stretch
+        unit = g0[: int(rng.integers(3, 40))]
+        genomes = [np.concatenate([g0[:500], np.tile(unit, 60), g0[500:1500], np.frombuffer(b"AC" * 200, dtype=np.uint8), g0[1500:]])]
+    elif shape == 3:      # several short sequences (many dummy nodes)
+        genomes = [g0[i:i + int(rng.integers(k, 4 * k + 10))].copy() for i in range(0, min(glen, 20_000), 997)]
+    else:                 # star of related genomes
+        genomes = [g0] + [synth.mutate(g0, 0.02, int(rng.integers(1, 1 << 30))) for _ in range(4)]
+    genomes = [g for g in genomes if len(g) >= k + 2]
+    ssup = bool(rng.integers(0, 2))
+    rc = bool(rng.integers(0, 2))
+    bits = hostlib.build_bits([g.tobytes() for g in genomes], k, rc, ssup, n_threads=4)
+    idx = capi.Index.create(bits.cols[0], bits.cols[1], bits.cols[2], bits.cols[3], bits.ssup if ssup else None,
+                            bits.n_nodes, k, bits.n_kmers, int(rng.choice([0, 0, 2, min(k, 8)])))
+    # reads
+    nr = int(rng.integers(200, 4000))
+    if rng.integers(0, 2):
+        L = int(rng.integers(max(k - 2, 1), 4 * k + 60))
+        long_enough = [g for g in genomes if len(g) >= L]
+        if not long_enough:
+            continue
+        bases, off = synth.sample_reads(long_enough, nr, L, float(rng.choice([0, 0.005, 0.02, 0.1])), int(rng.integers(1, 1 << 30)))
+    else:                 # ragged lengths
+        cat = np.concatenate(genomes)
+        lens = np.minimum(rng.integers(0, 3 * k + 40, size=nr), len(cat))
+        st = (rng.random(nr) * (len(cat) - lens + 1)).astype(np.int64)
+        off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+        bases = np.empty(int(off[-1]), dtype=np.uint8)
+        for r in range(nr):
+            bases[off[r]:off[r + 1]] = cat[st[r]:st[r] + lens[r]]
+        flip = rng.random(len(bases)) < 0.01
+        bases[flip] = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=int(flip.sum()))]
+    if len(bases) > 100:
+        bases = synth.inject(bases, int(rng.integers(0, 30)), ord("N"), int(rng.integers(1, 1 << 30)))
+        bases = synth.inject(bases, int(rng.integers(0, 30)), int(rng.choice(list(b"acgtn"))), int(rng.integers(1, 1 << 30)))
+    res = {}
+    for v in (0, 1, 2):
+        capi.set_tuning("search_variant", v)
+        for te in ((-1, 1) if v == 2 else (-1,)):
+            capi.set_tuning("trans_ext", te)
+            a = idx.streaming_search(bases, off)[0] if ssup else None
+            b = idx.search(bases, off)[0]
+            res[(v, te)] = (a, b)
+    capi.set_tuning("trans_ext", -1)
+    ref = res[(0, -1)]
+    for key, (a, b) in res.items():
+        if ssup and not np.array_equal(a, ref[0]):
+            print("MISMATCH streaming", key, "case", case, "k", k, "shape", shape, "ssup", ssup, "rc", rc); sys.exit(1)
+        if not np.array_equal(b, ref[1]):
+            print("MISMATCH search", key, "case", case, "k", k, "shape", shape, "ssup", ssup, "rc", rc); sys.exit(1)
+    if case % 10 == 1 and bits.n_nodes < 400_000:     # the oracle on a sample
+        orc = OracleIndex.from_bits(bits.cols[0], bits.cols[1], bits.cols[2], bits.cols[3], bits.ssup if ssup else None,
+                                    bits.n_nodes, k, bits.n_kmers, 0)
+        for r in range(min(nr, 40)):
+            s = bases[off[r]:off[r + 1]].tobytes()
+            want = orc.streaming_search(s) if ssup else orc.search_all(s)
+            oo = np.concatenate([[0], np.cumsum(np.maximum(np.diff(off) - k + 1, 0))])
+            got = (ref[0] if ssup else ref[1])[oo[r]:oo[r + 1]]
+            if not np.array_equal(got, want):
+                print("MISMATCH vs oracle case", case, "read", r); sys.exit(1)
+print("fuzz ok:", case, "cases")
