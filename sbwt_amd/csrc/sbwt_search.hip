@@ -670,6 +670,9 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
             bool sbit = false;                         // stopped at a char mismatch whose path step is substitution-safe?
             if (ix.has_safe && stopped && nm < nv) sbit = ((((((u64)v2.w << 32) | (u64)v1.w) >> sp) >> nm) & 1ull) != 0;
             qshort = stopped && n < 8;
+#ifdef SBWT_STATS
+            if (!stopped && i + n != m) atomicAdd(&ws->pad[17], 1ull);      // limited by the 32-step window / descriptor size
+#endif
             if (i + n == m) mode = M_IDLE;
             else if (stopped) mode = sbit ? M_BRIDGE : M_TRANS;
         } else if (have) {
@@ -875,7 +878,6 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
                         wl[u] = on ? (int)((ds.z >> 16) & 0xFFu) - j0 : 0;      // results of this lane's pair that go to `out`
                         tl[u] = on ? dt - j0 : 0;                                 // ... that exist at all
                         dd[u] = (i64)((u64)ds.x | ((u64)ds.y << 32)) + j0;
-                        if (ix.debug & 4) dd[u] &= 0xFFFE;            // timing experiment: all stores into one small region
                         // both sources are read unconditionally (clamped addresses) and selected afterwards: loads
                         // under divergent branches would be waited for one by one
                         const bool isc = ds.w != 0xFFFFFFFFu && on;
