@@ -272,6 +272,9 @@ def main() -> int:
             "traffic": None,
             "kernel_ms": kernel_ms,
             "algorithmic_bytes_per_launch": alg_bytes,
+            "pricing": ("per operation of the path-order algorithm: run k-mer 13.5 B, transition 41 B, walk start 16 B + p, "
+                        "interval update 144 B, other result 8 B (DESIGN.md section 4); the same work at SURVEY 8d's 89 B per "
+                        "streaming step is survey_8d_priced_*") if n_ext else "SURVEY 8d per-operation figures",
             "survey_8d_priced_bytes_per_launch": survey_priced_bytes,
             "survey_8d_priced_GBps": survey_priced_bytes / (kernel_ms * 1e-3) / 1e9,
             "nominal_bytes_per_launch_survey_8d": nominal_bytes,
