@@ -29,11 +29,9 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
-
-from sbwt_amd import capi, hostlib, synth  # noqa: E402
-from sbwt_amd import dist as sdist  # noqa: E402
+# torch and the HIP library are imported in main(), AFTER the decision whether this process is a launcher
+# (python bench.py --gpus N without a launcher starts the N ranks itself, before anything touches the GPU)
+torch = dist = capi = hostlib = synth = sdist = None
 
 K = 30                          # overridden by --config (3: k=31 pan-genome, 5: k=63 non-streaming)
 PRECALC = 8
@@ -99,6 +97,159 @@ def gpu_reads(genomes, n_reads: int, seed: int, dev: torch.device) -> torch.Tens
     return out
 
 
+KERNEL_SOURCES = ("sbwt_search.hip", "sbwt_api_kernels.hip", "sbwt_kernels_common.h", "sbwt_device.h")
+
+
+def kernel_source_sha16() -> str:
+    """Identifies the kernels a profile was taken on: sha256 of the kernel sources, first 16 hex digits."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in KERNEL_SOURCES:
+        h.update(open(os.path.join(ROOT, "sbwt_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def load_traffic(config: int, n_reads: int):
+    """profiles/traffic.json entry for this workload, if it was measured on the current kernel sources."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        tj = json.load(open(path))
+    except Exception:
+        return None
+    ent = tj.get("config%d" % config) if isinstance(tj.get("config%d" % config), dict) else None
+    if ent is None or ent.get("kernel_source_sha16") != kernel_source_sha16() or ent.get("reads_per_gpu") != n_reads:
+        return None
+    return ent
+
+
+RANK_B_SURVEY = 72              # SURVEY 8d: one rank = 8 B count + 64 B block bits
+RANK_B_LAYOUT = 8 + 1 + 16 + 8  # this layout: pos + symbol + one 16-byte quad {bits, count} + result
+
+
+def rank_bench(args, rank: int, world: int, local_rank: int, dev) -> int:
+    """bench.py --kernel rank: batched SubsetMatrixRank::rank (SubsetMatrixRank.hh:31-37) on uniform random
+    (pos, symbol) pairs, inputs and outputs resident in HBM.  Two images: four random bit vectors of --rank-columns
+    columns (HBM resident, the headline) and the config-2 index (cache resident).  Every rank builds its own images
+    and ranks its own queries (replicas; no collective)."""
+    stream = torch.cuda.current_stream().cuda_stream
+    Q = args.rank_queries
+    cores = effective_cores()
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    acgt = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(7 + rank)
+
+    def measure(index, n_cols, cols, label):
+        d_pos = torch.randint(0, n_cols + 1, (Q,), dtype=torch.int64, device=dev, generator=gen)
+        d_sym = acgt[torch.randint(0, 4, (Q,), device=dev, generator=gen)]
+        d_out = torch.empty(Q, dtype=torch.int64, device=dev)
+
+        def step():
+            capi._check(capi.lib().sbwtgpu_rank_dev(index.handle, d_pos.data_ptr(), d_sym.data_ptr(), Q, d_out.data_ptr(),
+                                                    stream))
+        for _ in range(args.warmup):
+            step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for a, b in evs:
+            a.record()
+            step()
+            b.record()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            elapsed = sdist.max_over_ranks(elapsed, dev)
+        kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
+        res = {"label": label, "columns": n_cols, "image_bytes": index.blob_bytes, "queries_per_gpu": Q,
+               "ms_per_step": elapsed / args.steps * 1e3, "kernel_ms": kernel_ms,
+               "ranks_per_s": Q * world * args.steps / elapsed, "kernel_only_ranks_per_s": Q / (kernel_ms * 1e-3)}
+        cpu = None
+        if rank == 0 and not args.no_cpu_baseline:
+            from oracle import OracleIndex
+            orc = OracleIndex.from_bits(cols[0], cols[1], cols[2], cols[3], None, n_cols, 1, 0, 0)
+            sample = min(Q, 4_000_000 * cores)
+            h_pos = d_pos[:sample].cpu().numpy()
+            h_sym = d_sym[:sample].cpu().numpy()
+            best = None
+            for _ in range(2):
+                want, secs = orc.batch_rank(h_pos, h_sym, cores)
+                best = secs if best is None else min(best, secs)
+            parity = bool(np.array_equal(want, d_out[:sample].cpu().numpy()))
+            cpu = {"value": sample / best, "unit": "ranks/s", "cores": cores, "kind": "port",
+                   "sample": "first %d of the same (pos, symbol) pairs, oracle rank (rank_support_v5-shaped directory), "
+                             "%d threads over contiguous ranges, slowest thread's loop time, best of 2" % (sample, cores),
+                   "gpu_output_bit_identical_on_sample": parity}
+            if not parity:
+                raise SystemExit("PARITY FAILURE: GPU ranks differ from the oracle (%s)" % label)
+        return res, cpu
+
+    # (1) HBM resident: four unrelated random rows (SubsetMatrixRank as a stand-alone structure)
+    n_cols = args.rank_columns
+    rng = np.random.Generator(np.random.PCG64(70 + rank))
+    nw = (n_cols + 63) // 64
+    cols = [rng.integers(0, 2**64, size=nw, dtype=np.uint64) for _ in range(4)]
+    t0 = time.time()
+    big = capi.Index.create(cols[0], cols[1], cols[2], cols[3], None, n_cols, 1, 0, 0, None, device=local_rank)
+    log(f"rank image: {n_cols} columns, {big.blob_bytes / 1e6:.0f} MB ({time.time() - t0:.1f} s)")
+    hbm, cpu_hbm = measure(big, n_cols, cols, "four random bit vectors, HBM resident")
+    big.close()
+    del cols
+    # (2) cache resident: the config-2 index
+    genomes = synth.coli3_like(args.genome_len)
+    bits = hostlib.build_bits([g.tobytes() for g in genomes], 30, False, True, n_threads=cores)
+    small = capi.Index.create(bits.cols[0], bits.cols[1], bits.cols[2], bits.cols[3], bits.ssup, bits.n_nodes, 30,
+                              bits.n_kmers, PRECALC, None, device=local_rank)
+    cache, cpu_cache = measure(small, bits.n_nodes, bits.cols, "config-2 index (coli3-like, k=30), cache resident")
+    if rank == 0:
+        ach = RANK_B_SURVEY * Q / (hbm["kernel_ms"] * 1e-3) / 1e9
+        result = {
+            "metric": "ranks/sec (whole node), batched SubsetMatrixRank::rank, plain-matrix",
+            "value": hbm["ranks_per_s"], "unit": "ranks/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": hbm["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u64", "data": "synthetic",
+            "config": {"workload": "rank kernel: %d uniform random (pos, symbol) pairs per GPU on four random bit vectors "
+                                   "of %d columns (image %d bytes, HBM resident)" % (Q, n_cols, hbm["image_bytes"]),
+                       "parallelism": "replicas x%d (independent queries, no collective)" % world},
+            "roofline": {"bound": "hbm", "kernel": "k_rank4", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": ach / HBM_PEAK_GBPS, "traffic": None, "kernel_ms": hbm["kernel_ms"],
+                         "algorithmic_bytes_per_launch": RANK_B_SURVEY * Q,
+                         "pricing": "SURVEY 8d: 72 B per rank (8 B count + 64 B block bits); this layout moves %d B per "
+                                    "rank (pos 8 + symbol 1 + one 16-byte quad + result 8): layout_priced_GBps"
+                                    % RANK_B_LAYOUT,
+                         "layout_priced_GBps": RANK_B_LAYOUT * Q / (hbm["kernel_ms"] * 1e-3) / 1e9,
+                         "kernel_only_ranks_per_s": hbm["kernel_only_ranks_per_s"]},
+            "cache_resident": cache,
+        }
+        if cpu_hbm:
+            result["cpu_baseline"] = cpu_hbm
+            result["cache_resident"]["cpu_baseline"] = cpu_cache
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
+def launch_ranks(n: int) -> int:
+    """One process per GPU through torch.distributed.run (the command line the driver itself uses), as a CHILD
+    process; its exit code is ours."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log("launching %d ranks: %s" % (n, " ".join(cmd)))
+    return subprocess.call(cmd)
+
+
 def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -112,8 +263,37 @@ def main() -> int:
                     help="BASELINE.json config: 2 = coli3-like k=30 (headline, default); 3 = pan-genome-like "
                          "k=31 (65 genomes, 100 M reads unless --reads); 5 = k=63 without streaming support")
     ap.add_argument("--derived", type=int, default=64, help="config 3: number of derived genomes")
+    ap.add_argument("--kernel", choices=["search", "rank"], default="search",
+                    help="search (default): the headline streaming-search pass; rank: the batched "
+                         "SubsetMatrixRank::rank kernel (SubsetMatrixRank.hh:31-37) on random (pos, symbol) pairs")
+    ap.add_argument("--rank-queries", type=int, default=1 << 30, help="--kernel rank: (pos, symbol) pairs per launch and GPU")
+    ap.add_argument("--rank-columns", type=int, default=(1 << 31) - 128,
+                    help="--kernel rank: columns of the four random bit vectors of the HBM-resident case (the image is "
+                         "1 byte per column: the default 2 GiB defeats the 256 MB Infinity Cache); the config-2 index "
+                         "(12.8 MB of blocks, cache resident) is measured beside it")
+    ap.add_argument("--check-ranks", action="store_true",
+                    help="every rank's first 2000 reads are compared with the oracle on rank 0 (rank_parity in the JSON "
+                         "line); used by the N > 1 tests")
     args = ap.parse_args()
-    global K
+
+    # ---- launcher: `python bench.py --gpus N` without RANK in the environment starts the N ranks itself.
+    # Decided here, before torch / HIP are even imported: a process that has touched the GPU is never re-executed.
+    if args.gpus > 1 and "RANK" not in os.environ:
+        return launch_ranks(args.gpus)
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    if world != args.gpus:
+        log(f"error: --gpus {args.gpus} but WORLD_SIZE={world}: start {args.gpus} ranks "
+            f"(python bench.py --gpus {args.gpus} does it itself when RANK is unset)")
+        return 2
+
+    global K, torch, dist, capi, hostlib, synth, sdist
+    import torch as _torch
+    import torch.distributed as _dist
+    from sbwt_amd import capi as _capi, hostlib as _hostlib, synth as _synth, dist as _sdist
+    torch, dist, capi, hostlib, synth, sdist = _torch, _dist, _capi, _hostlib, _synth, _sdist
+
     streaming = True
     if args.config == 3:
         K = 31
@@ -123,11 +303,6 @@ def main() -> int:
         K = 63
         streaming = False
 
-    rank = int(os.environ.get("RANK", 0))
-    world = int(os.environ.get("WORLD_SIZE", 1))
-    local_rank = int(os.environ.get("LOCAL_RANK", 0))
-    if world != args.gpus:
-        log(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the search path has no CPU fallback")
     # test hooks: run several ranks on one GPU (SBWT_BENCH_FORCE_DEVICE) over gloo (SBWT_BENCH_BACKEND) to
@@ -143,6 +318,9 @@ def main() -> int:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+
+    if args.kernel == "rank":
+        return rank_bench(args, rank, world, local_rank, dev)
 
     # ---- index: built once on rank 0 (host sort-based builder), replicated by one broadcast ----
     t0 = time.time()
@@ -285,14 +463,41 @@ def main() -> int:
     }
     if t_bcast is not None:
         result["index_broadcast_s"] = t_bcast
-    traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(traffic_file) and args.config == 2 and n_reads == 10_000_000:   # measured on this workload
-        try:
-            tj = json.load(open(traffic_file))
-            result["roofline"]["traffic"] = tj.get("hbm_bytes_per_launch")
-            result["roofline"]["traffic_source"] = tj.get("source")
-        except Exception:
-            pass
+    # HBM-side bytes per launch from the PMC counters: measured by tools/profile.sh in separate rocprofv3 passes (a
+    # bench run cannot collect counters on itself) and attached ONLY while the profile belongs to the kernels that
+    # just ran (same source hash, same workload); otherwise null, never a stale number
+    tj = load_traffic(args.config, n_reads)
+    if tj is not None:
+        result["roofline"]["traffic"] = tj.get("hbm_bytes_per_launch")
+        result["roofline"]["traffic_source"] = tj.get("source")
+    result["roofline"]["kernel_source_sha16"] = kernel_source_sha16()
+
+    # ---- N > 1 tests: every rank's first reads against the oracle (rank 0 holds the bits) ----
+    if args.check_ranks:
+        sample = min(n_reads, 2000)
+        mine_b = d_bases[: sample * READ_LEN].contiguous()
+        mine_o = d_out[: sample * m].contiguous()
+        if world > 1:
+            gb = [torch.empty_like(mine_b) for _ in range(world)]
+            go = [torch.empty_like(mine_o) for _ in range(world)]
+            dist.all_gather(gb, mine_b)
+            dist.all_gather(go, mine_o)
+        else:
+            gb, go = [mine_b], [mine_o]
+        if rank == 0:
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            from oracle import OracleIndex
+            orc = OracleIndex.from_bits(bits.cols[0], bits.cols[1], bits.cols[2], bits.cols[3], bits.ssup, bits.n_nodes,
+                                        K, bits.n_kmers, PRECALC)
+            roff = np.arange(sample + 1, dtype=np.int64) * READ_LEN
+            ooff = np.arange(sample + 1, dtype=np.int64) * m
+            par = []
+            for r in range(world):
+                want, _ = orc.batch_search(gb[r].cpu().numpy(), roff, ooff, effective_cores())
+                par.append(bool(np.array_equal(want, go[r].cpu().numpy())))
+            result["rank_parity"] = par
+            if world > 1:    # the ranks searched different reads
+                result["rank_reads_differ"] = bool(not torch.equal(gb[0], gb[1]))
 
     # ---- CPU baseline (restated reference CPU path = the oracle), rank 0 at N=1 only ----
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -89,6 +89,8 @@ int         sbwtgpu_device_count(int *count);
  *   "sparse_depth"    depth of the sparse (hashed) prefix table, 0 = none, default 31 (capped at k)
  *   "probe_filter"    1 (default): Bloom filter over the probe_len-mers of the index for the certificate probes
  *   "path_order"      1 (default): path order + transition table (32-bit indexes with suffix-group marks)
+ *   "force_mega"      1: rank-only images (arbitrary bit vectors) store their block counts relative to a 64-bit base as
+ *                     images whose counts pass 2^32 do (tests of that layout at small sizes); default 0
  *   "path_safe"       1 (default): substitution-safe bits along the paths (k <= 31; SBWTGPU_PATH_SAFE) */
 int         sbwtgpu_set_tuning(const char *key, int64_t value);
 
@@ -117,7 +119,8 @@ int  sbwtgpu_index_adopt(const void *header, int64_t header_bytes, void *dev_blo
                          int device, sbwtgpu_index **out);
 /* Single-process form used by the C++ CLI (--gpus N): replicates `root` onto the listed
  * devices with one RCCL ncclBroadcast; out[i] receives the handle for devs[i] (out[i] == root
- * where devs[i] is the root's device). */
+ * where devs[i] is the root's device).  devs[] may name a device more than once: the image is sent once
+ * per distinct device and the duplicates receive the SAME handle (destroy every distinct handle once). */
 int  sbwtgpu_index_bcast(sbwtgpu_index *root, int n_dev, const int *devs, sbwtgpu_index **out);
 
 /* ---- queries, host buffers ---- */
@@ -143,6 +146,16 @@ int  sbwtgpu_update_interval_batch(const sbwtgpu_index *idx, const char *bases, 
 /* SBWT::forward(node, c) (SBWT.hh:368-381) for n (node, sym) pairs. */
 int  sbwtgpu_forward_batch(const sbwtgpu_index *idx, const int64_t *node, const char *sym, int64_t n,
                            int64_t *out);
+/* SBWT::partial_search(input, len) (SBWT.hh:525-537) for n queries: query q = bases[off[q] .. off[q+1]); first/second
+ * receive the interval of the longest matched prefix (every char upper-cased first, :529), matched its length. */
+int  sbwtgpu_partial_search_batch(const sbwtgpu_index *idx, const char *bases, const int64_t *off, int64_t n,
+                                  int64_t *first, int64_t *second, int64_t *matched);
+/* SBWT::get_kmer / get_kmer_fast (SBWT.hh:700-746) for n columns: out[q*k .. q*k+k) = the k-mer of column
+ * colex_rank[q] ('$'-padded on the left for dummy columns), not NUL-terminated. */
+int  sbwtgpu_get_kmer_batch(const sbwtgpu_index *idx, const int64_t *colex_rank, int64_t n, char *out);
+/* SubsetMatrixSelectSupport::select(j, c) (SubsetMatrixSelectSupport.hh:27-33) for n (j, sym) pairs: the column
+ * holding the j-th set bit (1-based) of row sym; non-ACGT => 0.  j must be in [1, ones of the row]. */
+int  sbwtgpu_select_batch(const sbwtgpu_index *idx, const int64_t *j, const char *sym, int64_t n, int64_t *out);
 
 /* ---- queries, device buffers (asynchronous on `stream`) ----
  * The device entry points cannot look at the offsets: the caller guarantees that read_off/out_off are
@@ -201,7 +214,9 @@ int  sbwtgpu_search_text_batch(const sbwtgpu_index *idx, const char *bases, cons
                                int64_t n_reads, int streaming, char **text, int64_t *text_bytes,
                                int64_t *n_queries);
 void sbwtgpu_free_host(void *p);
-/* sbwtgpu_search_text_batch keeps its pinned staging and device buffers for the next call; this frees them. */
+/* sbwtgpu_search_text_batch keeps its pinned staging and device buffers for the next call, and every host thread
+ * keeps one small (1 MiB) pinned + device buffer pair and a stream per device for small host-buffer calls (the
+ * reference's scalar API arrives as batches of one); this frees the parked buffers and the calling thread's. */
 void sbwtgpu_release_cached_buffers(void);
 
 #ifdef __cplusplus

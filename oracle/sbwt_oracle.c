@@ -522,6 +522,71 @@ double orc_batch_search(const orc_index *idx, const char *bases, const int64_t *
     return mx;
 }
 
+/* SBWT::get_kmer, SBWT.hh:700-725: the k-mer of column colex_rank, spelled backwards one incoming edge at a
+ * time; the step backward is the reference's own galloping search on rank() (:713-720).  buf gets k chars, no NUL. */
+void orc_get_kmer(const orc_index *idx, int64_t colex_rank, char *buf) {
+    const int64_t k = idx->k, n = idx->n_nodes;
+    for (int64_t i = 0; i < k; i++) {
+        if (colex_rank == 0) {
+            buf[k - 1 - i] = '$';
+        } else {
+            int64_t char_idx = 0;
+            while (char_idx + 1 < 4 && colex_rank >= idx->C[char_idx + 1]) char_idx++;
+            char c = IDX_TO_DNA[char_idx];
+            buf[k - 1 - i] = c;
+            int64_t char_rel_rank = colex_rank - idx->C[char_idx];
+            int64_t p = 0, step = n;
+            while (step > 0) {
+                while (p + step <= n && orc_rank(idx, p + step, c) <= char_rel_rank) p += step;
+                step /= 2;
+            }
+            colex_rank = p;
+        }
+    }
+}
+
+/* SubsetMatrixSelectSupport::select(pos, c), SubsetMatrixSelectSupport.hh:27-33 with sdsl select_1 semantics
+ * [UPSTREAM-KNOWLEDGE: select(j) = index of the j-th set bit, j >= 1]; non-ACGT -> 0.  Linear scan: test sizes only. */
+int64_t orc_select(const orc_index *idx, int64_t j, char c) {
+    int ci = dna_to_idx(c);
+    if (ci < 0) return 0;
+    int64_t seen = 0;
+    for (int64_t i = 0; i < idx->n_nodes; i++)
+        if (orc_bitvec_get(&idx->col[ci], i) && ++seen == j) return i;
+    return -1;
+}
+
+/* ---- batched rank driver (bench.py --kernel rank cpu_baseline leg, rank parity tests) ----
+ * out[i] = SubsetMatrixRank::rank(pos[i], sym[i]) (SubsetMatrixRank.hh:31-37) with n_threads pthreads over
+ * contiguous ranges; returns the slowest thread's wall time of its loop. */
+typedef struct { const orc_index *idx; const int64_t *pos; const char *sym; int64_t i0, i1; int64_t *out; double secs; } rank_job;
+
+static void *rank_worker(void *arg) {
+    rank_job *jb = (rank_job *)arg;
+    double t0 = now_sec();
+    for (int64_t i = jb->i0; i < jb->i1; i++) jb->out[i] = orc_rank(jb->idx, jb->pos[i], jb->sym[i]);
+    jb->secs = now_sec() - t0;
+    return NULL;
+}
+
+double orc_batch_rank(const orc_index *idx, const int64_t *pos, const char *sym, int64_t n, int64_t *out,
+                      int n_threads) {
+    if (n_threads < 1) n_threads = 1;
+    if (n_threads > 256) n_threads = 256;
+    pthread_t th[256];
+    rank_job jobs[256];
+    for (int t = 0; t < n_threads; t++) {
+        jobs[t] = (rank_job){idx, pos, sym, n * t / n_threads, n * (t + 1) / n_threads, out, 0.0};
+        pthread_create(&th[t], NULL, rank_worker, &jobs[t]);
+    }
+    double mx = 0;
+    for (int t = 0; t < n_threads; t++) {
+        pthread_join(th[t], NULL);
+        if (jobs[t].secs > mx) mx = jobs[t].secs;
+    }
+    return mx;
+}
+
 void orc_count_work(const orc_index *idx, const char *bases, const int64_t *read_off,
                     int64_t n_reads, int64_t *n_stream_steps, int64_t *n_searches,
                     int64_t *n_lf_steps) {

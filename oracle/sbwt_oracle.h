@@ -106,6 +106,15 @@ int64_t orc_print_vector(const int64_t *v, int64_t n, char *buf);
 double orc_batch_search(const orc_index *idx, const char *bases, const int64_t *read_off,
                         int64_t n_reads, int64_t *out, const int64_t *out_off, int n_threads);
 
+/* SBWT.hh:700-725: writes the k chars of column colex_rank's k-mer ('$' for dummy positions), no NUL. */
+void    orc_get_kmer(const orc_index *idx, int64_t colex_rank, char *buf);
+/* SubsetMatrixSelectSupport.hh:27-33: column of the j-th (1-based) set bit of row c; non-ACGT -> 0; -1 if j too large. */
+int64_t orc_select(const orc_index *idx, int64_t j, char c);
+
+/* out[i] = orc_rank(pos[i], sym[i]) over n_threads pthreads; returns the slowest thread's loop time (seconds). */
+double orc_batch_rank(const orc_index *idx, const int64_t *pos, const char *sym, int64_t n, int64_t *out,
+                      int n_threads);
+
 /* Work accounting for the roofline's algorithmic bytes: replays the reference algorithm on
  * the batch and counts (a) streaming one-step extensions taken, (b) full search() calls,
  * (c) LF steps (interval updates actually executed inside update_sbwt_interval). */

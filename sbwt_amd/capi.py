@@ -33,6 +33,7 @@ EXPORTED_SYMBOLS = [
     "sbwtgpu_index_export_header", "sbwtgpu_index_blob", "sbwtgpu_index_copy_blob", "sbwtgpu_index_adopt", "sbwtgpu_index_bcast",
     "sbwtgpu_rank_batch", "sbwtgpu_streaming_search_batch", "sbwtgpu_search_batch",
     "sbwtgpu_update_interval_batch", "sbwtgpu_forward_batch",
+    "sbwtgpu_partial_search_batch", "sbwtgpu_get_kmer_batch", "sbwtgpu_select_batch",
     "sbwtgpu_search_workspace_bytes", "sbwtgpu_streaming_search_dev", "sbwtgpu_search_dev",
     "sbwtgpu_rank_dev", "sbwtgpu_encode_bases_dev", "sbwtgpu_search_encoded_dev",
     "sbwtgpu_workspace_status", "sbwtgpu_workspace_stats",
@@ -99,6 +100,9 @@ def lib() -> C.CDLL:
     L.sbwtgpu_search_batch.argtypes = [vp, vp, vp, i64, vp, vp]
     L.sbwtgpu_update_interval_batch.argtypes = [vp, vp, vp, i64, vp, vp]
     L.sbwtgpu_forward_batch.argtypes = [vp, vp, vp, i64, vp]
+    L.sbwtgpu_partial_search_batch.argtypes = [vp, vp, vp, i64, vp, vp, vp]
+    L.sbwtgpu_get_kmer_batch.argtypes = [vp, vp, i64, vp]
+    L.sbwtgpu_select_batch.argtypes = [vp, vp, vp, i64, vp]
     L.sbwtgpu_search_workspace_bytes.argtypes = [i64]
     L.sbwtgpu_search_workspace_bytes.restype = i64
     L.sbwtgpu_streaming_search_dev.argtypes = [vp, vp, i64, vp, i64, vp, vp, vp, i64, vp]
@@ -293,6 +297,30 @@ class Index:
         sym = np.ascontiguousarray(sym, dtype=np.uint8)
         out = np.empty(len(node), dtype=np.int64)
         _check(lib().sbwtgpu_forward_batch(self._h, node.ctypes.data, sym.ctypes.data, len(node), out.ctypes.data))
+        return out
+
+    def partial_search(self, bases, off):
+        """SBWT::partial_search for every query: (first, second, matched_len) arrays."""
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        off = np.ascontiguousarray(off, dtype=np.int64)
+        n = len(off) - 1
+        first, second, matched = (np.empty(n, dtype=np.int64) for _ in range(3))
+        _check(lib().sbwtgpu_partial_search_batch(self._h, bases.ctypes.data, off.ctypes.data, n, first.ctypes.data,
+                                                  second.ctypes.data, matched.ctypes.data))
+        return first, second, matched
+
+    def get_kmers(self, colex_ranks) -> np.ndarray:
+        """SBWT::get_kmer for every column: an (n, k) uint8 array of ASCII chars ('$' = dummy prefix)."""
+        cr = np.ascontiguousarray(colex_ranks, dtype=np.int64)
+        out = np.empty((len(cr), self.k), dtype=np.uint8)
+        _check(lib().sbwtgpu_get_kmer_batch(self._h, cr.ctypes.data, len(cr), out.ctypes.data))
+        return out
+
+    def select(self, j, sym) -> np.ndarray:
+        j = np.ascontiguousarray(j, dtype=np.int64)
+        sym = np.ascontiguousarray(sym, dtype=np.uint8)
+        out = np.empty(len(j), dtype=np.int64)
+        _check(lib().sbwtgpu_select_batch(self._h, j.ctypes.data, sym.ctypes.data, len(j), out.ctypes.data))
         return out
 
     # ---- device-buffer queries (raw pointers; torch tensors' data_ptr() go here) ----

@@ -98,6 +98,8 @@ public:
     }
     // used by SBWT to share its (full) device image instead of building a second one
     void attach(const std::shared_ptr<detail::DeviceIndex> &d) const { dev_ = d; }
+    // the device image serving this structure (SubsetMatrixSelectSupport shares it)
+    std::shared_ptr<detail::DeviceIndex> device_image() const { device(); return dev_; }
 
 private:
     const detail::DeviceIndex &device() const {
@@ -114,6 +116,27 @@ private:
         return *dev_;
     }
     mutable std::shared_ptr<detail::DeviceIndex> dev_;
+};
+
+// SubsetMatrixSelectSupport.hh:16-33: select on the four rows.  The reference builds sdsl select supports that
+// point into the SubsetMatrixRank; here select is answered from the same device image as rank (the block counts
+// are searched, sbwt_api_kernels.hip k_select), so this object only shares that image.
+class SubsetMatrixSelectSupport {
+public:
+    SubsetMatrixSelectSupport() {}
+    explicit SubsetMatrixSelectSupport(const SubsetMatrixRank &mr) : dev_(mr.device_image()) {}
+    int64_t select(int64_t pos, char c) const {             // SubsetMatrixSelectSupport.hh:27-33
+        if (!dev_) throw std::runtime_error("Error: empty select support");
+        int64_t out = 0;
+        detail::gpu_check(sbwtgpu_select_batch(dev_->h, &pos, &c, 1, &out));
+        return out;
+    }
+    void select_batch(const int64_t *pos, const char *sym, int64_t n, int64_t *out) const {
+        if (!dev_) throw std::runtime_error("Error: empty select support");
+        detail::gpu_check(sbwtgpu_select_batch(dev_->h, pos, sym, n, out));
+    }
+private:
+    std::shared_ptr<detail::DeviceIndex> dev_;
 };
 
 class SBWT {
@@ -267,9 +290,19 @@ public:
         if (devices.size() <= 1) return;
         std::vector<sbwtgpu_index *> hs(devices.size(), nullptr);
         detail::gpu_check(sbwtgpu_index_bcast(dev_->h, (int)devices.size(), devices.data(), hs.data()));
+        // one owner per distinct handle: duplicates of a device share its handle (and its owner), and the root's
+        // entries hold dev_ itself, so no handle can be freed while a replica entry still points at it
+        std::vector<std::pair<sbwtgpu_index *, std::shared_ptr<detail::DeviceIndex>>> owners;
         for (sbwtgpu_index *h : hs) {
-            auto p = std::make_shared<detail::DeviceIndex>();
-            if (h != dev_->h) p->h = h;   // owned replica; the root stays owned by dev_
+            std::shared_ptr<detail::DeviceIndex> p;
+            if (h == dev_->h) p = dev_;
+            for (auto &o : owners)
+                if (o.first == h) p = o.second;
+            if (!p) {
+                p = std::make_shared<detail::DeviceIndex>();
+                p->h = h;
+                owners.emplace_back(h, p);
+            }
             replicas_.push_back({p, h});
         }
     }
@@ -283,17 +316,28 @@ public:
         detail::gpu_check(sbwtgpu_update_interval_batch(need_device(), S, off, 1, &I.first, &I.second));
         return I;
     }
-    // SBWT.hh:525-542
+    // SBWT.hh:525-542 -- the whole loop is one kernel launch (one lane walks the query)
     std::pair<std::pair<int64_t, int64_t>, int64_t> partial_search(const char *input, int64_t len) const {
-        int64_t l = 0, r = n_nodes - 1;
-        for (int64_t i = 0; i < len; i++) {
-            char c = (char)toupper((unsigned char)input[i]);
-            std::pair<int64_t, int64_t> nw = update_sbwt_interval(&c, 1, {l, r});
-            if (nw.first == -1) return {{l, r}, i};
-            l = nw.first;
-            r = nw.second;
-        }
-        return {{l, r}, len};
+        int64_t off[2] = {0, len}, l = 0, r = 0, matched = 0;
+        detail::gpu_check(sbwtgpu_partial_search_batch(need_device(), input, off, 1, &l, &r, &matched));
+        return {{l, r}, matched};
+    }
+    // batch form: query q = bases[off[q] .. off[q+1])
+    void partial_search_batch(const char *bases, const int64_t *off, int64_t n, int64_t *first, int64_t *second,
+                              int64_t *matched) const {
+        detail::gpu_check(sbwtgpu_partial_search_batch(need_device(), bases, off, n, first, second, matched));
+    }
+    // SBWT.hh:700-725 / :727-746: the k-mer of a column into buf (k chars, '$' for dummy positions, no NUL).  Both run
+    // the same device kernel (select inside the block counts); `ss` is accepted for source compatibility.
+    void get_kmer(int64_t colex_rank, char *buf) const {
+        detail::gpu_check(sbwtgpu_get_kmer_batch(need_device(), &colex_rank, 1, buf));
+    }
+    template <typename subset_select_support_t>
+    void get_kmer_fast(int64_t colex_rank, char *buf, const subset_select_support_t &) const {
+        get_kmer(colex_rank, buf);
+    }
+    void get_kmer_batch(const int64_t *colex_ranks, int64_t n, char *out) const {
+        detail::gpu_check(sbwtgpu_get_kmer_batch(need_device(), colex_ranks, n, out));
     }
     std::pair<std::pair<int64_t, int64_t>, int64_t> partial_search(const std::string &input) const {
         return partial_search(input.c_str(), (int64_t)input.size());
@@ -434,6 +478,9 @@ private:
         d.n_kmers = n_kmers;
         d.precalc_k = precalc_k;
         d.precalc = file_precalc;
+        // a new image invalidates the replicas (they hold the old one): back to one device until use_devices() is
+        // called again
+        replicas_.clear();
         auto p = std::make_shared<detail::DeviceIndex>();
         detail::gpu_check(sbwtgpu_index_create(&d, detail::default_device(), &p->h));
         sbwtgpu_index_info info;

@@ -62,6 +62,8 @@ struct SbwtIndexView {
                                     // position, its path's next 8 steps (chars | go << 16 | safe << 24), - }
     int stab_pos;                   // sparse entries are whole k-mers stored with their path position
     int debug;                      // experiments only: bit0 = skip result stores
+    int force_mega;                 // one mega block whose counts do not fit 32 bits (dense rank-only images): cnt is relative
+                                    // to mega[c][0] although n_mega == 1
 };
 
 // Position-independent description of a blob (what index_export_header hands out).
@@ -84,7 +86,8 @@ struct SbwtBlobHeader {
     int64_t off_pfil;
     int32_t log2f;
     int32_t has_safe;               // pq carries the substitution-safe bits
-    int32_t reserved2;
+    int32_t force_mega;             // block counts are relative to mega[c][0] although n_mega == 1 (see SbwtIndexView)
+    int64_t row_ones[4];            // set bits of the rows A, C, G, T (select: valid j are 1 .. row_ones[c])
     int32_t log2b2;                 // second-level sparse table: log2 of its number of 32-byte entries (0 = none)
     int64_t off_stab2;
 };
@@ -141,6 +144,12 @@ void sbwt_launch_update_interval(const SbwtIndexView &ix, const char *d_bases, c
                                  long long *d_first, long long *d_second, hipStream_t stream);
 void sbwt_launch_forward(const SbwtIndexView &ix, const long long *d_node, const char *d_sym, long long n,
                          long long *d_out, hipStream_t stream);
+void sbwt_launch_partial_search(const SbwtIndexView &ix, const char *d_bases, const long long *d_off, long long n,
+                                long long *d_first, long long *d_second, long long *d_matched, hipStream_t stream);
+void sbwt_launch_get_kmer(const SbwtIndexView &ix, const long long *d_colex, long long n, char *d_out,
+                          hipStream_t stream);
+void sbwt_launch_select(const SbwtIndexView &ix, const long long *d_j, const char *d_sym, long long n,
+                        const long long row_ones[4], long long *d_out, hipStream_t stream);
 long long sbwt_format_scratch_bytes(long long n_reads);
 void sbwt_launch_format(const long long *d_vals, const long long *d_out_off, long long n_reads, char *d_text,
                         long long *d_line_off, void *d_scratch, hipStream_t stream);

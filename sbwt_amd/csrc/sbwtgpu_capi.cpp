@@ -88,6 +88,7 @@ static int g_variant_override = -1, g_probe_override = -1, g_debug = 0, g_derive
 // result the kernel never writes cannot inherit a correct value from an earlier launch
 static int g_poison = [] { const char *e = getenv("SBWTGPU_POISON_RESULTS"); return e ? atoi(e) : 0; }();
 static int g_probe_filter = [] { const char *e = getenv("SBWTGPU_PROBE_FILTER"); return e ? atoi(e) : 1; }();
+static int g_force_mega = 0;    // tests: store every image's block counts relative to mega[c][0] (the dense rank-only layout)
 static int g_trans_ext = -1;    // -1: adaptive per wave, 0/1: force
 static int g_path_safe = [] { const char *e = getenv("SBWTGPU_PATH_SAFE"); return e ? atoi(e) : 1; }();
 static int g_path_order = [] { const char *e = getenv("SBWTGPU_PATH_ORDER"); return e ? atoi(e) : 1; }();
@@ -123,6 +124,7 @@ struct sbwtgpu_index {
         v.has_ssup = h.has_ssup;
         v.probe_len = probe_len();
         v.debug = g_debug;
+        v.force_mega = h.force_mega;
         v.p_sparse = (int)h.p_sparse;
         v.log2b = (int)h.log2b;
         v.stab = h.p_sparse > 0 ? reinterpret_cast<const uint4 *>(blob + h.off_stab) : nullptr;
@@ -155,6 +157,7 @@ int sbwtgpu_set_tuning(const char *key, int64_t value) {
     if (!strcmp(key, "derive_ssup")) { g_derive_ssup = (int)value; return SBWTGPU_OK; }
     if (!strcmp(key, "poison_results")) { g_poison = (int)value; return SBWTGPU_OK; }
     if (!strcmp(key, "probe_filter")) { g_probe_filter = (int)value; return SBWTGPU_OK; }   // indexes created afterwards
+    if (!strcmp(key, "force_mega")) { g_force_mega = (int)value; return SBWTGPU_OK; }     // indexes created afterwards
     if (!strcmp(key, "trans_ext")) { g_trans_ext = (int)value; return SBWTGPU_OK; }
     if (!strcmp(key, "path_safe")) { g_path_safe = (int)value; return SBWTGPU_OK; }   // indexes created afterwards
     if (!strcmp(key, "path_order")) { g_path_order = (int)value; return SBWTGPU_OK; }   // indexes created afterwards
@@ -297,6 +300,10 @@ int sbwtgpu_index_create(const sbwtgpu_index_desc *d, int device, sbwtgpu_index 
     // leave the image.
     const bool consistent = (tot[0] + tot[1] + tot[2] + tot[3] == n - 1);
     h.rank_only = consistent ? 0 : 1;
+    // Dense arbitrary bit vectors: C[c] + rank_c can pass 2^32 well before n reaches 2^31 columns.  Then the 32-bit
+    // block counts are stored relative to mega[c][0] = C[c] (inside one mega block rank_c <= 2^31 always fits).
+    for (int c = 0; c < 4; c++) h.row_ones[c] = tot[c];
+    h.force_mega = (n_mega == 1 && ((uint64_t)(h.C[3] + tot[3]) >= (1ull << 32) || (g_force_mega && !consistent))) ? 1 : 0;
     if (!consistent) {
         if (p_file > 0) {
             delete idx;
@@ -344,7 +351,7 @@ int sbwtgpu_index_create(const sbwtgpu_index_desc *d, int device, sbwtgpu_index 
                 int64_t mb = b / blocks_per_mega;
                 // a single mega block keeps base 0 so that cnt alone is the absolute value
                 for (int c = 0; c < 4; c++) {
-                    mbase[c] = (n_mega > 1) ? run[c] : 0;
+                    mbase[c] = (n_mega > 1 || h.force_mega) ? run[c] : 0;
                     mega[(size_t)(c * n_mega + mb)] = mbase[c];
                 }
             }
@@ -553,11 +560,26 @@ int sbwtgpu_index_adopt(const void *header, int64_t header_bytes, void *dev_blob
 }
 
 // RCCL is loaded lazily so that single-GPU use never needs it.
+// devs[] may name a device more than once (several host threads per GPU): the image travels once per DISTINCT
+// device and the duplicates share that device's handle.
 int sbwtgpu_index_bcast(sbwtgpu_index *root, int n_dev, const int *devs, sbwtgpu_index **out) {
     if (!root || n_dev <= 0 || !devs || !out) return fail(SBWTGPU_ERR_INVALID_ARG, "NULL/empty argument");
-    bool only_root = true;
-    for (int i = 0; i < n_dev; i++) only_root = only_root && (devs[i] == root->device);
-    if (only_root) {
+    std::vector<int> uniq;                              // distinct devices, in order of first appearance
+    std::vector<int> slot((size_t)n_dev, 0);            // devs[i] -> its index in uniq
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess) ndev = 0;
+    for (int i = 0; i < n_dev; i++) {
+        if (devs[i] < 0 || devs[i] >= ndev) return fail(SBWTGPU_ERR_NO_DEVICE, "device %d out of range", devs[i]);
+        size_t u = 0;
+        while (u < uniq.size() && uniq[u] != devs[i]) u++;
+        if (u == uniq.size()) uniq.push_back(devs[i]);
+        slot[(size_t)i] = (int)u;
+    }
+    int root_rank = -1;
+    for (size_t u = 0; u < uniq.size(); u++)
+        if (uniq[u] == root->device) root_rank = (int)u;
+    if (root_rank < 0) return fail(SBWTGPU_ERR_INVALID_ARG, "the root's device must be in devs[]");
+    if (uniq.size() == 1) {
         for (int i = 0; i < n_dev; i++) out[i] = root;
         return SBWTGPU_OK;
     }
@@ -573,56 +595,68 @@ int sbwtgpu_index_bcast(sbwtgpu_index *root, int n_dev, const int *devs, sbwtgpu
     bcast_t bcast = (bcast_t)dlsym(lib, "ncclBroadcast");
     grp_t gstart = (grp_t)dlsym(lib, "ncclGroupStart"), gend = (grp_t)dlsym(lib, "ncclGroupEnd");
     destroy_t destroy = (destroy_t)dlsym(lib, "ncclCommDestroy");
-    if (!init_all || !bcast || !gstart || !gend || !destroy) return fail(SBWTGPU_ERR_HIP, "RCCL symbols missing");
-    int root_rank = -1;
-    for (int i = 0; i < n_dev; i++)
-        if (devs[i] == root->device) root_rank = i;
-    if (root_rank < 0) return fail(SBWTGPU_ERR_INVALID_ARG, "the root's device must be in devs[]");
-    std::vector<comm_t> comms((size_t)n_dev);
-    std::vector<hipStream_t> streams((size_t)n_dev);
-    std::vector<sbwtgpu_index *> made((size_t)n_dev, nullptr);
+    if (!init_all || !bcast || !gstart || !gend || !destroy) {
+        dlclose(lib);
+        return fail(SBWTGPU_ERR_HIP, "RCCL symbols missing");
+    }
+    const int nu = (int)uniq.size();
+    std::vector<comm_t> comms((size_t)nu, nullptr);
+    std::vector<hipStream_t> streams((size_t)nu, nullptr);
+    std::vector<char> have_stream((size_t)nu, 0);
+    std::vector<sbwtgpu_index *> made((size_t)nu, nullptr);
+    bool have_comms = false;
     int rc = SBWTGPU_OK;
-    for (int i = 0; i < n_dev && rc == SBWTGPU_OK; i++) {
-        if (hipSetDevice(devs[i]) != hipSuccess || hipStreamCreate(&streams[i]) != hipSuccess)
-            rc = fail(SBWTGPU_ERR_HIP, "cannot set up device %d", devs[i]);
-        if (rc == SBWTGPU_OK && i != root_rank) {
+    for (int u = 0; u < nu && rc == SBWTGPU_OK; u++) {
+        if (hipSetDevice(uniq[u]) != hipSuccess || hipStreamCreate(&streams[u]) != hipSuccess) {
+            rc = fail(SBWTGPU_ERR_HIP, "cannot set up device %d", uniq[u]);
+            break;
+        }
+        have_stream[u] = 1;
+        if (u != root_rank) {
             sbwtgpu_index *c = new (std::nothrow) sbwtgpu_index();
             if (!c || hipMalloc((void **)&c->blob, (size_t)root->h.blob_bytes) != hipSuccess) {
                 delete c;
-                rc = fail(SBWTGPU_ERR_OOM, "hipMalloc on device %d", devs[i]);
+                rc = fail(SBWTGPU_ERR_OOM, "hipMalloc on device %d", uniq[u]);
                 break;
             }
             c->h = root->h;
-            c->device = devs[i];
-            made[i] = c;
+            c->device = uniq[u];
+            made[u] = c;
         }
     }
-    if (rc == SBWTGPU_OK && init_all(comms.data(), n_dev, devs) != 0) rc = fail(SBWTGPU_ERR_HIP, "ncclCommInitAll failed");
+    if (rc == SBWTGPU_OK) {
+        if (init_all(comms.data(), nu, uniq.data()) != 0) rc = fail(SBWTGPU_ERR_HIP, "ncclCommInitAll failed");
+        else have_comms = true;
+    }
     if (rc == SBWTGPU_OK) {
         gstart();
-        for (int i = 0; i < n_dev; i++) {
-            (void)hipSetDevice(devs[i]);
-            void *buf = (i == root_rank) ? (void *)root->blob : (void *)made[i]->blob;
-            if (bcast(buf, buf, (size_t)root->h.blob_bytes, /*ncclChar*/ 0, root_rank, comms[i], streams[i]) != 0)
+        for (int u = 0; u < nu; u++) {
+            (void)hipSetDevice(uniq[u]);
+            void *buf = (u == root_rank) ? (void *)root->blob : (void *)made[u]->blob;
+            if (bcast(buf, buf, (size_t)root->h.blob_bytes, /*ncclChar*/ 0, root_rank, comms[u], streams[u]) != 0)
                 rc = fail(SBWTGPU_ERR_HIP, "ncclBroadcast failed");
         }
-        gend();
-        for (int i = 0; i < n_dev; i++) {
-            (void)hipSetDevice(devs[i]);
-            (void)hipStreamSynchronize(streams[i]);
-            destroy(comms[i]);
+        if (gend() != 0 && rc == SBWTGPU_OK) rc = fail(SBWTGPU_ERR_HIP, "ncclGroupEnd failed");
+        for (int u = 0; u < nu; u++) {
+            (void)hipSetDevice(uniq[u]);
+            if (hipStreamSynchronize(streams[u]) != hipSuccess && rc == SBWTGPU_OK)
+                rc = fail(SBWTGPU_ERR_HIP, "broadcast to device %d failed", uniq[u]);
         }
     }
-    for (int i = 0; i < n_dev; i++) {
-        (void)hipSetDevice(devs[i]);
-        (void)hipStreamDestroy(streams[i]);
+    for (int u = 0; u < nu; u++) {                       // only what was actually created
+        if (!have_stream[u] && !have_comms) continue;
+        (void)hipSetDevice(uniq[u]);
+        if (have_comms) destroy(comms[u]);
+        if (have_stream[u]) (void)hipStreamDestroy(streams[u]);
     }
     (void)hipSetDevice(root->device);
     if (rc != SBWTGPU_OK) {
         for (auto *c : made) sbwtgpu_index_destroy(c);
+        dlclose(lib);
         return rc;
     }
-    for (int i = 0; i < n_dev; i++) out[i] = (i == root_rank) ? root : made[i];
+    // success: librccl stays loaded for the life of the process (it keeps per-process state)
+    for (int i = 0; i < n_dev; i++) out[i] = (slot[(size_t)i] == root_rank) ? root : made[(size_t)slot[(size_t)i]];
     return SBWTGPU_OK;
 }
 
@@ -777,6 +811,53 @@ struct Stream {
         if (s) (void)hipStreamDestroy(s);
     }
 };
+
+// Small calls (the scalar API of the reference -- SBWT::search(kmer), rank(pos, c), one update_sbwt_interval -- arrives
+// here as batches of one): no hipMalloc / hipStreamCreate per call.  Every host thread keeps, per device, one stream,
+// one pinned host buffer and one device buffer of SLOT_CAP bytes; a call whose data fits stages its inputs in the pinned
+// buffer, moves them with ONE H2D copy, runs its kernels, and brings the results back with ONE D2H copy + one sync.
+constexpr size_t SLOT_CAP = (size_t)1 << 20;
+bool g_exiting = false;                                  // set at process exit: HIP may be gone, leak instead of freeing
+struct SmallSlot {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    char *host = nullptr, *dev = nullptr;
+    void release() {
+        if (device < 0 || g_exiting) return;
+        DeviceGuard guard(device);
+        if (stream) (void)hipStreamDestroy(stream);
+        if (host) (void)hipHostFree(host);
+        if (dev) (void)hipFree(dev);
+        stream = nullptr; host = dev = nullptr; device = -1;
+    }
+};
+struct SlotSet {
+    std::vector<SmallSlot> v;
+    ~SlotSet() { for (auto &s : v) s.release(); }
+};
+thread_local SlotSet t_slots;
+// The calling thread's slot on `device` (the current device must already be `device`), or nullptr when `need` does not
+// fit or the buffers cannot be allocated (the caller then takes the general path).
+SmallSlot *small_slot(int device, size_t need) {
+    if (need > SLOT_CAP) return nullptr;
+    static const bool once = [] { atexit([] { g_exiting = true; }); return true; }();
+    (void)once;
+    for (auto &s : t_slots.v)
+        if (s.device == device) return &s;
+    SmallSlot s;
+    if (hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    if (hipHostMalloc((void **)&s.host, SLOT_CAP, hipHostMallocDefault) != hipSuccess ||
+        hipMalloc((void **)&s.dev, SLOT_CAP) != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipStreamDestroy(s.stream);
+        if (s.host) (void)hipHostFree(s.host);
+        return nullptr;
+    }
+    s.device = device;
+    t_slots.v.push_back(s);
+    return &t_slots.v.back();
+}
+inline size_t up256(size_t x) { return (x + 255) & ~(size_t)255; }
 }  // namespace
 
 static int check_reads(const int64_t *read_off, const int64_t *out_off, int64_t n_reads, int64_t k) {
@@ -892,10 +973,32 @@ static int search_host_common(const sbwtgpu_index *idx, const char *bases, const
         return fail(SBWTGPU_ERR_OOM, "out of host memory");
     }
     DeviceGuard guard(idx->device);
+    const int64_t ws_bytes = sbwtgpu_search_workspace_bytes(vtotal);
+    {   // small call: layout [roff][ooff][bases] (in) | [out][workspace] (the D2H copy ends with the workspace header)
+        const size_t o_roff = 0, o_ooff = up256((size_t)(nv + 1) * 8), o_bases = o_ooff + up256((size_t)(nv + 1) * 8);
+        const size_t o_out = o_bases + up256((size_t)vtotal + 16), o_ws = o_out + up256((size_t)n_out * 8);
+        SmallSlot *sl = small_slot(idx->device, o_ws + (size_t)ws_bytes);
+        if (sl) {
+            memcpy(sl->host + o_roff, ro.data(), (size_t)(nv + 1) * 8);
+            memcpy(sl->host + o_ooff, oo.data(), (size_t)(nv + 1) * 8);
+            memcpy(sl->host + o_bases, src_bases, (size_t)vtotal);
+            HIP_TRY(hipMemcpyAsync(sl->dev, sl->host, o_bases + (size_t)vtotal, hipMemcpyHostToDevice, sl->stream));
+            rc = search_dev_common(idx, sl->dev + o_bases, vtotal, (const int64_t *)(sl->dev + o_roff), nv,
+                                   (int64_t *)(sl->dev + o_out), (const int64_t *)(sl->dev + o_ooff), sl->dev + o_ws, ws_bytes,
+                                   sl->stream, streaming);
+            if (rc != SBWTGPU_OK) return rc;
+            const size_t back = (o_ws - o_out) + sizeof(SbwtWorkHeader);
+            HIP_TRY(hipMemcpyAsync(sl->host + o_out, sl->dev + o_out, back, hipMemcpyDeviceToHost, sl->stream));
+            HIP_TRY(hipStreamSynchronize(sl->stream));
+            memcpy(out + out0, sl->host + o_out, (size_t)n_out * 8);
+            if (reinterpret_cast<const SbwtWorkHeader *>(sl->host + o_ws)->status != 0)
+                return fail(SBWTGPU_ERR_NOT_SINGLETON, "Bug: k-mer search did not give a singleton interval");
+            return SBWTGPU_OK;
+        }
+    }
     Stream st;
     HIP_TRY(hipStreamCreateWithFlags(&st.s, hipStreamNonBlocking));
     DevBuf d_bases, d_roff, d_ooff, d_out, d_ws;
-    const int64_t ws_bytes = sbwtgpu_search_workspace_bytes(vtotal);
     HIP_TRY(d_bases.alloc((size_t)vtotal + 16));
     HIP_TRY(d_roff.alloc((size_t)(nv + 1) * 8));
     HIP_TRY(d_ooff.alloc((size_t)(nv + 1) * 8));
@@ -935,6 +1038,21 @@ int sbwtgpu_rank_batch(const sbwtgpu_index *idx, const int64_t *pos, const char 
         if (pos[t] < 0 || pos[t] > idx->h.n_nodes)
             return fail(SBWTGPU_ERR_INVALID_ARG, "pos[%lld] = %lld outside [0, n_nodes]", (long long)t, (long long)pos[t]);
     DeviceGuard guard(idx->device);
+    {   // small call: [pos][sym] in, [out] back
+        const size_t o_sym = up256((size_t)n * 8), o_out = o_sym + up256((size_t)n);
+        SmallSlot *sl = small_slot(idx->device, o_out + (size_t)n * 8);
+        if (sl) {
+            memcpy(sl->host, pos, (size_t)n * 8);
+            memcpy(sl->host + o_sym, sym, (size_t)n);
+            HIP_TRY(hipMemcpyAsync(sl->dev, sl->host, o_sym + (size_t)n, hipMemcpyHostToDevice, sl->stream));
+            int rc = sbwtgpu_rank_dev(idx, (const int64_t *)sl->dev, sl->dev + o_sym, n, (int64_t *)(sl->dev + o_out), sl->stream);
+            if (rc != SBWTGPU_OK) return rc;
+            HIP_TRY(hipMemcpyAsync(sl->host + o_out, sl->dev + o_out, (size_t)n * 8, hipMemcpyDeviceToHost, sl->stream));
+            HIP_TRY(hipStreamSynchronize(sl->stream));
+            memcpy(out, sl->host + o_out, (size_t)n * 8);
+            return SBWTGPU_OK;
+        }
+    }
     Stream st;
     HIP_TRY(hipStreamCreateWithFlags(&st.s, hipStreamNonBlocking));
     DevBuf d_pos, d_sym, d_out;
@@ -965,6 +1083,26 @@ int sbwtgpu_update_interval_batch(const sbwtgpu_index *idx, const char *bases, c
             return fail(SBWTGPU_ERR_INVALID_ARG, "interval %lld out of range", (long long)t);
     }
     DeviceGuard guard(idx->device);
+    {   // small call: [first][second] (in and back) [off][bases]
+        const size_t o_s = up256((size_t)n * 8), o_off = 2 * o_s, o_bases = o_off + up256((size_t)(n + 1) * 8);
+        SmallSlot *sl = small_slot(idx->device, o_bases + (size_t)total + 16);
+        if (sl) {
+            memcpy(sl->host, first, (size_t)n * 8);
+            memcpy(sl->host + o_s, second, (size_t)n * 8);
+            int64_t *o = reinterpret_cast<int64_t *>(sl->host + o_off);
+            for (int64_t t = 0; t <= n; t++) o[t] = off[t] - base0;
+            if (total) memcpy(sl->host + o_bases, bases + base0, (size_t)total);
+            HIP_TRY(hipMemcpyAsync(sl->dev, sl->host, o_bases + (size_t)total, hipMemcpyHostToDevice, sl->stream));
+            sbwt_launch_update_interval(idx->view(), sl->dev + o_bases, (const long long *)(sl->dev + o_off), n,
+                                        (long long *)sl->dev, (long long *)(sl->dev + o_s), sl->stream);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipMemcpyAsync(sl->host, sl->dev, o_s + (size_t)n * 8, hipMemcpyDeviceToHost, sl->stream));
+            HIP_TRY(hipStreamSynchronize(sl->stream));
+            memcpy(first, sl->host, (size_t)n * 8);
+            memcpy(second, sl->host + o_s, (size_t)n * 8);
+            return SBWTGPU_OK;
+        }
+    }
     Stream st;
     HIP_TRY(hipStreamCreateWithFlags(&st.s, hipStreamNonBlocking));
     DevBuf d_bases, d_off, d_f, d_s;
@@ -999,6 +1137,22 @@ int sbwtgpu_forward_batch(const sbwtgpu_index *idx, const int64_t *node, const c
         if (node[t] < 0 || node[t] >= idx->h.n_nodes)
             return fail(SBWTGPU_ERR_INVALID_ARG, "node[%lld] out of range", (long long)t);
     DeviceGuard guard(idx->device);
+    {   // small call: [node][sym] in, [out] back
+        const size_t o_sym = up256((size_t)n * 8), o_out = o_sym + up256((size_t)n);
+        SmallSlot *sl = small_slot(idx->device, o_out + (size_t)n * 8);
+        if (sl) {
+            memcpy(sl->host, node, (size_t)n * 8);
+            memcpy(sl->host + o_sym, sym, (size_t)n);
+            HIP_TRY(hipMemcpyAsync(sl->dev, sl->host, o_sym + (size_t)n, hipMemcpyHostToDevice, sl->stream));
+            sbwt_launch_forward(idx->view(), (const long long *)sl->dev, sl->dev + o_sym, n, (long long *)(sl->dev + o_out),
+                                sl->stream);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipMemcpyAsync(sl->host + o_out, sl->dev + o_out, (size_t)n * 8, hipMemcpyDeviceToHost, sl->stream));
+            HIP_TRY(hipStreamSynchronize(sl->stream));
+            memcpy(out, sl->host + o_out, (size_t)n * 8);
+            return SBWTGPU_OK;
+        }
+    }
     Stream st;
     HIP_TRY(hipStreamCreateWithFlags(&st.s, hipStreamNonBlocking));
     DevBuf d_node, d_sym, d_out;
@@ -1014,6 +1168,115 @@ int sbwtgpu_forward_batch(const sbwtgpu_index *idx, const int64_t *node, const c
     return SBWTGPU_OK;
 }
 
+
+// One host-buffer call of the small API neighbours: inputs staged contiguously, one H2D, the kernel, one D2H.
+// `in` / `back` describe byte ranges of the staging buffer; small calls use the thread's slot, large ones a
+// temporary stream + device buffer.
+namespace {
+struct Staged {
+    SmallSlot *sl = nullptr;
+    Stream st;
+    DevBuf dbuf;
+    std::vector<char> hbuf;
+    char *host = nullptr, *dev = nullptr;
+    hipStream_t stream = nullptr;
+    int open(int device, size_t bytes) {
+        sl = small_slot(device, bytes);
+        if (sl) { host = sl->host; dev = sl->dev; stream = sl->stream; return SBWTGPU_OK; }
+        HIP_TRY(hipStreamCreateWithFlags(&st.s, hipStreamNonBlocking));
+        HIP_TRY(dbuf.alloc(bytes));
+        try { hbuf.resize(bytes); } catch (...) { return fail(SBWTGPU_ERR_OOM, "out of host memory"); }
+        host = hbuf.data(); dev = (char *)dbuf.p; stream = st.s;
+        return SBWTGPU_OK;
+    }
+};
+}  // namespace
+
+int sbwtgpu_partial_search_batch(const sbwtgpu_index *idx, const char *bases, const int64_t *off, int64_t n,
+                                 int64_t *first, int64_t *second, int64_t *matched) {
+    if (!idx) return fail(SBWTGPU_ERR_INVALID_ARG, "idx is NULL");
+    if (idx->h.rank_only) return fail(SBWTGPU_ERR_INVALID_ARG, "%s", RANK_ONLY_MSG);
+    if (n < 0) return fail(SBWTGPU_ERR_INVALID_ARG, "negative n");
+    if (n == 0) return SBWTGPU_OK;
+    if (!off || !first || !second || !matched) return fail(SBWTGPU_ERR_INVALID_ARG, "NULL argument");
+    const int64_t base0 = off[0], total = off[n] - base0;
+    if (total < 0 || (total > 0 && !bases)) return fail(SBWTGPU_ERR_INVALID_ARG, "bad bases/offsets");
+    for (int64_t t = 0; t < n; t++)
+        if (off[t + 1] < off[t]) return fail(SBWTGPU_ERR_INVALID_ARG, "off is not non-decreasing");
+    DeviceGuard guard(idx->device);
+    // [first][second][matched] (back) [off][bases] (in)
+    const size_t o_s = up256((size_t)n * 8), o_m = 2 * o_s, o_off = 3 * o_s, o_bases = o_off + up256((size_t)(n + 1) * 8);
+    Staged sg;
+    int rc = sg.open(idx->device, o_bases + (size_t)total + 16);
+    if (rc != SBWTGPU_OK) return rc;
+    int64_t *o = reinterpret_cast<int64_t *>(sg.host + o_off);
+    for (int64_t t = 0; t <= n; t++) o[t] = off[t] - base0;
+    if (total) memcpy(sg.host + o_bases, bases + base0, (size_t)total);
+    HIP_TRY(hipMemcpyAsync(sg.dev + o_off, sg.host + o_off, (o_bases - o_off) + (size_t)total, hipMemcpyHostToDevice, sg.stream));
+    sbwt_launch_partial_search(idx->view(), sg.dev + o_bases, (const long long *)(sg.dev + o_off), n, (long long *)sg.dev,
+                               (long long *)(sg.dev + o_s), (long long *)(sg.dev + o_m), sg.stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(sg.host, sg.dev, o_m + (size_t)n * 8, hipMemcpyDeviceToHost, sg.stream));
+    HIP_TRY(hipStreamSynchronize(sg.stream));
+    memcpy(first, sg.host, (size_t)n * 8);
+    memcpy(second, sg.host + o_s, (size_t)n * 8);
+    memcpy(matched, sg.host + o_m, (size_t)n * 8);
+    return SBWTGPU_OK;
+}
+
+int sbwtgpu_get_kmer_batch(const sbwtgpu_index *idx, const int64_t *colex_rank, int64_t n, char *out) {
+    if (!idx) return fail(SBWTGPU_ERR_INVALID_ARG, "idx is NULL");
+    if (idx->h.rank_only) return fail(SBWTGPU_ERR_INVALID_ARG, "%s", RANK_ONLY_MSG);
+    if (n < 0) return fail(SBWTGPU_ERR_INVALID_ARG, "negative n");
+    if (n == 0) return SBWTGPU_OK;
+    if (!colex_rank || !out) return fail(SBWTGPU_ERR_INVALID_ARG, "NULL argument");
+    for (int64_t t = 0; t < n; t++)
+        if (colex_rank[t] < 0 || colex_rank[t] >= idx->h.n_nodes)
+            return fail(SBWTGPU_ERR_INVALID_ARG, "colex_rank[%lld] out of range", (long long)t);
+    DeviceGuard guard(idx->device);
+    const int64_t k = idx->h.k;
+    const size_t o_out = up256((size_t)n * 8);
+    Staged sg;
+    int rc = sg.open(idx->device, o_out + (size_t)(n * k) + 16);
+    if (rc != SBWTGPU_OK) return rc;
+    memcpy(sg.host, colex_rank, (size_t)n * 8);
+    HIP_TRY(hipMemcpyAsync(sg.dev, sg.host, (size_t)n * 8, hipMemcpyHostToDevice, sg.stream));
+    sbwt_launch_get_kmer(idx->view(), (const long long *)sg.dev, n, sg.dev + o_out, sg.stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(sg.host + o_out, sg.dev + o_out, (size_t)(n * k), hipMemcpyDeviceToHost, sg.stream));
+    HIP_TRY(hipStreamSynchronize(sg.stream));
+    memcpy(out, sg.host + o_out, (size_t)(n * k));
+    return SBWTGPU_OK;
+}
+
+int sbwtgpu_select_batch(const sbwtgpu_index *idx, const int64_t *j, const char *sym, int64_t n, int64_t *out) {
+    if (!idx) return fail(SBWTGPU_ERR_INVALID_ARG, "idx is NULL");
+    if (n < 0) return fail(SBWTGPU_ERR_INVALID_ARG, "negative n");
+    if (n == 0) return SBWTGPU_OK;
+    if (!j || !sym || !out) return fail(SBWTGPU_ERR_INVALID_ARG, "NULL argument");
+    for (int64_t t = 0; t < n; t++) {
+        const char ch = sym[t];
+        const int c = ch == 'A' ? 0 : ch == 'C' ? 1 : ch == 'G' ? 2 : ch == 'T' ? 3 : -1;
+        if (c >= 0 && (j[t] < 1 || j[t] > idx->h.row_ones[c]))
+            return fail(SBWTGPU_ERR_INVALID_ARG, "j[%lld] = %lld outside [1, %lld] (ones in row %c)", (long long)t,
+                        (long long)j[t], (long long)idx->h.row_ones[c], ch);
+    }
+    DeviceGuard guard(idx->device);
+    const size_t o_sym = up256((size_t)n * 8), o_out = o_sym + up256((size_t)n);
+    Staged sg;
+    int rc = sg.open(idx->device, o_out + (size_t)n * 8);
+    if (rc != SBWTGPU_OK) return rc;
+    memcpy(sg.host, j, (size_t)n * 8);
+    memcpy(sg.host + o_sym, sym, (size_t)n);
+    HIP_TRY(hipMemcpyAsync(sg.dev, sg.host, o_sym + (size_t)n, hipMemcpyHostToDevice, sg.stream));
+    long long ones[4] = {idx->h.row_ones[0], idx->h.row_ones[1], idx->h.row_ones[2], idx->h.row_ones[3]};
+    sbwt_launch_select(idx->view(), (const long long *)sg.dev, sg.dev + o_sym, n, ones, (long long *)(sg.dev + o_out), sg.stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(sg.host + o_out, sg.dev + o_out, (size_t)n * 8, hipMemcpyDeviceToHost, sg.stream));
+    HIP_TRY(hipStreamSynchronize(sg.stream));
+    memcpy(out, sg.host + o_out, (size_t)n * 8);
+    return SBWTGPU_OK;
+}
 
 // ---- device-side formatting + pipelined host path ------------------------------------------------
 int64_t sbwtgpu_format_text_bound(const sbwtgpu_index *idx, int64_t n_values, int64_t n_reads) {
@@ -1112,6 +1375,8 @@ void sbwtgpu_release_cached_buffers(void) {
         if (prev >= 0) (void)hipSetDevice(prev);
     }
     g_parked.clear();
+    for (auto &sl : t_slots.v) sl.release();            // the calling thread's small-call slots
+    t_slots.v.clear();
 }
 
 int sbwtgpu_search_text_batch(const sbwtgpu_index *idx, const char *bases, const int64_t *read_off, int64_t n_reads,

@@ -15,6 +15,7 @@
 #include <string>
 #include <vector>
 
+#include <chrono>
 #include "SBWT.hh"
 
 using namespace sbwt;
@@ -156,6 +157,49 @@ int main() {
             }
             CHECK(big.get_subset_rank_structure().rank(colex + 1, 'A') - big.get_subset_rank_structure().rank(colex, 'A') ==
                   (big.get_subset_rank_structure().contains(colex, 'A') ? 1 : 0));
+        }
+        // get_kmer / get_kmer_fast / select (SBWT.hh:700-746, SubsetMatrixSelectSupport.hh; usage as in tests/test_large.hh:52-72)
+        SubsetMatrixSelectSupport ss(big.get_subset_rank_structure());
+        vector<char> buf(31, 0), buf2(31, 0);
+        for (int t = 0; t < 50; t++) {
+            string kmer = g.substr(rand() % (g.size() - 31), 30);
+            int64_t colex = big.search(kmer);
+            big.get_kmer(colex, buf.data());
+            big.get_kmer_fast(colex, buf2.data(), ss);
+            CHECK(string(buf.data(), 30) == kmer);
+            CHECK(string(buf2.data(), 30) == kmer);
+            // select is the inverse of rank on set bits
+            for (char c : string("ACGT")) {
+                if (!big.get_subset_rank_structure().contains(colex, c)) continue;
+                int64_t j = big.get_subset_rank_structure().rank(colex, c) + 1;
+                CHECK(ss.select(j, c) == colex);
+            }
+        }
+        big.get_kmer(0, buf.data());
+        CHECK(string(buf.data(), 30) == string(30, '$'));
+        // partial_search: a full k-mer matches k chars; a k-mer with a foreign tail stops early (SBWT.hh:525-537)
+        {
+            string kmer = g.substr(777, 30);
+            auto ps = big.partial_search(kmer);
+            CHECK(ps.second == 30 && ps.first.first == ps.first.second && ps.first.first == big.search(kmer));
+            auto lower = big.partial_search(string("acgt"));
+            auto upper = big.partial_search(string("ACGT"));
+            CHECK(lower == upper);                        // every char is upper-cased first (:529)
+            auto withn = big.partial_search(string("ACNGT"));
+            CHECK(withn.second == 2 && withn.first == big.partial_search(string("AC")).first);
+        }
+        // cost of the scalar API (batches of one through the small-call path): printed, not asserted
+        {
+            string kmer = g.substr(4242, 30);
+            auto t0 = std::chrono::steady_clock::now();
+            int64_t acc = 0;
+            const int reps = 2000;
+            for (int t = 0; t < reps; t++) acc += big.search(kmer.c_str());
+            double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / reps;
+            auto t1 = std::chrono::steady_clock::now();
+            for (int t = 0; t < reps; t++) acc += big.get_subset_rank_structure().rank(1000 + t, 'C');
+            double us2 = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t1).count() / reps;
+            printf("scalar search(): %.1f us/call, scalar rank(): %.1f us/call (checksum %ld)\n", us, us2, (long)acc);
         }
         // batch API == scalar API
         vector<int64_t> off = {0, 150, 150, 400}, ooff = {0, 121, 121, 121 + 221}, out(342, -7);

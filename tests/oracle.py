@@ -76,6 +76,12 @@ def lib() -> C.CDLL:
     L.orc_print_vector.argtypes = [vp, i64, C.c_char_p]
     L.orc_batch_search.restype = C.c_double
     L.orc_batch_search.argtypes = [P, vp, vp, i64, vp, vp, C.c_int]
+    L.orc_get_kmer.restype = None
+    L.orc_get_kmer.argtypes = [P, i64, C.c_char_p]
+    L.orc_select.restype = i64
+    L.orc_select.argtypes = [P, i64, C.c_char]
+    L.orc_batch_rank.restype = C.c_double
+    L.orc_batch_rank.argtypes = [P, vp, vp, i64, vp, C.c_int]
     L.orc_count_work.restype = None
     L.orc_count_work.argtypes = [P, vp, vp, i64, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)]
     _lib = L
@@ -175,6 +181,14 @@ class OracleIndex:
         n = lib().orc_partial_search(self._p, s, len(s), C.byref(a), C.byref(b))
         return (a.value, b.value), n
 
+    def get_kmer(self, colex_rank: int) -> bytes:
+        buf = C.create_string_buffer(int(self.k) + 1)
+        lib().orc_get_kmer(self._p, colex_rank, buf)
+        return buf.raw[: self.k]
+
+    def select(self, j: int, c: bytes) -> int:
+        return lib().orc_select(self._p, j, c)
+
     def mark_suffix_groups(self) -> np.ndarray:
         out = np.zeros((self.n_nodes + 63) // 64, dtype=np.uint64)
         lib().orc_mark_suffix_groups(self._p, out.ctypes.data)
@@ -192,6 +206,14 @@ class OracleIndex:
             out = np.full(int(out_off[-1]), -3, dtype=np.int64)
         secs = lib().orc_batch_search(self._p, bases.ctypes.data, read_off.ctypes.data, len(read_off) - 1,
                                       out.ctypes.data, out_off.ctypes.data, n_threads)
+        return out, secs
+
+    def batch_rank(self, pos: np.ndarray, sym: np.ndarray, n_threads: int = 1):
+        """(out, seconds): SubsetMatrixRank::rank for every (pos, sym) pair."""
+        pos = np.ascontiguousarray(pos, dtype=np.int64)
+        sym = np.ascontiguousarray(sym, dtype=np.uint8)
+        out = np.full(len(pos), -3, dtype=np.int64)
+        secs = lib().orc_batch_rank(self._p, pos.ctypes.data, sym.ctypes.data, len(pos), out.ctypes.data, n_threads)
         return out, secs
 
     def count_work(self, bases: np.ndarray, read_off: np.ndarray):

@@ -1,0 +1,150 @@
+"""GPU parity tests of the batched API neighbours of the search path, through the C ABI:
+SubsetMatrixRank::rank on arbitrary bit vectors (the 4-pairs-per-lane kernel, its scalar tail, the 64-bit count
+layout), SBWT::partial_search, SBWT::get_kmer / get_kmer_fast and SubsetMatrixSelectSupport::select."""
+import numpy as np
+import pytest
+
+from oracle import OracleIndex
+from sbwt_amd import capi, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def gpu_index_from_oracle(orc: OracleIndex) -> capi.Index:
+    cols = orc.columns()
+    return capi.Index.create(cols[0], cols[1], cols[2], cols[3], orc.ssup_words(), orc.n_nodes, orc.k,
+                             orc.n_kmers, orc.precalc_k, None)
+
+
+@pytest.fixture(scope="module")
+def case():
+    k = 31
+    genomes = [synth.random_genome(150_000, 11)]
+    genomes.append(synth.mutate(genomes[0], 0.03, 12))
+    orc = OracleIndex.build([g.tobytes() for g in genomes], k, True, False, 6)
+    return genomes, orc
+
+
+@pytest.mark.parametrize("force_mega", [0, 1])
+@pytest.mark.parametrize("n_bits", [1, 63, 64, 65, 4097, 1_000_003])
+def test_rank_arbitrary_bit_vectors(gpu, n_bits, force_mega):
+    """SubsetMatrixRank as a stand-alone structure (SubsetMatrixRank.hh:52-58): four unrelated random rows."""
+    rng = np.random.default_rng(n_bits)
+    nw = (n_bits + 63) // 64
+    cols = [rng.integers(0, 2**64, size=nw, dtype=np.uint64) for _ in range(4)]
+    capi.set_tuning("force_mega", force_mega)
+    try:
+        idx = capi.Index.create(cols[0], cols[1], cols[2], cols[3], None, n_bits, 1, 0, 0)
+    finally:
+        capi.set_tuning("force_mega", 0)
+    orc = OracleIndex.from_bits(cols[0], cols[1], cols[2], cols[3], None, n_bits, 1, 0, 0)
+    for n in (1, 2, 3, 4, 5, 7, 8, 1023, 20_001):      # n % 4 != 0 exercises the scalar tail next to the 4-wide kernel
+        pos = rng.integers(0, n_bits + 1, size=n)
+        pos[0] = n_bits
+        pos[-1] = 0
+        sym = rng.choice(np.frombuffer(b"ACGTNacgt$\x00\xff", dtype=np.uint8), size=n)
+        got = idx.rank(pos, sym)
+        want, _ = orc.batch_rank(pos, sym, 1)
+        assert np.array_equal(got, want), (n_bits, n)
+
+
+def test_rank_dev_misaligned_buffers(gpu, case):
+    """The device entry point takes any 8-byte aligned pos/out and any sym pointer: misaligned ones take the scalar kernel."""
+    import torch
+    _, orc = case
+    idx = gpu_index_from_oracle(orc)
+    rng = np.random.default_rng(5)
+    n = 10_001
+    pos = rng.integers(0, orc.n_nodes + 1, size=n)
+    sym = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=n)
+    want, _ = orc.batch_rank(pos, sym, 1)
+    dev = torch.device("cuda", 0)
+    for shift_pos, shift_sym in ((0, 0), (1, 0), (0, 1), (1, 3)):
+        d_pos = torch.zeros(n + 2, dtype=torch.int64, device=dev)
+        d_sym = torch.zeros(n + 8, dtype=torch.uint8, device=dev)
+        d_out = torch.full((n + 2,), -9, dtype=torch.int64, device=dev)
+        d_pos[shift_pos:shift_pos + n] = torch.from_numpy(pos).to(dev)
+        d_sym[shift_sym:shift_sym + n] = torch.from_numpy(sym).to(dev)
+        capi._check(capi.lib().sbwtgpu_rank_dev(idx.handle, d_pos.data_ptr() + 8 * shift_pos, d_sym.data_ptr() + shift_sym,
+                                                n, d_out.data_ptr() + 8 * shift_pos,
+                                                torch.cuda.current_stream().cuda_stream))
+        torch.cuda.synchronize()
+        assert np.array_equal(d_out[shift_pos:shift_pos + n].cpu().numpy(), want)
+
+
+def test_partial_search_batch(gpu, case):
+    genomes, orc = case
+    idx = gpu_index_from_oracle(orc)
+    rng = np.random.default_rng(9)
+    g = genomes[0]
+    queries = []
+    for _ in range(3000):
+        L = int(rng.integers(0, 80))
+        s = int(rng.integers(0, len(g) - 100))
+        q = bytearray(g[s:s + L].tobytes())
+        r = rng.random()
+        if L and r < 0.3:
+            q[int(rng.integers(0, L))] = ord("ACGT"[int(rng.integers(0, 4))])     # a substitution somewhere
+        elif L and r < 0.4:
+            q[int(rng.integers(0, L))] = ord("N")
+        elif L and r < 0.5:
+            q = bytearray(bytes(q).lower())                                         # lower case matches (SBWT.hh:529)
+        queries.append(bytes(q))
+    queries += [b"", b"N", b"a", b"$", b"ACGT" * 30]
+    bases, off = capi.concat_reads(queries)
+    first, second, matched = idx.partial_search(bases, off)
+    for q, a, c, m in zip(queries, first, second, matched):
+        (wl, wr), wm = orc.partial_search(q)
+        assert (a, c, m) == (wl, wr, wm), q
+
+
+def test_get_kmer_and_select(gpu, case):
+    genomes, orc = case
+    idx = gpu_index_from_oracle(orc)
+    rng = np.random.default_rng(10)
+    n = orc.n_nodes
+    cols = np.concatenate([rng.integers(0, n, size=3000), np.array([0, 1, 2, n - 1, n - 2])])
+    got = idx.get_kmers(cols)
+    for v, row in zip(cols, got):
+        assert row.tobytes() == orc.get_kmer(int(v)), int(v)
+    # a found k-mer spells itself
+    bases, off = synth.sample_reads(genomes, 50, 31, 0.0, 3)
+    res, _ = idx.search(bases, off)
+    assert (res >= 0).all()
+    back = idx.get_kmers(res)
+    for r in range(50):
+        assert back[r].tobytes() == bases[off[r]:off[r + 1]].tobytes()
+    # select inverts rank on set bits; first and last one of every row; non-ACGT -> 0
+    words = orc.columns()
+    for ci, ch in enumerate(b"ACGT"):
+        bits = np.unpackbits(words[ci].view(np.uint8), bitorder="little")[:n]
+        ones = np.flatnonzero(bits)
+        pick = np.unique(np.concatenate([[0, len(ones) - 1], rng.integers(0, len(ones), size=2000)]))
+        got = idx.select(pick + 1, np.full(len(pick), ch, dtype=np.uint8))
+        assert np.array_equal(got, ones[pick])
+        with pytest.raises(capi.SbwtGpuError):
+            idx.select(np.array([len(ones) + 1]), np.array([ch], dtype=np.uint8))
+    assert list(idx.select(np.array([5, 6]), np.frombuffer(b"N$", dtype=np.uint8))) == [0, 0]
+
+
+def test_small_calls_equal_large_calls(gpu, case):
+    """Batches of one go through the per-thread small-call slots, big batches through temporary buffers: same bits."""
+    genomes, orc = case
+    idx = gpu_index_from_oracle(orc)
+    bases, off = synth.sample_reads(genomes, 3000, 150, 0.01, 77)
+    bases = synth.inject(bases, 40, ord("N"), 7)
+    big, oo = idx.streaming_search(bases, off)                     # one large call
+    for r in list(range(40)) + [2999]:
+        one, _ = idx.streaming_search(bases[off[r]:off[r + 1]], np.array([0, off[r + 1] - off[r]]))
+        assert np.array_equal(one, big[oo[r]:oo[r + 1]])
+        kmer = bases[off[r] + 7:off[r] + 7 + orc.k]
+        got, _ = idx.search(kmer, np.array([0, orc.k]))
+        assert got[0] == orc.search(kmer.tobytes())
+    # a call larger than the slot (1 MiB) right after small ones, and small ones again
+    big2, _ = idx.streaming_search(bases, off)
+    assert np.array_equal(big, big2)
+    one, _ = idx.streaming_search(bases[:150], np.array([0, 150]))
+    assert np.array_equal(one, big[:oo[1]])
+    capi.lib().sbwtgpu_release_cached_buffers()
+    one, _ = idx.streaming_search(bases[:150], np.array([0, 150]))
+    assert np.array_equal(one, big[:oo[1]])
