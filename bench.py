@@ -73,6 +73,7 @@ def log(msg: str) -> None:
 def gpu_reads(genomes, n_reads: int, seed: int, dev: torch.device) -> torch.Tensor:
     """n_reads x READ_LEN substrings at uniform (genome, offset) with per-base substitutions,
     generated on the GPU (seeded) so that the inputs are resident in HBM."""
+    import torch
     gen = torch.Generator(device=dev)
     gen.manual_seed(seed)
     lens = torch.tensor([len(g) for g in genomes], device=dev)

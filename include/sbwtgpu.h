@@ -76,7 +76,8 @@ const char *sbwtgpu_last_error(void);
 int         sbwtgpu_device_count(int *count);
 /* Process-wide tuning knobs for experiments (results never depend on them):
  *   "search_variant"  0 = k_search (the reference's order of searches), 1 = k_search_cert on the blocks,
- *                     2 = k_search_cert along the path order when the index has one (default)
+ *                     2 = k_search_cert along the path order when the index has one (default),
+ *                     3 = k_search_pool: the path order with the reads pooled in LDS and re-assigned to lanes by state
  *   "probe_len"       length of the certificate probes (-1 = automatic, 0 = off)
  *   "derive_ssup"     1 (default): indexes created without suffix_group_starts get the marks derived on
  *                     the device so that the per-k-mer search loop can use streaming steps internally

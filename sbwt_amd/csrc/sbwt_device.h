@@ -137,6 +137,9 @@ void sbwt_launch_encode(const char *d_bases, long long total_bases, uint4 *d_pac
 void sbwt_launch_search(const SbwtIndexView &ix, const uint4 *d_packed, const long long *d_read_off,
                         const long long *d_out_off, long long *d_out, long long n_reads, SbwtWorkHeader *ws,
                         int streaming, hipStream_t stream, int variant, long long total_groups);
+void sbwt_launch_search_pool(const SbwtIndexView &ix, const uint4 *d_packed, const long long *d_read_off,
+                             const long long *d_out_off, long long *d_out, long long n_reads, SbwtWorkHeader *ws,
+                             int streaming, hipStream_t stream);
 void sbwt_launch_rank(const SbwtIndexView &ix, const long long *d_pos, const char *d_sym, long long n,
                       long long *d_out, hipStream_t stream);
 void sbwt_launch_precalc(const SbwtIndexView &ix, int p, longlong2 *d_table, hipStream_t stream);

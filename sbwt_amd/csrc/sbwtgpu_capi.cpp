@@ -77,7 +77,8 @@ struct DeviceGuard {
 }  // namespace
 
 // tuning knobs (A/B experiments; defaults are the shipped configuration)
-// 0 = k_search (reference order), 1 = k_search_cert, 2 = k_search_cert along the path order (when the index has one)
+// 0 = k_search (reference order), 1 = k_search_cert, 2 = k_search_cert along the path order (when the index has one),
+// 3 = k_search_pool: the path order with pooled reads (experiment: same bits, 18 % slower -- DESIGN.md section 3)
 static int tuning_variant() {
     static int v = [] { const char *e = getenv("SBWTGPU_SEARCH_VARIANT"); return e ? atoi(e) : 2; }();
     return v;

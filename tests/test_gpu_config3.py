@@ -28,7 +28,7 @@ def test_config3_pangenome_k31(gpu):
                             bits.n_kmers, 8)
     assert idx.n_nodes > 10_000_000 and idx.has_streaming_support
     dev = torch.device("cuda:0")
-    bench.torch = torch                     # bench imports torch lazily (its launcher decision comes first)
+
     d_bases = bench.gpu_reads(genomes, n_reads, 31337, dev)
     d_roff = torch.arange(n_reads + 1, dtype=torch.int64, device=dev) * L
     d_ooff = torch.arange(n_reads + 1, dtype=torch.int64, device=dev) * m
@@ -50,14 +50,17 @@ def test_config3_pangenome_k31(gpu):
             capi.set_tuning("trans_ext", -1)
         return out
 
-    a = run(True, 2)                          # the product path (transitions decide per wave whether to run on)
+    a = run(True, 3)                          # the product path (transitions decide per wave whether to run on)
     stats = idx.workspace_stats(d_ws.data_ptr(), st)
     assert stats[4] > 0, "the path-order kernel did not run"      # k-mers answered along path runs
-    assert torch.equal(a, run(True, 2, 1))    # transitions always run on along the quoted steps
-    assert torch.equal(a, run(True, 2, 0))    # ... never
+    assert torch.equal(a, run(True, 3, 1))    # transitions always run on along the quoted steps
+    assert torch.equal(a, run(True, 3, 0))    # ... never
+    assert torch.equal(a, run(True, 2))       # path order, one lane per read
+    assert torch.equal(a, run(True, 2, 1))
+    assert torch.equal(a, run(True, 2, 0))
     assert torch.equal(a, run(True, 1))       # certificates on the blocks only
     assert torch.equal(a, run(True, 0))       # the reference's order of searches
-    assert torch.equal(a, run(False, 2))      # per-k-mer search loop == streaming (upper-case input)
+    assert torch.equal(a, run(False, 3))      # per-k-mer search loop == streaming (upper-case input)
     assert int(a.min()) == -1 and int(a.max()) < bits.n_nodes
     hit = (a >= 0).double().mean().item()
     assert 0.68 < hit < 0.80                  # 0.99^31 = 0.73 of the k-mers avoid every substituted base

@@ -46,10 +46,13 @@ def test_config2_full_size_properties(gpu):
             capi.set_tuning("search_variant", -1)
         return out
 
-    a = run(True, 2)                      # the product path: certificates along the path order
+    a = run(True, 3)                      # the product path: path order, pooled reads (k_search_pool)
+    assert idx.workspace_stats(d_ws.data_ptr(), st)[4] > 0
+    assert torch.equal(a, run(True, 2))   # path order, one lane per read (k_search_cert<PATH>)
     assert torch.equal(a, run(True, 1))   # certificates on the blocks only
     assert torch.equal(a, run(True, 0))   # the reference's order of searches
-    assert torch.equal(a, run(False, 2))  # per-k-mer search loop (internal streaming) == streaming (upper-case input)
+    assert torch.equal(a, run(False, 3))  # per-k-mer search loop (internal streaming) == streaming (upper-case input)
+    assert torch.equal(a, run(False, 2))
     assert torch.equal(a, run(False, 1))  # per-k-mer search loop == streaming (upper-case input)
     assert torch.equal(a, run(True, 1))   # deterministic
     assert int(a.min()) == -1 and int(a.max()) < bits.n_nodes
