@@ -324,15 +324,22 @@ def main() -> int:
         return rank_bench(args, rank, world, local_rank, dev)
 
     # ---- index: built once on rank 0 (host sort-based builder), replicated by one broadcast ----
-    t0 = time.time()
     genomes = synth.pan_like(args.derived, args.genome_len) if args.config == 3 else synth.coli3_like(args.genome_len)
+    t0 = time.time()
     bits = None
     if rank == 0:
-        bits = hostlib.build_bits([g.tobytes() for g in genomes], K, False, streaming, n_threads=effective_cores())
+        # columns: on the GPU for k <= 32 (sbwtgpu_build_plain_matrix), host sort-based builder beyond
+        if K <= 32:
+            bits = capi.build_bits_gpu([g.tobytes() for g in genomes], K, False, streaming, device=local_rank)
+        else:
+            bits = hostlib.build_bits([g.tobytes() for g in genomes], K, False, streaming, n_threads=effective_cores())
+        t_cols = time.time() - t0
         index = capi.Index.create(bits.cols[0], bits.cols[1], bits.cols[2], bits.cols[3], bits.ssup, bits.n_nodes, K,
                                   bits.n_kmers, PRECALC, None, device=local_rank)
         log(f"index: n_nodes={index.n_nodes} n_kmers={index.n_kmers} image={index.blob_bytes / 1e6:.1f} MB "
-            f"device_precalc={index.device_precalc_k} ({time.time() - t0:.1f} s)")
+            f"device_precalc={index.device_precalc_k} (columns {t_cols:.2f} s + image {time.time() - t0 - t_cols:.2f} s)")
+        build_times = {"columns_s": t_cols, "image_s": time.time() - t0 - t_cols,
+                       "columns_on": "gpu" if K <= 32 else "host", "image_bytes_per_column": index.blob_bytes / index.n_nodes}
     t_bcast = None
     if world > 1:
         hdr, blob = None, None
@@ -464,6 +471,8 @@ def main() -> int:
     }
     if t_bcast is not None:
         result["index_broadcast_s"] = t_bcast
+    if rank == 0:
+        result["index_build"] = build_times
     # HBM-side bytes per launch from the PMC counters: measured by tools/profile.sh in separate rocprofv3 passes (a
     # bench run cannot collect counters on itself) and attached ONLY while the profile belongs to the kernels that
     # just ran (same source hash, same workload); otherwise null, never a stale number

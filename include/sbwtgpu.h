@@ -105,6 +105,23 @@ int  sbwtgpu_index_get_info(const sbwtgpu_index *idx, sbwtgpu_index_info *info);
 /* get_precalc() (SBWT.hh:131): copies the 4^precalc_k (first,second) pairs to host memory. */
 int  sbwtgpu_index_get_precalc(const sbwtgpu_index *idx, int64_t *out_pairs);
 
+/* ---- construction on the device ---- */
+/* The plain-matrix SBWT of a set of sequences, built on the GPU: what the reference's constructors produce
+ * (build_nodeboss_in_memory, include/sbwt/NodeBOSSInMemoryConstructor.hh:98-213; the KMC-based SBWT(config) ctor,
+ * SBWT.hh:300-332, gives the same bits): the four rows A, C, G, T and suffix_group_starts as sdsl-ordered words.
+ * k-mers with anything but upper-case ACGT are skipped (:156-159); add_revcomp adds every reverse complement
+ * (src/CLI/sbwt_build.cpp:108-123).  2 <= k <= 32 (a k-mer is packed into 64 bits); for longer k the C++ host
+ * mirror (sbwt::build_plain_matrix_bits) builds on the CPU.  Release with sbwtgpu_free_plain_matrix(). */
+typedef struct {
+    int64_t   n_nodes, n_kmers, k;
+    uint64_t *A_bits, *C_bits, *G_bits, *T_bits;   /* ceil(n_nodes/64) words each */
+    uint64_t *suffix_group_starts;                 /* NULL when not requested */
+} sbwtgpu_plain_matrix_bits;
+int  sbwtgpu_build_plain_matrix(const char *const *seqs, const int64_t *seq_len, int64_t n_seqs, int64_t k,
+                                int add_revcomp, int build_streaming_support, int device,
+                                sbwtgpu_plain_matrix_bits *out);
+void sbwtgpu_free_plain_matrix(sbwtgpu_plain_matrix_bits *bits);
+
 /* ---- multi-GPU replication (no reference equivalent) ---- */
 /* One process per GPU (torch.distributed / any launcher): rank 0 exports the device image,
  * the launcher broadcasts header (host bytes) and blob (device bytes, e.g. RCCL broadcast over

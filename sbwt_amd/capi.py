@@ -33,6 +33,7 @@ EXPORTED_SYMBOLS = [
     "sbwtgpu_index_export_header", "sbwtgpu_index_blob", "sbwtgpu_index_copy_blob", "sbwtgpu_index_adopt", "sbwtgpu_index_bcast",
     "sbwtgpu_rank_batch", "sbwtgpu_streaming_search_batch", "sbwtgpu_search_batch",
     "sbwtgpu_update_interval_batch", "sbwtgpu_forward_batch",
+    "sbwtgpu_build_plain_matrix", "sbwtgpu_free_plain_matrix",
     "sbwtgpu_partial_search_batch", "sbwtgpu_get_kmer_batch", "sbwtgpu_select_batch",
     "sbwtgpu_search_workspace_bytes", "sbwtgpu_streaming_search_dev", "sbwtgpu_search_dev",
     "sbwtgpu_rank_dev", "sbwtgpu_encode_bases_dev", "sbwtgpu_search_encoded_dev",
@@ -68,6 +69,12 @@ class IndexInfo(C.Structure):
     ]
 
 
+class PlainMatrixBitsC(C.Structure):
+    _fields_ = [("n_nodes", C.c_int64), ("n_kmers", C.c_int64), ("k", C.c_int64),
+                ("A_bits", C.c_void_p), ("C_bits", C.c_void_p), ("G_bits", C.c_void_p), ("T_bits", C.c_void_p),
+                ("suffix_group_starts", C.c_void_p)]
+
+
 _lib: Optional[C.CDLL] = None
 
 
@@ -100,6 +107,9 @@ def lib() -> C.CDLL:
     L.sbwtgpu_search_batch.argtypes = [vp, vp, vp, i64, vp, vp]
     L.sbwtgpu_update_interval_batch.argtypes = [vp, vp, vp, i64, vp, vp]
     L.sbwtgpu_forward_batch.argtypes = [vp, vp, vp, i64, vp]
+    L.sbwtgpu_build_plain_matrix.argtypes = [C.POINTER(C.c_char_p), vp, i64, i64, ci, ci, ci, C.POINTER(PlainMatrixBitsC)]
+    L.sbwtgpu_free_plain_matrix.argtypes = [C.POINTER(PlainMatrixBitsC)]
+    L.sbwtgpu_free_plain_matrix.restype = None
     L.sbwtgpu_partial_search_batch.argtypes = [vp, vp, vp, i64, vp, vp, vp]
     L.sbwtgpu_get_kmer_batch.argtypes = [vp, vp, i64, vp]
     L.sbwtgpu_select_batch.argtypes = [vp, vp, vp, i64, vp]
@@ -160,6 +170,33 @@ def out_offsets(read_off: np.ndarray, k: int) -> np.ndarray:
     off = np.zeros(len(read_off), dtype=np.int64)
     np.cumsum(m, out=off[1:])
     return off
+
+
+class BuiltBits:
+    """What the builders return: the four rows + suffix_group_starts as uint64 word arrays (numpy copies)."""
+
+    def __init__(self, cols, ssup, n_nodes, n_kmers, k):
+        self.cols, self.ssup, self.n_nodes, self.n_kmers, self.k = cols, ssup, n_nodes, n_kmers, k
+
+
+def build_bits_gpu(seqs: Sequence[bytes], k: int, add_revcomp: bool = False, streaming_support: bool = True,
+                   device: int = 0) -> BuiltBits:
+    """sbwtgpu_build_plain_matrix: the plain-matrix SBWT columns of `seqs`, built on the GPU (2 <= k <= 32)."""
+    arr = (C.c_char_p * len(seqs))(*[bytes(s) for s in seqs])
+    lens = np.array([len(s) for s in seqs], dtype=np.int64)
+    out = PlainMatrixBitsC()
+    _check(lib().sbwtgpu_build_plain_matrix(arr, lens.ctypes.data, len(seqs), k, int(add_revcomp), int(streaming_support),
+                                            device, C.byref(out)))
+    try:
+        nw = (out.n_nodes + 63) // 64
+
+        def words(p):
+            return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint64)), shape=(nw,)).copy()
+        cols = [words(out.A_bits), words(out.C_bits), words(out.G_bits), words(out.T_bits)]
+        ssup = words(out.suffix_group_starts) if out.suffix_group_starts else None
+        return BuiltBits(cols, ssup, out.n_nodes, out.n_kmers, out.k)
+    finally:
+        lib().sbwtgpu_free_plain_matrix(C.byref(out))
 
 
 class Index:

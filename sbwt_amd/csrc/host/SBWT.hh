@@ -45,6 +45,28 @@ struct DeviceIndex {
 // Selects the HIP device new indexes are placed on (default 0).
 inline void set_default_device(int device) { detail::default_device() = device; }
 
+// The plain-matrix columns of a set of sequences: on the GPU for k <= 32 (sbwtgpu_build_plain_matrix: radix sort of the
+// packed k-mers and searches in the sorted array), with the multi-threaded host builder (index_builder.hh) for longer
+// k-mers.  Both give the reference constructors' bits (NodeBOSSInMemoryConstructor.hh:98-213).
+inline PlainMatrixBits build_plain_matrix_bits_any(const std::vector<std::string> &seqs, int k, bool add_revcomp,
+                                                   bool build_streaming_support, int n_threads) {
+    if (k < 2 || k > 32) return build_plain_matrix_bits(seqs, k, add_revcomp, build_streaming_support, n_threads);
+    std::vector<const char *> ptr(seqs.size());
+    std::vector<int64_t> len(seqs.size());
+    for (size_t i = 0; i < seqs.size(); i++) { ptr[i] = seqs[i].data(); len[i] = (int64_t)seqs[i].size(); }
+    sbwtgpu_plain_matrix_bits b;
+    detail::gpu_check(sbwtgpu_build_plain_matrix(ptr.data(), len.data(), (int64_t)seqs.size(), k, add_revcomp ? 1 : 0,
+                                                 build_streaming_support ? 1 : 0, detail::default_device(), &b));
+    PlainMatrixBits out;
+    out.n_nodes = b.n_nodes; out.n_kmers = b.n_kmers; out.k = b.k;
+    const size_t nw = (size_t)((b.n_nodes + 63) / 64);
+    out.A.assign(b.A_bits, b.A_bits + nw); out.C.assign(b.C_bits, b.C_bits + nw);
+    out.G.assign(b.G_bits, b.G_bits + nw); out.T.assign(b.T_bits, b.T_bits + nw);
+    if (b.suffix_group_starts) out.ssup.assign(b.suffix_group_starts, b.suffix_group_starts + nw);
+    sbwtgpu_free_plain_matrix(&b);
+    return out;
+}
+
 class SubsetMatrixRank {
 public:
     // public like the reference (SubsetMatrixRank.hh:19-23); the rank supports live on the GPU
@@ -179,7 +201,7 @@ public:
                 seqs.emplace_back(reader.read_buf, (size_t)len);
             }
         }
-        PlainMatrixBits b = build_plain_matrix_bits(seqs, config.k, false, config.build_streaming_support, config.n_threads);
+        PlainMatrixBits b = build_plain_matrix_bits_any(seqs, config.k, false, config.build_streaming_support, config.n_threads);
         adopt_bits(b, config.precalc_k);
     }
 

@@ -399,7 +399,7 @@ int build_main(int argc, char **argv) {
         }
     }
     write_log("Building SBWT subset sequence in memory", LogLevel::MAJOR);
-    PlainMatrixBits bits = build_plain_matrix_bits(seqs, (int)k, opts.count("add-reverse-complements"),
+    PlainMatrixBits bits = build_plain_matrix_bits_any(seqs, (int)k, opts.count("add-reverse-complements"),
                                                    !opts.count("no-streaming-support"), atoi(opts.get("n-threads").c_str()));
     plain_matrix_sbwt_t index(bits, 0);
     write_log("Build SBWT for " + std::to_string(index.number_of_kmers()) + " distinct k-mers", LogLevel::MAJOR);

@@ -1,0 +1,317 @@
+// sbwt_build.hip -- construction on the device.
+//   (1) the interleaved 64-column blocks of the device image from the four bit vectors (+ suffix_group_starts):
+//       what SubsetMatrixRank's constructor does with sdsl::util::init_support (SubsetMatrixRank.hh:52-58) and
+//       SBWT's constructor with the C array (SBWT.hh:344-349), for this layout;
+//   (2) the plain-matrix SBWT columns themselves from sequences, k <= 32: every k-mer packed so that integer order is
+//       the colexicographic order (Kmer.hh:108-123), radix sort (rocPRIM), predecessors / edges / suffix groups by
+//       searches in the sorted array, dummy prefixes of the predecessor-less k-mers, merged emission of the columns --
+//       the node and edge rules of NodeBOSSInMemoryConstructor.hh:98-213 (edges only on suffix-group starts; k-mers
+//       without a predecessor get all their proper prefixes as dummy nodes; the empty root always exists; colex
+//       order with the shorter label first), bit-identical to host/index_builder.hh and to the oracle's literal
+//       restatement of that constructor (tests/test_gpu_build.py).
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
+#include "sbwt_kernels_common.h"
+#include "sbwt_scan.h"
+
+// ---------------------------------------------------------------------------------------------
+// (1) blocks
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ u64 masked_word(const u64 *__restrict__ v, i64 w, i64 nw, i64 n) {
+    if (w >= nw) return 0;
+    u64 x = v[w];
+    if (w == nw - 1 && (n & 63)) x &= (~0ull) >> (64 - (n & 63));
+    return x;
+}
+// ones of every block, per row: cnt[c * (nb + 1) + b]
+__global__ void __launch_bounds__(256) k_blk_count(const u64 *__restrict__ bits, i64 nw, i64 n, i64 nb, i64 *__restrict__ cnt) {
+    const i64 b = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (b >= nb) return;
+#pragma unroll
+    for (int c = 0; c < 4; c++) cnt[(i64)c * (nb + 1) + b] = __popcll(masked_word(bits + (i64)c * nw, b, nw, n));
+}
+// blocks[b] = four quads { bits lo, bits hi, C[c] + ones before the block - mega base, suffix-group piece }
+__global__ void __launch_bounds__(256) k_blk_fill(const u64 *__restrict__ bits, const u64 *__restrict__ ssup, i64 nw, i64 n,
+                                                  i64 nb, const i64 *__restrict__ pre, i64 C0, i64 C1, i64 C2, i64 C3,
+                                                  int use_mega, int n_mega, uint4 *__restrict__ blocks, u64 *__restrict__ mega) {
+    const i64 b = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (b >= nb) return;
+    const i64 bpm = (i64)1 << (SBWT_MEGA_SHIFT - 6);
+    const i64 mb = b / bpm;
+    const u64 s = ssup ? masked_word(ssup, b, nw, n) : 0;
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        const i64 Cc = c == 0 ? C0 : c == 1 ? C1 : c == 2 ? C2 : C3;
+        const u64 run = (u64)(Cc + pre[(i64)c * (nb + 1) + b]);
+        const u64 base = use_mega ? (u64)(Cc + pre[(i64)c * (nb + 1) + mb * bpm]) : 0;
+        if (b % bpm == 0) mega[(i64)c * n_mega + mb] = base;
+        const u64 w = masked_word(bits + (i64)c * nw, b, nw, n);
+        blocks[4 * b + c] = make_uint4((unsigned)w, (unsigned)(w >> 32), (unsigned)(run - base),
+                                       (c & 1) ? (unsigned)(s >> 32) : (unsigned)s);
+    }
+}
+
+long long sbwt_blocks_scratch_bytes(long long n_nodes) {
+    const i64 nb = n_nodes / 64 + 1;
+    return 2 * 4 * (nb + 1) * 8 + ((nb + 1023) / 1024 + 2) * 8 + 256;
+}
+// d_bits: the four rows back to back (nw words each); d_ssup may be null.  Step 1 counts and scans; totals[4] (host)
+// receives the ones per row (the caller decides about the count layout); step 2 fills blocks and the mega table.
+int sbwt_blocks_count(const unsigned long long *d_bits, long long n_nodes, void *d_scratch, long long totals[4], hipStream_t st) {
+    const i64 n = n_nodes, nw = (n + 63) / 64, nb = n / 64 + 1;
+    i64 *cnt = static_cast<i64 *>(d_scratch), *pre = cnt + 4 * (nb + 1), *bsum = pre + 4 * (nb + 1);
+    hipLaunchKernelGGL(k_blk_count, dim3(grid_for(nb)), dim3(256), 0, st, reinterpret_cast<const u64 *>(d_bits), nw, n, nb, cnt);
+    const unsigned gb = (unsigned)((nb + 1023) / 1024);
+    for (int c = 0; c < 4; c++) {
+        hipLaunchKernelGGL(k_scan_block_sums, dim3(gb), dim3(256), 0, st, cnt + (i64)c * (nb + 1), nb, bsum);
+        hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, st, bsum, (i64)gb);
+        hipLaunchKernelGGL(k_scan_apply, dim3(gb), dim3(256), 0, st, cnt + (i64)c * (nb + 1), nb, bsum, pre + (i64)c * (nb + 1));
+    }
+    i64 t[4];
+    for (int c = 0; c < 4; c++)
+        if (hipMemcpyAsync(&t[c], pre + (i64)c * (nb + 1) + nb, 8, hipMemcpyDeviceToHost, st) != hipSuccess) return -1;
+    if (hipStreamSynchronize(st) != hipSuccess) return -1;
+    for (int c = 0; c < 4; c++) totals[c] = t[c];
+    return 0;
+}
+void sbwt_blocks_fill(const unsigned long long *d_bits, const unsigned long long *d_ssup, long long n_nodes, void *d_scratch,
+                      const long long C[4], int use_mega, int n_mega, uint4 *d_blocks, unsigned long long *d_mega, hipStream_t st) {
+    const i64 n = n_nodes, nw = (n + 63) / 64, nb = n / 64 + 1;
+    const i64 *pre = static_cast<const i64 *>(d_scratch) + 4 * (nb + 1);
+    hipLaunchKernelGGL(k_blk_fill, dim3(grid_for(nb)), dim3(256), 0, st, reinterpret_cast<const u64 *>(d_bits),
+                       reinterpret_cast<const u64 *>(d_ssup), nw, n, nb, pre, (i64)C[0], (i64)C[1], (i64)C[2], (i64)C[3], use_mega,
+                       n_mega, d_blocks, reinterpret_cast<u64 *>(d_mega));
+}
+
+// ---------------------------------------------------------------------------------------------
+// (2) plain-matrix SBWT columns from sequences, k <= 32
+// ---------------------------------------------------------------------------------------------
+// packed text: the k_encode format (sbwt_search.hip): group = { codes lo, codes hi, validU, validRaw }, 32 bases per
+// 16 bytes; validRaw = upper-case ACGT, which is what the reference's constructors accept
+// (NodeBOSSInMemoryConstructor.hh:156-159).  Sequences are separated by one non-ACGT byte by the caller, so a k-mer
+// window that crosses a boundary is invalid like one that holds an N.
+__device__ __forceinline__ u64 rev2(u64 x) {               // reverses the order of the 32 two-bit groups
+    x = ((x >> 2) & 0x3333333333333333ull) | ((x & 0x3333333333333333ull) << 2);
+    x = ((x >> 4) & 0x0F0F0F0F0F0F0F0Full) | ((x & 0x0F0F0F0F0F0F0F0Full) << 4);
+    x = ((x >> 8) & 0x00FF00FF00FF00FFull) | ((x & 0x00FF00FF00FF00FFull) << 8);
+    x = ((x >> 16) & 0x0000FFFF0000FFFFull) | ((x & 0x0000FFFF0000FFFFull) << 16);
+    return (x >> 32) | (x << 32);
+}
+// every valid k-mer start p -> key (char i of the k-mer at bits 2i: integer order = colex order); with rc also the
+// reverse complement's key.  Output slots from a wave-aggregated counter (the order does not matter: they get sorted).
+__global__ void __launch_bounds__(256) k_bld_extract(const uint4 *__restrict__ packed, i64 n_pos, int k, int rc,
+                                                     u64 *__restrict__ keys, unsigned long long *__restrict__ counter) {
+    const i64 p = (i64)blockIdx.x * 256 + threadIdx.x;
+    bool ok = false;
+    u64 key = 0;
+    if (p < n_pos) {
+        const uint4 g0 = packed[p >> 5], g1 = packed[(p >> 5) + 1];
+        const int s = (int)(p & 31);
+        u64 w = quad_bits(g0) >> (2 * s);
+        if (s) w |= quad_bits(g1) << (64 - 2 * s);
+        const u64 vr = (((u64)g1.w << 32) | (u64)g0.w) >> s;
+        const u64 vm = (k >= 64) ? ~0ull : low_mask(k);
+        ok = (vr & vm) == vm;
+        key = (k == 32) ? w : (w & low_mask(2 * k));
+    }
+    const u64 m = __ballot(ok);
+    if (m == 0) return;
+    const int lane = threadIdx.x & 63, cnt = __popcll(m), per = rc ? 2 : 1;
+    unsigned long long base = 0;
+    if (lane == (int)(__ffsll((i64)m) - 1)) base = atomicAdd(counter, (unsigned long long)(cnt * per));
+    base = uniform64(__shfl(base, __ffsll((i64)m) - 1));
+    if (ok) {
+        const i64 at = (i64)base + (i64)__popcll(m & low_mask(lane)) * per;
+        keys[at] = key;
+        if (rc) keys[at + 1] = (~rev2(key)) >> (64 - 2 * k);      // complement = 3 - code, order reversed
+    }
+}
+// flag[i] = first of its run of equal values (shifted right by `shift`: 0 = distinct k-mers, 2 = suffix groups)
+__global__ void __launch_bounds__(256) k_bld_flag_first(const u64 *__restrict__ v, i64 n, int shift, i64 *__restrict__ flag) {
+    const i64 i = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) flag[i] = (i == 0 || (v[i] >> shift) != (v[i - 1] >> shift)) ? 1 : 0;
+}
+__global__ void __launch_bounds__(256) k_bld_compact(const u64 *__restrict__ v, const i64 *__restrict__ flag,
+                                                     const i64 *__restrict__ pos, i64 n, u64 *__restrict__ out) {
+    const i64 i = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (i < n && flag[i]) out[pos[i]] = v[i];
+}
+// group starts: gstart[g] = index of the first k-mer of suffix group g, gsuf[g] = its (k-1)-suffix
+__global__ void __launch_bounds__(256) k_bld_groups(const u64 *__restrict__ km, const i64 *__restrict__ flag,
+                                                    const i64 *__restrict__ pos, i64 n, i64 *__restrict__ gstart,
+                                                    u64 *__restrict__ gsuf) {
+    const i64 i = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (i < n && flag[i]) { gstart[pos[i]] = i; gsuf[pos[i]] = km[i] >> 2; }
+}
+__device__ __forceinline__ i64 lower_bound_u64(const u64 *__restrict__ a, i64 n, u64 x) {   // first index with a[i] >= x
+    i64 lo = 0, hi = n;
+    while (lo < hi) { const i64 mid = (lo + hi) >> 1; if (a[mid] < x) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+// predecessor join (NodeBOSSInMemoryConstructor.hh:113-147): k-mer z = y c has an edge from the suffix group of x iff x's
+// (k-1)-suffix equals z's (k-1)-prefix y; otherwise z has no predecessor (nopred[z] = 1)
+__global__ void __launch_bounds__(256) k_bld_pred(const u64 *__restrict__ km, i64 nk, int k, const i64 *__restrict__ gstart,
+                                                  const u64 *__restrict__ gsuf, i64 ng, unsigned *__restrict__ edges,
+                                                  i64 *__restrict__ nopred) {
+    const i64 z = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (z >= nk) return;
+    const u64 key = km[z];
+    const int c = (int)(key >> (2 * k - 2));
+    const u64 pre = (k > 1) ? (key & low_mask(2 * k - 2)) : 0;
+    const i64 g = lower_bound_u64(gsuf, ng, pre);
+    if (g < ng && gsuf[g] == pre) {
+        atomicOr(&edges[gstart[g]], 1u << c);
+        nopred[z] = 0;
+    } else {
+        nopred[z] = 1;
+    }
+}
+// merged emission: k-mer i goes to column i + #(dummies with label <= key) (a dummy sorts before the k-mer it is a
+// prefix-padding of: shorter first, Kmer.hh:108-123), dummy d to column d + #(k-mers with key < label)
+__device__ __forceinline__ void put_column(u64 *__restrict__ rows, i64 nw, i64 col, unsigned e, bool start, int ssup) {
+    const u64 bit = 1ull << (col & 63);
+#pragma unroll
+    for (int c = 0; c < 4; c++)
+        if (e & (1u << c)) atomicOr(reinterpret_cast<unsigned long long *>(rows + (i64)c * nw + (col >> 6)), (unsigned long long)bit);
+    if (ssup && start) atomicOr(reinterpret_cast<unsigned long long *>(rows + 4 * nw + (col >> 6)), (unsigned long long)bit);
+}
+__global__ void __launch_bounds__(256) k_bld_emit_kmers(const u64 *__restrict__ km, i64 nk, const unsigned *__restrict__ edges,
+                                                        const u64 *__restrict__ ddata, i64 nd, u64 *__restrict__ rows, i64 nw,
+                                                        int ssup) {
+    const i64 i = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (i >= nk) return;
+    const u64 key = km[i];
+    i64 lo = 0, hi = nd;                                   // dummies with label <= key
+    while (lo < hi) { const i64 mid = (lo + hi) >> 1; if (ddata[mid] <= key) lo = mid + 1; else hi = mid; }
+    const bool start = (i == 0) || ((key >> 2) != (km[i - 1] >> 2));
+    put_column(rows, nw, i + lo, edges[i], start, ssup);
+}
+__global__ void __launch_bounds__(256) k_bld_emit_dummies(const u64 *__restrict__ ddata, const unsigned *__restrict__ dedges,
+                                                          i64 nd, const u64 *__restrict__ km, i64 nk, u64 *__restrict__ rows,
+                                                          i64 nw, int ssup) {
+    const i64 d = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (d >= nd) return;
+    put_column(rows, nw, d + lower_bound_u64(km, nk, ddata[d]), dedges[d], true, ssup);   // a dummy is its own group
+}
+
+static void scan_i64(const i64 *in, i64 n, i64 *out, i64 *bsum, hipStream_t st) {
+    const unsigned gb = (unsigned)((n + 1023) / 1024);
+    hipLaunchKernelGGL(k_scan_block_sums, dim3(gb), dim3(256), 0, st, in, n, bsum);
+    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, st, bsum, (i64)gb);
+    hipLaunchKernelGGL(k_scan_apply, dim3(gb), dim3(256), 0, st, in, n, bsum, out);
+}
+
+// Device part of the builder.  Phase A: text (separator-joined) -> sorted distinct k-mers, suffix groups, edges, the
+// list of predecessor-less k-mers (returned to the host, which makes and sorts their dummy prefixes: few).  Phase B:
+// the columns.  All device memory is owned by SbwtBuildState.
+#define BLD_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { err = e_; goto fail; } } while (0)
+
+int sbwt_build_phase_a(const char *h_text, long long n_text, int k, int rc, SbwtBuildState *S, hipStream_t st) {
+    hipError_t err = hipSuccess;
+    S->k = k; S->rc = rc; S->n_text = n_text;
+    const i64 n_groups = (n_text + 31) / 32 + 2;
+    const i64 n_pos = n_text;                              // windows that run past the end meet zero validity bits
+    const i64 cap = (rc ? 2 : 1) * n_text;
+    char *d_text = nullptr; uint4 *d_packed = nullptr; u64 *keys = nullptr, *keys2 = nullptr; unsigned long long *d_cnt = nullptr;
+    i64 *flag = nullptr, *pos = nullptr, *bsum = nullptr, *gstart = nullptr; u64 *gsuf = nullptr;
+    void *tmp = nullptr; size_t tmp_bytes = 0;
+    SbwtWorkHeader *ws = nullptr;
+    unsigned long long h_cnt = 0;
+    i64 nv = 0, nk = 0, ng = 0, nn = 0;
+    BLD_TRY(hipMalloc((void **)&d_text, (size_t)n_text + 64));
+    BLD_TRY(hipMalloc((void **)&d_packed, (size_t)n_groups * 16));
+    BLD_TRY(hipMalloc((void **)&ws, sizeof(SbwtWorkHeader)));
+    BLD_TRY(hipMalloc((void **)&d_cnt, 8));
+    BLD_TRY(hipMemcpyAsync(d_text, h_text, (size_t)n_text, hipMemcpyHostToDevice, st));
+    BLD_TRY(hipMemsetAsync(d_cnt, 0, 8, st));
+    sbwt_launch_encode(d_text, n_text, d_packed, ws, st);
+    BLD_TRY(hipMalloc((void **)&keys, (size_t)(cap + 1) * 8));
+    hipLaunchKernelGGL(k_bld_extract, dim3(grid_for(n_pos)), dim3(256), 0, st, d_packed, n_pos, k, rc, keys, d_cnt);
+    BLD_TRY(hipMemcpyAsync(&h_cnt, d_cnt, 8, hipMemcpyDeviceToHost, st));
+    BLD_TRY(hipStreamSynchronize(st));
+    (void)hipFree(d_text); d_text = nullptr;
+    (void)hipFree(d_packed); d_packed = nullptr;
+    nv = (i64)h_cnt;
+    if (nv > 0) {
+        BLD_TRY(hipMalloc((void **)&keys2, (size_t)nv * 8));
+        BLD_TRY(rocprim::radix_sort_keys(nullptr, tmp_bytes, keys, keys2, (size_t)nv, 0, 2 * k, st));
+        BLD_TRY(hipMalloc(&tmp, tmp_bytes + 16));
+        BLD_TRY(rocprim::radix_sort_keys(tmp, tmp_bytes, keys, keys2, (size_t)nv, 0, 2 * k, st));
+        BLD_TRY(hipStreamSynchronize(st));
+        (void)hipFree(tmp); tmp = nullptr;
+        (void)hipFree(keys); keys = nullptr;
+        // distinct k-mers
+        BLD_TRY(hipMalloc((void **)&flag, (size_t)(nv + 1) * 8));
+        BLD_TRY(hipMalloc((void **)&pos, (size_t)(nv + 2) * 8));
+        BLD_TRY(hipMalloc((void **)&bsum, (size_t)((nv + 1023) / 1024 + 2) * 8));
+        hipLaunchKernelGGL(k_bld_flag_first, dim3(grid_for(nv)), dim3(256), 0, st, keys2, nv, 0, flag);
+        scan_i64(flag, nv, pos, bsum, st);
+        BLD_TRY(hipMemcpyAsync(&nk, pos + nv, 8, hipMemcpyDeviceToHost, st));
+        BLD_TRY(hipStreamSynchronize(st));
+        BLD_TRY(hipMalloc((void **)&S->km, (size_t)nk * 8));
+        hipLaunchKernelGGL(k_bld_compact, dim3(grid_for(nv)), dim3(256), 0, st, keys2, flag, pos, nv, S->km);
+        BLD_TRY(hipStreamSynchronize(st));
+        (void)hipFree(keys2); keys2 = nullptr;
+        // suffix groups
+        hipLaunchKernelGGL(k_bld_flag_first, dim3(grid_for(nk)), dim3(256), 0, st, S->km, nk, 2, flag);
+        scan_i64(flag, nk, pos, bsum, st);
+        BLD_TRY(hipMemcpyAsync(&ng, pos + nk, 8, hipMemcpyDeviceToHost, st));
+        BLD_TRY(hipStreamSynchronize(st));
+        BLD_TRY(hipMalloc((void **)&gstart, (size_t)ng * 8));
+        BLD_TRY(hipMalloc((void **)&gsuf, (size_t)ng * 8));
+        hipLaunchKernelGGL(k_bld_groups, dim3(grid_for(nk)), dim3(256), 0, st, S->km, flag, pos, nk, gstart, gsuf);
+        // predecessors and edges
+        BLD_TRY(hipMalloc((void **)&S->edges, (size_t)nk * 4));
+        BLD_TRY(hipMemsetAsync(S->edges, 0, (size_t)nk * 4, st));
+        hipLaunchKernelGGL(k_bld_pred, dim3(grid_for(nk)), dim3(256), 0, st, S->km, nk, k, gstart, gsuf, ng, S->edges, flag);
+        scan_i64(flag, nk, pos, bsum, st);
+        BLD_TRY(hipMemcpyAsync(&nn, pos + nk, 8, hipMemcpyDeviceToHost, st));
+        BLD_TRY(hipStreamSynchronize(st));
+        if (nn > 0) {
+            BLD_TRY(hipMalloc((void **)&S->nopred_keys, (size_t)nn * 8));
+            hipLaunchKernelGGL(k_bld_compact, dim3(grid_for(nk)), dim3(256), 0, st, S->km, flag, pos, nk, S->nopred_keys);
+        }
+        BLD_TRY(hipStreamSynchronize(st));
+    }
+    S->nk = nk; S->ng = ng; S->n_nopred = nn;
+fail:
+    (void)hipFree(d_text); (void)hipFree(d_packed); (void)hipFree(ws); (void)hipFree(d_cnt); (void)hipFree(keys); (void)hipFree(keys2);
+    (void)hipFree(tmp); (void)hipFree(flag); (void)hipFree(pos); (void)hipFree(bsum); (void)hipFree(gstart); (void)hipFree(gsuf);
+    if (err != hipSuccess) { (void)hipGetLastError(); return err == hipErrorOutOfMemory ? -8 : -3; }
+    return 0;
+}
+
+int sbwt_build_copy_nopred(const SbwtBuildState *S, unsigned long long *h_keys) {
+    if (S->n_nopred == 0) return 0;
+    return hipMemcpy(h_keys, S->nopred_keys, (size_t)S->n_nopred * 8, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -3;
+}
+
+// Phase B: dummies (sorted by (label, length), edges merged; label top-aligned in 2k bits) + k-mers -> the five rows
+// (A, C, G, T, suffix_group_starts; nw words each) in host memory.
+int sbwt_build_phase_b(SbwtBuildState *S, const unsigned long long *h_ddata, const unsigned *h_dedges, long long nd, int ssup,
+                       unsigned long long *h_rows, hipStream_t st) {
+    hipError_t err = hipSuccess;
+    const i64 n = S->nk + nd, nw = (n + 63) / 64;
+    u64 *ddata = nullptr, *rows = nullptr; unsigned *dedges = nullptr;
+    BLD_TRY(hipMalloc((void **)&ddata, (size_t)(nd + 1) * 8));
+    BLD_TRY(hipMalloc((void **)&dedges, (size_t)(nd + 1) * 4));
+    BLD_TRY(hipMalloc((void **)&rows, (size_t)(5 * nw + 1) * 8));
+    BLD_TRY(hipMemcpyAsync(ddata, h_ddata, (size_t)nd * 8, hipMemcpyHostToDevice, st));
+    BLD_TRY(hipMemcpyAsync(dedges, h_dedges, (size_t)nd * 4, hipMemcpyHostToDevice, st));
+    BLD_TRY(hipMemsetAsync(rows, 0, (size_t)(5 * nw) * 8, st));
+    if (S->nk > 0)
+        hipLaunchKernelGGL(k_bld_emit_kmers, dim3(grid_for(S->nk)), dim3(256), 0, st, S->km, S->nk, S->edges, ddata, (i64)nd, rows,
+                           nw, ssup);
+    hipLaunchKernelGGL(k_bld_emit_dummies, dim3(grid_for(nd)), dim3(256), 0, st, ddata, dedges, (i64)nd, S->km, S->nk, rows, nw, ssup);
+    BLD_TRY(hipMemcpyAsync(h_rows, rows, (size_t)(5 * nw) * 8, hipMemcpyDeviceToHost, st));
+    BLD_TRY(hipStreamSynchronize(st));
+fail:
+    (void)hipFree(ddata); (void)hipFree(dedges); (void)hipFree(rows);
+    if (err != hipSuccess) { (void)hipGetLastError(); return err == hipErrorOutOfMemory ? -8 : -3; }
+    return 0;
+}
+
+void sbwt_build_release(SbwtBuildState *S) {
+    (void)hipFree(S->km); (void)hipFree(S->edges); (void)hipFree(S->nopred_keys);
+    S->km = nullptr; S->edges = nullptr; S->nopred_keys = nullptr;
+}

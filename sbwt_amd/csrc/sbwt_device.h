@@ -156,6 +156,10 @@ void sbwt_launch_select(const SbwtIndexView &ix, const long long *d_j, const cha
 long long sbwt_format_scratch_bytes(long long n_reads);
 void sbwt_launch_format(const long long *d_vals, const long long *d_out_off, long long n_reads, char *d_text,
                         long long *d_line_off, void *d_scratch, hipStream_t stream);
+long long sbwt_blocks_scratch_bytes(long long n_nodes);
+int sbwt_blocks_count(const unsigned long long *d_bits, long long n_nodes, void *d_scratch, long long totals[4], hipStream_t st);
+void sbwt_blocks_fill(const unsigned long long *d_bits, const unsigned long long *d_ssup, long long n_nodes, void *d_scratch,
+                      const long long C[4], int use_mega, int n_mega, uint4 *d_blocks, unsigned long long *d_mega, hipStream_t st);
 long long sbwt_derive_scratch_bytes(long long n_nodes);
 void sbwt_launch_derive_marks(const SbwtIndexView &ix, uint4 *d_blocks, void *d_scratch, hipStream_t stream);
 long long sbwt_sparse_scratch_bytes(long long n_nodes);
@@ -168,3 +172,18 @@ int sbwt_launch_build_path(const SbwtIndexView &ix, unsigned *d_col, unsigned *d
 int sbwt_launch_build_sparse(const SbwtIndexView &ix, int p_dense, int p_sparse, int log2b, uint4 *d_table,
                              void *d_scratch, const unsigned *d_pos, int p_filter, int log2f, uint4 *d_filter,
                              int log2b2, uint4 *d_table2, hipStream_t stream);
+
+// device builder (sbwt_build.hip): phase A = text -> sorted distinct k-mers, edges, predecessor-less k-mers; phase B =
+// dummies + k-mers -> the five rows in host memory
+struct SbwtBuildState {
+    int k = 0, rc = 0, ssup = 0;
+    long long n_text = 0, nk = 0, ng = 0, n_nopred = 0;
+    unsigned long long *km = nullptr;            // sorted distinct k-mers
+    unsigned *edges = nullptr;                   // per k-mer (set on suffix-group starts)
+    unsigned long long *nopred_keys = nullptr;   // the k-mers without a predecessor
+};
+int sbwt_build_phase_a(const char *h_text, long long n_text, int k, int rc, SbwtBuildState *S, hipStream_t st);
+int sbwt_build_copy_nopred(const SbwtBuildState *S, unsigned long long *h_keys);
+int sbwt_build_phase_b(SbwtBuildState *S, const unsigned long long *h_ddata, const unsigned *h_dedges, long long nd, int ssup,
+                       unsigned long long *h_rows, hipStream_t st);
+void sbwt_build_release(SbwtBuildState *S);

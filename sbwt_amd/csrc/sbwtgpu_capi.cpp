@@ -62,6 +62,13 @@ int default_device_precalc(int64_t n_nodes, bool derived) {
     return v;
 }
 
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf() {
+        if (p) (void)hipFree(p);
+    }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16); }
+};
 struct DeviceGuard {
     int prev = -1;
     bool ok = false;
@@ -282,17 +289,30 @@ int sbwtgpu_index_create(const sbwtgpu_index_desc *d, int device, sbwtgpu_index 
     }
     idx->device = device;
 
-    // C array (SBWT.hh:344-349): C[0] = 1 (ghost dollar into the root), C[i+1] = C[i] + rank(n, sigma_i)
+    // The bit vectors go to the device once; counting, the per-block prefix counts and the interleaving all happen
+    // there (sbwt_build.hip) -- 142 M columns took seconds in host loops.
     const uint64_t *cols[4] = {d->A_bits, d->C_bits, d->G_bits, d->T_bits};
-    auto word = [&](const uint64_t *v, int64_t w) -> uint64_t {
-        if (w >= nw) return 0;
-        uint64_t x = v[w];
-        if (w == nw - 1 && (n & 63)) x &= (~0ull) >> (64 - (n & 63));
-        return x;
-    };
-    int64_t tot[4] = {0, 0, 0, 0};
-    for (int c = 0; c < 4; c++)
-        for (int64_t w = 0; w < nw; w++) tot[c] += __builtin_popcountll(word(cols[c], w));
+    DevBuf d_bits, d_bscr;
+    {
+        hipError_t eb = d_bits.alloc((size_t)(5 * nw) * 8);
+        if (eb == hipSuccess) eb = d_bscr.alloc((size_t)sbwt_blocks_scratch_bytes(n));
+        for (int c = 0; c < 4 && eb == hipSuccess; c++)
+            eb = hipMemcpy(static_cast<char *>(d_bits.p) + (size_t)c * (size_t)nw * 8, cols[c], (size_t)nw * 8, hipMemcpyHostToDevice);
+        if (eb == hipSuccess && d->suffix_group_starts)
+            eb = hipMemcpy(static_cast<char *>(d_bits.p) + (size_t)4 * (size_t)nw * 8, d->suffix_group_starts, (size_t)nw * 8,
+                           hipMemcpyHostToDevice);
+        if (eb != hipSuccess) {
+            delete idx;
+            return fail(eb == hipErrorOutOfMemory ? SBWTGPU_ERR_OOM : SBWTGPU_ERR_HIP, "uploading the bit vectors: %s",
+                        hipGetErrorString(eb));
+        }
+    }
+    // C array (SBWT.hh:344-349): C[0] = 1 (ghost dollar into the root), C[i+1] = C[i] + rank(n, sigma_i)
+    long long tot[4] = {0, 0, 0, 0};
+    if (sbwt_blocks_count(static_cast<const unsigned long long *>(d_bits.p), n, d_bscr.p, tot, 0) != 0) {
+        delete idx;
+        return fail(SBWTGPU_ERR_HIP, "counting the set bits on the device failed");
+    }
     h.C[0] = 1;
     for (int c = 1; c < 4; c++) h.C[c] = h.C[c - 1] + tot[c - 1];
     // In an SBWT every column except the root has exactly one incoming edge, so the matrix holds
@@ -333,42 +353,6 @@ int sbwtgpu_index_create(const sbwtgpu_index_desc *d, int device, sbwtgpu_index 
         }
     }
 
-    // interleaved blocks + mega table, built on the host in one pass, then uploaded
-    std::vector<uint32_t> blocks;
-    std::vector<uint64_t> mega;
-    try {
-        blocks.resize((size_t)n_blocks * 16);
-        mega.assign((size_t)(4 * n_mega), 0);
-    } catch (...) {
-        delete idx;
-        return fail(SBWTGPU_ERR_OOM, "out of host memory building the index image");
-    }
-    {
-        uint64_t run[4] = {(uint64_t)h.C[0], (uint64_t)h.C[1], (uint64_t)h.C[2], (uint64_t)h.C[3]};
-        uint64_t mbase[4] = {0, 0, 0, 0};
-        const int64_t blocks_per_mega = (int64_t)1 << (SBWT_MEGA_SHIFT - 6);
-        for (int64_t b = 0; b < n_blocks; b++) {
-            if (b % blocks_per_mega == 0) {
-                int64_t mb = b / blocks_per_mega;
-                // a single mega block keeps base 0 so that cnt alone is the absolute value
-                for (int c = 0; c < 4; c++) {
-                    mbase[c] = (n_mega > 1 || h.force_mega) ? run[c] : 0;
-                    mega[(size_t)(c * n_mega + mb)] = mbase[c];
-                }
-            }
-            uint64_t s = d->suffix_group_starts ? word(d->suffix_group_starts, b) : 0;
-            uint32_t *q = &blocks[(size_t)b * 16];
-            for (int c = 0; c < 4; c++) {
-                uint64_t bits = word(cols[c], b);
-                q[4 * c + 0] = (uint32_t)bits;
-                q[4 * c + 1] = (uint32_t)(bits >> 32);
-                q[4 * c + 2] = (uint32_t)(run[c] - mbase[c]);
-                q[4 * c + 3] = (c & 1) ? (uint32_t)(s >> 32) : (uint32_t)s;
-                run[c] += (uint64_t)__builtin_popcountll(bits);
-            }
-        }
-    }
-
     if (h.rank_only) {   // no tables in a rank-only image
         ptab_bytes = 0;
         ftab_bytes = 0;
@@ -397,12 +381,17 @@ int sbwtgpu_index_create(const sbwtgpu_index_desc *d, int device, sbwtgpu_index 
     int rc = SBWTGPU_OK;
     do {
         if ((e = hipMemset(idx->blob, 0, (size_t)h.blob_bytes)) != hipSuccess) break;
-        if ((e = hipMemcpy(idx->blob + h.off_blocks, blocks.data(), (size_t)n_blocks * 64, hipMemcpyHostToDevice)) !=
-            hipSuccess)
-            break;
-        if ((e = hipMemcpy(idx->blob + h.off_mega, mega.data(), (size_t)(4 * n_mega * 8), hipMemcpyHostToDevice)) !=
-            hipSuccess)
-            break;
+        {
+            const long long Cs[4] = {h.C[0], h.C[1], h.C[2], h.C[3]};
+            sbwt_blocks_fill(static_cast<const unsigned long long *>(d_bits.p),
+                             d->suffix_group_starts ? static_cast<const unsigned long long *>(d_bits.p) + 4 * nw : nullptr, n,
+                             d_bscr.p, Cs, (n_mega > 1 || h.force_mega) ? 1 : 0, (int)n_mega,
+                             reinterpret_cast<uint4 *>(idx->blob + h.off_blocks),
+                             reinterpret_cast<unsigned long long *>(idx->blob + h.off_mega), 0);
+            if ((e = hipDeviceSynchronize()) != hipSuccess) break;
+            (void)hipFree(d_bits.p); d_bits.p = nullptr;          // the derived structures need the room
+            (void)hipFree(d_bscr.p); d_bscr.p = nullptr;
+        }
         SbwtIndexView v = idx->view();
         if (!d->suffix_group_starts && !h.rank_only && g_derive_ssup && d->k >= 2) {
             // no streaming support in the file: derive the marks for internal use (has_ssup stays 0)
@@ -799,13 +788,6 @@ int sbwtgpu_workspace_stats(const void *d_ws, void *stream, int64_t stats[8]) {
 
 // ---- host-buffer entry points --------------------------------------------------------------
 namespace {
-struct DevBuf {
-    void *p = nullptr;
-    ~DevBuf() {
-        if (p) (void)hipFree(p);
-    }
-    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16); }
-};
 struct Stream {
     hipStream_t s = nullptr;
     ~Stream() {
@@ -1277,6 +1259,93 @@ int sbwtgpu_select_batch(const sbwtgpu_index *idx, const int64_t *j, const char 
     HIP_TRY(hipStreamSynchronize(sg.stream));
     memcpy(out, sg.host + o_out, (size_t)n * 8);
     return SBWTGPU_OK;
+}
+
+// ---- construction on the device ---------------------------------------------------
+int sbwtgpu_build_plain_matrix(const char *const *seqs, const int64_t *seq_len, int64_t n_seqs, int64_t k, int add_revcomp,
+                               int build_streaming_support, int device, sbwtgpu_plain_matrix_bits *out) {
+    if (!out) return fail(SBWTGPU_ERR_INVALID_ARG, "out is NULL");
+    memset(out, 0, sizeof(*out));
+    if (n_seqs < 0 || (n_seqs > 0 && (!seqs || !seq_len))) return fail(SBWTGPU_ERR_INVALID_ARG, "bad sequence list");
+    if (k < 2 || k > 32) return fail(SBWTGPU_ERR_INVALID_ARG, "the device builder packs a k-mer into 64 bits: 2 <= k <= 32");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(SBWTGPU_ERR_NO_DEVICE, "no HIP device");
+    if (device < 0 || device >= ndev) return fail(SBWTGPU_ERR_NO_DEVICE, "device %d out of range", device);
+    DeviceGuard guard(device);
+    if (!guard.ok) return fail(SBWTGPU_ERR_NO_DEVICE, "hipSetDevice(%d) failed", device);
+    // one text, sequences separated by a byte that is not ACGT: a k-mer window across a boundary is invalid like one with N
+    int64_t n_text = 0;
+    for (int64_t i = 0; i < n_seqs; i++) {
+        if (seq_len[i] < 0) return fail(SBWTGPU_ERR_INVALID_ARG, "negative sequence length");
+        n_text += seq_len[i] + 1;
+    }
+    std::vector<char> text;
+    std::vector<unsigned long long> nopred, ddata, rows;
+    std::vector<unsigned> dedges;
+    SbwtBuildState S;
+    int rc = SBWTGPU_OK;
+    try {
+        text.resize((size_t)n_text + 1);
+        int64_t w = 0;
+        for (int64_t i = 0; i < n_seqs; i++) {
+            if (seq_len[i]) memcpy(text.data() + w, seqs[i], (size_t)seq_len[i]);
+            w += seq_len[i];
+            text[(size_t)w++] = '$';
+        }
+        int ra = sbwt_build_phase_a(text.data(), n_text, (int)k, add_revcomp ? 1 : 0, &S, 0);
+        if (ra != 0) { sbwt_build_release(&S); return fail(ra == -8 ? SBWTGPU_ERR_OOM : SBWTGPU_ERR_HIP, "device builder, phase A"); }
+        std::vector<char>().swap(text);
+        nopred.resize((size_t)S.n_nopred);
+        if (sbwt_build_copy_nopred(&S, nopred.data()) != 0) { sbwt_build_release(&S); return fail(SBWTGPU_ERR_HIP, "device builder: copy"); }
+        // dummy prefixes of the predecessor-less k-mers (NodeBOSSInMemoryConstructor.hh:70-79) + the root, sorted like
+        // Kmer::operator< (label, then length), equal nodes merged.  These are few (about one k-mer per input sequence).
+        struct Dm { unsigned long long data; unsigned len, edges; };
+        std::vector<Dm> dm;
+        dm.reserve((size_t)S.n_nopred * (size_t)k + 1);
+        dm.push_back(Dm{0, 0, 0});
+        const int kbits = 2 * (int)k;
+        for (unsigned long long zk : nopred)
+            for (int j = 0; j < (int)k; j++) {
+                unsigned long long label = (j == 0) ? 0ull : ((zk & ((1ull << (2 * j)) - 1ull)) << (kbits - 2 * j));
+                dm.push_back(Dm{label, (unsigned)j, 1u << (unsigned)((zk >> (2 * j)) & 3ull)});
+            }
+        std::sort(dm.begin(), dm.end(), [](const Dm &a, const Dm &b) { return a.data != b.data ? a.data < b.data : a.len < b.len; });
+        size_t wd = 0;
+        for (size_t i = 0; i < dm.size(); i++) {
+            if (wd > 0 && dm[wd - 1].data == dm[i].data && dm[wd - 1].len == dm[i].len) dm[wd - 1].edges |= dm[i].edges;
+            else dm[wd++] = dm[i];
+        }
+        dm.resize(wd);
+        ddata.resize(wd);
+        dedges.resize(wd);
+        for (size_t i = 0; i < wd; i++) { ddata[i] = dm[i].data; dedges[i] = dm[i].edges; }
+        const int64_t n = S.nk + (int64_t)wd, nw = (n + 63) / 64;
+        rows.resize((size_t)(5 * nw));
+        int rb = sbwt_build_phase_b(&S, ddata.data(), dedges.data(), (long long)wd, build_streaming_support ? 1 : 0, rows.data(), 0);
+        sbwt_build_release(&S);
+        if (rb != 0) return fail(rb == -8 ? SBWTGPU_ERR_OOM : SBWTGPU_ERR_HIP, "device builder, phase B");
+        uint64_t *mem = static_cast<uint64_t *>(malloc((size_t)(5 * nw) * 8 + 8));
+        if (!mem) return fail(SBWTGPU_ERR_OOM, "out of host memory");
+        memcpy(mem, rows.data(), (size_t)(5 * nw) * 8);
+        out->n_nodes = n;
+        out->n_kmers = S.nk;
+        out->k = k;
+        out->A_bits = mem;
+        out->C_bits = mem + nw;
+        out->G_bits = mem + 2 * nw;
+        out->T_bits = mem + 3 * nw;
+        out->suffix_group_starts = build_streaming_support ? mem + 4 * nw : nullptr;
+    } catch (const std::bad_alloc &) {
+        sbwt_build_release(&S);
+        rc = fail(SBWTGPU_ERR_OOM, "out of host memory");
+    }
+    return rc;
+}
+
+void sbwtgpu_free_plain_matrix(sbwtgpu_plain_matrix_bits *b) {
+    if (!b) return;
+    free(b->A_bits);                                   // one allocation holds all five rows
+    memset(b, 0, sizeof(*b));
 }
 
 // ---- device-side formatting + pipelined host path ------------------------------------------------
