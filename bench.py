@@ -272,6 +272,11 @@ def main() -> int:
                     help="--kernel rank: columns of the four random bit vectors of the HBM-resident case (the image is "
                          "1 byte per column: the default 2 GiB defeats the 256 MB Infinity Cache); the config-2 index "
                          "(12.8 MB of blocks, cache resident) is measured beside it")
+    ap.add_argument("--image-level", type=int, default=0, choices=[0, 1, 2],
+                    help="device image: 0 = all derived structures (default), 1 = no path order, 2 = blocks + dense table")
+    ap.add_argument("--replicate", choices=["image", "rebuild"], default="image",
+                    help="N > 1: broadcast the finished device image (default), or broadcast the five bit vectors "
+                         "(0.7 bytes per column) and let every rank derive its own image")
     ap.add_argument("--check-ranks", action="store_true",
                     help="every rank's first 2000 reads are compared with the oracle on rank 0 (rank_parity in the JSON "
                          "line); used by the N > 1 tests")
@@ -334,14 +339,43 @@ def main() -> int:
         else:
             bits = hostlib.build_bits([g.tobytes() for g in genomes], K, False, streaming, n_threads=effective_cores())
         t_cols = time.time() - t0
+    capi.set_tuning("image_level", args.image_level)
+    build_times = None
+    t_bcast = None
+    if world > 1 and args.replicate == "rebuild":
+        # the five bit vectors travel (RCCL / gloo broadcast of one uint64 tensor), every rank derives its own image
+        torch.cuda.synchronize()
+        dist.barrier()
+        tb = time.time()
+        meta = torch.zeros(4, dtype=torch.int64, device=dev)
+        if rank == 0:
+            meta[0], meta[1], meta[2] = bits.n_nodes, bits.n_kmers, 1 if bits.ssup is not None else 0
+        dist.broadcast(meta, src=0)
+        n_nodes_b, n_kmers_b, has_ssup_b = int(meta[0]), int(meta[1]), int(meta[2])
+        nw = (n_nodes_b + 63) // 64
+        rows = torch.empty((4 + has_ssup_b) * nw, dtype=torch.int64, device=dev)
+        if rank == 0:
+            parts = list(bits.cols) + ([bits.ssup] if has_ssup_b else [])
+            rows.copy_(torch.from_numpy(np.concatenate([np.asarray(p)[:nw] for p in parts]).view(np.int64)))
+        dist.broadcast(rows, src=0)
+        torch.cuda.synchronize()
+        t_bcast = time.time() - tb
+        if rank != 0:
+            h = rows.cpu().numpy().view(np.uint64)
+            bits = capi.BuiltBits([h[c * nw:(c + 1) * nw] for c in range(4)], h[4 * nw:5 * nw] if has_ssup_b else None,
+                                  n_nodes_b, n_kmers_b, K)
+        del rows
+    if rank == 0 or (world > 1 and args.replicate == "rebuild"):
+        t1 = time.time()
         index = capi.Index.create(bits.cols[0], bits.cols[1], bits.cols[2], bits.cols[3], bits.ssup, bits.n_nodes, K,
                                   bits.n_kmers, PRECALC, None, device=local_rank)
-        log(f"index: n_nodes={index.n_nodes} n_kmers={index.n_kmers} image={index.blob_bytes / 1e6:.1f} MB "
-            f"device_precalc={index.device_precalc_k} (columns {t_cols:.2f} s + image {time.time() - t0 - t_cols:.2f} s)")
-        build_times = {"columns_s": t_cols, "image_s": time.time() - t0 - t_cols,
-                       "columns_on": "gpu" if K <= 32 else "host", "image_bytes_per_column": index.blob_bytes / index.n_nodes}
-    t_bcast = None
-    if world > 1:
+        t_img = time.time() - t1
+    if rank == 0:
+        log(f"index: n_nodes={index.n_nodes} n_kmers={index.n_kmers} image={index.blob_bytes / 1e6:.1f} MB level={index.image_level} "
+            f"device_precalc={index.device_precalc_k} (columns {t_cols:.2f} s + image {t_img:.2f} s)")
+        build_times = {"columns_s": t_cols, "image_s": t_img, "columns_on": "gpu" if K <= 32 else "host",
+                       "image_level": index.image_level, "image_bytes_per_column": index.blob_bytes / index.n_nodes}
+    if world > 1 and args.replicate == "image":
         hdr, blob = None, None
         if rank == 0:
             hdr = index.export_header()
@@ -471,6 +505,7 @@ def main() -> int:
     }
     if t_bcast is not None:
         result["index_broadcast_s"] = t_bcast
+        result["index_replication"] = args.replicate
     if rank == 0:
         result["index_build"] = build_times
     # HBM-side bytes per launch from the PMC counters: measured by tools/profile.sh in separate rocprofv3 passes (a

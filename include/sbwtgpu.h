@@ -68,6 +68,8 @@ typedef struct {
     int32_t device;
     int64_t device_precalc_k;     /* depth of the library's own device-side prefix table (>= precalc_k) */
     int64_t blob_bytes;           /* size of the device image (what index_bcast moves) */
+    int64_t image_level;          /* what the image holds: 0 = all derived structures, 1 = no path order / transition
+                                     table, 2 = blocks + dense prefix table only (see "image_level" below) */
 } sbwtgpu_index_info;
 
 /* ---- library ---- */
@@ -90,6 +92,13 @@ int         sbwtgpu_device_count(int *count);
  *   "sparse_depth"    depth of the sparse (hashed) prefix table, 0 = none, default 31 (capped at k)
  *   "probe_filter"    1 (default): Bloom filter over the probe_len-mers of the index for the certificate probes
  *   "path_order"      1 (default): path order + transition table (32-bit indexes with suffix-group marks)
+ *   "image_level"     0 (default): the image carries every derived structure (path order + transition table, sparse
+ *                     prefix table, probe filter: 139-168 bytes per column); 1: no path order (about 66 bytes per
+ *                     column); 2: blocks + dense prefix table only (1 byte per column + the table).  Results are the
+ *                     same at every level; throughput is not.  SBWTGPU_IMAGE_LEVEL.
+ *   "max_image_bytes" > 0: index_create moves to the next level while the image would be larger than this (and fails
+ *                     with SBWTGPU_ERR_OOM if level 2 is still larger); it also steps down by itself when device
+ *                     memory runs out.  SBWTGPU_MAX_IMAGE_BYTES.
  *   "force_mega"      1: rank-only images (arbitrary bit vectors) store their block counts relative to a 64-bit base as
  *                     images whose counts pass 2^32 do (tests of that layout at small sizes); default 0
  *   "path_safe"       1 (default): substitution-safe bits along the paths (k <= 31; SBWTGPU_PATH_SAFE) */

@@ -65,7 +65,7 @@ class IndexInfo(C.Structure):
         ("n_nodes", C.c_int64), ("n_kmers", C.c_int64), ("k", C.c_int64), ("precalc_k", C.c_int64),
         ("C", C.c_int64 * 4),
         ("has_streaming_support", C.c_int32), ("device", C.c_int32),
-        ("device_precalc_k", C.c_int64), ("blob_bytes", C.c_int64),
+        ("device_precalc_k", C.c_int64), ("blob_bytes", C.c_int64), ("image_level", C.c_int64),
     ]
 
 
@@ -214,6 +214,7 @@ class Index:
         self.device = info.device
         self.device_precalc_k = info.device_precalc_k
         self.blob_bytes = info.blob_bytes
+        self.image_level = info.image_level
 
     @property
     def handle(self) -> C.c_void_p:

@@ -87,6 +87,7 @@ struct SbwtBlobHeader {
     int32_t log2f;
     int32_t has_safe;               // pq carries the substitution-safe bits
     int32_t force_mega;             // block counts are relative to mega[c][0] although n_mega == 1 (see SbwtIndexView)
+    int64_t image_level;            // 0 full, 1 no path order, 2 blocks + dense prefix table only
     int64_t row_ones[4];            // set bits of the rows A, C, G, T (select: valid j are 1 .. row_ones[c])
     int32_t log2b2;                 // second-level sparse table: log2 of its number of 32-byte entries (0 = none)
     int64_t off_stab2;

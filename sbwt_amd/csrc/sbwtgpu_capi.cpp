@@ -96,6 +96,8 @@ static int g_variant_override = -1, g_probe_override = -1, g_debug = 0, g_derive
 // result the kernel never writes cannot inherit a correct value from an earlier launch
 static int g_poison = [] { const char *e = getenv("SBWTGPU_POISON_RESULTS"); return e ? atoi(e) : 0; }();
 static int g_probe_filter = [] { const char *e = getenv("SBWTGPU_PROBE_FILTER"); return e ? atoi(e) : 1; }();
+static int g_image_level = [] { const char *e = getenv("SBWTGPU_IMAGE_LEVEL"); return e ? atoi(e) : 0; }();
+static int64_t g_max_image_bytes = [] { const char *e = getenv("SBWTGPU_MAX_IMAGE_BYTES"); return e ? (int64_t)atoll(e) : (int64_t)0; }();
 static int g_force_mega = 0;    // tests: store every image's block counts relative to mega[c][0] (the dense rank-only layout)
 static int g_trans_ext = -1;    // -1: adaptive per wave, 0/1: force
 static int g_path_safe = [] { const char *e = getenv("SBWTGPU_PATH_SAFE"); return e ? atoi(e) : 1; }();
@@ -165,6 +167,8 @@ int sbwtgpu_set_tuning(const char *key, int64_t value) {
     if (!strcmp(key, "derive_ssup")) { g_derive_ssup = (int)value; return SBWTGPU_OK; }
     if (!strcmp(key, "poison_results")) { g_poison = (int)value; return SBWTGPU_OK; }
     if (!strcmp(key, "probe_filter")) { g_probe_filter = (int)value; return SBWTGPU_OK; }   // indexes created afterwards
+    if (!strcmp(key, "image_level")) { g_image_level = (int)value; return SBWTGPU_OK; }          // indexes created afterwards
+    if (!strcmp(key, "max_image_bytes")) { g_max_image_bytes = value; return SBWTGPU_OK; }     // indexes created afterwards
     if (!strcmp(key, "force_mega")) { g_force_mega = (int)value; return SBWTGPU_OK; }     // indexes created afterwards
     if (!strcmp(key, "trans_ext")) { g_trans_ext = (int)value; return SBWTGPU_OK; }
     if (!strcmp(key, "path_safe")) { g_path_safe = (int)value; return SBWTGPU_OK; }   // indexes created afterwards
@@ -192,7 +196,11 @@ int sbwtgpu_device_count(int *count) {
 static inline int64_t align256(int64_t x) { return (x + 255) & ~(int64_t)255; }
 
 // set while sbwtgpu_index_create retries without the derived structures after running out of device memory
-static thread_local bool t_minimal_image = false;
+// Image levels: 0 = everything (path order, transition table, sparse table, probe filter: 139-168 bytes per column),
+// 1 = no path order (sparse table + filter + dense prefix table: ~66 bytes per column), 2 = blocks + dense prefix table
+// only (1 byte per column + the table).  index_create starts at "image_level" (tuning / SBWTGPU_IMAGE_LEVEL), and moves
+// to the next level when the image would exceed "max_image_bytes" (SBWTGPU_MAX_IMAGE_BYTES) or device memory runs out.
+static thread_local int t_image_level = -1;
 
 int sbwtgpu_index_create(const sbwtgpu_index_desc *d, int device, sbwtgpu_index **out) {
     if (!d || !out) return fail(SBWTGPU_ERR_INVALID_ARG, "desc/out is NULL");
@@ -218,11 +226,27 @@ int sbwtgpu_index_create(const sbwtgpu_index_desc *d, int device, sbwtgpu_index 
     const int64_t n_blocks = n / 64 + 1;
     const int64_t n_mega = (n >> SBWT_MEGA_SHIFT) + 1;
     int64_t p_file = d->precalc_k;
+    const int level = t_image_level >= 0 ? t_image_level : (g_image_level < 0 ? 0 : g_image_level > 2 ? 2 : g_image_level);
+    const bool t_minimal_image = level >= 2;
+    auto retry_next_level = [&]() {
+        t_image_level = level + 1;
+        const int rc2 = sbwtgpu_index_create(d, device, out);
+        t_image_level = -1;
+        return rc2;
+    };
     const bool derived = !t_minimal_image && g_sparse_depth > 0 && g_probe_filter && n < ((int64_t)1 << 31) - 64 &&
                          n_mega == 1 && d->k > 16;
     int64_t p_dev = default_device_precalc(n, derived);
     if (p_dev < p_file) p_dev = p_file;
     if (p_dev > d->k) p_dev = d->k;
+    if (level >= 2 && g_max_image_bytes > 0) {
+        // the smallest kind of image under a cap: the deepest dense table that still fits (each level is 4x the bytes)
+        auto est = [&](int64_t pd) {
+            return align256(n_blocks * 64) + (pd > 0 ? (int64_t)16 << (2 * pd) : 0) +
+                   ((p_file > 0 && p_file != pd) ? (int64_t)16 << (2 * p_file) : 0) + 4 * n_mega * 8 + 1024;
+        };
+        while (p_dev > p_file && p_dev > 0 && est(p_dev) > g_max_image_bytes) p_dev--;
+    }
 
     sbwtgpu_index *idx = new (std::nothrow) sbwtgpu_index();
     if (!idx) return fail(SBWTGPU_ERR_OOM, "out of host memory");
@@ -279,7 +303,7 @@ int sbwtgpu_index_create(const sbwtgpu_index_desc *d, int device, sbwtgpu_index 
     }
     // path order: needs suffix-group marks (given or derived) and 32-bit columns
     const bool marks = d->suffix_group_starts || (g_derive_ssup && d->k >= 2);
-    if (g_path_order && !t_minimal_image && marks && n < ((int64_t)1 << 31) - 64 && n_mega == 1) {
+    if (g_path_order && level == 0 && marks && n < ((int64_t)1 << 31) - 64 && n_mega == 1) {
         h.has_path = 1;
         h.off_col = h.blob_bytes;
         h.off_pos = align256(h.off_col + (n + 4) * 4);
@@ -363,15 +387,22 @@ int sbwtgpu_index_create(const sbwtgpu_index_desc *d, int device, sbwtgpu_index 
         h.log2b = 0;
         h.off_col = h.off_pos = h.off_pq = h.off_trans = 0;
     }
+    h.image_level = (h.has_path ? 0 : h.p_sparse > 0 ? 1 : 2);
+    if (g_max_image_bytes > 0 && h.blob_bytes > g_max_image_bytes) {
+        if (level < 2 && (h.has_path || h.p_sparse > 0)) {          // the derived structures are optional
+            delete idx;
+            return retry_next_level();
+        }
+        delete idx;
+        return fail(SBWTGPU_ERR_OOM, "the smallest image of this index (%lld bytes: blocks + depth-%lld prefix table) exceeds "
+                    "max_image_bytes = %lld", (long long)h.blob_bytes, (long long)h.p_dev, (long long)g_max_image_bytes);
+    }
     hipError_t e = hipMalloc((void **)&idx->blob, (size_t)h.blob_bytes);
-    if (e != hipSuccess && !t_minimal_image && (h.has_path || h.p_sparse > 0)) {
-        // the derived structures are optional (about 100 bytes per column): without them the blocks-only kernel serves
+    if (e != hipSuccess && level < 2 && (h.has_path || h.p_sparse > 0)) {
+        // the derived structures are optional: without them the blocks-only kernel serves
         (void)hipGetLastError();
         delete idx;
-        t_minimal_image = true;
-        const int rc2 = sbwtgpu_index_create(d, device, out);
-        t_minimal_image = false;
-        return rc2;
+        return retry_next_level();
     }
     if (e != hipSuccess) {
         delete idx;
@@ -454,14 +485,11 @@ int sbwtgpu_index_create(const sbwtgpu_index_desc *d, int device, sbwtgpu_index 
         if ((e = hipGetLastError()) != hipSuccess) break;
         e = hipDeviceSynchronize();
     } while (0);
-    if (e == hipErrorOutOfMemory && !t_minimal_image && (h.has_path || h.p_sparse > 0)) {
+    if (e == hipErrorOutOfMemory && level < 2 && (h.has_path || h.p_sparse > 0)) {
         (void)hipGetLastError();                       // scratch of a derived structure did not fit: build without them
         (void)hipFree(idx->blob);
         delete idx;
-        t_minimal_image = true;
-        const int rc2 = sbwtgpu_index_create(d, device, out);
-        t_minimal_image = false;
-        return rc2;
+        return retry_next_level();
     }
     if (e != hipSuccess) {
         rc = fail(SBWTGPU_ERR_HIP, "building the index image: %s", hipGetErrorString(e));
@@ -493,6 +521,7 @@ int sbwtgpu_index_get_info(const sbwtgpu_index *idx, sbwtgpu_index_info *info) {
     info->device = idx->device;
     info->device_precalc_k = idx->h.p_dev;
     info->blob_bytes = idx->h.blob_bytes;
+    info->image_level = idx->h.image_level;
     return SBWTGPU_OK;
 }
 

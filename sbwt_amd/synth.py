@@ -73,3 +73,73 @@ def inject(bases: np.ndarray, n: int, char: int, seed: int) -> np.ndarray:
     if len(b) and n:
         b[rng.integers(0, len(b), size=n)] = char
     return b
+
+
+# ---- harder workloads (robustness table) ----
+def repeat_genome(n: int, seed: int, repeat_fraction: float = 0.05) -> np.ndarray:
+    """A random genome of n bases in which about `repeat_fraction` of the positions are repeated content:
+    insertion-sequence-like elements (10 families of 1-5 kbp, several copies each, 1 % diverged between copies),
+    one rRNA-operon-like 5 kbp element in 7 exact copies, and low-complexity tracts (homopolymers of 15-40 bases and
+    tandem repeats of 2-6 bp units, 30-120 bases long)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    g = random_genome(n, seed + 1000003)
+    budget = int(n * repeat_fraction)
+    used = 0
+
+    def paste(seq):
+        nonlocal used
+        at = int(rng.integers(0, max(1, n - len(seq))))
+        g[at:at + len(seq)] = seq[: n - at]
+        used += len(seq)
+    rrna = random_genome(5000, seed + 7)
+    for _ in range(7):
+        paste(rrna)
+    families = [random_genome(int(rng.integers(1000, 5001)), seed + 100 + f) for f in range(10)]
+    while used < 0.8 * budget:
+        paste(mutate(families[int(rng.integers(0, 10))], 0.01, int(rng.integers(1, 1 << 30))))
+    while used < budget:
+        if rng.random() < 0.5:
+            paste(np.full(int(rng.integers(15, 41)), ACGT[int(rng.integers(0, 4))], dtype=np.uint8))
+        else:
+            unit = ACGT[rng.integers(0, 4, size=int(rng.integers(2, 7)))]
+            paste(np.tile(unit, int(rng.integers(30, 121)) // len(unit) + 1))
+    return g
+
+
+def ragged_reads(genomes: List[np.ndarray], n_reads: int, min_len: int, max_len: int, sub_rate: float, seed: int
+                 ) -> Tuple[np.ndarray, np.ndarray]:
+    """Reads of uniformly distributed lengths in [min_len, max_len] at uniform (genome, offset), substitutions as in
+    sample_reads; returns (bases, read_off)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    lens_g = np.array([len(g) for g in genomes])
+    cat = np.concatenate(genomes)
+    starts = np.concatenate([[0], np.cumsum(lens_g)[:-1]])
+    L = rng.integers(min_len, max_len + 1, size=n_reads)
+    which = rng.integers(0, len(genomes), size=n_reads)
+    off = (rng.random(n_reads) * (lens_g[which] - L + 1)).astype(np.int64) + starts[which]
+    read_off = np.zeros(n_reads + 1, dtype=np.int64)
+    np.cumsum(L, out=read_off[1:])
+    idx = np.repeat(off - read_off[:-1], L) + np.arange(read_off[-1], dtype=np.int64)
+    bases = cat[idx]
+    if sub_rate > 0:
+        bases = mutate(bases, sub_rate, seed + 1)
+    return bases, read_off
+
+
+def indel_reads(genomes: List[np.ndarray], n_reads: int, read_len: int, sub_rate: float, indel_rate: float, seed: int
+                ) -> Tuple[np.ndarray, np.ndarray]:
+    """Reads with substitutions AND insertions/deletions: every base is deleted with probability indel_rate/2 and
+    followed by one inserted random base with probability indel_rate/2 (so the reads come out ragged, read_len +- a
+    few bases); returns (bases, read_off)."""
+    bases, off = sample_reads(genomes, n_reads, read_len, sub_rate, seed)
+    rng = np.random.Generator(np.random.PCG64(seed + 17))
+    u = rng.random(len(bases))
+    count = np.ones(len(bases), dtype=np.int64)
+    count[u < indel_rate / 2] = 0                                   # deletions
+    ins = (u >= indel_rate / 2) & (u < indel_rate)
+    count[ins] = 2                                                  # the base + one inserted base
+    out = np.repeat(bases, count)
+    pos = np.cumsum(count)                                          # end position (exclusive) of every source base in out
+    out[pos[ins] - 1] = ACGT[rng.integers(0, 4, size=int(ins.sum()))]
+    read_off = np.concatenate([[0], pos[off[1:] - 1]]).astype(np.int64)
+    return out, read_off

@@ -148,3 +148,39 @@ def test_small_calls_equal_large_calls(gpu, case):
     capi.lib().sbwtgpu_release_cached_buffers()
     one, _ = idx.streaming_search(bases[:150], np.array([0, 150]))
     assert np.array_equal(one, big[:oo[1]])
+
+
+def test_image_levels_and_memory_cap(gpu, case):
+    """The derived structures are optional: a capped / minimal image gives the same bits."""
+    genomes, orc = case
+    bases, off = synth.sample_reads(genomes, 3000, 150, 0.02, 99)
+    bases = synth.inject(bases, 50, ord("N"), 3)
+    want = np.concatenate([orc.streaming_search(bases[off[r]:off[r + 1]].tobytes()) for r in range(3000)])
+    sizes = []
+    for level in (0, 1, 2):
+        capi.set_tuning("image_level", level)
+        try:
+            idx = gpu_index_from_oracle(orc)
+        finally:
+            capi.set_tuning("image_level", 0)
+        assert idx.image_level == level
+        sizes.append(idx.blob_bytes)
+        assert np.array_equal(idx.streaming_search(bases, off)[0], want)
+        assert np.array_equal(idx.search(bases, off)[0], want)
+    assert sizes[0] > sizes[1]          # level 2 carries a deeper dense table instead: smaller only for large indexes
+    # a cap selects the first level whose image fits; at level 2 the dense table gets as shallow as it has to
+    for cap, expect in ((sizes[0] - 1, 1), (sizes[1] - 1, 2), (sizes[0], 0), (2_000_000, 2)):
+        capi.set_tuning("max_image_bytes", cap)
+        try:
+            idx = gpu_index_from_oracle(orc)
+        finally:
+            capi.set_tuning("max_image_bytes", 0)
+        assert idx.image_level == expect and idx.blob_bytes <= cap, (cap, idx.image_level, idx.blob_bytes)
+        assert np.array_equal(idx.streaming_search(bases, off)[0], want)
+    capi.set_tuning("max_image_bytes", 1000)
+    try:
+        with pytest.raises(capi.SbwtGpuError) as ei:
+            gpu_index_from_oracle(orc)
+        assert ei.value.code == capi.ERR_OOM
+    finally:
+        capi.set_tuning("max_image_bytes", 0)

@@ -29,10 +29,11 @@ def _bench_env(n_dev):
     return env
 
 
-def test_bench_gpus2_launches_two_ranks(gpu):
+@pytest.mark.parametrize("replicate", ["image", "rebuild"])
+def test_bench_gpus2_launches_two_ranks(gpu, replicate):
     n_dev = capi.device_count()
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--reads", "200000", "--genome-len", "300000",
-           "--steps", "2", "--warmup", "1", "--check-ranks"]
+           "--steps", "2", "--warmup", "1", "--check-ranks", "--replicate", replicate]
     p = subprocess.run(cmd, env=_bench_env(n_dev), capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stderr[-3000:]
     line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1]
@@ -40,7 +41,8 @@ def test_bench_gpus2_launches_two_ranks(gpu):
     assert res["n_gpus"] == 2
     assert res["config"]["reads_per_gpu"] == 200000
     assert res["rank_parity"] == [True, True], res.get("rank_parity")
-    assert res["value"] > 0 and res["index_broadcast_s"] >= 0
+    assert res["rank_reads_differ"] is True
+    assert res["value"] > 0 and res["index_broadcast_s"] >= 0 and res["index_replication"] == replicate
 
 
 def test_bench_rejects_world_mismatch(gpu):

@@ -1,0 +1,54 @@
+"""GPU parity on the harder synthetic workloads of DESIGN.md section 7 (one test per generator in sbwt_amd/synth.py):
+repeated content in the genome, reads with indels, ragged read lengths -- every kernel variant against the oracle."""
+import numpy as np
+import pytest
+
+from oracle import OracleIndex
+from sbwt_amd import capi, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def check(genomes, k, bases, off):
+    seqs = [g.tobytes() for g in genomes]
+    bits = capi.build_bits_gpu(seqs, k, False, True)
+    orc = OracleIndex.from_bits(bits.cols[0], bits.cols[1], bits.cols[2], bits.cols[3], bits.ssup, bits.n_nodes, k,
+                                bits.n_kmers, 8)
+    idx = capi.Index.create(bits.cols[0], bits.cols[1], bits.cols[2], bits.cols[3], bits.ssup, bits.n_nodes, k,
+                            bits.n_kmers, 8)
+    want = [orc.streaming_search(bases[off[r]:off[r + 1]].tobytes()) for r in range(len(off) - 1)]
+    want = np.concatenate(want) if want else np.zeros(0, np.int64)
+    for variant in (2, 3, 1, 0):
+        capi.set_tuning("search_variant", variant)
+        try:
+            got, _ = idx.streaming_search(bases, off)
+            got2, _ = idx.search(bases, off)
+        finally:
+            capi.set_tuning("search_variant", -1)
+        assert np.array_equal(got, want), variant
+        assert np.array_equal(got2, want), variant      # upper-case input: search == streaming_search
+    return want
+
+
+def test_repeated_content_genome(gpu):
+    g0 = synth.repeat_genome(300_000, 5, 0.08)
+    genomes = [g0, synth.mutate(g0, 0.05, 2)]
+    bases, off = synth.sample_reads(genomes, 3000, 150, 0.01, 46)
+    want = check(genomes, 30, bases, off)
+    assert 0.6 < (want >= 0).mean() < 0.85
+
+
+def test_reads_with_indels(gpu):
+    genomes = [synth.random_genome(200_000, 1), None]
+    genomes[1] = synth.mutate(genomes[0], 0.05, 2)
+    bases, off = synth.indel_reads(genomes, 3000, 150, 0.01, 0.004, 44)
+    assert np.diff(off).min() < 150 < np.diff(off).max()
+    check(genomes, 30, bases, off)
+
+
+def test_ragged_read_lengths(gpu):
+    genomes = [synth.random_genome(200_000, 1), None]
+    genomes[1] = synth.mutate(genomes[0], 0.05, 2)
+    bases, off = synth.ragged_reads(genomes, 3000, 20, 250, 0.01, 43)      # some reads shorter than k
+    assert (np.diff(off) < 31).any()
+    check(genomes, 31, bases, off)

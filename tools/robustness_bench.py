@@ -1,0 +1,68 @@
+"""Kernel-only throughput of the search path on harder inputs than the headline workload:
+repeated content in the genome, indels in the reads, ragged read lengths.  Index size as in config 2 (3 x 5 Mbp).
+Prints one line per workload: k-mers/s (encode + search kernels, HIP events, median of 5) and the work mix per read."""
+import os, sys, json
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from sbwt_amd import capi, synth
+
+K, PRE = 30, 8
+n_reads = int(os.environ.get("NREADS", 4_000_000))
+glen = int(os.environ.get("GLEN", 5_000_000))
+dev = torch.device("cuda", 0)
+st = torch.cuda.current_stream().cuda_stream
+
+
+def make_index(genomes):
+    bits = capi.build_bits_gpu([g.tobytes() for g in genomes], K, False, True)
+    return capi.Index.create(bits.cols[0], bits.cols[1], bits.cols[2], bits.cols[3], bits.ssup, bits.n_nodes, K, bits.n_kmers, PRE)
+
+
+def run(name, idx, bases, off):
+    d_bases = torch.from_numpy(bases).to(dev)
+    ooff = capi.out_offsets(off, K)
+    d_roff, d_ooff = torch.from_numpy(off).to(dev), torch.from_numpy(ooff).to(dev)
+    n_k = int(ooff[-1])
+    d_out = torch.empty(n_k, dtype=torch.int64, device=dev)
+    wsb = capi.search_workspace_bytes(len(bases))
+    d_ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    ts = []
+    for r in range(6):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        idx.streaming_search_dev(d_bases.data_ptr(), len(bases), d_roff.data_ptr(), len(off) - 1, d_out.data_ptr(),
+                                 d_ooff.data_ptr(), d_ws.data_ptr(), wsb, st, True)
+        e1.record(); torch.cuda.synchronize()
+        if r: ts.append(e0.elapsed_time(e1))
+    s = idx.workspace_stats(d_ws.data_ptr(), st)
+    nr = len(off) - 1
+    hit = float((d_out >= 0).double().mean().item())
+    res = {"workload": name, "reads": nr, "kmers": n_k, "ms": float(np.median(ts)), "G_kmers_per_s": n_k / np.median(ts) / 1e6,
+           "hit_rate": round(hit, 4), "per_read": {"run_kmers": s[4] / nr, "transition_steps": s[0] / nr, "walks": s[1] / nr,
+                                                   "interval_updates": s[2] / nr}}
+    print(json.dumps(res), flush=True)
+    return d_out
+
+
+base = synth.coli3_like(glen)
+idx0 = make_index(base)
+b, o = synth.sample_reads(base, n_reads, 150, 0.01, 42)
+run("config 2: 3 strains 5% apart, 150 bp reads, 1% substitutions", idx0, b, o)
+b, o = synth.ragged_reads(base, n_reads, 80, 250, 0.01, 43)
+run("ragged read lengths 80-250", idx0, b, o)
+b, o = synth.indel_reads(base, n_reads, 150, 0.01, 0.002, 44)
+run("0.2% indels + 1% substitutions", idx0, b, o)
+b, o = synth.random_reads(n_reads, 150, 45)
+run("random reads (every k-mer absent)", idx0, b, o)
+g0 = synth.repeat_genome(glen, 5)
+rep = [g0, synth.mutate(g0, 0.05, 2), synth.mutate(g0, 0.05, 3)]
+idx1 = make_index(rep)
+print(json.dumps({"repeat_index": {"n_nodes": idx1.n_nodes, "image_MB": idx1.blob_bytes / 1e6}}), flush=True)
+b, o = synth.sample_reads(rep, n_reads, 150, 0.01, 46)
+run("5% repeated content (IS-like, rRNA x7, homopolymer/tandem tracts), 150 bp, 1% substitutions", idx1, b, o)
+single = [synth.random_genome(3 * glen, 9)]
+idx2 = make_index(single)
+b, o = synth.sample_reads(single, n_reads, 150, 0.01, 47)
+run("one 15 Mbp strain (long unbranched paths)", idx2, b, o)
