@@ -62,7 +62,9 @@ int orc_bitvec_init(orc_bitvec *bv, const uint64_t *words, int64_t n_bits) {
         uint64_t packed = 0, in_sb = 0;
         for (int w = 0; w < 32; w++) {
             int64_t wi = sb * 32 + w;
-            if (w > 0 && w % 6 == 0) packed |= in_sb << (60 - 12 * (w / 6));
+            /* sdsl's construction loop packs a field only once the vector has the 6*m words before it [UPSTREAM-KNOWLEDGE];
+             * fields past the last word stay 0 (no rank query ever reads them) */
+            if (w > 0 && w % 6 == 0 && wi <= nw) packed |= in_sb << (60 - 12 * (w / 6));
             if (wi < nw) in_sb += (uint64_t)__builtin_popcountll(bv->words[wi]);
         }
         bv->dir[2 * sb + 1] = packed;

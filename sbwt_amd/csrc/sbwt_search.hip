@@ -354,17 +354,10 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
     constexpr int DEPTH = SearchTypes<WIDE>::DEPTH;
     __shared__ stage_t stage[DEPTH][256];
     __shared__ uint4 desc[PATH ? 4 : 1][PATH ? 128 : 1];      // PATH: run descriptors, per wave
-    // The view's rarely used members (one use each, inside one state's block) are read from this LDS copy where they
-    // are needed instead of being held in scalar registers for the whole loop: the kernel is at the architectural limit
-    // of scalar registers and the compiler was spilling them into vector lanes (v_writelane/v_readlane: 170 of the
-    // loop's 1400 vector instructions).
-    __shared__ SbwtIndexView six;
     const int tid = threadIdx.x, lane = tid & 63;
-    if (tid == 0) six = ix;
-    __syncthreads();
     const int k = ix.k, p = ix.p_dev, L0 = ix.probe_len;
     const int ps = WIDE ? 0 : ix.p_sparse;          // sparse table: 32-bit intervals only
-    const bool pfon = six.pfil && ix.p_filter == L0 && L0 > p;
+    const bool pfon = ix.pfil && ix.p_filter == L0 && L0 > p;
     const u64 m2 = (k - ps >= 32) ? ~0ull : low_mask(2 * ((k - ps) & 31));   // key mask of the second-level window
     const int pw = pfon ? L0 : p;                   // window of a range probe: the filter's when there is one
     const pos_t last_node = (pos_t)(ix.n_nodes - 1);
@@ -445,7 +438,7 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
         bool qshort = false;                           // PATH: a run of fewer than 8 k-mers ended in this iteration
         // run on from transitions while short runs are a sizeable part of this wave's work (one lane-iteration in
         // eight: pan-genomes; on a few strains the saved iterations do not pay for the extra instructions)
-        const bool use_q = PATH && (six.trans_ext > 0 || (six.trans_ext < 0 && c_short >= 8u * c_iter));
+        const bool use_q = PATH && (ix.trans_ext > 0 || (ix.trans_ext < 0 && c_short >= 8u * c_iter));
         c_iter++;
         int tnext = M_EXT;                             // PATH: where a transition's quoted steps already end the run
         pos_t tpos = -1;
@@ -457,7 +450,7 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
             a2 = reinterpret_cast<const uint4 *>(out_off + rd);
         } else if (PATH && mode == M_POS) {
             kind = K_MODE;                             // the aligned 16 bytes holding pos[l]
-            a1 = reinterpret_cast<const uint4 *>(six.pos + ((unsigned)l & ~3u));
+            a1 = reinterpret_cast<const uint4 *>(ix.pos + ((unsigned)l & ~3u));
             a2 = a1;
         } else if (mode != M_IDLE && mode != M_DEAD) {
             // M_INIT reads the window at wstart (j counts extra hash buckets there); M_STEP the base at wstart + j
@@ -485,7 +478,7 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
                     a2 = a1 + 1;
                 } else if (trn) {
                     if (((streaming == 2 ? g0.w : g0.z) >> s) & 1u) {     // validity as in M_STREAM below
-                        a1 = six.trans + (4 * (size_t)(unsigned)r + (unsigned)c);   // the quad of this char's successor
+                        a1 = ix.trans + (4 * (size_t)(unsigned)r + (unsigned)c);   // the quad of this char's successor
                         a2 = a1;
                     } else {
                         ev = EV_EMIT1;
@@ -512,21 +505,21 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
                         if (wk == 1) {                 // bucket (hash + j) of the sparse table: two entries
                             const u64 key = w & low_mask(2 * ps);
                             hk = key;
-                            const u64 bkt = (((key * SBWT_SP_HASH) >> (64 - six.log2b)) + (u64)j) & low_mask(six.log2b);
-                            a1 = six.stab + 2 * bkt;
+                            const u64 bkt = (((key * SBWT_SP_HASH) >> (64 - ix.log2b)) + (u64)j) & low_mask(ix.log2b);
+                            a1 = ix.stab + 2 * bkt;
                             a2 = a1 + 1;
                         } else if (wk == 5) {          // second level: (prefix interval, rest of the k-mer) -> one entry
                             hk = w & m2;
-                            const u64 bkt = ((sp2_hash((unsigned)l, hk) >> (64 - six.log2b2)) + (u64)j) & low_mask(six.log2b2);
-                            a1 = six.stab2 + 2 * bkt;
+                            const u64 bkt = ((sp2_hash((unsigned)l, hk) >> (64 - ix.log2b2)) + (u64)j) & low_mask(ix.log2b2);
+                            a1 = ix.stab2 + 2 * bkt;
                             a2 = a1 + 1;
                         } else if (wk == 2 || (wk == 3 && pfon)) {   // the window's block of the probe filter
                             const u64 h = sbwt_pf_hash(w & low_mask(2 * L0));
                             hk = (u64)sbwt_pf_bits(h);
-                            a1 = six.pfil + (h >> (64 - six.log2f));
+                            a1 = ix.pfil + (h >> (64 - ix.log2f));
                             a2 = a1;
                         } else {
-                            a1 = reinterpret_cast<const uint4 *>(six.ptab + (w & low_mask(2 * p)));
+                            a1 = reinterpret_cast<const uint4 *>(ix.ptab + (w & low_mask(2 * p)));
                             a2 = a1;
                         }
                     } else {
@@ -630,7 +623,7 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
                     seg_src = (unsigned)r + 1u;
                     r += (pos_t)n2;
                     c_ext += (unsigned)n2;
-                    if (stop2) tnext = (six.has_safe && nm < nv && ((v1.z >> 24 >> nm) & 1u)) ? M_BRIDGE : M_TRANS;
+                    if (stop2) tnext = (ix.has_safe && nm < nv && ((v1.z >> 24 >> nm) & 1u)) ? M_BRIDGE : M_TRANS;
                     qshort = stop2;
                 }
             }
@@ -675,7 +668,7 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
             r += (pos_t)n;
             c_ext += (unsigned)n;
             bool sbit = false;                         // stopped at a char mismatch whose path step is substitution-safe?
-            if (six.has_safe && stopped && nm < nv) sbit = ((((((u64)v2.w << 32) | (u64)v1.w) >> sp) >> nm) & 1ull) != 0;
+            if (ix.has_safe && stopped && nm < nv) sbit = ((((((u64)v2.w << 32) | (u64)v1.w) >> sp) >> nm) & 1ull) != 0;
             qshort = stopped && n < 8;
 #ifdef SBWT_STATS
             if (!stopped && i + n != m) atomicAdd(&ws->pad[17], 1ull);      // limited by the 32-step window / descriptor size
@@ -696,7 +689,7 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
                     const int gb = 63 - __clzll((i64)msk);
                     const u64 bits = quad_bits(mine);
                     pos_t val = (pos_t)mine.z + (pos_t)__popcll(bits & low_mask(gb));
-                    if (WIDE) val += (pos_t)six.mega[(i64)c * six.n_mega + (((blk << 6) | gb) >> SBWT_MEGA_SHIFT)];
+                    if (WIDE) val += (pos_t)ix.mega[(i64)c * ix.n_mega + (((blk << 6) | gb) >> SBWT_MEGA_SHIFT)];
                     // node_left == node_right <=> column c has its bit set at the group start (SBWT.hh:572-575)
                     res = ((bits >> gb) & 1ull) ? val : (pos_t)-1;
                     ev = EV_EMIT1;
@@ -741,7 +734,7 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
                     wl = ps;
                     if (m0 | m1) {
                         l = (pos_t)(m0 ? v1.z : v2.z);
-                        if (six.stab_pos) {             // depth-k entries: one column, stored with its path position
+                        if (ix.stab_pos) {             // depth-k entries: one column, stored with its path position
                             r = l;
                             if (PATH) tpos = (pos_t)(m0 ? v1.w : v2.w);
                         } else {
@@ -766,7 +759,7 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
                         imprecise = (wk != 2);         // ... but where inside the window it fails is not known
                     } else if (wk == 3) {
                         ev = EV_PRES;
-                    } else if (wk == 1 && ps < k && six.stab2) {
+                    } else if (wk == 1 && ps < k && ix.stab2) {
                         wk = 5;                        // the prefix is there (l = its first column): the rest in one more gather
                         j = 0;
                     } else {

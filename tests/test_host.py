@@ -131,6 +131,51 @@ def test_index_file_v5_directory_values(tmp_path):
     assert not hasattr(f, "x") and f.precalc is None and f.n_nodes == b.n_nodes
 
 
+@pytest.mark.parametrize("n_bits", [1, 63, 64, 383, 384, 385, 2047, 2048, 2049, 4096 + 777, 100_000])
+def test_written_rank_support_equals_oracle_directory_and_serves_ranks(tmp_path, n_bits):
+    """f1 (upstream file format): no upstream-built .sbwt exists offline, so the sdsl members cannot be pinned to golden
+    bytes; what CAN be checked here: the rank_support_v5 blob the writer emits is word for word the directory the oracle
+    builds (oracle/sbwt_oracle.c, orc_bitvec_init), and a rank computed from the WRITTEN bytes alone with SURVEY App. A's
+    formula (superblock word + 11-bit field + whole-word popcounts + masked popcount) equals the prefix popcount at
+    every tested position -- so the only missing piece is an upstream file to compare with."""
+    rng = np.random.default_rng(n_bits)
+    nw = (n_bits + 63) // 64
+    cols = [rng.integers(0, 2**64, size=nw, dtype=np.uint64) for _ in range(4)]
+    for c in cols:                                            # bits past n_bits are zero in a bit_vector
+        if n_bits & 63:
+            c[-1] &= np.uint64((1 << (n_bits & 63)) - 1)
+    path = str(tmp_path / "rs.sbwt")
+    hostlib.write_index_file(path, cols, None, [1, 2, 3, 4], None, 0, n_bits, 0, 3)
+    raw = open(path, "rb").read()
+    orc = OracleIndex.from_bits(cols[0], cols[1], cols[2], cols[3], None, n_bits, 3, 0, 0)
+    pos = 8 + 12 + 8 + 4 + 4 * (8 + 8 * nw)
+    for c in range(4):
+        bits = struct.unpack_from("<Q", raw, pos)[0]
+        words = np.frombuffer(raw, dtype=np.uint64, count=bits // 64, offset=pos + 8)
+        pos += 8 + bits // 8
+        bv = orc._p.contents.col[c]
+        assert bv.n_dir == len(words) == 2 * (((64 * nw) >> 11) + 1)
+        assert np.array_equal(words, np.ctypeslib.as_array(bv.dir, shape=(bv.n_dir,)))
+        # App. A: rank(idx) from the written directory and the written bit vector words only
+        data = np.frombuffer(raw, dtype=np.uint64, count=nw, offset=8 + 12 + 8 + 4 + c * (8 + 8 * nw) + 8)
+        pc = np.array([bin(int(w)).count("1") for w in data], dtype=np.int64)
+        cum = np.concatenate([[0], np.cumsum(pc)])
+        idxs = np.unique(np.concatenate([[0, n_bits, n_bits - 1, min(n_bits, 384), min(n_bits, 2048)],
+                                         rng.integers(0, n_bits + 1, size=300)]))
+        for idx in idxs:
+            idx = int(idx)
+            p0, p1 = int(words[(idx >> 11) * 2]), int(words[(idx >> 11) * 2 + 1])
+            blk = (idx & 0x7FF) // 384
+            r = p0 + ((p1 >> (60 - 12 * blk)) & 0x7FF)
+            first = ((idx >> 11) << 5) + blk * 6
+            for w in range(first, idx >> 6):
+                r += int(pc[w])
+            if idx & 63:
+                r += bin(int(data[idx >> 6]) & ((1 << (idx & 63)) - 1)).count("1")
+            want = int(cum[idx >> 6]) + (bin(int(data[idx >> 6]) & ((1 << (idx & 63)) - 1)).count("1") if idx & 63 else 0)
+            assert r == want == orc.rank(idx, b"ACGT"[c:c + 1]), (n_bits, c, idx)
+
+
 def test_index_file_without_streaming_support_and_errors(tmp_path):
     seqs = [b"CCCGTGATGGCTA", b"TAATGCTGTAGC"]
     orc = OracleIndex.build(seqs, 4, False, False, 2)

@@ -1,27 +1,41 @@
-"""Writes profiles/traffic.json from a tools/profile.sh summary: HBM-side bytes per k_search launch from
-the PMC counters FETCH_SIZE and WRITE_SIZE (separate rocprofv3 passes, kernel-trace only).
+"""Adds one workload's entry to profiles/traffic.json from a tools/profile.sh summary: HBM-side bytes per k_search
+launch from the PMC counters FETCH_SIZE and WRITE_SIZE (separate rocprofv3 passes, kernel-trace only).
 
-Calibration (tools/micro/calib.sh, gpurun_out/calib): for this kernel's access pattern -- random 16-byte
-gathers that miss L2 -- TCC_EA0_RDREQ counts exactly one request per gather and FETCH_SIZE[KB]*1024 equals
-TCC_EA0_RDREQ*64 B (838.9 M gathers -> 838.0 M requests, 53.6 GB), so FETCH_SIZE is taken as is; the
-guide's x2 correction applies to wide coalesced streams (128-byte requests tallied at 64 B), which here
-are only the k_encode pass and the packed-base reloads (< 3 % of the requests)."""
-import json, re, sys
-summary = sys.argv[1]
-tag = sys.argv[2] if len(sys.argv) > 2 else summary
+Correction (MI355X_MICROARCH.md, HBM section; re-measured here): FETCH_SIZE = TCC_EA0_RDREQ x 64 B, but on gfx950 every
+L2 read miss is a 128-byte fabric request -- TCC_EA0_RDREQ_128B equals TCC_EA0_RDREQ for this kernel (gpurun pmc_reqsize)
+and for every access shape of tools/micro/ceilings.hip, 16-byte random gathers included -- so the bytes read are
+2 x FETCH_SIZE.  WRITE_SIZE counts the 64-byte write requests exactly.
+usage: python tools/make_traffic_json.py <summary.txt> <config number> <reads per gpu> [tag]"""
+import hashlib, json, os, re, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench
+summary, config, reads = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+tag = sys.argv[4] if len(sys.argv) > 4 else os.path.basename(summary)
 vals = {}
 for line in open(summary):
-    m = re.match(r"void k_search\S*.*\s(FETCH_SIZE|WRITE_SIZE|TCC_EA0_RDREQ_sum|TCC_EA0_WRREQ_sum|TCC_HIT_sum|TCC_MISS_sum)\s+n=\s*\d+ avg=([0-9.e+]+)", line)
+    m = re.match(r"void k_search\S*.*\s(FETCH_SIZE|WRITE_SIZE|TCC_EA0_RDREQ_sum|TCC_EA0_WRREQ_sum|TCC_HIT_sum|TCC_MISS_sum|SQ_INSTS_VALU|SQ_INSTS_SALU)\s+n=\s*\d+ avg=([0-9.e+]+)", line)
     if m:
         vals[m.group(1)] = float(m.group(2))
-out = {
-    "hbm_bytes_per_launch": (vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024,
-    "fetch_bytes": vals["FETCH_SIZE"] * 1024, "write_bytes": vals["WRITE_SIZE"] * 1024,
-    "read_requests": vals.get("TCC_EA0_RDREQ_sum"), "write_requests": vals.get("TCC_EA0_WRREQ_sum"),
+path = os.path.join(ROOT, "profiles", "traffic.json")
+try:
+    allv = json.load(open(path))
+    if "hbm_bytes_per_launch" in allv:      # round-1 format: one flat entry
+        allv = {}
+except Exception:
+    allv = {}
+fetch = 2 * vals["FETCH_SIZE"] * 1024
+write = vals["WRITE_SIZE"] * 1024
+allv["config%d" % config] = {
+    "hbm_bytes_per_launch": fetch + write, "fetch_bytes": fetch, "write_bytes": write,
+    "fetch_size_counter_bytes": vals["FETCH_SIZE"] * 1024,
+    "read_requests_128B": vals.get("TCC_EA0_RDREQ_sum"), "write_requests_64B": vals.get("TCC_EA0_WRREQ_sum"),
     "l2_hit_rate": vals["TCC_HIT_sum"] / (vals["TCC_HIT_sum"] + vals["TCC_MISS_sum"]) if "TCC_HIT_sum" in vals else None,
-    "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on `python bench.py --steps 3 --warmup 1`, "
-              "summary " + tag + "; per k_search launch over 10 M reads; fabric-side (L2 miss) bytes, Infinity "
-              "Cache hits included; FETCH_SIZE calibrated 1:1 for 16-byte gathers (tools/micro/calib.sh)",
+    "valu_instructions": vals.get("SQ_INSTS_VALU"), "salu_instructions": vals.get("SQ_INSTS_SALU"),
+    "reads_per_gpu": reads, "kernel_source_sha16": bench.kernel_source_sha16(),
+    "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on bench.py, summary profiles/" + tag +
+              "; per k_search launch; bytes read = 2 x FETCH_SIZE (every L2 read miss is a 128-byte fabric request on "
+              "gfx950: TCC_EA0_RDREQ_128B == TCC_EA0_RDREQ), bytes written = WRITE_SIZE; Infinity Cache hits included",
 }
-json.dump(out, open("profiles/traffic.json", "w"), indent=1)
-print(json.dumps(out, indent=1))
+json.dump(allv, open(path, "w"), indent=1)
+print(json.dumps(allv["config%d" % config], indent=1))
