@@ -45,7 +45,7 @@ B_LF = 2 * 72                   # interval update: two ranks, (8 count + 64 bloc
 B_OUT = 8                       # one int64 result
 # the path-order kernel's own operations: what they must read and write
 B_RUN = 8 + 4 + 0.5 + 1         # k-mer answered along a path run: int64 out + col[t] + its share of the path quad + 1 base
-B_TRANS = 32 + 1 + 8            # streaming step at a branch point: one transition entry + 1 base + out
+B_TRANS = 16 + 1 + 8            # streaming step at a branch point: one 16-byte transition quad + 1 base + out
 
 
 def effective_cores() -> int:
@@ -492,7 +492,7 @@ def main() -> int:
             "traffic": None,
             "kernel_ms": kernel_ms,
             "algorithmic_bytes_per_launch": alg_bytes,
-            "pricing": ("per operation of the path-order algorithm: run k-mer 13.5 B, transition 41 B, walk start 16 B + p, "
+            "pricing": ("per operation of the path-order algorithm: run k-mer 13.5 B, transition 25 B, walk start 16 B + p, "
                         "interval update 144 B, other result 8 B (DESIGN.md section 4); the same work at SURVEY 8d's 89 B per "
                         "streaming step is survey_8d_priced_*") if n_ext else "SURVEY 8d per-operation figures",
             "survey_8d_priced_bytes_per_launch": survey_priced_bytes,
@@ -515,6 +515,9 @@ def main() -> int:
     if tj is not None:
         result["roofline"]["traffic"] = tj.get("hbm_bytes_per_launch")
         result["roofline"]["traffic_source"] = tj.get("source")
+        # what the memory system actually moved per second during the kernel (every gather drags a 128-byte line):
+        result["roofline"]["traffic_GBps"] = tj.get("hbm_bytes_per_launch") / (kernel_ms * 1e-3) / 1e9
+        result["roofline"]["traffic_frac_of_peak"] = result["roofline"]["traffic_GBps"] / HBM_PEAK_GBPS
     result["roofline"]["kernel_source_sha16"] = kernel_source_sha16()
 
     # ---- N > 1 tests: every rank's first reads against the oracle (rank 0 holds the bits) ----

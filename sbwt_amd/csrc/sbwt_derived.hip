@@ -57,16 +57,27 @@ __global__ void __launch_bounds__(256) k_sg_patch(uint4 *__restrict__ blocks, co
 // hashing the survivors into buckets of two entries; a bucket that a key had to skip carries an overflow
 // flag, so a lookup that meets a bucket without the flag knows the prefix is absent.
 // ---------------------------------------------------------------------------------------------
+// Output slot of a compacting append: one atomic per wave instead of one per lane (every expansion level appends
+// ~n_nodes items to ONE counter).  Returns ~0 for lanes that append nothing.  All lanes of the wave must call it.
+__device__ __forceinline__ u64 wave_append_slot(u64 *counter, bool ok) {
+    const u64 m = __ballot(ok);
+    if (m == 0) return ~0ull;
+    const int lane = threadIdx.x & 63, leader = __ffsll((i64)m) - 1;
+    u64 base = 0;
+    if (lane == leader) base = atomicAdd(counter, (u64)__popcll(m));
+    base = uniform64(__shfl(base, leader));
+    return ok ? base + (u64)__popcll(m & low_mask(lane)) : ~0ull;
+}
+
 struct SpItem { u64 key; i64 l; i64 r; };
 
 __global__ void __launch_bounds__(256) k_sp_collect(const longlong2 *__restrict__ ptab, u64 n_entries,
                                                     SpItem *__restrict__ out, u64 *counter) {
     u64 t = (u64)blockIdx.x * 256 + threadIdx.x;
-    if (t >= n_entries) return;
-    longlong2 e = ptab[t];
-    if (e.x < 0) return;
-    u64 slot = atomicAdd(counter, 1ull);
-    out[slot] = SpItem{t, e.x, e.y};
+    longlong2 e = make_longlong2(-1, -1);
+    if (t < n_entries) e = ptab[t];
+    const u64 slot = wave_append_slot(counter, e.x >= 0);
+    if (slot != ~0ull) out[slot] = SpItem{t, e.x, e.y};
 }
 // ---- second level (31 < k <= 63): the 31-prefix's interval (named by its first column) + the remaining bases ----
 struct SpItem2 { u64 key2; unsigned origin, l, r, pad; };
@@ -80,16 +91,19 @@ __global__ void __launch_bounds__(256) k_sp2_seed(SpItem *items, const u64 *n) {
 __global__ void __launch_bounds__(256) k_sp2_expand(SbwtIndexView ix, const SpItem2 *__restrict__ in, const u64 *n_in,
                                                     int d2, SpItem2 *__restrict__ out, u64 *n_out) {
     u64 t = (u64)blockIdx.x * 256 + threadIdx.x;
-    if ((t >> 2) >= *n_in) return;
-    const SpItem2 it = in[t >> 2];
+    const bool live = (t >> 2) < *n_in;
+    SpItem2 it = SpItem2{0ull, 0u, 0u, 0u, 0u};
+    if (live) it = in[t >> 2];
     const int c = (int)(t & 3);
-    uint4 q1 = ix.blocks[(((i64)it.l >> 6) << 2) + c];
-    uint4 q2 = ix.blocks[((((i64)it.r + 1) >> 6) << 2) + c];
-    i64 l = (i64)quad_rank<false>(ix, q1, (i64)it.l, c);
-    i64 r = (i64)quad_rank<false>(ix, q2, (i64)it.r + 1, c) - 1;
-    if (l > r) return;
-    u64 slot = atomicAdd(n_out, 1ull);
-    out[slot] = SpItem2{it.key2 | ((u64)c << (2 * d2)), it.origin, (unsigned)l, (unsigned)r, 0u};
+    i64 l = 1, r = 0;
+    if (live) {
+        uint4 q1 = ix.blocks[(((i64)it.l >> 6) << 2) + c];
+        uint4 q2 = ix.blocks[((((i64)it.r + 1) >> 6) << 2) + c];
+        l = (i64)quad_rank<false>(ix, q1, (i64)it.l, c);
+        r = (i64)quad_rank<false>(ix, q2, (i64)it.r + 1, c) - 1;
+    }
+    const u64 slot = wave_append_slot(n_out, l <= r);
+    if (slot != ~0ull) out[slot] = SpItem2{it.key2 | ((u64)c << (2 * d2)), it.origin, (unsigned)l, (unsigned)r, 0u};
 }
 __global__ void __launch_bounds__(256) k_sp2_insert(const SpItem2 *__restrict__ items, const u64 *n, uint4 *table,
                                                     int log2b2, const unsigned *__restrict__ pos, int *wide_flag) {
@@ -125,16 +139,19 @@ template <bool MEGA>
 __global__ void __launch_bounds__(256) k_sp_expand(SbwtIndexView ix, const SpItem *__restrict__ in, const u64 *n_in,
                                                    int depth, SpItem *__restrict__ out, u64 *n_out) {
     u64 t = (u64)blockIdx.x * 256 + threadIdx.x;
-    if ((t >> 2) >= *n_in) return;
-    const SpItem it = in[t >> 2];
+    const bool live = (t >> 2) < *n_in;
+    SpItem it = SpItem{0, 0, 0};
+    if (live) it = in[t >> 2];
     const int c = (int)(t & 3);
-    uint4 q1 = ix.blocks[((it.l >> 6) << 2) + c];
-    uint4 q2 = ix.blocks[(((it.r + 1) >> 6) << 2) + c];
-    i64 l = (i64)quad_rank<MEGA>(ix, q1, it.l, c);
-    i64 r = (i64)quad_rank<MEGA>(ix, q2, it.r + 1, c) - 1;
-    if (l > r) return;
-    u64 slot = atomicAdd(n_out, 1ull);
-    out[slot] = SpItem{it.key | ((u64)c << (2 * depth)), l, r};   // char `depth` of the prefix is c
+    i64 l = 1, r = 0;
+    if (live) {
+        uint4 q1 = ix.blocks[((it.l >> 6) << 2) + c];
+        uint4 q2 = ix.blocks[(((it.r + 1) >> 6) << 2) + c];
+        l = (i64)quad_rank<MEGA>(ix, q1, it.l, c);
+        r = (i64)quad_rank<MEGA>(ix, q2, it.r + 1, c) - 1;
+    }
+    const u64 slot = wave_append_slot(n_out, l <= r);
+    if (slot != ~0ull) out[slot] = SpItem{it.key | ((u64)c << (2 * depth)), l, r};   // char `depth` of the prefix is c
 }
 // Probe filter: a blocked Bloom filter (128-bit blocks, two bits per key) over every p_filter-mer the index
 // holds.  A certificate probe asks "is this window absent?": a clear bit answers yes in one gather; two set bits

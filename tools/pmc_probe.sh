@@ -33,4 +33,5 @@ for f in sorted(glob.glob(os.path.join(root, "g*/**/*counter_collection.csv"), r
             for c, v in cs.items():
                 print(f"{name[:48]:48s} {c:28s} n={len(v):3d} avg={sum(v)/len(v):.6g}")
 PY
+rm -rf $OUT/g*/
 cat $OUT/summary.txt; cat $OUT/errors.txt 2>/dev/null

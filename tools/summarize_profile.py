@@ -30,6 +30,6 @@ for f in find("pmc_*/**/*counter_collection.csv"):
     for row in csv.DictReader(open(f)):
         agg[row.get("Kernel_Name", "?")][row["Counter_Name"]].append(float(row["Counter_Value"]))
     for name, cs in agg.items():
-        if "k_search" in name or "k_encode" in name:
+        if "k_search" in name or "k_encode" in name or "k_rank" in name:
             for c, v in cs.items():
                 print(f"{name[:60]:60s} {c:28s} n={len(v):3d} avg={sum(v)/len(v):.6g}")
