@@ -77,9 +77,16 @@ const char *sbwtgpu_version(void);
 const char *sbwtgpu_last_error(void);
 int         sbwtgpu_device_count(int *count);
 /* Process-wide tuning knobs for experiments (results never depend on them):
- *   "search_variant"  0 = k_search (the reference's order of searches), 1 = k_search_cert on the blocks,
- *                     2 = k_search_cert along the path order when the index has one (default),
- *                     3 = k_search_pool: the path order with the reads pooled in LDS and re-assigned to lanes by state
+ *   "search_variant"  -1 (default) = by the index: 4 where reads can follow their paths for a while (average path of
+ *                     at least 8 columns), else 2; 0 = k_search (the reference's order of searches), 1 = k_search_cert on
+ *                     the blocks, 2 = k_search_cert along the path order, results staged per lane and written by
+ *                     descriptors, 3 = k_search_pool (reads pooled in LDS, re-assigned to lanes by state), 4 = the path
+ *                     order with per-read segment lists, a read's results written by the whole wave when it ends
+ *   "sort_reads"      1: the path-order kernels take the reads sorted by where they start in the path order (a lookup of one
+ *                     k-mer per read + a radix sort of (position, read) pairs before the search; lanes of a wave then
+ *                     share lines of the index); default 0: the pre-pass costs more than it saves while the path order
+ *                     numbers its paths in column order.  Reads that ARRIVE sorted by genome
+ *                     position need no switch and run 18 % faster.  Set it before sizing workspaces.  SBWTGPU_SORT_READS.
  *   "probe_len"       length of the certificate probes (-1 = automatic, 0 = off)
  *   "derive_ssup"     1 (default): indexes created without suffix_group_starts get the marks derived on
  *                     the device so that the per-k-mer search loop can use streaming steps internally
@@ -188,9 +195,9 @@ int  sbwtgpu_select_batch(const sbwtgpu_index *idx, const int64_t *j, const char
  * The device entry points cannot look at the offsets: the caller guarantees that read_off/out_off are
  * non-decreasing, that out_off matches max(0, len-k+1) per read, that no read has 2^31 or more bases
  * and that one call carries fewer than 2^36 bases. */
-/* Scratch the search kernels need: the 2-bit re-encoding of the bases (total_bases/2 + 64
- * bytes) plus a work-queue header.  The caller allocates it once and may reuse it across
- * calls on the same stream. */
+/* Scratch the search kernels need: a work-queue header, the 2-bit re-encoding of the bases (total_bases/2 + 64
+ * bytes) and, while "sort_reads" is on, room to sort the reads (about one more byte per base).  The caller
+ * allocates it once and may reuse it across calls on the same stream. */
 int64_t sbwtgpu_search_workspace_bytes(int64_t total_bases);
 int  sbwtgpu_streaming_search_dev(const sbwtgpu_index *idx, const char *d_bases, int64_t total_bases,
                                   const int64_t *d_read_off, int64_t n_reads, int64_t *d_out,

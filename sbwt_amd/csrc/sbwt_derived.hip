@@ -492,6 +492,29 @@ long long sbwt_path_scratch_bytes(long long n_nodes) {
     return np * 4 * 8 + np + np * 8 * 2 + (nb + 2) * 8 + 4096;
 }
 long long sbwt_path_quads(long long n_nodes) { return n_nodes / 32 + 4; }
+// number of paths = positions whose "path goes on" bit is clear
+__global__ void __launch_bounds__(256) k_path_count_ends(const uint4 *__restrict__ pq, i64 n, unsigned long long *counter) {
+    const i64 q = (i64)blockIdx.x * 256 + threadIdx.x;
+    unsigned ends = 0;
+    if (q * 32 < n) {
+        const i64 left = n - q * 32;
+        const unsigned valid = left >= 32 ? 0xFFFFFFFFu : ((1u << (int)left) - 1u);
+        ends = (unsigned)__popc(~pq[q].z & valid);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) ends += __shfl_down(ends, off);
+    if ((threadIdx.x & 63) == 0 && ends) atomicAdd(counter, (unsigned long long)ends);
+}
+long long sbwt_count_paths(const SbwtIndexView &ix, hipStream_t stream) {
+    unsigned long long *d = nullptr, h = 0;
+    if (hipMalloc((void **)&d, 8) != hipSuccess) return -1;
+    (void)hipMemsetAsync(d, 0, 8, stream);
+    hipLaunchKernelGGL(k_path_count_ends, dim3(grid_for(ix.n_nodes / 32 + 1)), dim3(256), 0, stream, ix.pq, (i64)ix.n_nodes, d);
+    hipError_t e = hipMemcpyAsync(&h, d, 8, hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    (void)hipFree(d);
+    return e == hipSuccess ? (long long)h : -1;
+}
 void sbwt_launch_path_safe(const SbwtIndexView &ix, uint4 *d_pq, hipStream_t stream) {
     hipLaunchKernelGGL(k_path_safe, dim3(grid_for(ix.n_nodes)), dim3(256), 0, stream, ix, reinterpret_cast<unsigned *>(d_pq));
 }

@@ -87,6 +87,7 @@ struct SbwtBlobHeader {
     int32_t log2f;
     int32_t has_safe;               // pq carries the substitution-safe bits
     int32_t force_mega;             // block counts are relative to mega[c][0] although n_mega == 1 (see SbwtIndexView)
+    int64_t n_paths;                // paths of the path order (n_nodes / n_paths = average run a read can follow)
     int64_t image_level;            // 0 full, 1 no path order, 2 blocks + dense prefix table only
     int64_t row_ones[4];            // set bits of the rows A, C, G, T (select: valid j are 1 .. row_ones[c])
     int32_t log2b2;                 // second-level sparse table: log2 of its number of 32-byte entries (0 = none)
@@ -137,7 +138,12 @@ void sbwt_launch_encode(const char *d_bases, long long total_bases, uint4 *d_pac
                         hipStream_t stream);
 void sbwt_launch_search(const SbwtIndexView &ix, const uint4 *d_packed, const long long *d_read_off,
                         const long long *d_out_off, long long *d_out, long long n_reads, SbwtWorkHeader *ws,
-                        int streaming, hipStream_t stream, int variant, long long total_groups);
+                        int streaming, hipStream_t stream, int variant, long long total_groups, void *d_sort_scratch,
+                        long long sort_scratch_bytes, int sort_key_bits);
+long long sbwt_sort_scratch_bytes(long long n_reads, int key_bits);
+const unsigned *sbwt_launch_sort_reads(const SbwtIndexView &ix, const uint4 *d_packed, const long long *d_read_off,
+                                       long long n_reads, const SbwtWorkHeader *ws, void *d_scratch, long long scratch_bytes,
+                                       int key_bits, hipStream_t stream);
 void sbwt_launch_search_pool(const SbwtIndexView &ix, const uint4 *d_packed, const long long *d_read_off,
                              const long long *d_out_off, long long *d_out, long long n_reads, SbwtWorkHeader *ws,
                              int streaming, hipStream_t stream);
@@ -166,6 +172,7 @@ void sbwt_launch_derive_marks(const SbwtIndexView &ix, uint4 *d_blocks, void *d_
 long long sbwt_sparse_scratch_bytes(long long n_nodes);
 long long sbwt_path_scratch_bytes(long long n_nodes);
 long long sbwt_path_quads(long long n_nodes);
+long long sbwt_count_paths(const SbwtIndexView &ix, hipStream_t stream);
 void sbwt_launch_path_safe(const SbwtIndexView &ix, uint4 *d_pq, hipStream_t stream);
 void sbwt_launch_path_trans(const SbwtIndexView &ix, uint4 *d_trans, hipStream_t stream);
 int sbwt_launch_build_path(const SbwtIndexView &ix, unsigned *d_col, unsigned *d_pos, uint4 *d_pq, uint4 *d_trans,

@@ -344,17 +344,31 @@ __device__ __forceinline__ typename SearchTypes<WIDE>::pos_t quad_rank_t(const S
 //     step is one 16-byte quad of the transition table (the successor of position t by that char: column,
 //     path position and the next 8 steps of its path, so that short runs end in the same iteration).  A third load per iteration prefetches the next packed group of the
 //     read, so that 32-base windows rarely wait for a reload.
-template <bool WIDE, int WPS, bool PATH>
+// (5) SEG = true (with PATH): results are not staged as values.  What a read has produced since its last flush is kept as
+//     a short list of SEGMENTS in LDS -- { source, first k-mer }: a run out of col[] (source = path position of its first
+//     result), a stretch of -1, or one literal column -- and when the read ends (or the list is full) the whole wave
+//     writes the read's results together: every lane finds the segment of its two results, fetches col[] and stores 16
+//     bytes.  One cooperative pass per read instead of one descriptor per run and iteration (the descriptor writer is
+//     53 % of this kernel's vector instructions).
+#define SBWT_NSEG 12
+template <bool WIDE, int WPS, bool PATH, bool SEG = false>
 __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, const uint4 *__restrict__ packed,
                                                         const i64 *__restrict__ read_off,
                                                         const i64 *__restrict__ out_off, i64 *__restrict__ out,
-                                                        i64 n_reads, SbwtWorkHeader *ws, int streaming) {
+                                                        i64 n_reads, SbwtWorkHeader *ws, int streaming,
+                                                        const unsigned *__restrict__ perm) {
+    // perm != nullptr: ticket t is read perm[t] (the reads sorted by where they start in the path order, sbwt_sort.hip:
+    // the lanes of a wave then walk the same paths and share their lines of col / pq / trans)
     typedef typename SearchTypes<WIDE>::pos_t pos_t;
     typedef typename SearchTypes<WIDE>::stage_t stage_t;
     constexpr int DEPTH = SearchTypes<WIDE>::DEPTH;
-    __shared__ stage_t stage[DEPTH][256];
-    __shared__ uint4 desc[PATH ? 4 : 1][PATH ? 128 : 1];      // PATH: run descriptors, per wave
+    static_assert(!SEG || (PATH && !WIDE), "segment lists: 32-bit path-order kernel only");
+    __shared__ stage_t stage[SEG ? 1 : DEPTH][SEG ? 1 : 256];
+    __shared__ uint4 desc[(PATH && !SEG) ? 4 : 1][(PATH && !SEG) ? 128 : 1];      // PATH: run descriptors, per wave
+    __shared__ uint2 segs[SEG ? SBWT_NSEG : 1][SEG ? 256 : 1];                      // SEG: { source, first k-mer } per lane
     const int tid = threadIdx.x, lane = tid & 63;
+    int nseg = 0, i0 = 0, last_start = 0;           // SEG: segments listed; first result of the read not written yet
+    unsigned last_src = 0, emit_pos = 0;
     const int k = ix.k, p = ix.p_dev, L0 = ix.probe_len;
     const int ps = WIDE ? 0 : ix.p_sparse;          // sparse table: 32-bit intervals only
     const bool pfon = ix.pfil && ix.p_filter == L0 && L0 > p;
@@ -374,6 +388,7 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
     int m = 0, i = 0, j = 0, b = -1, wstart = 0, cnt = 0;
     pos_t l = 0, r = 0;             // walk interval; M_STREAM: l = previous answer; M_BACK: r = block
     i64 rd = 0;                     // M_FETCH: the read whose offsets are being fetched
+    bool rdok = true;               // false: rd is still a ticket, the fetch step reads perm[rd] first
     int tag = -2;                   // g0 = packed group `tag`; g1 = group tag+1 if g1ok
     bool g1ok = false;
     // PATH: fixed-length reads (checked by k_check_uniform just before this launch)
@@ -402,7 +417,8 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
             if (mode == M_IDLE && rank < avail) {
                 rd = (i64)(pool_next + rank);
                 mode = (rd < n_reads) ? M_FETCH : M_DEAD;
-                if (uni && mode == M_FETCH) {
+                rdok = (perm == nullptr);
+                if (uni && mode == M_FETCH && rdok) {
                     // reads of one length: offsets by arithmetic, the walk for the first k-mer starts right away
                     const i64 P0 = u_read0 + rd * u_len;
                     obase = u_out0 + rd * u_stride;
@@ -410,6 +426,7 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
                     poff = (int)(P0 & 31);
                     m = (int)u_len - k + 1;
                     i = 0;
+                    if (SEG) { nseg = 0; i0 = 0; }
                     b = -1;
                     blo = -1;
                     wstart = 0;
@@ -446,8 +463,13 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
         unsigned seg_src = 0;
         if (mode == M_FETCH) {
             kind = K_FETCH;                            // {read_off[rd], read_off[rd+1]}, {out_off[rd], ..}
-            a1 = reinterpret_cast<const uint4 *>(read_off + rd);
-            a2 = reinterpret_cast<const uint4 *>(out_off + rd);
+            if (rdok) {
+                a1 = reinterpret_cast<const uint4 *>(read_off + rd);
+                a2 = reinterpret_cast<const uint4 *>(out_off + rd);
+            } else {                                   // the aligned 16 bytes holding perm[ticket]
+                a1 = reinterpret_cast<const uint4 *>(perm + (rd & ~(i64)3));
+                a2 = a1;
+            }
         } else if (PATH && mode == M_POS) {
             kind = K_MODE;                             // the aligned 16 bytes holding pos[l]
             a1 = reinterpret_cast<const uint4 *>(ix.pos + ((unsigned)l & ~3u));
@@ -568,16 +590,32 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
         bool imprecise = false;                        // this iteration's failure is a table-level miss
         int burst_to = -1;                             // M_BRIDGE: k-mers i .. burst_to are certified absent
         if (kind == K_FETCH) {
-            const i64 P0 = (i64)quad_bits(v1);
+            bool have_off = rdok;
+            i64 P0 = (i64)quad_bits(v1);
+            i64 P1 = (i64)((u64)v1.z | ((u64)v1.w << 32));
             obase = (i64)quad_bits(v2);
-            pgrp = (int)(P0 >> 5);
-            poff = (int)(P0 & 31);
-            m = (int)((i64)((u64)v1.z | ((u64)v1.w << 32)) - P0) - k + 1;
-            i = 0;
-            b = -1;
-            blo = -1;
-            if (m > 0) { do_plan = true; force = true; }
-            else mode = M_IDLE;
+            if (!rdok) {
+                const unsigned sl = (unsigned)rd & 3u;
+                rd = (i64)(sl == 0 ? v1.x : sl == 1 ? v1.y : sl == 2 ? v1.z : v1.w);
+                rdok = true;
+                if (uni) {                             // fixed-length reads: offsets by arithmetic
+                    P0 = u_read0 + rd * u_len;
+                    P1 = P0 + u_len;
+                    obase = u_out0 + rd * u_stride;
+                    have_off = true;
+                }                                      // else: the next iteration fetches the offsets of read rd
+            }
+            if (have_off) {
+                pgrp = (int)(P0 >> 5);
+                poff = (int)(P0 & 31);
+                m = (int)(P1 - P0) - k + 1;
+                i = 0;
+                if (SEG) { nseg = 0; i0 = 0; }
+                b = -1;
+                blo = -1;
+                if (m > 0) { do_plan = true; force = true; }
+                else mode = M_IDLE;
+            }
         } else if (kind == K_RELOAD) {
             g0 = v1;
             g1 = v2;
@@ -595,6 +633,7 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
             } else {
                 res = (pos_t)v1.x;
                 r = (pos_t)v1.y;
+                emit_pos = v1.y;
                 rknown = true;
                 // the read's next bases against the 8 steps quoted in the entry: short runs (pan-genomes branch every
                 // few k-mers) end here without a separate M_EXT iteration
@@ -791,7 +830,7 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
             if (wstart == i) {                         // k chars matched from i: the k-mer is there
                 res = l;
                 if (l != r) ws->status = SBWT_ERR_NOT_SINGLETON;   // SBWT.hh:410-413
-                if (PATH && tpos >= 0) { r = tpos; rknown = true; }
+                if (PATH && tpos >= 0) { r = tpos; rknown = true; emit_pos = (unsigned)tpos; }
                 ev = EV_EMIT1;
                 b = -1;
             } else {
@@ -824,7 +863,7 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
             if (blo > b) b = -1;
             do_plan = true;
         }
-        if (ev == EV_EMIT1) {
+        if (ev == EV_EMIT1 && !SEG) {
             stage[cnt][tid] = (stage_t)res;
             cnt++;
             i++;
@@ -835,7 +874,113 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
         // end.  A certified burst is a run of -1.  Each run is written by a group of DEPTH lanes with one
         // coalesced store (64/DEPTH runs per store instruction) instead of a per-lane loop of 8-byte
         // stores that would execute in almost every iteration for a handful of lanes.
-        if (PATH) {
+        if (SEG) {
+            // ---- append this iteration's results to the lane's segment list (at most two segments; contiguous ones merge) ----
+            auto append = [&](int at, unsigned src) {
+                const bool merge = nseg > 0 && ((src == 0xFFFFFFFFu && last_src == 0xFFFFFFFFu) ||
+                                                (!(src >> 31) && !(last_src >> 31) && last_src + (unsigned)(at - last_start) == src));
+                if (!merge) {
+                    segs[nseg][tid] = make_uint2(src, (unsigned)at);
+                    nseg++;
+                    last_src = src;
+                    last_start = at;
+                }
+            };
+            if (ev == EV_EMIT1) {
+                append(i, res == -1 ? 0xFFFFFFFFu : (rknown ? emit_pos : (0x80000000u | (unsigned)res)));
+                i++;
+            }
+            {
+                const int nleft = (burst_hi >= 0) ? (burst_hi - i + 1) : seg_n;
+                if (nleft > 0) {
+                    append(i, (burst_hi >= 0) ? 0xFFFFFFFFu : seg_src);
+                    i += nleft;
+                }
+            }
+            // ---- flush: the read is done, or the list could overflow in the next iteration.  Up to four reads per trip: the
+            //      col[] loads of all four are in flight before the first store (a trip would otherwise wait for one
+            //      memory round trip per read) ----
+            u64 fm = __ballot(nseg > 0 && (i == m || nseg > SBWT_NSEG - 2));
+            while (fm) {
+                constexpr int FP = 4;
+                int fL[FP], fe[FP], fj[FP], w0[FP], w1[FP];
+                i64 fob[FP];
+                unsigned x0[FP], x1[FP];
+                bool long_read = false;
+#pragma unroll
+                for (int u = 0; u < FP; u++) {
+                    fL[u] = -1; fe[u] = 0; fj[u] = 0; fob[u] = 0; x0[u] = x1[u] = 0xFFFFFFFFu; w0[u] = w1[u] = 0;
+                    if (fm == 0) continue;                       // wave-uniform: unused slots cost nothing
+                    const int L = __ffsll((i64)fm) - 1;
+                    fm &= fm - 1;
+                    const int ns = __shfl(nseg, L), a = __shfl(i0, L), e = __shfl(i, L);
+                    fL[u] = L;
+                    fe[u] = e;
+                    fob[u] = (i64)uniform64((u64)__shfl(obase, L));
+                    long_read = long_read || (e - a > 128);
+                    const int tl = (tid & ~63) + L;
+                    const int j0 = a + 2 * lane, j1 = j0 + 1;
+                    fj[u] = j0;
+                    // the segment of result j0: the last one that starts at or before it (bisection over <= 12 starts);
+                    // result j1 is in the same segment or the next
+                    int idx = 0;
+#pragma unroll
+                    for (int step = 8; step > 0; step >>= 1) {
+                        const int t = idx + step;
+                        const unsigned st = segs[t < SBWT_NSEG ? t : SBWT_NSEG - 1][tl].y;
+                        if (t < ns && (int)st <= j0) idx = t;
+                    }
+                    const uint2 c0 = segs[idx][tl];
+                    const uint2 nx = segs[idx + 1 < SBWT_NSEG ? idx + 1 : SBWT_NSEG - 1][tl];
+                    const uint2 c1 = (idx + 1 < ns && (int)nx.y <= j1) ? nx : c0;
+                    x0[u] = c0.x;
+                    x1[u] = c1.x;
+                    const unsigned p0 = (j0 < e && !(c0.x >> 31)) ? c0.x + (unsigned)(j0 - (int)c0.y) : 0u;
+                    const unsigned p1 = (j1 < e && !(c1.x >> 31)) ? c1.x + (unsigned)(j1 - (int)c1.y) : 0u;
+                    w0[u] = (int)ix.col[p0];
+                    w1[u] = (int)ix.col[p1];
+                }
+#pragma unroll
+                for (int u = 0; u < FP; u++) {
+                    const int v0 = (x0[u] >> 31) ? ((x0[u] == 0xFFFFFFFFu) ? -1 : (int)(x0[u] & 0x7FFFFFFFu)) : w0[u];
+                    const int v1 = (x1[u] >> 31) ? ((x1[u] == 0xFFFFFFFFu) ? -1 : (int)(x1[u] & 0x7FFFFFFFu)) : w1[u];
+                    if (!(ix.debug & 1)) {
+                        if (fj[u] + 1 < fe[u]) st_stream2(out + fob[u] + fj[u], (i64)v0, (i64)v1);
+                        else if (fj[u] < fe[u]) st_stream(out + fob[u] + fj[u], (i64)v0);
+                    }
+                }
+                if (long_read) {
+                    // reads of more than 128 results since their last flush: the remaining passes, one read at a time
+#pragma unroll
+                    for (int u = 0; u < FP; u++) {
+                        if (fL[u] < 0) continue;
+                        const int L = fL[u], ns = __shfl(nseg, L), a = __shfl(i0, L), e = fe[u];
+                        const int tl = (tid & ~63) + L;
+                        for (int base = a + 128; base < e; base += 128) {
+                            const int j0 = base + 2 * lane, j1 = j0 + 1;
+                            uint2 c0 = segs[0][tl], c1 = c0;
+                            for (int sx = 1; sx < ns; sx++) {
+                                const uint2 sg = segs[sx][tl];
+                                if ((int)sg.y <= j0) c0 = sg;
+                                if ((int)sg.y <= j1) c1 = sg;
+                            }
+                            const unsigned p0 = (j0 < e && !(c0.x >> 31)) ? c0.x + (unsigned)(j0 - (int)c0.y) : 0u;
+                            const unsigned p1 = (j1 < e && !(c1.x >> 31)) ? c1.x + (unsigned)(j1 - (int)c1.y) : 0u;
+                            const int q0 = (int)ix.col[p0], q1 = (int)ix.col[p1];
+                            const int v0 = (c0.x >> 31) ? ((c0.x == 0xFFFFFFFFu) ? -1 : (int)(c0.x & 0x7FFFFFFFu)) : q0;
+                            const int v1 = (c1.x >> 31) ? ((c1.x == 0xFFFFFFFFu) ? -1 : (int)(c1.x & 0x7FFFFFFFu)) : q1;
+                            if (!(ix.debug & 1)) {
+                                if (j1 < e) st_stream2(out + fob[u] + j0, (i64)v0, (i64)v1);
+                                else if (j0 < e) st_stream(out + fob[u] + j0, (i64)v0);
+                            }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < FP; u++)
+                    if (lane == fL[u]) { nseg = 0; i0 = i; }
+            }
+        } else if (PATH) {
             // One writer, whole lines.  The results of a read leave in order.  What a lane has not written yet --
             // `cnt` results staged in LDS, always starting on a 64-byte line of `out` (or at the read's first
             // result) -- is joined with this iteration's run (a certified burst of -1, or a path run out of col[]),
@@ -1043,8 +1188,10 @@ void sbwt_launch_encode(const char *d_bases, long long total_bases, uint4 *d_pac
 
 void sbwt_launch_search(const SbwtIndexView &ix, const uint4 *d_packed, const long long *d_read_off,
                         const long long *d_out_off, long long *d_out, long long n_reads, SbwtWorkHeader *ws,
-                        int streaming, hipStream_t stream, int variant, long long total_groups) {
+                        int streaming, hipStream_t stream, int variant, long long total_groups, void *d_sort_scratch,
+                        long long sort_scratch_bytes, int sort_key_bits) {
     if (n_reads <= 0) return;
+    const unsigned *d_perm = nullptr;
     if (variant >= 1) {
         i64 want1 = (n_reads + 255) / 256;
         unsigned grid1 = (unsigned)(want1 < 2048 ? want1 : 2048);
@@ -1055,8 +1202,21 @@ void sbwt_launch_search(const SbwtIndexView &ix, const uint4 *d_packed, const lo
         unsigned g = grid1 < cap ? grid1 : cap;
         if (wide)
             hipLaunchKernelGGL((k_search_cert<true, 4, false>), dim3(g), dim3(256), 0, stream, ix, d_packed, d_read_off,
-                               d_out_off, d_out, (i64)n_reads, ws, streaming);
+                               d_out_off, d_out, (i64)n_reads, ws, streaming, d_perm);
         else if (variant >= 2 && ix.col && streaming) {    // path order (the default when the index has one)
+            if (variant >= 4) {                             // segment lists instead of staged results (SEG)
+                if (!(ix.debug & 8))
+                    hipLaunchKernelGGL(k_check_uniform, dim3(grid_for(n_reads)), dim3(256), 0, stream, d_read_off, d_out_off,
+                                       (i64)n_reads, ws);
+                else
+                    (void)hipMemsetAsync(&ws->u_bad, 0xFF, 8, stream);
+                if (d_sort_scratch)
+                    d_perm = sbwt_launch_sort_reads(ix, d_packed, d_read_off, n_reads, ws, d_sort_scratch, sort_scratch_bytes,
+                                                    sort_key_bits, stream);
+                hipLaunchKernelGGL((k_search_cert<false, 4, true, true>), dim3(g), dim3(256), 0, stream, ix, d_packed, d_read_off,
+                                   d_out_off, d_out, (i64)n_reads, ws, streaming, d_perm);
+                return;
+            }
             if (variant >= 3) {                             // pooled reads: one state per wave iteration (sbwt_search_pool.hip)
                 if (!(ix.debug & 8))
                     hipLaunchKernelGGL(k_check_uniform, dim3(grid_for(n_reads)), dim3(256), 0, stream, d_read_off, d_out_off,
@@ -1071,11 +1231,14 @@ void sbwt_launch_search(const SbwtIndexView &ix, const uint4 *d_packed, const lo
                                    (i64)n_reads, ws);
             else
                 (void)hipMemsetAsync(&ws->u_bad, 0xFF, 8, stream);       // experiment: the general path
+            if (d_sort_scratch)
+                d_perm = sbwt_launch_sort_reads(ix, d_packed, d_read_off, n_reads, ws, d_sort_scratch, sort_scratch_bytes,
+                                                sort_key_bits, stream);
             hipLaunchKernelGGL((k_search_cert<false, 4, true>), dim3(g), dim3(256), 0, stream, ix, d_packed, d_read_off,
-                               d_out_off, d_out, (i64)n_reads, ws, streaming);
+                               d_out_off, d_out, (i64)n_reads, ws, streaming, d_perm);
         } else
             hipLaunchKernelGGL((k_search_cert<false, 4, false>), dim3(g), dim3(256), 0, stream, ix, d_packed, d_read_off,
-                               d_out_off, d_out, (i64)n_reads, ws, streaming);
+                               d_out_off, d_out, (i64)n_reads, ws, streaming, d_perm);
         return;
     }
     // persistent-style grid: enough 256-thread workgroups to fill 256 CUs x 8 workgroups, never

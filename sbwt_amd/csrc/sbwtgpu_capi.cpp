@@ -87,7 +87,7 @@ struct DeviceGuard {
 // 0 = k_search (reference order), 1 = k_search_cert, 2 = k_search_cert along the path order (when the index has one),
 // 3 = k_search_pool: the path order with pooled reads (experiment: same bits, 18 % slower -- DESIGN.md section 3)
 static int tuning_variant() {
-    static int v = [] { const char *e = getenv("SBWTGPU_SEARCH_VARIANT"); return e ? atoi(e) : 2; }();
+    static int v = [] { const char *e = getenv("SBWTGPU_SEARCH_VARIANT"); return e ? atoi(e) : -1; }();
     return v;
 }
 static int g_variant_override = -1, g_probe_override = -1, g_debug = 0, g_derive_ssup = 1;
@@ -98,6 +98,7 @@ static int g_poison = [] { const char *e = getenv("SBWTGPU_POISON_RESULTS"); ret
 static int g_probe_filter = [] { const char *e = getenv("SBWTGPU_PROBE_FILTER"); return e ? atoi(e) : 1; }();
 static int g_image_level = [] { const char *e = getenv("SBWTGPU_IMAGE_LEVEL"); return e ? atoi(e) : 0; }();
 static int64_t g_max_image_bytes = [] { const char *e = getenv("SBWTGPU_MAX_IMAGE_BYTES"); return e ? (int64_t)atoll(e) : (int64_t)0; }();
+static int g_sort_reads = [] { const char *e = getenv("SBWTGPU_SORT_READS"); return e ? atoi(e) : -1; }();   // -1 auto, 0 off, 1 on
 static int g_force_mega = 0;    // tests: store every image's block counts relative to mega[c][0] (the dense rank-only layout)
 static int g_trans_ext = -1;    // -1: adaptive per wave, 0/1: force
 static int g_path_safe = [] { const char *e = getenv("SBWTGPU_PATH_SAFE"); return e ? atoi(e) : 1; }();
@@ -169,6 +170,7 @@ int sbwtgpu_set_tuning(const char *key, int64_t value) {
     if (!strcmp(key, "probe_filter")) { g_probe_filter = (int)value; return SBWTGPU_OK; }   // indexes created afterwards
     if (!strcmp(key, "image_level")) { g_image_level = (int)value; return SBWTGPU_OK; }          // indexes created afterwards
     if (!strcmp(key, "max_image_bytes")) { g_max_image_bytes = value; return SBWTGPU_OK; }     // indexes created afterwards
+    if (!strcmp(key, "sort_reads")) { g_sort_reads = (int)value; return SBWTGPU_OK; }
     if (!strcmp(key, "force_mega")) { g_force_mega = (int)value; return SBWTGPU_OK; }     // indexes created afterwards
     if (!strcmp(key, "trans_ext")) { g_trans_ext = (int)value; return SBWTGPU_OK; }
     if (!strcmp(key, "path_safe")) { g_path_safe = (int)value; return SBWTGPU_OK; }   // indexes created afterwards
@@ -453,6 +455,8 @@ int sbwtgpu_index_create(const sbwtgpu_index_desc *d, int device, sbwtgpu_index 
                                              reinterpret_cast<uint4 *>(idx->blob + h.off_trans), scr, 0);
             (void)hipFree(scr);
             if (prc != 0) { e = hipErrorUnknown; break; }
+            h.n_paths = sbwt_count_paths(idx->view(), 0);
+            if (h.n_paths < 0) { e = hipErrorUnknown; break; }
         }
         if (h.p_sparse > 0) {
             void *scr = nullptr;
@@ -680,10 +684,20 @@ int sbwtgpu_index_bcast(sbwtgpu_index *root, int n_dev, const int *devs, sbwtgpu
 }
 
 // ---- device-pointer entry points -----------------------------------------------------------
+// Workspace = header | packed bases (16 bytes per 32 bases) | with "sort_reads" = 1, room to sort the reads by their place
+// in the path order (sbwt_sort.hip): four 32-bit arrays of one entry per read + the radix sort's own temporary, sized
+// for reads of >= 32 bases on average (a batch of shorter reads is searched unsorted).
+static inline int64_t ws_packed_bytes(int64_t total_bases) {
+    const int64_t groups = (total_bases + SBWT_GROUP_BASES - 1) / SBWT_GROUP_BASES + 2;
+    return (int64_t)sizeof(SbwtWorkHeader) + groups * 16;
+}
+static inline int64_t ws_sort_capacity(int64_t total_bases) {      // only when sorting is switched on ("sort_reads" = 1)
+    return g_sort_reads > 0 ? total_bases / 32 + 4096 : 0;
+}
 int64_t sbwtgpu_search_workspace_bytes(int64_t total_bases) {
     if (total_bases < 0) total_bases = 0;
-    int64_t groups = (total_bases + SBWT_GROUP_BASES - 1) / SBWT_GROUP_BASES + 2;
-    return (int64_t)sizeof(SbwtWorkHeader) + groups * 16;
+    const int64_t n_cap = ws_sort_capacity(total_bases);
+    return align256(ws_packed_bytes(total_bases)) + (n_cap ? 32 * n_cap + ((int64_t)16 << 20) : 0);
 }
 
 static const char *RANK_ONLY_MSG =
@@ -741,11 +755,31 @@ int sbwtgpu_search_encoded_dev(const sbwtgpu_index *idx, int64_t total_bases, co
         HIP_TRY(hipStreamSynchronize(st));
         if (ends[1] > ends[0]) HIP_TRY(hipMemsetAsync(d_out + ends[0], 0xA5, (size_t)(ends[1] - ends[0]) * 8, st));
     }
+    // kernel: an explicit choice ("search_variant" / SBWTGPU_SEARCH_VARIANT), else by the index: the segment-list writer
+    // where a read can follow its path for a while (average path >= 8 columns), the staged writer on branchy indexes
+    int variant = g_variant_override >= 0 ? g_variant_override : tuning_variant();
+    if (variant < 0) variant = (idx->h.has_path && idx->h.n_paths > 0 && idx->h.n_paths * 8 <= idx->h.n_nodes) ? 4 : 2;
+    const int eff_streaming = (!streaming && (idx->h.has_ssup || idx->h.ssup_derived) && g_derive_ssup) ? 2 : streaming;
+    // reads sorted by their place in the path order (sbwt_sort.hip): when the batch covers the index a few times
+    void *sort_scratch = nullptr;
+    long long sort_bytes = 0;
+    int key_bits = 1;
+    while (key_bits < 32 && ((int64_t)1 << key_bits) <= idx->h.n_nodes) key_bits++;
+    const bool path_kernel = (variant == 2 || variant == 4) && idx->h.has_path && eff_streaming && idx->h.stab_pos &&
+                             idx->h.n_nodes < ((int64_t)1 << 31) - 128 && n_reads < ((int64_t)1 << 31);
+    // Off unless asked for ("sort_reads" = 1): the path order numbers its paths in column order, not along the genome, so
+    // reads sorted by path position share lines only within one path (kernel 6.45 -> 6.16 ms on config 2) and the
+    // pre-pass costs 0.7 ms; reads that arrive in genome order get the full effect (5.3 ms) without any pre-pass.
+    const bool want_sort = path_kernel && g_sort_reads > 0;
+    if (want_sort) {
+        // the scratch lives in the caller's workspace, behind the packed bases (no allocation, nothing shared between calls)
+        const int64_t off = align256(ws_packed_bytes(total_bases));
+        sort_bytes = sbwt_sort_scratch_bytes(n_reads, key_bits);
+        if (n_reads <= ws_sort_capacity(total_bases) && off + sort_bytes <= ws_bytes) sort_scratch = static_cast<char *>(d_ws) + off;
+    }
     sbwt_launch_search(idx->view(), packed, reinterpret_cast<const long long *>(d_read_off),
                        reinterpret_cast<const long long *>(d_out_off), reinterpret_cast<long long *>(d_out), n_reads,
-                       ws, (!streaming && (idx->h.has_ssup || idx->h.ssup_derived) && g_derive_ssup) ? 2 : streaming, st,
-                       g_variant_override >= 0 ? g_variant_override : tuning_variant(),
-                       total_bases / SBWT_GROUP_BASES + 2);
+                       ws, eff_streaming, st, variant, total_bases / SBWT_GROUP_BASES + 2, sort_scratch, sort_bytes, key_bits);
     e = hipGetLastError();
     if (e != hipSuccess) return fail(SBWTGPU_ERR_HIP, "kernel launch: %s", hipGetErrorString(e));
     return SBWTGPU_OK;
@@ -1448,7 +1482,7 @@ bool take_parked(int device, int64_t bases, int64_t reads, int64_t vals, int64_t
     for (size_t i = 0; i < g_parked.size(); i++) {
         Slot &S = g_parked[i].slot;
         if (g_parked[i].device == device && S.cap_bases >= bases && S.cap_reads >= reads && S.cap_vals >= vals &&
-            S.cap_text >= text) {
+            S.cap_text >= text && S.ws_bytes >= sbwtgpu_search_workspace_bytes(S.cap_bases)) {   // (tuning may have changed it)
             *out = S;
             g_parked.erase(g_parked.begin() + (long)i);
             return true;

@@ -56,6 +56,8 @@ def test_config3_pangenome_k31(gpu):
     assert torch.equal(a, run(True, 3, 1))    # transitions always run on along the quoted steps
     assert torch.equal(a, run(True, 3, 0))    # ... never
     assert torch.equal(a, run(True, 2))       # path order, one lane per read
+    assert torch.equal(a, run(True, 4))       # ... with segment lists
+    assert torch.equal(a, run(True, 4, 1))
     assert torch.equal(a, run(True, 2, 1))
     assert torch.equal(a, run(True, 2, 0))
     assert torch.equal(a, run(True, 1))       # certificates on the blocks only

@@ -49,6 +49,7 @@ def test_config2_full_size_properties(gpu):
     a = run(True, 3)                      # the product path: path order, pooled reads (k_search_pool)
     assert idx.workspace_stats(d_ws.data_ptr(), st)[4] > 0
     assert torch.equal(a, run(True, 2))   # path order, one lane per read (k_search_cert<PATH>)
+    assert torch.equal(a, run(True, 4))   # ... with segment lists instead of staged results
     assert torch.equal(a, run(True, 1))   # certificates on the blocks only
     assert torch.equal(a, run(True, 0))   # the reference's order of searches
     assert torch.equal(a, run(False, 3))  # per-k-mer search loop (internal streaming) == streaming (upper-case input)

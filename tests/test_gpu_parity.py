@@ -217,7 +217,8 @@ def test_streaming_equals_search_at_scale_properties(gpu, genome_case):
 
 @pytest.mark.parametrize("variant,probe", [(0, -1), (1, -1), (1, 0), (1, 9), (1, 11), (1, 12), (1, 13), (1, 20), (1, 29),
                                            (2, -1), (2, 0), (2, 9), (2, 13), (2, 29),
-                                           (3, -1), (3, 0), (3, 9), (3, 12), (3, 13), (3, 29)])
+                                           (3, -1), (3, 0), (3, 9), (3, 12), (3, 13), (3, 29),
+                                           (4, -1), (4, 0), (4, 9), (4, 12), (4, 13), (4, 29)])
 def test_results_do_not_depend_on_search_variant_or_probe_length(gpu, genome_case, variant, probe):
     # k_search (reference order), k_search_cert (absent-substring certificates) and its path-order form
     # must give the same bits for every probe length, including reads with N / lower case and all-miss reads
@@ -484,7 +485,7 @@ def test_periodic_sequences_cycles_in_the_path_order(gpu, k):
     woff = np.concatenate([[0], np.cumsum([len(g) for g in genomes])]).astype(np.int64)
     bases = np.concatenate([bases, whole])
     off = np.concatenate([off, woff[1:] + off[-1]])
-    for variant in (3, 2, 1):
+    for variant in (4, 3, 2, 1):
         capi.set_tuning("search_variant", variant)
         try:
             got, _ = idx.streaming_search(bases, off)
@@ -590,3 +591,32 @@ def test_transition_quoted_steps_on_and_off(gpu, genome_case, mode):
         capi.set_tuning("trans_ext", -1)
     assert np.array_equal(got, oracle_batch(orc, bases, off, True))
     assert np.array_equal(got2, oracle_batch(orc, bases, off, False))
+
+
+@pytest.mark.parametrize("variant", [2, 4])
+def test_sorted_reads_give_the_same_bits(gpu, genome_case, variant):
+    # "sort_reads": the path-order kernels take the reads in the order of their first k-mer's path position (a radix
+    # sort before the search); every result still lands at its own place.  Fixed-length and ragged batches, reads
+    # without any anchor (random, N-only, shorter than k), lower case.
+    genomes, orc = genome_case
+    idx = gpu_index_from_oracle(orc)
+    bases, off = synth.sample_reads(genomes, 5000, 150, 0.02, 123)
+    bases = synth.inject(bases, 120, ord("N"), 1)
+    bases = synth.inject(bases, 60, ord("a"), 2)
+    rb, ro = synth.random_reads(400, 150, 9)
+    bases = np.concatenate([bases, rb, np.full(300, ord("N"), dtype=np.uint8)])
+    off = np.concatenate([off, ro[1:] + off[-1], [off[-1] + ro[-1] + 150, off[-1] + ro[-1] + 300]])
+    rg_b, rg_o = synth.ragged_reads(genomes, 3000, 0, 260, 0.01, 77)
+    capi.set_tuning("search_variant", variant)
+    try:
+        for b_, o_ in ((bases, off), (rg_b, rg_o)):
+            want = oracle_batch(orc, b_, o_, True)
+            for sort in (1, 0):
+                capi.set_tuning("sort_reads", sort)
+                got, _ = idx.streaming_search(b_, o_)
+                assert np.array_equal(got, want), (variant, sort)
+                got, _ = idx.search(b_, o_)
+                assert np.array_equal(got, oracle_batch(orc, b_, o_, False)), (variant, sort)
+    finally:
+        capi.set_tuning("search_variant", -1)
+        capi.set_tuning("sort_reads", -1)
