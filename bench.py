@@ -374,7 +374,9 @@ def main() -> int:
         log(f"index: n_nodes={index.n_nodes} n_kmers={index.n_kmers} image={index.blob_bytes / 1e6:.1f} MB level={index.image_level} "
             f"device_precalc={index.device_precalc_k} (columns {t_cols:.2f} s + image {t_img:.2f} s)")
         build_times = {"columns_s": t_cols, "image_s": t_img, "columns_on": "gpu" if K <= 32 else "host",
-                       "image_level": index.image_level, "image_bytes_per_column": index.blob_bytes / index.n_nodes}
+                       "image_level": index.image_level, "image_bytes_per_column": index.blob_bytes / index.n_nodes,
+                       "paths": index.n_paths, "branching_columns": index.n_branch,
+                       "search_variant": index.default_search_variant}
     if world > 1 and args.replicate == "image":
         hdr, blob = None, None
         if rank == 0:
@@ -484,7 +486,9 @@ def main() -> int:
         },
         "roofline": {
             "bound": "hbm",
-            "kernel": "k_search_cert",
+            "kernel": {4: "k_search_cert<PATH,SEG>", 2: "k_search_cert<PATH>"}.get(
+                index.default_search_variant if os.environ.get("SBWTGPU_SEARCH_VARIANT") is None else
+                int(os.environ["SBWTGPU_SEARCH_VARIANT"]), "k_search_cert") if index.image_level == 0 else "k_search_cert",
             "achieved": alg_bytes / (kernel_ms * 1e-3) / 1e9,
             "peak": HBM_PEAK_GBPS,
             "unit": "GB/s",

@@ -70,6 +70,9 @@ typedef struct {
     int64_t blob_bytes;           /* size of the device image (what index_bcast moves) */
     int64_t image_level;          /* what the image holds: 0 = all derived structures, 1 = no path order / transition
                                      table, 2 = blocks + dense prefix table only (see "image_level" below) */
+    int64_t n_paths;              /* path order: number of paths (0 without one) */
+    int64_t n_branch;             /* columns with two or more successors */
+    int64_t default_search_variant; /* the kernel "search_variant" = -1 picks for this index (see below) */
 } sbwtgpu_index_info;
 
 /* ---- library ---- */
@@ -77,8 +80,8 @@ const char *sbwtgpu_version(void);
 const char *sbwtgpu_last_error(void);
 int         sbwtgpu_device_count(int *count);
 /* Process-wide tuning knobs for experiments (results never depend on them):
- *   "search_variant"  -1 (default) = by the index: 4 where reads can follow their paths for a while (average path of
- *                     at least 8 columns), else 2; 0 = k_search (the reference's order of searches), 1 = k_search_cert on
+ *   "search_variant"  -1 (default) = by the index: 4 where reads can follow their paths for a while (fewer than one
+ *                     column in 64 has a choice of successors), else 2; 0 = k_search (the reference's order of searches), 1 = k_search_cert on
  *                     the blocks, 2 = k_search_cert along the path order, results staged per lane and written by
  *                     descriptors, 3 = k_search_pool (reads pooled in LDS, re-assigned to lanes by state), 4 = the path
  *                     order with per-read segment lists, a read's results written by the whole wave when it ends

@@ -66,6 +66,7 @@ class IndexInfo(C.Structure):
         ("C", C.c_int64 * 4),
         ("has_streaming_support", C.c_int32), ("device", C.c_int32),
         ("device_precalc_k", C.c_int64), ("blob_bytes", C.c_int64), ("image_level", C.c_int64),
+        ("n_paths", C.c_int64), ("n_branch", C.c_int64), ("default_search_variant", C.c_int64),
     ]
 
 
@@ -215,6 +216,7 @@ class Index:
         self.device_precalc_k = info.device_precalc_k
         self.blob_bytes = info.blob_bytes
         self.image_level = info.image_level
+        self.n_paths, self.n_branch, self.default_search_variant = info.n_paths, info.n_branch, info.default_search_variant
 
     @property
     def handle(self) -> C.c_void_p:

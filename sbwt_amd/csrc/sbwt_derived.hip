@@ -357,7 +357,7 @@ __global__ void __launch_bounds__(256) k_path_safe(SbwtIndexView ix, unsigned *p
 // its path position p, the next 8 steps of its path: chars p..p+7 (16 bits) | go bits (8) | safe bits (8), - }
 // (built last: the path's chars and safe bits must be final)
 __global__ void __launch_bounds__(256) k_path_trans(SbwtIndexView ix, const unsigned *__restrict__ pos,
-                                                    uint4 *__restrict__ trans) {
+                                                    uint4 *__restrict__ trans, unsigned long long *n_branch) {
     const i64 v = (i64)blockIdx.x * 256 + threadIdx.x;
     if (v >= ix.n_nodes) return;
     i64 blk = v >> 6;
@@ -390,6 +390,11 @@ __global__ void __launch_bounds__(256) k_path_trans(SbwtIndexView ix, const unsi
         }
         trans[4 * t + c] = make_uint4(nc[c], np[c], ext, 0u);
     }
+    // columns with two or more successors: how often a read that follows a path has a choice (see sbwtgpu_capi.cpp: the
+    // kernel with per-read segment lists is chosen where such columns are rare)
+    const int deg = (nc[0] != PATH_NONE) + (nc[1] != PATH_NONE) + (nc[2] != PATH_NONE) + (nc[3] != PATH_NONE);
+    const u64 m = __ballot(deg >= 2);
+    if (m && (threadIdx.x & 63) == (unsigned)(__ffsll((i64)m) - 1)) atomicAdd(n_branch, (unsigned long long)__popcll(m));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -572,7 +577,15 @@ int sbwt_launch_build_path(const SbwtIndexView &ix, unsigned *d_col, unsigned *d
     (void)d_trans;                                      // filled by sbwt_launch_path_trans once the safe bits are final
     return 0;
 }
-void sbwt_launch_path_trans(const SbwtIndexView &ix, uint4 *d_trans, hipStream_t stream) {
-    hipLaunchKernelGGL(k_path_trans, dim3(grid_for(ix.n_nodes)), dim3(256), 0, stream, ix, ix.pos, d_trans);
+// Returns the number of columns with two or more successors (synchronises the stream), or -1.
+long long sbwt_launch_path_trans(const SbwtIndexView &ix, uint4 *d_trans, hipStream_t stream) {
+    unsigned long long *d = nullptr, h = 0;
+    if (hipMalloc((void **)&d, 8) != hipSuccess) return -1;
+    (void)hipMemsetAsync(d, 0, 8, stream);
+    hipLaunchKernelGGL(k_path_trans, dim3(grid_for(ix.n_nodes)), dim3(256), 0, stream, ix, ix.pos, d_trans, d);
+    hipError_t e = hipMemcpyAsync(&h, d, 8, hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    (void)hipFree(d);
+    return e == hipSuccess ? (long long)h : -1;
 }
 

@@ -87,7 +87,8 @@ struct SbwtBlobHeader {
     int32_t log2f;
     int32_t has_safe;               // pq carries the substitution-safe bits
     int32_t force_mega;             // block counts are relative to mega[c][0] although n_mega == 1 (see SbwtIndexView)
-    int64_t n_paths;                // paths of the path order (n_nodes / n_paths = average run a read can follow)
+    int64_t n_paths;                // paths of the path order
+    int64_t n_branch;               // columns with two or more successors (n_nodes / n_branch = columns between choices)
     int64_t image_level;            // 0 full, 1 no path order, 2 blocks + dense prefix table only
     int64_t row_ones[4];            // set bits of the rows A, C, G, T (select: valid j are 1 .. row_ones[c])
     int32_t log2b2;                 // second-level sparse table: log2 of its number of 32-byte entries (0 = none)
@@ -174,7 +175,7 @@ long long sbwt_path_scratch_bytes(long long n_nodes);
 long long sbwt_path_quads(long long n_nodes);
 long long sbwt_count_paths(const SbwtIndexView &ix, hipStream_t stream);
 void sbwt_launch_path_safe(const SbwtIndexView &ix, uint4 *d_pq, hipStream_t stream);
-void sbwt_launch_path_trans(const SbwtIndexView &ix, uint4 *d_trans, hipStream_t stream);
+long long sbwt_launch_path_trans(const SbwtIndexView &ix, uint4 *d_trans, hipStream_t stream);
 int sbwt_launch_build_path(const SbwtIndexView &ix, unsigned *d_col, unsigned *d_pos, uint4 *d_pq, uint4 *d_trans,
                            void *d_scratch, hipStream_t stream);
 int sbwt_launch_build_sparse(const SbwtIndexView &ix, int p_dense, int p_sparse, int log2b, uint4 *d_table,

@@ -484,7 +484,8 @@ int sbwtgpu_index_create(const sbwtgpu_index_desc *d, int device, sbwtgpu_index 
         }
         if (h.has_path) {                               // last: the transition entries quote the final path chars / safe bits
             SbwtIndexView v3 = idx->view();
-            sbwt_launch_path_trans(v3, reinterpret_cast<uint4 *>(idx->blob + h.off_trans), 0);
+            h.n_branch = sbwt_launch_path_trans(v3, reinterpret_cast<uint4 *>(idx->blob + h.off_trans), 0);
+            if (h.n_branch < 0) { e = hipErrorUnknown; break; }
         }
         if ((e = hipGetLastError()) != hipSuccess) break;
         e = hipDeviceSynchronize();
@@ -526,6 +527,9 @@ int sbwtgpu_index_get_info(const sbwtgpu_index *idx, sbwtgpu_index_info *info) {
     info->device_precalc_k = idx->h.p_dev;
     info->blob_bytes = idx->h.blob_bytes;
     info->image_level = idx->h.image_level;
+    info->n_paths = idx->h.n_paths;
+    info->n_branch = idx->h.n_branch;
+    info->default_search_variant = !idx->h.has_path ? 1 : (idx->h.n_branch * 64 <= idx->h.n_nodes ? 4 : 2);
     return SBWTGPU_OK;
 }
 
@@ -756,9 +760,11 @@ int sbwtgpu_search_encoded_dev(const sbwtgpu_index *idx, int64_t total_bases, co
         if (ends[1] > ends[0]) HIP_TRY(hipMemsetAsync(d_out + ends[0], 0xA5, (size_t)(ends[1] - ends[0]) * 8, st));
     }
     // kernel: an explicit choice ("search_variant" / SBWTGPU_SEARCH_VARIANT), else by the index: the segment-list writer
-    // where a read can follow its path for a while (average path >= 8 columns), the staged writer on branchy indexes
+    // where reads follow their paths for long (fewer than one column in 64 offers a choice of successors: config 2 has one
+    // in 107, config 5 one in 586), the staged writer on branchy indexes (the star pan-genome of config 3: one in 31 --
+    // its reads leave their path every 3-4 k-mers, and short segments fill the lists: 146.4 vs 143.8 ms)
     int variant = g_variant_override >= 0 ? g_variant_override : tuning_variant();
-    if (variant < 0) variant = (idx->h.has_path && idx->h.n_paths > 0 && idx->h.n_paths * 8 <= idx->h.n_nodes) ? 4 : 2;
+    if (variant < 0) variant = (idx->h.has_path && idx->h.n_branch * 64 <= idx->h.n_nodes) ? 4 : 2;
     const int eff_streaming = (!streaming && (idx->h.has_ssup || idx->h.ssup_derived) && g_derive_ssup) ? 2 : streaming;
     // reads sorted by their place in the path order (sbwt_sort.hip): when the batch covers the index a few times
     void *sort_scratch = nullptr;
