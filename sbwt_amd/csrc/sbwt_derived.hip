@@ -357,7 +357,8 @@ __global__ void __launch_bounds__(256) k_path_safe(SbwtIndexView ix, unsigned *p
 // its path position p, the next 8 steps of its path: chars p..p+7 (16 bits) | go bits (8) | safe bits (8), - }
 // (built last: the path's chars and safe bits must be final)
 __global__ void __launch_bounds__(256) k_path_trans(SbwtIndexView ix, const unsigned *__restrict__ pos,
-                                                    uint4 *__restrict__ trans, unsigned long long *n_branch) {
+                                                    uint4 *__restrict__ trans, unsigned long long *n_branch,
+                                                    unsigned *__restrict__ only) {
     const i64 v = (i64)blockIdx.x * 256 + threadIdx.x;
     if (v >= ix.n_nodes) return;
     i64 blk = v >> 6;
@@ -393,8 +394,30 @@ __global__ void __launch_bounds__(256) k_path_trans(SbwtIndexView ix, const unsi
     // columns with two or more successors: how often a read that follows a path has a choice (see sbwtgpu_capi.cpp: the
     // kernel with per-read segment lists is chosen where such columns are rare)
     const int deg = (nc[0] != PATH_NONE) + (nc[1] != PATH_NONE) + (nc[2] != PATH_NONE) + (nc[3] != PATH_NONE);
+    // exactly one successor: where the path goes on from here (k_path_reencode checks that), no other char has one --
+    // a read that differs from the path at this step gets -1 without asking the transition table
+    if (deg == 1) atomicOr(&only[t >> 5], 1u << (unsigned)(t & 31));
     const u64 m = __ballot(deg >= 2);
     if (m && (threadIdx.x & 63) == (unsigned)(__ffsll((i64)m) - 1)) atomicAdd(n_branch, (unsigned long long)__popcll(m));
+}
+
+// Final form of the path groups.  While the path order is built, quad t>>5 = { chars lo, chars hi, GO, SAFE }.  The search
+// kernels want a third bit per position (ONLY: the path's char is the only successor) in the same 16 bytes, and a
+// substitution-safe step is necessarily an only-successor step, so two words encode the four states of a position:
+//     A B
+//     0 0   the path goes on                        A = SAFE | ~GO
+//     0 1   ... and its char is the only successor   B = SAFE | (ONLY & GO)
+//     1 1   ... and the step is substitution-safe
+//     1 0   the path ends here
+// decoded by the kernels as  go = ~A | B,  safe = A & B,  only = ~A & B.
+__global__ void __launch_bounds__(256) k_path_reencode(uint4 *__restrict__ pq, i64 n_quads, const unsigned *__restrict__ only) {
+    const i64 q = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (q >= n_quads) return;
+    uint4 v = pq[q];
+    const unsigned go = v.z, safe = v.w, on = only[q];
+    v.z = safe | ~go;
+    v.w = safe | (on & go);
+    pq[q] = v;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -504,7 +527,7 @@ __global__ void __launch_bounds__(256) k_path_count_ends(const uint4 *__restrict
     if (q * 32 < n) {
         const i64 left = n - q * 32;
         const unsigned valid = left >= 32 ? 0xFFFFFFFFu : ((1u << (int)left) - 1u);
-        ends = (unsigned)__popc(~pq[q].z & valid);
+        ends = (unsigned)__popc(pq[q].z & ~pq[q].w & valid);      // A & ~B: the path ends (final encoding, k_path_reencode)
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) ends += __shfl_down(ends, off);
@@ -577,15 +600,22 @@ int sbwt_launch_build_path(const SbwtIndexView &ix, unsigned *d_col, unsigned *d
     (void)d_trans;                                      // filled by sbwt_launch_path_trans once the safe bits are final
     return 0;
 }
-// Returns the number of columns with two or more successors (synchronises the stream), or -1.
-long long sbwt_launch_path_trans(const SbwtIndexView &ix, uint4 *d_trans, hipStream_t stream) {
+// Builds the transition table, then gives the path groups their final encoding (k_path_reencode).  Returns the number
+// of columns with two or more successors (synchronises the stream), or -1.
+long long sbwt_launch_path_trans(const SbwtIndexView &ix, uint4 *d_trans, uint4 *d_pq, hipStream_t stream) {
     unsigned long long *d = nullptr, h = 0;
+    unsigned *only = nullptr;
+    const i64 n_quads = sbwt_path_quads(ix.n_nodes);
     if (hipMalloc((void **)&d, 8) != hipSuccess) return -1;
+    if (hipMalloc((void **)&only, (size_t)n_quads * 4) != hipSuccess) { (void)hipFree(d); return -1; }
     (void)hipMemsetAsync(d, 0, 8, stream);
-    hipLaunchKernelGGL(k_path_trans, dim3(grid_for(ix.n_nodes)), dim3(256), 0, stream, ix, ix.pos, d_trans, d);
+    (void)hipMemsetAsync(only, 0, (size_t)n_quads * 4, stream);
+    hipLaunchKernelGGL(k_path_trans, dim3(grid_for(ix.n_nodes)), dim3(256), 0, stream, ix, ix.pos, d_trans, d, only);
+    hipLaunchKernelGGL(k_path_reencode, dim3(grid_for(n_quads)), dim3(256), 0, stream, d_pq, n_quads, only);
     hipError_t e = hipMemcpyAsync(&h, d, 8, hipMemcpyDeviceToHost, stream);
     if (e == hipSuccess) e = hipStreamSynchronize(stream);
     (void)hipFree(d);
+    (void)hipFree(only);
     return e == hipSuccess ? (long long)h : -1;
 }
 

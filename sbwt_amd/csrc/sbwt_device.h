@@ -50,7 +50,8 @@ struct SbwtIndexView {
     int p_sparse;                   // its depth (0 = none)
     int log2b;                      // log2 of its number of buckets
     const unsigned *col, *pos;      // path order: column at path position t, path position of column v (nullptr = none)
-    const uint4 *pq;                // packed path chars: quad t>>5 = { 32 chars (2 bits each), go mask, safe mask }
+    const uint4 *pq;                // packed path chars: quad t>>5 = { 32 chars (2 bits each), A, B }: go = ~A | B, safe = A & B,
+                                    // only successor = ~A & B (k_path_reencode, sbwt_derived.hip)
     int has_safe;                   // the safe masks are filled in (k_path_safe)
     int trans_ext;                  // run on from a transition along the 8 steps its entry quotes: 1 always, 0 never,
                                     // -1 (default) while most runs after a transition are shorter than that (per wave)
@@ -175,7 +176,7 @@ long long sbwt_path_scratch_bytes(long long n_nodes);
 long long sbwt_path_quads(long long n_nodes);
 long long sbwt_count_paths(const SbwtIndexView &ix, hipStream_t stream);
 void sbwt_launch_path_safe(const SbwtIndexView &ix, uint4 *d_pq, hipStream_t stream);
-long long sbwt_launch_path_trans(const SbwtIndexView &ix, uint4 *d_trans, hipStream_t stream);
+long long sbwt_launch_path_trans(const SbwtIndexView &ix, uint4 *d_trans, uint4 *d_pq, hipStream_t stream);
 int sbwt_launch_build_path(const SbwtIndexView &ix, unsigned *d_col, unsigned *d_pos, uint4 *d_pq, uint4 *d_trans,
                            void *d_scratch, hipStream_t stream);
 int sbwt_launch_build_sparse(const SbwtIndexView &ix, int p_dense, int p_sparse, int log2b, uint4 *d_table,

@@ -453,6 +453,7 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
         const bool brg = PATH && (mode == M_BRIDGE);
         bool rknown = false;                           // PATH: this iteration's answer came with its path position (in r)
         bool qshort = false;                           // PATH: a run of fewer than 8 k-mers ended in this iteration
+        bool ext_absent = false;                       // SEG: the k-mer after this iteration's run is absent (only-successor step)
         // run on from transitions while short runs are a sizeable part of this wave's work (one lane-iteration in
         // eight: pan-genomes; on a few strains the saved iterations do not pay for the extra instructions)
         const bool use_q = PATH && (ix.trans_ext > 0 || (ix.trans_ext < 0 && c_short >= 8u * c_iter));
@@ -682,7 +683,12 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
                 burst_to = i + need;
                 c_brg++;
             } else {
-                mode = M_TRANS;
+                // no bridge (a second difference within k-1 bases).  The streaming step itself needs no gather either: a
+                // substitution-safe step has no successor by any other char (the k-mer that ends at the substituted base is
+                // one of the k windows the safe bit vouches for), so k-mer i is absent like after a transition that
+                // found nothing
+                ev = EV_EMIT1;
+                b = blo = i + k - 1;
             }
         } else if (ext && have) {
             // k-mer i-1 sits at path position r.  Read bases i+k-1.. against path chars r..: while they agree
@@ -692,7 +698,9 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
             if (s) rw |= quad_bits(g1) << (64 - 2 * s);
             if (sp) pw |= quad_bits(v2) << (64 - 2 * sp);
             const u64 rv = ((streaming == 2) ? (((u64)g1.w << 32) | (u64)g0.w) : (((u64)g1.z << 32) | (u64)g0.z)) >> s;
-            const u64 pg = (((u64)v2.z << 32) | (u64)v1.z) >> sp;
+            // the path groups' two flag words (k_path_reencode): go = ~A | B, safe = A & B, only successor = ~A & B
+            const u64 fA = (((u64)v2.z << 32) | (u64)v1.z) >> sp, fB = (((u64)v2.w << 32) | (u64)v1.w) >> sp;
+            const u64 pg = ~fA | fB;
             const u64 x = rw ^ pw;
             const u64 mm = (x | (x >> 1)) & 0x5555555555555555ull;
             const int nm = mm ? ((__ffsll((i64)mm) - 1) >> 1) : 32;
@@ -700,19 +708,50 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
             const int nv = __ffsll((i64)bad) - 1;
             int n = nm < nv ? nm : nv;
             bool stopped = n < 32;                     // a mismatch, an invalid base or the end of the path
+            int nmt = nm, nvt = nv;
+            if (SEG && !stopped && g1ok) {
+                // the cached group pair and the two path quads reach further than 32 steps: 32 - s more bases of the read,
+                // 32 - sp more chars of the path, and a segment list takes a run of any length (same-box A/B: -1.7 %,
+                // read lines 229 M -> 217 M per 10 M reads)
+                const int w2 = (s > sp) ? 32 - s : 32 - sp;
+                const u64 x2 = (quad_bits(g1) >> (2 * s)) ^ (quad_bits(v2) >> (2 * sp));
+                const u64 mm2 = (x2 | (x2 >> 1)) & 0x5555555555555555ull;
+                const int nm2 = mm2 ? ((__ffsll((i64)mm2) - 1) >> 1) : 32;
+                const u64 bad2 = ~((rv >> 32) & (pg >> 32)) | (1ull << 32);
+                const int nv2 = __ffsll((i64)bad2) - 1;
+                int n2 = nm2 < nv2 ? nm2 : nv2;
+                if (n2 >= w2) n2 = w2;                 // the end of what is cached is not a stop
+                else stopped = true;
+                n = 32 + n2;
+                nmt = 32 + nm2;
+                nvt = 32 + nv2;
+            }
             if (n > m - i) n = m - i;
-            if (n > 32 - cnt) { n = 32 - cnt; stopped = false; }   // staged results + run travel in one descriptor
+            if (!SEG && n > 32 - cnt) { n = 32 - cnt; stopped = false; }   // staged results + run travel in one descriptor
             seg_n = n;
             seg_src = (unsigned)r + 1u;
             r += (pos_t)n;
             c_ext += (unsigned)n;
             bool sbit = false;                         // stopped at a char mismatch whose path step is substitution-safe?
-            if (ix.has_safe && stopped && nm < nv) sbit = ((((((u64)v2.w << 32) | (u64)v1.w) >> sp) >> nm) & 1ull) != 0;
+            if (stopped && nmt < nvt) {
+                const int nm = nmt;
+                sbit = (((fA & fB) >> nm) & 1ull) != 0;
+                // ... or a step whose char is the only successor of its column: the read's char has none, the streaming
+                // step gives -1 (SBWT.hh:572-575) without a look at the transition table
+                ext_absent = SEG && !sbit && (((~fA & fB) >> nm) & 1ull) != 0;
+                if (SEG && sbit && nm < 32) {
+                    // a bridge needs the next k-1 bases to agree with the path; where this window already shows a second
+                    // difference among them, skip the attempt: the safe step has no successor by the read's char either
+                    const int after = 31 - nm, want = (k - 1 < m - 1 - (i + nm)) ? (k - 1) : (m - 1 - (i + nm));
+                    const int chk = after < want ? after : want;
+                    if (chk > 0 && ((mm >> (2 * (nm + 1))) & low_mask(2 * chk)) != 0) { sbit = false; ext_absent = true; }
+                }
+            }
             qshort = stopped && n < 8;
 #ifdef SBWT_STATS
             if (!stopped && i + n != m) atomicAdd(&ws->pad[17], 1ull);      // limited by the 32-step window / descriptor size
 #endif
-            if (i + n == m) mode = M_IDLE;
+            if (i + n == m) { mode = M_IDLE; ext_absent = false; }
             else if (stopped) mode = sbit ? M_BRIDGE : M_TRANS;
         } else if (have) {
             if (strm) {
@@ -895,6 +934,13 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
                 if (nleft > 0) {
                     append(i, (burst_hi >= 0) ? 0xFFFFFFFFu : seg_src);
                     i += nleft;
+                }
+                if (ext_absent) {                      // the k-mer that left the path: -1, then the certificates as after
+                    append(i, 0xFFFFFFFFu);            // any failed streaming step
+                    b = blo = i + k - 1;
+                    i++;
+                    if (i == m) mode = M_IDLE;
+                    else do_plan = true;
                 }
             }
             // ---- flush: the read is done, or the list could overflow in the next iteration.  Up to four reads per trip: the

@@ -366,8 +366,9 @@ __global__ void __launch_bounds__(256, 4) k_search_pool(SbwtIndexView ix, const 
                         ev = PEV_FAIL;
                         burst_to = i + need;
                         c_brg++;
-                    } else {
-                        mode = P_TRANS;
+                    } else {                               // a safe step has no successor by another char: -1 without a gather
+                        ev = PEV_EMIT1;
+                        b = blo = i + k - 1;
                     }
                 }
             } else if (M == P_EXT) {
@@ -377,7 +378,8 @@ __global__ void __launch_bounds__(256, 4) k_search_pool(SbwtIndexView ix, const 
                     if (s) rw |= quad_bits(g1) << (64 - 2 * s);
                     if (sp) pwd |= quad_bits(v2) << (64 - 2 * sp);
                     const u64 rv = ((streaming == 2) ? (((u64)g1.w << 32) | (u64)g0.w) : (((u64)g1.z << 32) | (u64)g0.z)) >> s;
-                    const u64 pg = (((u64)v2.z << 32) | (u64)v1.z) >> sp;
+                    const u64 fA = (((u64)v2.z << 32) | (u64)v1.z) >> sp, fB = (((u64)v2.w << 32) | (u64)v1.w) >> sp;
+                    const u64 pg = ~fA | fB;               // go = ~A | B, safe = A & B (k_path_reencode)
                     const u64 x = rw ^ pwd;
                     const u64 mmk = (x | (x >> 1)) & 0x5555555555555555ull;
                     const int nm = mmk ? ((__ffsll((i64)mmk) - 1) >> 1) : 32;
@@ -392,7 +394,7 @@ __global__ void __launch_bounds__(256, 4) k_search_pool(SbwtIndexView ix, const 
                     r += nn;
                     c_ext += (unsigned)nn;
                     bool sbit = false;
-                    if (ix.has_safe && stopped && nm < nv) sbit = ((((((u64)v2.w << 32) | (u64)v1.w) >> sp) >> nm) & 1ull) != 0;
+                    if (stopped && nm < nv) sbit = (((fA & fB) >> nm) & 1ull) != 0;
                     qshort = stopped && nn < 8;
                     if (i + nn == m) mode = P_IDLE;
                     else if (stopped) mode = sbit ? P_BRIDGE : P_TRANS;

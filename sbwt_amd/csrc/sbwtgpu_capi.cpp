@@ -455,8 +455,6 @@ int sbwtgpu_index_create(const sbwtgpu_index_desc *d, int device, sbwtgpu_index 
                                              reinterpret_cast<uint4 *>(idx->blob + h.off_trans), scr, 0);
             (void)hipFree(scr);
             if (prc != 0) { e = hipErrorUnknown; break; }
-            h.n_paths = sbwt_count_paths(idx->view(), 0);
-            if (h.n_paths < 0) { e = hipErrorUnknown; break; }
         }
         if (h.p_sparse > 0) {
             void *scr = nullptr;
@@ -484,8 +482,11 @@ int sbwtgpu_index_create(const sbwtgpu_index_desc *d, int device, sbwtgpu_index 
         }
         if (h.has_path) {                               // last: the transition entries quote the final path chars / safe bits
             SbwtIndexView v3 = idx->view();
-            h.n_branch = sbwt_launch_path_trans(v3, reinterpret_cast<uint4 *>(idx->blob + h.off_trans), 0);
+            h.n_branch = sbwt_launch_path_trans(v3, reinterpret_cast<uint4 *>(idx->blob + h.off_trans),
+                                                reinterpret_cast<uint4 *>(idx->blob + h.off_pq), 0);
             if (h.n_branch < 0) { e = hipErrorUnknown; break; }
+            h.n_paths = sbwt_count_paths(idx->view(), 0);          // (reads the final encoding of the path groups)
+            if (h.n_paths < 0) { e = hipErrorUnknown; break; }
         }
         if ((e = hipGetLastError()) != hipSuccess) break;
         e = hipDeviceSynchronize();
