@@ -23,12 +23,23 @@ __device__ __forceinline__ u64 masked_word(const u64 *__restrict__ v, i64 w, i64
     if (w == nw - 1 && (n & 63)) x &= (~0ull) >> (64 - (n & 63));
     return x;
 }
-// ones of every block, per row: cnt[c * (nb + 1) + b]
-__global__ void __launch_bounds__(256) k_blk_count(const u64 *__restrict__ bits, i64 nw, i64 n, i64 nb, i64 *__restrict__ cnt) {
+// ones of every block, per row: cnt[c * (nb + 1) + b]; and the number of columns that carry two or more chars
+// (suffix-group starts with a choice of successors), summed into *n_multi
+__global__ void __launch_bounds__(256) k_blk_count(const u64 *__restrict__ bits, i64 nw, i64 n, i64 nb, i64 *__restrict__ cnt,
+                                                   unsigned long long *n_multi) {
     const i64 b = (i64)blockIdx.x * 256 + threadIdx.x;
-    if (b >= nb) return;
+    u64 w[4] = {0, 0, 0, 0};
+    if (b < nb) {
 #pragma unroll
-    for (int c = 0; c < 4; c++) cnt[(i64)c * (nb + 1) + b] = __popcll(masked_word(bits + (i64)c * nw, b, nw, n));
+        for (int c = 0; c < 4; c++) {
+            w[c] = masked_word(bits + (i64)c * nw, b, nw, n);
+            cnt[(i64)c * (nb + 1) + b] = __popcll(w[c]);
+        }
+    }
+    unsigned multi = (unsigned)__popcll((w[0] & w[1]) | (w[0] & w[2]) | (w[0] & w[3]) | (w[1] & w[2]) | (w[1] & w[3]) | (w[2] & w[3]));
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) multi += __shfl_down(multi, off);
+    if ((threadIdx.x & 63) == 0 && multi) atomicAdd(n_multi, (unsigned long long)multi);
 }
 // blocks[b] = four quads { bits lo, bits hi, C[c] + ones before the block - mega base, suffix-group piece }
 __global__ void __launch_bounds__(256) k_blk_fill(const u64 *__restrict__ bits, const u64 *__restrict__ ssup, i64 nw, i64 n,
@@ -53,25 +64,28 @@ __global__ void __launch_bounds__(256) k_blk_fill(const u64 *__restrict__ bits, 
 
 long long sbwt_blocks_scratch_bytes(long long n_nodes) {
     const i64 nb = n_nodes / 64 + 1;
-    return 2 * 4 * (nb + 1) * 8 + ((nb + 1023) / 1024 + 2) * 8 + 256;
+    return 2 * 4 * (nb + 1) * 8 + ((nb + 1023) / 1024 + 2) * 8 + 512;
 }
 // d_bits: the four rows back to back (nw words each); d_ssup may be null.  Step 1 counts and scans; totals[4] (host)
 // receives the ones per row (the caller decides about the count layout); step 2 fills blocks and the mega table.
-int sbwt_blocks_count(const unsigned long long *d_bits, long long n_nodes, void *d_scratch, long long totals[4], hipStream_t st) {
+int sbwt_blocks_count(const unsigned long long *d_bits, long long n_nodes, void *d_scratch, long long totals[5], hipStream_t st) {
     const i64 n = n_nodes, nw = (n + 63) / 64, nb = n / 64 + 1;
     i64 *cnt = static_cast<i64 *>(d_scratch), *pre = cnt + 4 * (nb + 1), *bsum = pre + 4 * (nb + 1);
-    hipLaunchKernelGGL(k_blk_count, dim3(grid_for(nb)), dim3(256), 0, st, reinterpret_cast<const u64 *>(d_bits), nw, n, nb, cnt);
+    unsigned long long *n_multi = reinterpret_cast<unsigned long long *>(bsum + ((nb + 1023) / 1024 + 2));
+    (void)hipMemsetAsync(n_multi, 0, 8, st);
+    hipLaunchKernelGGL(k_blk_count, dim3(grid_for(nb)), dim3(256), 0, st, reinterpret_cast<const u64 *>(d_bits), nw, n, nb, cnt, n_multi);
     const unsigned gb = (unsigned)((nb + 1023) / 1024);
     for (int c = 0; c < 4; c++) {
         hipLaunchKernelGGL(k_scan_block_sums, dim3(gb), dim3(256), 0, st, cnt + (i64)c * (nb + 1), nb, bsum);
         hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, st, bsum, (i64)gb);
         hipLaunchKernelGGL(k_scan_apply, dim3(gb), dim3(256), 0, st, cnt + (i64)c * (nb + 1), nb, bsum, pre + (i64)c * (nb + 1));
     }
-    i64 t[4];
+    i64 t[5];
     for (int c = 0; c < 4; c++)
         if (hipMemcpyAsync(&t[c], pre + (i64)c * (nb + 1) + nb, 8, hipMemcpyDeviceToHost, st) != hipSuccess) return -1;
+    if (hipMemcpyAsync(&t[4], n_multi, 8, hipMemcpyDeviceToHost, st) != hipSuccess) return -1;
     if (hipStreamSynchronize(st) != hipSuccess) return -1;
-    for (int c = 0; c < 4; c++) totals[c] = t[c];
+    for (int c = 0; c < 5; c++) totals[c] = t[c];
     return 0;
 }
 void sbwt_blocks_fill(const unsigned long long *d_bits, const unsigned long long *d_ssup, long long n_nodes, void *d_scratch,

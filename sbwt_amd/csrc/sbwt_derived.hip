@@ -389,7 +389,20 @@ __global__ void __launch_bounds__(256) k_path_trans(SbwtIndexView ix, const unsi
             const u64 go = ((((u64)b.z << 32) | (u64)a.z) >> s), sf = ((((u64)b.w << 32) | (u64)a.w) >> s);
             ext = (unsigned)(ch & 0xFFFFull) | ((unsigned)(go & 0xFFull) << 16) | ((unsigned)(sf & 0xFFull) << 24);
         }
-        trans[4 * t + c] = make_uint4(nc[c], np[c], ext, 0u);
+        if (ix.trans_wide) {
+            // + the columns of the successor's next four path steps (used only as far as the quoted go bits reach)
+            uint4 nx = make_uint4(0u, 0u, 0u, 0u);
+            if (nc[c] != PATH_NONE) {
+                const i64 last = ix.n_nodes - 1;
+                const i64 p1 = (i64)np[c] + 1;
+                nx = make_uint4(ix.col[p1 <= last ? p1 : last], ix.col[p1 + 1 <= last ? p1 + 1 : last],
+                                ix.col[p1 + 2 <= last ? p1 + 2 : last], ix.col[p1 + 3 <= last ? p1 + 3 : last]);
+            }
+            trans[2 * (4 * t + c)] = make_uint4(nc[c], np[c], ext, 0u);
+            trans[2 * (4 * t + c) + 1] = nx;
+        } else {
+            trans[4 * t + c] = make_uint4(nc[c], np[c], ext, 0u);
+        }
     }
     // columns with two or more successors: how often a read that follows a path has a choice (see sbwtgpu_capi.cpp: the
     // kernel with per-read segment lists is chosen where such columns are rare)

@@ -8,7 +8,8 @@
 //   [ mega     : 4 x n_mega x 8 B]   absolute (C[c] + rank_c) at every 2^31-column boundary
 //   [ col, pos : n_nodes x 4 B each ]  path order (see k_path_* in sbwt_derived.hip)
 //   [ pq       : (n/32+2) x 16 B ]   packed chars + go bits along the paths
-//   [ trans    : n_nodes x 64 B  ]   the four successors of every path position (column, path position, next 8 steps)
+//   [ trans    : n_nodes x 64 B  ]   the four successors of every path position (column, path position, next 8 steps);
+//                                    x 128 B on branchy indexes (trans_wide): + the columns of the successor's next 4 steps
 //   [ pfil     : 2^log2f x 16 B  ]   probe filter (see k_pf_insert)
 //   [ stab2    : 2^log2b2 x 32 B ]   second level for 31 < k <= 63: { rest key (8 B), first column of the 31-prefix's
 //                                    interval, flags } { column, path position, -, - }
@@ -61,6 +62,8 @@ struct SbwtIndexView {
     int p_filter, log2f;            // its depth and log2 of its number of 16-byte blocks
     const uint4 *trans;             // transition table: 4 quads per path position, one per char: { successor column, its path
                                     // position, its path's next 8 steps (chars | go << 16 | safe << 24), - }
+    int trans_wide;                 // transition entries are two quads: the second = the columns of the successor's next four
+                                    // path steps (branchy indexes: short runs after a transition need no look at col[])
     int stab_pos;                   // sparse entries are whole k-mers stored with their path position
     int debug;                      // experiments only: bit0 = skip result stores
     int force_mega;                 // one mega block whose counts do not fit 32 bits (dense rank-only images): cnt is relative
@@ -88,6 +91,7 @@ struct SbwtBlobHeader {
     int32_t log2f;
     int32_t has_safe;               // pq carries the substitution-safe bits
     int32_t force_mega;             // block counts are relative to mega[c][0] although n_mega == 1 (see SbwtIndexView)
+    int64_t trans_wide;             // 1: 32-byte transition entries (see SbwtIndexView)
     int64_t n_paths;                // paths of the path order
     int64_t n_branch;               // columns with two or more successors (n_nodes / n_branch = columns between choices)
     int64_t image_level;            // 0 full, 1 no path order, 2 blocks + dense prefix table only
@@ -166,7 +170,7 @@ long long sbwt_format_scratch_bytes(long long n_reads);
 void sbwt_launch_format(const long long *d_vals, const long long *d_out_off, long long n_reads, char *d_text,
                         long long *d_line_off, void *d_scratch, hipStream_t stream);
 long long sbwt_blocks_scratch_bytes(long long n_nodes);
-int sbwt_blocks_count(const unsigned long long *d_bits, long long n_nodes, void *d_scratch, long long totals[4], hipStream_t st);
+int sbwt_blocks_count(const unsigned long long *d_bits, long long n_nodes, void *d_scratch, long long totals[5], hipStream_t st);
 void sbwt_blocks_fill(const unsigned long long *d_bits, const unsigned long long *d_ssup, long long n_nodes, void *d_scratch,
                       const long long C[4], int use_mega, int n_mega, uint4 *d_blocks, unsigned long long *d_mega, hipStream_t st);
 long long sbwt_derive_scratch_bytes(long long n_nodes);

@@ -454,6 +454,8 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
         bool rknown = false;                           // PATH: this iteration's answer came with its path position (in r)
         bool qshort = false;                           // PATH: a run of fewer than 8 k-mers ended in this iteration
         bool ext_absent = false;                       // SEG: the k-mer after this iteration's run is absent (only-successor step)
+        int nlit = 0;                                  // trans_wide: results that came with the transition entry ...
+        uint4 lit = make_uint4(0u, 0u, 0u, 0u);        // ... the columns of the successor's next path steps
         // run on from transitions while short runs are a sizeable part of this wave's work (one lane-iteration in
         // eight: pan-genomes; on a few strains the saved iterations do not pay for the extra instructions)
         const bool use_q = PATH && (ix.trans_ext > 0 || (ix.trans_ext < 0 && c_short >= 8u * c_iter));
@@ -501,8 +503,9 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
                     a2 = a1 + 1;
                 } else if (trn) {
                     if (((streaming == 2 ? g0.w : g0.z) >> s) & 1u) {     // validity as in M_STREAM below
-                        a1 = ix.trans + (4 * (size_t)(unsigned)r + (unsigned)c);   // the quad of this char's successor
-                        a2 = a1;
+                        // the entry of this char's successor: one quad, or two on branchy indexes (trans_wide)
+                        a1 = ix.trans + ((4 * (size_t)(unsigned)r + (unsigned)c) << ix.trans_wide);
+                        a2 = a1 + ix.trans_wide;
                     } else {
                         ev = EV_EMIT1;
                         b = blo = i + k - 1;
@@ -659,8 +662,15 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
                     if (n2 > m - 1 - i) { n2 = m - 1 - i; stop2 = false; }
                     if (n2 > 31 - cnt) { n2 = 31 - cnt; stop2 = false; }
                     if (n2 < 0) n2 = 0;
-                    seg_n = n2;
-                    seg_src = (unsigned)r + 1u;
+                    if (!SEG && ix.trans_wide && n2 <= 4 && cnt + 1 + n2 <= DEPTH) {
+                        // a short run right after the transition: its columns came with the entry (v2), they go straight
+                        // into the stage behind the transition's own result -- no descriptor, no look at col[]
+                        nlit = n2;
+                        lit = v2;
+                    } else {
+                        seg_n = n2;
+                        seg_src = (unsigned)r + 1u;
+                    }
                     r += (pos_t)n2;
                     c_ext += (unsigned)n2;
                     if (stop2) tnext = (ix.has_safe && nm < nv && ((v1.z >> 24 >> nm) & 1u)) ? M_BRIDGE : M_TRANS;
@@ -906,6 +916,14 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
             stage[cnt][tid] = (stage_t)res;
             cnt++;
             i++;
+            if (nlit > 0) {
+                stage[cnt][tid] = (stage_t)lit.x;
+                if (nlit > 1) stage[cnt + 1][tid] = (stage_t)lit.y;
+                if (nlit > 2) stage[cnt + 2][tid] = (stage_t)lit.z;
+                if (nlit > 3) stage[cnt + 3][tid] = (stage_t)lit.w;
+                cnt += nlit;
+                i += nlit;
+            }
         }
         // ---- result writes, wave-cooperative ----
         // Staged results are those of k-mers [i-cnt, i); they leave as one run that ends on a line
@@ -1049,7 +1067,9 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
                 const int total = cnt + nn;
                 const bool end = (i + nn == m);
                 const int over = (int)((unsigned)(dst0 + total) & lmask);   // results past the last line boundary
-                const bool post = nn > 0 || (cnt > 0 && (end || over == 0));
+                // (a line boundary inside the staged block: reached exactly when results arrive one at a time, possibly
+                // jumped over when a transition brings up to five)
+                const bool post = nn > 0 || (cnt > 0 && (end || over < total));
                 const int w = !post ? 0 : (end ? total : (over <= total ? total - over : 0));
                 const u64 pm = __ballot(post);
                 if (pm == 0) break;

@@ -226,7 +226,7 @@ __global__ void __launch_bounds__(256, 4) k_search_pool(SbwtIndexView ix, const 
                         a2 = a1 + 1;
                     } else if (M == P_TRANS) {
                         if (((streaming == 2 ? g0.w : g0.z) >> s) & 1u) {
-                            a1 = ix.trans + (4 * (size_t)(unsigned)r + (unsigned)c);
+                            a1 = ix.trans + ((4 * (size_t)(unsigned)r + (unsigned)c) << ix.trans_wide);
                             a2 = a1;
                         } else {
                             ev = PEV_EMIT1;            // non-ACGT (after toupper: SBWT.hh:565-568) -> -1

@@ -99,6 +99,7 @@ static int g_probe_filter = [] { const char *e = getenv("SBWTGPU_PROBE_FILTER");
 static int g_image_level = [] { const char *e = getenv("SBWTGPU_IMAGE_LEVEL"); return e ? atoi(e) : 0; }();
 static int64_t g_max_image_bytes = [] { const char *e = getenv("SBWTGPU_MAX_IMAGE_BYTES"); return e ? (int64_t)atoll(e) : (int64_t)0; }();
 static int g_sort_reads = [] { const char *e = getenv("SBWTGPU_SORT_READS"); return e ? atoi(e) : -1; }();   // -1 auto, 0 off, 1 on
+static int g_trans_wide = [] { const char *e = getenv("SBWTGPU_TRANS_WIDE"); return e ? atoi(e) : -1; }();   // -1 by the index
 static int g_force_mega = 0;    // tests: store every image's block counts relative to mega[c][0] (the dense rank-only layout)
 static int g_trans_ext = -1;    // -1: adaptive per wave, 0/1: force
 static int g_path_safe = [] { const char *e = getenv("SBWTGPU_PATH_SAFE"); return e ? atoi(e) : 1; }();
@@ -144,6 +145,7 @@ struct sbwtgpu_index {
         v.pq = h.has_path ? reinterpret_cast<const uint4 *>(blob + h.off_pq) : nullptr;
         v.trans = h.has_path ? reinterpret_cast<const uint4 *>(blob + h.off_trans) : nullptr;
         v.stab_pos = h.stab_pos;
+        v.trans_wide = (int)h.trans_wide;
         v.has_safe = h.has_safe;
         v.trans_ext = g_trans_ext;
         v.stab2 = h.log2b2 > 0 ? reinterpret_cast<const uint4 *>(blob + h.off_stab2) : nullptr;
@@ -171,6 +173,7 @@ int sbwtgpu_set_tuning(const char *key, int64_t value) {
     if (!strcmp(key, "image_level")) { g_image_level = (int)value; return SBWTGPU_OK; }          // indexes created afterwards
     if (!strcmp(key, "max_image_bytes")) { g_max_image_bytes = value; return SBWTGPU_OK; }     // indexes created afterwards
     if (!strcmp(key, "sort_reads")) { g_sort_reads = (int)value; return SBWTGPU_OK; }
+    if (!strcmp(key, "trans_wide")) { g_trans_wide = (int)value; return SBWTGPU_OK; }     // indexes created afterwards
     if (!strcmp(key, "force_mega")) { g_force_mega = (int)value; return SBWTGPU_OK; }     // indexes created afterwards
     if (!strcmp(key, "trans_ext")) { g_trans_ext = (int)value; return SBWTGPU_OK; }
     if (!strcmp(key, "path_safe")) { g_path_safe = (int)value; return SBWTGPU_OK; }   // indexes created afterwards
@@ -311,7 +314,7 @@ int sbwtgpu_index_create(const sbwtgpu_index_desc *d, int device, sbwtgpu_index 
         h.off_pos = align256(h.off_col + (n + 4) * 4);
         h.off_pq = align256(h.off_pos + (n + 4) * 4);
         h.off_trans = align256(h.off_pq + sbwt_path_quads(n) * 16);
-        h.blob_bytes = align256(h.off_trans + (n + 1) * 64);
+        h.blob_bytes = align256(h.off_trans + (n + 1) * 64);          // (n + 1) x 128 on branchy indexes: revised below
     }
     idx->device = device;
 
@@ -334,13 +337,20 @@ int sbwtgpu_index_create(const sbwtgpu_index_desc *d, int device, sbwtgpu_index 
         }
     }
     // C array (SBWT.hh:344-349): C[0] = 1 (ghost dollar into the root), C[i+1] = C[i] + rank(n, sigma_i)
-    long long tot[4] = {0, 0, 0, 0};
+    long long tot[5] = {0, 0, 0, 0, 0};
     if (sbwt_blocks_count(static_cast<const unsigned long long *>(d_bits.p), n, d_bscr.p, tot, 0) != 0) {
         delete idx;
         return fail(SBWTGPU_ERR_HIP, "counting the set bits on the device failed");
     }
     h.C[0] = 1;
     for (int c = 1; c < 4; c++) h.C[c] = h.C[c - 1] + tot[c - 1];
+    // Branchy index (more than one column in 64 offers a choice of successors: pan-genomes): reads leave their path every
+    // few k-mers, and what follows a transition is mostly a run of 1-4 k-mers.  Their columns go into the transition entry
+    // itself (32 instead of 16 bytes per entry, +64 bytes per column of image).
+    if (h.has_path && g_trans_wide != 0 && (g_trans_wide > 0 || tot[4] * 64 > n)) {
+        h.trans_wide = 1;
+        h.blob_bytes = align256(h.off_trans + (n + 1) * 128);
+    }
     // In an SBWT every column except the root has exactly one incoming edge, so the matrix holds
     // n_nodes - 1 set bits and every LF step stays inside [0, n_nodes).  Arbitrary bit vectors (the
     // stand-alone SubsetMatrixRank use) are still served, but only by rank(): walking them would
@@ -366,6 +376,7 @@ int sbwtgpu_index_create(const sbwtgpu_index_desc *d, int device, sbwtgpu_index 
         h.log2b2 = 0;
         h.p_filter = 0;
         h.has_path = 0;
+        h.trans_wide = 0;
     }
     if (d->precalc && p_file > 0) {
         const int64_t np = (int64_t)1 << (2 * p_file);

@@ -620,3 +620,38 @@ def test_sorted_reads_give_the_same_bits(gpu, genome_case, variant):
     finally:
         capi.set_tuning("search_variant", -1)
         capi.set_tuning("sort_reads", -1)
+
+
+@pytest.mark.parametrize("wide", [0, 1])
+@pytest.mark.parametrize("variant", [2, 3, 4])
+def test_wide_transition_entries(gpu, genome_case, variant, wide):
+    # "trans_wide": transition entries that carry the columns of the successor's next four path steps (branchy
+    # indexes; forced here) -- short runs after a transition are served from the entry; same bits either way, with the
+    # transitions running on along their quoted steps (trans_ext = 1) or deciding per wave
+    genomes, orc = genome_case
+    capi.set_tuning("trans_wide", wide)
+    try:
+        idx = gpu_index_from_oracle(orc)
+    finally:
+        capi.set_tuning("trans_wide", -1)
+    # reads that hop between the strains every few bases leave their path all the time
+    rng = np.random.default_rng(4)
+    n, L = 3000, 150
+    start = rng.integers(0, len(genomes[0]) - L, size=n)
+    which = rng.integers(0, 3, size=(n, L // 10))
+    bases = np.empty(n * L, dtype=np.uint8)
+    for r in range(n):
+        for seg in range(L // 10):
+            bases[r * L + seg * 10:r * L + seg * 10 + 10] = genomes[which[r, seg]][start[r] + seg * 10:start[r] + seg * 10 + 10]
+    bases = synth.mutate(bases, 0.005, 9)
+    off = np.arange(n + 1, dtype=np.int64) * L
+    want = oracle_batch(orc, bases, off, True)
+    capi.set_tuning("search_variant", variant)
+    try:
+        for te in (1, -1, 0):
+            capi.set_tuning("trans_ext", te)
+            got, _ = idx.streaming_search(bases, off)
+            assert np.array_equal(got, want), (variant, wide, te)
+    finally:
+        capi.set_tuning("search_variant", -1)
+        capi.set_tuning("trans_ext", -1)

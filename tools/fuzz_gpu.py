@@ -34,6 +34,7 @@ while time.time() < t_end:
     ssup = bool(rng.integers(0, 2))
     rc = bool(rng.integers(0, 2))
     bits = hostlib.build_bits([g.tobytes() for g in genomes], k, rc, ssup, n_threads=4)
+    capi.set_tuning("trans_wide", int(rng.integers(-1, 2)))
     idx = capi.Index.create(bits.cols[0], bits.cols[1], bits.cols[2], bits.cols[3], bits.ssup if ssup else None,
                             bits.n_nodes, k, bits.n_kmers, int(rng.choice([0, 0, 2, min(k, 8)])))
     # reads
