@@ -57,16 +57,27 @@ __global__ void __launch_bounds__(256) k_sg_patch(uint4 *__restrict__ blocks, co
 // hashing the survivors into buckets of two entries; a bucket that a key had to skip carries an overflow
 // flag, so a lookup that meets a bucket without the flag knows the prefix is absent.
 // ---------------------------------------------------------------------------------------------
-// Output slot of a compacting append: one atomic per wave instead of one per lane (every expansion level appends
-// ~n_nodes items to ONE counter).  Returns ~0 for lanes that append nothing.  All lanes of the wave must call it.
-__device__ __forceinline__ u64 wave_append_slot(u64 *counter, bool ok) {
+// Output slot of a compacting append: ONE atomic per 256-thread workgroup (every expansion level appends ~n_nodes items
+// to one counter, and a single address takes only ~10^8 atomics per second: one per lane or even one per wave made the
+// 17 levels of a 142 M-column index cost 1.4 s).  Returns ~0 for threads that append nothing.  Every thread of the
+// workgroup must call it (it synchronises the workgroup).
+__device__ __forceinline__ u64 block_append_slot(u64 *counter, bool ok) {
+    __shared__ unsigned wcount[4];
+    __shared__ u64 wbase;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const u64 m = __ballot(ok);
-    if (m == 0) return ~0ull;
-    const int lane = threadIdx.x & 63, leader = __ffsll((i64)m) - 1;
-    u64 base = 0;
-    if (lane == leader) base = atomicAdd(counter, (u64)__popcll(m));
-    base = uniform64(__shfl(base, leader));
-    return ok ? base + (u64)__popcll(m & low_mask(lane)) : ~0ull;
+    if (lane == 0) wcount[wv] = (unsigned)__popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned total = wcount[0] + wcount[1] + wcount[2] + wcount[3];
+        wbase = total ? atomicAdd(counter, (u64)total) : 0ull;
+    }
+    __syncthreads();
+    unsigned before = 0;
+    for (int w = 0; w < wv; w++) before += wcount[w];
+    const u64 slot = wbase + before + (u64)__popcll(m & low_mask(lane));
+    __syncthreads();                                    // (the shared words are reused by the caller's next append)
+    return ok ? slot : ~0ull;
 }
 
 struct SpItem { u64 key; i64 l; i64 r; };
@@ -76,7 +87,7 @@ __global__ void __launch_bounds__(256) k_sp_collect(const longlong2 *__restrict_
     u64 t = (u64)blockIdx.x * 256 + threadIdx.x;
     longlong2 e = make_longlong2(-1, -1);
     if (t < n_entries) e = ptab[t];
-    const u64 slot = wave_append_slot(counter, e.x >= 0);
+    const u64 slot = block_append_slot(counter, e.x >= 0);
     if (slot != ~0ull) out[slot] = SpItem{t, e.x, e.y};
 }
 // ---- second level (31 < k <= 63): the 31-prefix's interval (named by its first column) + the remaining bases ----
@@ -102,7 +113,7 @@ __global__ void __launch_bounds__(256) k_sp2_expand(SbwtIndexView ix, const SpIt
         l = (i64)quad_rank<false>(ix, q1, (i64)it.l, c);
         r = (i64)quad_rank<false>(ix, q2, (i64)it.r + 1, c) - 1;
     }
-    const u64 slot = wave_append_slot(n_out, l <= r);
+    const u64 slot = block_append_slot(n_out, l <= r);
     if (slot != ~0ull) out[slot] = SpItem2{it.key2 | ((u64)c << (2 * d2)), it.origin, (unsigned)l, (unsigned)r, 0u};
 }
 __global__ void __launch_bounds__(256) k_sp2_insert(const SpItem2 *__restrict__ items, const u64 *n, uint4 *table,
@@ -150,7 +161,7 @@ __global__ void __launch_bounds__(256) k_sp_expand(SbwtIndexView ix, const SpIte
         l = (i64)quad_rank<MEGA>(ix, q1, it.l, c);
         r = (i64)quad_rank<MEGA>(ix, q2, it.r + 1, c) - 1;
     }
-    const u64 slot = wave_append_slot(n_out, l <= r);
+    const u64 slot = block_append_slot(n_out, l <= r);
     if (slot != ~0ull) out[slot] = SpItem{it.key | ((u64)c << (2 * depth)), l, r};   // char `depth` of the prefix is c
 }
 // Probe filter: a blocked Bloom filter (128-bit blocks, two bits per key) over every p_filter-mer the index
