@@ -503,6 +503,7 @@ def main() -> int:
             "survey_8d_priced_GBps": survey_priced_bytes / (kernel_ms * 1e-3) / 1e9,
             "nominal_bytes_per_launch_survey_8d": nominal_bytes,
             "work_per_launch": {"path_run_kmers": n_ext, "stream_steps": n_stream, "walks": n_search,
+                                "bridged_substitutions": index.workspace_bridges(d_ws.data_ptr(), stream),
                                 "interval_updates": n_lf, "table_hits": n_tab, "kmers_not_streamed": n_full},
             "kernel_only_kmers_per_s": n_kmers / (kernel_ms * 1e-3),
         },

@@ -383,6 +383,12 @@ class Index:
         _check(lib().sbwtgpu_workspace_stats(d_ws, stream, st))
         return tuple(int(x) for x in st[:5])
 
+    def workspace_bridges(self, d_ws: int, stream: int = 0) -> int:
+        """Substitutions bridged along a path (M_BRIDGE) by the last search on this workspace."""
+        st = (C.c_int64 * 8)()
+        _check(lib().sbwtgpu_workspace_stats(d_ws, stream, st))
+        return int(st[5])
+
     def workspace_status(self, d_ws: int, stream: int = 0) -> int:
         st = C.c_int(0)
         _check(lib().sbwtgpu_workspace_status(d_ws, stream, C.byref(st)))

@@ -168,49 +168,7 @@ __global__ void __launch_bounds__(256) k_partial_search(SbwtIndexView ix, const 
 // one of row c; here it is found in the block counts themselves -- the last block whose count is <= the
 // target (interpolated first guess, gallop, bisection), then the j-th set bit inside the block's 64 bits.
 // ---------------------------------------------------------------------------------------------
-template <bool MEGA>
-__device__ __forceinline__ u64 block_count(const SbwtIndexView &ix, i64 blk, int c, uint4 *q) {
-    *q = ix.blocks[(blk << 2) + c];
-    u64 v = (u64)q->z;
-    if (MEGA) v += ix.mega[(i64)c * ix.n_mega + (blk >> (SBWT_MEGA_SHIFT - 6))];
-    return v;
-}
-
-// the column whose row-c bit is the one numbered `target` - C[c] (0-based): the last block whose count (= C[c] + rank_c
-// of its first column) is <= target, then the right set bit inside it.  target in [C[c], C[c] + ones of row c).
-template <bool MEGA>
-__device__ __forceinline__ i64 select_in_row(const SbwtIndexView &ix, int c, i64 target_i, i64 row_ones) {
-    const u64 target = (u64)target_i;
-    const i64 n_blocks = ix.n_nodes / 64 + 1;
-    i64 g = row_ones > 0 ? (i64)((double)(target_i - ix.C[c]) / (double)row_ones * (double)n_blocks) : 0;
-    if (g < 0) g = 0;
-    if (g > n_blocks - 1) g = n_blocks - 1;
-    uint4 q;
-    i64 lo, hi;                                             // invariant: count(lo) <= target < count(hi) (hi may be n_blocks)
-    if (block_count<MEGA>(ix, g, c, &q) <= target) {
-        lo = g;
-        i64 step = 1;
-        hi = g + step;
-        while (hi < n_blocks && block_count<MEGA>(ix, hi, c, &q) <= target) { lo = hi; step <<= 1; hi = lo + step; }
-        if (hi > n_blocks) hi = n_blocks;
-    } else {
-        hi = g;
-        i64 step = 1;
-        lo = g - step;
-        while (lo > 0 && block_count<MEGA>(ix, lo, c, &q) > target) { hi = lo; step <<= 1; lo = hi - step; }
-        if (lo < 0) lo = 0;
-    }
-    while (hi - lo > 1) {
-        const i64 mid = lo + ((hi - lo) >> 1);
-        if (block_count<MEGA>(ix, mid, c, &q) <= target) lo = mid; else hi = mid;
-    }
-    const u64 cnt = block_count<MEGA>(ix, lo, c, &q);
-    u64 bits = quad_bits(q);
-    const int skip = (int)(target - cnt);                   // ones of this block before the wanted one
-    for (int s = 0; s < skip; s++) bits &= bits - 1;
-    return (lo << 6) + (bits ? (__ffsll((i64)bits) - 1) : 0);
-}
-
+// (block_count / select_in_row: sbwt_kernels_common.h -- the path order's build uses them too)
 template <bool MEGA>
 __global__ void __launch_bounds__(256) k_get_kmer(SbwtIndexView ix, const i64 *__restrict__ colex, i64 n,
                                                   char *__restrict__ out) {

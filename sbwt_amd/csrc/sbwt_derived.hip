@@ -364,6 +364,67 @@ __global__ void __launch_bounds__(256) k_path_safe(SbwtIndexView ix, unsigned *p
     atomicOr(&pq_words[(size_t)(u >> 5) * 4 + 3], 1u << (int)(u & 31));
 }
 
+// The same bit by a wider rule (the default): the k-1 steps BEFORE u need not lie on u's path.  What the k windows hold
+// left of the substituted base are the last k-1 chars of the label of column col[u], and near the head of a path those
+// come from the head's own label (k_path_head_labels: k backward steps, SBWT.hh:700-746) followed by the path's chars.
+// Only the k steps u .. u+k-1 must be on the path -- M_BRIDGE compares the read with exactly those, and goes on from
+// position u+k.  On genomes whose paths are ~100 columns long this makes about half as many steps again bridgeable.
+template <bool MEGA>
+__global__ void __launch_bounds__(256) k_path_head_labels(SbwtIndexView ix, u64 *__restrict__ hlab) {
+    const i64 t = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (t >= ix.n_nodes) return;
+    if (t > 0 && ((ix.pq[(t - 1) >> 5].z >> (int)((t - 1) & 31)) & 1u)) return;      // step t-1 goes on: t is not a head
+    const int k = ix.k;
+    i64 v = ix.col[t];
+    u64 lab = 0;                                        // char j of the label at bits 2j (first char lowest, as the table keys)
+    for (int i = 0; i < k; i++) {
+        if (v == 0) { lab = ~0ull; break; }             // a dummy column: its label starts with '$' -- never vouched for
+        int c = 0;
+        while (c + 1 < 4 && v >= ix.C[c + 1]) c++;
+        lab |= (u64)c << (2 * (k - 1 - i));
+        const i64 hi_c = (c < 3) ? ix.C[c + 1] : ix.n_nodes;
+        v = select_in_row<MEGA>(ix, c, v, hi_c - ix.C[c]);
+    }
+    hlab[t] = lab;
+}
+__global__ void __launch_bounds__(256) k_path_safe_labels(SbwtIndexView ix, unsigned *pq_words, const u64 *__restrict__ hlab) {
+    const i64 u = (i64)blockIdx.x * 256 + threadIdx.x;
+    const int k = ix.k;
+    if (u >= ix.n_nodes) return;
+    // steps 32(q-1) .. 32(q+2)-1 in three quads; step u is number o = 32 + s of them
+    const i64 q = u >> 5;
+    const int s = (int)(u & 31), o = 32 + s;
+    const uint4 zero = make_uint4(0u, 0u, 0u, 0u);
+    const uint4 qa = q > 0 ? ix.pq[q - 1] : zero, qb = ix.pq[q], qc = ix.pq[q + 1];
+    const u64 A = quad_bits(qa), B = quad_bits(qb), C = quad_bits(qc);
+    // the k steps u .. u+k-1 and their chars
+    const u64 gr = ((((u64)qc.z << 32) | (u64)qb.z) >> s) & low_mask(k);
+    if (gr != low_mask(k)) return;
+    const u64 right = ((B >> (2 * s)) | (s ? (C << (64 - 2 * s)) : 0ull)) & low_mask(2 * k);
+    // the k-1 steps before u: on this path, or as far back as its head and then the head's label
+    const int f = o - (k - 1);                          // first of them, in [2, 62]
+    const u64 gl = (((((u64)qb.z << 32) | (u64)qa.z) >> f)) & low_mask(k - 1);
+    const u64 val = ((f < 32) ? ((A >> (2 * f)) | (B << (64 - 2 * f))) : (B >> (2 * (f - 32)))) & low_mask(2 * (k - 1));
+    u64 left = val;
+    if (gl != low_mask(k - 1)) {
+        const int jz = 63 - __clzll((i64)(~gl & low_mask(k - 1)));      // the last step that does not go on
+        const int d = k - 2 - jz;                       // u is d steps after its path's head
+        const u64 H = hlab[u - d];
+        if (H == ~0ull) return;
+        const u64 lm = low_mask(2 * (k - 1 - d));
+        left = ((H >> (2 * (d + 1))) & lm) | (val & ~lm);
+    }
+    // S = left (k-1 chars) . ch[u] . right's other k-1 chars; window number w starts at char w, ch[u] is its char k-1-w
+    const u64 Slo = left | (right << (2 * (k - 1))), Shi = right >> (64 - 2 * (k - 1));
+    const u64 km = low_mask(2 * k);
+    for (int w = 0; w < k; w++) {
+        const u64 key = ((Slo >> (2 * w)) | (w ? (Shi << (64 - 2 * w)) : 0ull)) & km;
+        for (u64 alt = 1; alt < 4; alt++)
+            if (sp_present(ix, key ^ (alt << (2 * (k - 1 - w))))) return;
+    }
+    atomicOr(&pq_words[(size_t)q * 4 + 3], 1u << s);
+}
+
 // transition table: entry t = four 16-byte quads, one per char c: { column of the successor of col[t] by c (or none),
 // its path position p, the next 8 steps of its path: chars p..p+7 (16 bits) | go bits (8) | safe bits (8), - }
 // (built last: the path's chars and safe bits must be final)
@@ -567,8 +628,19 @@ long long sbwt_count_paths(const SbwtIndexView &ix, hipStream_t stream) {
     (void)hipFree(d);
     return e == hipSuccess ? (long long)h : -1;
 }
-void sbwt_launch_path_safe(const SbwtIndexView &ix, uint4 *d_pq, hipStream_t stream) {
-    hipLaunchKernelGGL(k_path_safe, dim3(grid_for(ix.n_nodes)), dim3(256), 0, stream, ix, reinterpret_cast<unsigned *>(d_pq));
+// rule 1: 2k steps around u on one path; rule 2 (needs d_hlab, n_nodes x 8 bytes of scratch): k steps from u on
+void sbwt_launch_path_safe(const SbwtIndexView &ix, uint4 *d_pq, int rule, void *d_hlab, hipStream_t stream) {
+    if (rule < 2 || !d_hlab) {
+        hipLaunchKernelGGL(k_path_safe, dim3(grid_for(ix.n_nodes)), dim3(256), 0, stream, ix, reinterpret_cast<unsigned *>(d_pq));
+        return;
+    }
+    u64 *hlab = reinterpret_cast<u64 *>(d_hlab);
+    if (ix.n_mega > 1)
+        hipLaunchKernelGGL(k_path_head_labels<true>, dim3(grid_for(ix.n_nodes)), dim3(256), 0, stream, ix, hlab);
+    else
+        hipLaunchKernelGGL(k_path_head_labels<false>, dim3(grid_for(ix.n_nodes)), dim3(256), 0, stream, ix, hlab);
+    hipLaunchKernelGGL(k_path_safe_labels, dim3(grid_for(ix.n_nodes)), dim3(256), 0, stream, ix,
+                       reinterpret_cast<unsigned *>(d_pq), hlab);
 }
 
 // d_col, d_pos: n_nodes (+4 padding) u32 each; d_pq: sbwt_path_quads() quads.  Synchronises the stream.

@@ -363,6 +363,9 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
     typedef typename SearchTypes<WIDE>::stage_t stage_t;
     constexpr int DEPTH = SearchTypes<WIDE>::DEPTH;
     static_assert(!SEG || (PATH && !WIDE), "segment lists: 32-bit path-order kernel only");
+    // a third cached packed group, fetched in pairs (see the loads below).  SEG only: the descriptor-writer kernel would
+    // pay for the registers with a wave per SIMD (config 3: 123 -> 150 ms)
+    constexpr bool G3 = SEG;
     __shared__ stage_t stage[SEG ? 1 : DEPTH][SEG ? 1 : 256];
     __shared__ uint4 desc[(PATH && !SEG) ? 4 : 1][(PATH && !SEG) ? 128 : 1];      // PATH: run descriptors, per wave
     __shared__ uint2 segs[SEG ? SBWT_NSEG : 1][SEG ? 256 : 1];                      // SEG: { source, first k-mer } per lane
@@ -389,14 +392,14 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
     pos_t l = 0, r = 0;             // walk interval; M_STREAM: l = previous answer; M_BACK: r = block
     i64 rd = 0;                     // M_FETCH: the read whose offsets are being fetched
     bool rdok = true;               // false: rd is still a ticket, the fetch step reads perm[rd] first
-    int tag = -2;                   // g0 = packed group `tag`; g1 = group tag+1 if g1ok
-    bool g1ok = false;
+    int tag = -2;                   // g0 = packed group `tag`; g1 = group tag+1 if g1ok; PATH: g2 = group tag+2 if g2ok
+    bool g1ok = false, g2ok = false;
     // PATH: fixed-length reads (checked by k_check_uniform just before this launch)
     const bool uni = PATH && ws->u_bad == 0 && ws->u_len > 0;
     const i64 u_read0 = ws->u_read0, u_len = ws->u_len, u_out0 = ws->u_out0, u_stride = ws->u_stride;
     unsigned c_ext = 0;             // PATH: k-mers answered along paths (per lane)
     unsigned c_brg = 0;             // PATH: substitutions bridged (per lane)
-    uint4 g0 = make_uint4(0, 0, 0, 0), g1 = make_uint4(0, 0, 0, 0);
+    uint4 g0 = make_uint4(0, 0, 0, 0), g1 = make_uint4(0, 0, 0, 0), g2 = make_uint4(0, 0, 0, 0);
     u64 pool_next = 0, pool_end = 0;                              // wave-uniform pool of read tickets
     unsigned c_stream = 0, c_search = 0, c_lf = 0, c_tab = 0;     // wave-uniform (scalar) work counters
     unsigned c_iter = 0, c_short = 0;                             // PATH: iterations of this wave; runs shorter than 8 k-mers
@@ -485,9 +488,15 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
             // bases the table window of this walk covers
             const int wl = (wk == 1) ? ps : (wk == 2) ? L0 : (wk == 3) ? pw : (wk == 5) ? k - ps : p;
             grp = pgrp + (P >> 5);
-            if (grp == tag + 1 && g1ok && (mode != M_INIT || s + wl <= 32)) {
+            if (grp == tag + 1 && g1ok && (mode != M_INIT || s + wl <= 32 || (G3 && g2ok))) {
                 g0 = g1;                               // crossed into the group that is already here
                 g1ok = false;
+                if (G3) { g1 = g2; g1ok = g2ok; g2ok = false; }
+                tag = grp;
+            } else if (G3 && grp == tag + 2 && g1ok && g2ok && (mode != M_INIT || s + wl <= 32)) {
+                g0 = g2;                               // ... or two groups on (after a certified burst)
+                g1ok = false;
+                g2ok = false;
                 tag = grp;
             }
             if (grp != tag || (mode == M_INIT && s + wl > 32 && !g1ok)) {
@@ -579,20 +588,29 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
         c_lf = uniform32(c_lf + (unsigned)__popcll(__ballot(have && mode == M_STEP)));
 
         // ---- the one memory round trip of this iteration ----
-        // PATH: the read's next packed group rides along when it is not here yet
+        // PATH: the read's next packed group -- G3: the next TWO -- ride along when the next one is not here yet (two at a time: a group
+        // fetched in a later iteration is another request to the fabric even when it lies in the same line -- the L2 turns
+        // over faster than a lane comes back); a reload brings three
         const bool pf = PATH && !g1ok && kind == K_MODE;
-        const uint4 *a3 = pf ? (packed + (tag + 1)) : a1;
+        const bool rl3 = G3 && kind == K_RELOAD;
+        const uint4 *a3 = pf ? (packed + (tag + 1)) : rl3 ? (a1 + 2) : a1;
         const uint4 v1 = *a1;
         const uint4 v2 = *a2;
         if (PATH) {
             const uint4 v3 = *a3;
             if (pf) { g1 = v3; g1ok = true; }
+            if (G3) {
+                const uint4 v4 = *(pf ? (a3 + 1) : a1);
+                if (pf) { g2 = v4; g2ok = true; }
+                if (rl3) { g2 = v3; g2ok = true; }
+            }
         }
 
         // ---- consume ----
         bool tabhit = false, do_plan = false, force = false;
         bool imprecise = false;                        // this iteration's failure is a table-level miss
         int burst_to = -1;                             // M_BRIDGE: k-mers i .. burst_to are certified absent
+        bool bridged = false;                          // M_BRIDGE: ... and the read goes on along the path
         if (kind == K_FETCH) {
             bool have_off = rdok;
             i64 P0 = (i64)quad_bits(v1);
@@ -623,7 +641,7 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
         } else if (kind == K_RELOAD) {
             g0 = v1;
             g1 = v2;
-            g1ok = true;
+            g1ok = true;                               // (PATH: g2 and g2ok were set with the loads)
             tag = grp;
         } else if (PATH && have && mode == M_POS) {
             const unsigned sel = (unsigned)l & 3u;
@@ -688,10 +706,19 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
             const u64 mm = (x | (x >> 1)) & 0x5555555555555555ull;
             const int nm = mm ? ((__ffsll((i64)mm) - 1) >> 1) : 32;
             const int need = (k - 1 < m - 1 - i) ? (k - 1) : (m - 1 - i);
-            if (nm >= need) {
+            // (a base that is not ACGT among them: packed as 'A' it may seem to agree -- no bridge, the certificates sort it out)
+            const u64 rvb = ((streaming == 2) ? (((u64)g1.w << 32) | (u64)g0.w) : (((u64)g1.z << 32) | (u64)g0.z)) >> s;
+            if (nm >= need && (~rvb & low_mask(need)) == 0) {
                 ev = EV_FAIL;
                 burst_to = i + need;
                 c_brg++;
+                // the read is back on the path: its k-mer i+k-1 (the last one with the substituted base) stands where the path's
+                // own k-mer would, at position r + k, as far as the next streaming step is concerned -- that step depends on the
+                // last k-1 bases only, and those are the path's.  On with M_EXT from there, no walk.
+                // The reference finds that next k-mer with SBWT::search (the one before it is -1, SBWT.hh:557-559), which
+                // takes upper-case ACGT only (SBWT.hh:398-399,427-428): all k of its bases must be that, else the walk decides.
+                const u64 vraw = (((u64)g1.w << 32) | (u64)g0.w) >> s;
+                bridged = need == k - 1 && (~vraw & low_mask(k)) == 0;
             } else {
                 // no bridge (a second difference within k-1 bases).  The streaming step itself needs no gather either: a
                 // substitution-safe step has no successor by any other char (the k-mer that ends at the substituted base is
@@ -723,11 +750,20 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
                 // the cached group pair and the two path quads reach further than 32 steps: 32 - s more bases of the read,
                 // 32 - sp more chars of the path, and a segment list takes a run of any length (same-box A/B: -1.7 %,
                 // read lines 229 M -> 217 M per 10 M reads)
-                const int w2 = (s > sp) ? 32 - s : 32 - sp;
-                const u64 x2 = (quad_bits(g1) >> (2 * s)) ^ (quad_bits(v2) >> (2 * sp));
+                // (with the third cached group the read's side is whole: only the path's 32 - sp chars limit the window)
+                const bool r3 = g2ok && s != 0;
+                const int w2 = (r3 || s <= sp) ? 32 - sp : 32 - s;
+                u64 rw2 = quad_bits(g1) >> (2 * s);
+                u64 rv2 = rv >> 32;
+                if (r3) {
+                    rw2 |= quad_bits(g2) << (64 - 2 * s);
+                    const u64 vb = (streaming == 2) ? (((u64)g2.w << 32) | (u64)g1.w) : (((u64)g2.z << 32) | (u64)g1.z);
+                    rv2 = (vb >> s) & 0xFFFFFFFFull;
+                }
+                const u64 x2 = rw2 ^ (quad_bits(v2) >> (2 * sp));
                 const u64 mm2 = (x2 | (x2 >> 1)) & 0x5555555555555555ull;
                 const int nm2 = mm2 ? ((__ffsll((i64)mm2) - 1) >> 1) : 32;
-                const u64 bad2 = ~((rv >> 32) & (pg >> 32)) | (1ull << 32);
+                const u64 bad2 = ~(rv2 & (pg >> 32)) | (1ull << 32);
                 const int nv2 = __ffsll((i64)bad2) - 1;
                 int n2 = nm2 < nv2 ? nm2 : nv2;
                 if (n2 >= w2) n2 = w2;                 // the end of what is cached is not a stop
@@ -1180,6 +1216,9 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
             } else if (ev == EV_EMIT1 && res != -1 && streaming) {
                 mode = PATH ? (rknown ? tnext : M_POS) : M_STREAM;   // SBWT.hh:560-
                 l = res;
+            } else if (PATH && bridged) {
+                mode = M_EXT;                          // (i < m: the burst was k k-mers long)
+                r += (pos_t)k;
             } else {
                 do_plan = true;                        // SBWT.hh:557-559 (with certificates)
             }

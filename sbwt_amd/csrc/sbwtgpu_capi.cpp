@@ -102,7 +102,7 @@ static int g_sort_reads = [] { const char *e = getenv("SBWTGPU_SORT_READS"); ret
 static int g_trans_wide = [] { const char *e = getenv("SBWTGPU_TRANS_WIDE"); return e ? atoi(e) : -1; }();   // -1 by the index
 static int g_force_mega = 0;    // tests: store every image's block counts relative to mega[c][0] (the dense rank-only layout)
 static int g_trans_ext = -1;    // -1: adaptive per wave, 0/1: force
-static int g_path_safe = [] { const char *e = getenv("SBWTGPU_PATH_SAFE"); return e ? atoi(e) : 1; }();
+static int g_path_safe = [] { const char *e = getenv("SBWTGPU_PATH_SAFE"); return e ? atoi(e) : 2; }();   // 0 off, 1 narrow rule, 2 wide
 static int g_path_order = [] { const char *e = getenv("SBWTGPU_PATH_ORDER"); return e ? atoi(e) : 1; }();
 static int g_sparse_depth = [] { const char *e = getenv("SBWTGPU_SPARSE_PRECALC"); return e ? atoi(e) : 31; }();
 
@@ -486,7 +486,9 @@ int sbwtgpu_index_create(const sbwtgpu_index_desc *d, int device, sbwtgpu_index 
             // substitution-safe bits of the path: need the whole k-mers in the sparse table
             if (h.has_path && h.p_sparse == d->k && g_path_safe) {
                 SbwtIndexView v2 = idx->view();
-                sbwt_launch_path_safe(v2, reinterpret_cast<uint4 *>(idx->blob + h.off_pq), 0);
+                // (rule 2 keeps the path heads' labels in the transition table's room, which is filled afterwards)
+                sbwt_launch_path_safe(v2, reinterpret_cast<uint4 *>(idx->blob + h.off_pq), g_path_safe,
+                                      idx->blob + h.off_trans, 0);
                 if ((e = hipDeviceSynchronize()) != hipSuccess) break;
                 h.has_safe = 1;
             }
@@ -704,7 +706,9 @@ int sbwtgpu_index_bcast(sbwtgpu_index *root, int n_dev, const int *devs, sbwtgpu
 // in the path order (sbwt_sort.hip): four 32-bit arrays of one entry per read + the radix sort's own temporary, sized
 // for reads of >= 32 bases on average (a batch of shorter reads is searched unsorted).
 static inline int64_t ws_packed_bytes(int64_t total_bases) {
-    const int64_t groups = (total_bases + SBWT_GROUP_BASES - 1) / SBWT_GROUP_BASES + 2;
+    // + 2 groups that the encoder zero-fills (windows that run past the last base) + 2 that are only ever loaded (the
+    // search kernel fetches the packed groups of a read ahead of their use, three at a time)
+    const int64_t groups = (total_bases + SBWT_GROUP_BASES - 1) / SBWT_GROUP_BASES + 4;
     return (int64_t)sizeof(SbwtWorkHeader) + groups * 16;
 }
 static inline int64_t ws_sort_capacity(int64_t total_bases) {      // only when sorting is switched on ("sort_reads" = 1)

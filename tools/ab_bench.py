@@ -77,7 +77,8 @@ for rnd in range(rounds + 1):
         if rnd == 0:
             chk = int((d_out * torch.arange(1, d_out.numel() + 1, device=dev)).sum().item())
             if ref is None: ref = chk
-            print("config", c, "checksum", chk, "same" if chk == ref else "DIFFERENT", "stats", idx.workspace_stats(d_ws.data_ptr(), st), flush=True)
+            print("config", c, "checksum", chk, "same" if chk == ref else "DIFFERENT", "stats", idx.workspace_stats(d_ws.data_ptr(), st),
+                  "bridges", idx.workspace_bridges(d_ws.data_ptr(), st) if hasattr(idx, "workspace_bridges") else "-", flush=True)
         else:
             times[tuple(c)].append(e0.elapsed_time(e1))
 for c, v in times.items():
