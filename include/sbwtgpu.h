@@ -111,6 +111,9 @@ int         sbwtgpu_device_count(int *count);
  *                     memory runs out.  SBWTGPU_MAX_IMAGE_BYTES.
  *   "force_mega"      1: rank-only images (arbitrary bit vectors) store their block counts relative to a 64-bit base as
  *                     images whose counts pass 2^32 do (tests of that layout at small sizes); default 0
+ *   "path_lookahead"  8 (default): how many steps ahead / behind the path order looks for branch points when it chooses
+ *                     which successor a column's path takes (paths follow the core of a pan-genome); 0: blind choice
+ *                     (SBWTGPU_PATH_LOOKAHEAD)
  *   "path_safe"       substitution-safe bits along the paths (k <= 31; SBWTGPU_PATH_SAFE): 2 (default) wherever the next k
  *                     steps lie on the path, 1 only where the k steps before do too (the first rule), 0 none */
 int         sbwtgpu_set_tuning(const char *key, int64_t value);

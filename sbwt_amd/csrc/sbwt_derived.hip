@@ -265,6 +265,117 @@ __global__ void __launch_bounds__(256) k_path_succ(SbwtIndexView ix, unsigned *_
     sch[v] = (unsigned char)pick;
     atomicMin(&prv[target], (unsigned)v);
 }
+// Which successor does a column take, which predecessor does a column keep?  Any choice gives a valid path order; a good
+// one keeps the paths on the graph's CORE.  In a pan-genome nearly every column of the shared sequence has a variant
+// branching off somewhere within k steps, and a rule that is blind to that sends the path into every second private
+// bubble: the reads (most of which follow the majority) then leave their path every few k-mers (config 3: 21
+// transitions per read).  The core is recognisable from the matrix alone: it has branch points AHEAD (F: columns
+// with two or more successors met within the next D steps, following the best successor) and merges BEHIND (G: columns
+// that join another within the last D steps); a private bubble has neither.  D rounds of
+//     F'[v] = [v branches] + max over successors F[s]        G'[s] = [s's predecessors are a group of >= 2] + max over them G[p]
+// (streaming passes: consecutive columns share blocks, successors by one char are consecutive), then within every suffix
+// group the members ranked by G take the successors ranked by F, best to best.  With all weights equal this is the
+// rule above (member r takes char r, the smallest claimant wins).
+struct PathGroup {
+    i64 g, gend;                    // the suffix group [g, gend) of the column
+    int deg;                        // chars the group offers
+    unsigned target[4];             // successor column by char (PATH_NONE: none)
+};
+__device__ __forceinline__ PathGroup path_group(const SbwtIndexView &ix, i64 v) {
+    PathGroup pg;
+    i64 blk = v >> 6;
+    const u64 here = (u64)ix.blocks[blk * 4].w | ((u64)ix.blocks[blk * 4 + 1].w << 32);
+    u64 msk = here & ((2ull << (int)(v & 63)) - 1ull);
+    i64 gblk = blk;
+    while (msk == 0 && gblk > 0) {
+        gblk--;
+        msk = (u64)ix.blocks[gblk * 4].w | ((u64)ix.blocks[gblk * 4 + 1].w << 32);
+    }
+    if (msk == 0) msk = 1;
+    const int gb = 63 - __clzll((i64)msk);
+    pg.g = (gblk << 6) | gb;
+    // the next group start after v.  (A suffix group has at most five members -- one per first char and '$'; the bound
+    // below only keeps the loops short on marks that are not an SBWT's.)
+    u64 nxt = here & ~((2ull << (int)(v & 63)) - 1ull);
+    i64 eblk = blk;
+    const i64 nblk = ix.n_nodes / 64 + 1;
+    if (nxt == 0 && eblk + 1 < nblk) {
+        eblk++;
+        nxt = (u64)ix.blocks[eblk * 4].w | ((u64)ix.blocks[eblk * 4 + 1].w << 32);
+    }
+    pg.gend = nxt ? ((eblk << 6) | (i64)(__ffsll((i64)nxt) - 1)) : ix.n_nodes;
+    if (pg.gend > pg.g + 8) pg.gend = pg.g + 8;
+    if (pg.gend > ix.n_nodes) pg.gend = ix.n_nodes;
+    if (pg.gend <= v) pg.gend = v + 1;
+    pg.deg = 0;
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        const uint4 q = ix.blocks[gblk * 4 + c];
+        const u64 bits = quad_bits(q);
+        const bool has = ((bits >> gb) & 1ull) != 0;
+        pg.target[c] = has ? (q.z + (unsigned)__popcll(bits & low_mask(gb))) : PATH_NONE;
+        pg.deg += has;
+    }
+    return pg;
+}
+__global__ void __launch_bounds__(256) k_path_weigh(SbwtIndexView ix, const unsigned char *__restrict__ Fin,
+                                                    unsigned char *__restrict__ Fout, const unsigned char *__restrict__ Gin,
+                                                    unsigned char *__restrict__ Gout) {
+    const i64 v = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (v >= ix.n_nodes) return;
+    const PathGroup pg = path_group(ix, v);
+    unsigned f = 0;
+#pragma unroll
+    for (int c = 0; c < 4; c++)
+        if (pg.target[c] != PATH_NONE) { const unsigned x = Fin[pg.target[c]]; f = x > f ? x : f; }
+    f += (pg.deg >= 2);
+    Fout[v] = (unsigned char)(f > 255u ? 255u : f);
+    if (v == 0) Gout[0] = 0;                            // the root has no incoming edge
+    if (v == pg.g) {                                    // the group's first column speaks for its successors
+        unsigned gm = 0;
+        for (i64 p = pg.g; p < pg.gend; p++) { const unsigned x = Gin[p]; gm = x > gm ? x : gm; }
+        gm += (pg.gend - pg.g >= 2);
+        const unsigned char out = (unsigned char)(gm > 255u ? 255u : gm);
+#pragma unroll
+        for (int c = 0; c < 4; c++)
+            if (pg.target[c] != PATH_NONE) Gout[pg.target[c]] = out;
+    }
+}
+__global__ void __launch_bounds__(256) k_path_succ_weighted(SbwtIndexView ix, const unsigned char *__restrict__ F,
+                                                            const unsigned char *__restrict__ G, unsigned *__restrict__ succ,
+                                                            unsigned char *__restrict__ sch, unsigned *__restrict__ prv) {
+    const i64 v = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (v >= ix.n_nodes) return;
+    const PathGroup pg = path_group(ix, v);
+    succ[v] = PATH_NONE;
+    sch[v] = 0;
+    if (pg.deg == 0) return;
+    // this member's rank among the group's members: larger G first, then the smaller column
+    const unsigned gv = G[v];
+    int rk = 0;
+    for (i64 p = pg.g; p < pg.gend; p++) {
+        const unsigned gp = G[p];
+        rk += (gp > gv) || (gp == gv && p < v);
+    }
+    if (rk >= pg.deg) return;                           // more members than chars: this one's path ends here
+    // the successor of that rank: larger F first, then the smaller char
+    unsigned fw[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++) fw[c] = (pg.target[c] != PATH_NONE) ? (unsigned)F[pg.target[c]] : 0u;
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        if (pg.target[c] == PATH_NONE) continue;
+        int before = 0;
+#pragma unroll
+        for (int d = 0; d < 4; d++)
+            before += (pg.target[d] != PATH_NONE) && (fw[d] > fw[c] || (fw[d] == fw[c] && d < c));
+        if (before == rk) {
+            succ[v] = pg.target[c];
+            sch[v] = (unsigned char)c;
+            prv[pg.target[c]] = (unsigned)v;            // the only claimant: ranks within a group are distinct
+        }
+    }
+}
 __global__ void __launch_bounds__(256) k_path_keep(i64 n, unsigned *__restrict__ succ, const unsigned *__restrict__ prv,
                                                    unsigned *__restrict__ jump, unsigned *__restrict__ dist,
                                                    unsigned *__restrict__ mn) {
@@ -645,7 +756,7 @@ void sbwt_launch_path_safe(const SbwtIndexView &ix, uint4 *d_pq, int rule, void 
 
 // d_col, d_pos: n_nodes (+4 padding) u32 each; d_pq: sbwt_path_quads() quads.  Synchronises the stream.
 int sbwt_launch_build_path(const SbwtIndexView &ix, unsigned *d_col, unsigned *d_pos, uint4 *d_pq, uint4 *d_trans,
-                           void *d_scratch, hipStream_t stream) {
+                           void *d_scratch, int lookahead, hipStream_t stream) {
     const i64 n = ix.n_nodes;
     const long long np = path_pad(n);
     const i64 nb = (n + 1023) / 1024;
@@ -663,7 +774,18 @@ int sbwt_launch_build_path(const SbwtIndexView &ix, unsigned *d_col, unsigned *d
     i64 *bsum = reinterpret_cast<i64 *>(base);
     const unsigned g = grid_for(n);
     hipLaunchKernelGGL(k_path_fill, dim3(g), dim3(256), 0, stream, prv, n, PATH_NONE);
-    hipLaunchKernelGGL(k_path_succ, dim3(g), dim3(256), 0, stream, ix, succ, sch, prv);
+    if (lookahead > 0) {
+        // weights in the room of `len` / `pbase` (not in use yet): four byte arrays
+        unsigned char *W = reinterpret_cast<unsigned char *>(len);
+        unsigned char *F[2] = {W, W + np}, *G[2] = {W + 2 * np, W + 3 * np};
+        (void)hipMemsetAsync(W, 0, (size_t)np * 4, stream);
+        int w = 0;
+        for (int round = 0; round < lookahead; round++, w ^= 1)
+            hipLaunchKernelGGL(k_path_weigh, dim3(g), dim3(256), 0, stream, ix, F[w], F[w ^ 1], G[w], G[w ^ 1]);
+        hipLaunchKernelGGL(k_path_succ_weighted, dim3(g), dim3(256), 0, stream, ix, F[w], G[w], succ, sch, prv);
+    } else {
+        hipLaunchKernelGGL(k_path_succ, dim3(g), dim3(256), 0, stream, ix, succ, sch, prv);
+    }
     int rounds = 1;
     while (((i64)1 << rounds) < n) rounds++;
     rounds++;

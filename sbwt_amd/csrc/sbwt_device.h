@@ -98,6 +98,7 @@ struct SbwtBlobHeader {
     int64_t row_ones[4];            // set bits of the rows A, C, G, T (select: valid j are 1 .. row_ones[c])
     int32_t log2b2;                 // second-level sparse table: log2 of its number of 32-byte entries (0 = none)
     int64_t off_stab2;
+    int64_t path_lookahead;         // steps the path order looked ahead / behind when it chose successors (0: blind rule)
 };
 #define SBWT_BLOB_MAGIC 0x3155504754574253ull   // "SBWTGPU1" little endian
 
@@ -182,7 +183,7 @@ long long sbwt_count_paths(const SbwtIndexView &ix, hipStream_t stream);
 void sbwt_launch_path_safe(const SbwtIndexView &ix, uint4 *d_pq, int rule, void *d_hlab, hipStream_t stream);
 long long sbwt_launch_path_trans(const SbwtIndexView &ix, uint4 *d_trans, uint4 *d_pq, hipStream_t stream);
 int sbwt_launch_build_path(const SbwtIndexView &ix, unsigned *d_col, unsigned *d_pos, uint4 *d_pq, uint4 *d_trans,
-                           void *d_scratch, hipStream_t stream);
+                           void *d_scratch, int lookahead, hipStream_t stream);
 int sbwt_launch_build_sparse(const SbwtIndexView &ix, int p_dense, int p_sparse, int log2b, uint4 *d_table,
                              void *d_scratch, const unsigned *d_pos, int p_filter, int log2f, uint4 *d_filter,
                              int log2b2, uint4 *d_table2, hipStream_t stream);

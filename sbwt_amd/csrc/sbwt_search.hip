@@ -574,9 +574,9 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
         }
         const bool have = (kind == K_MODE && ev == EV_NONE);
 #ifdef SBWT_STATS
-        {   // lane-iterations by kind: pad[8..]: fetch, reload, init, step, trans, pos, ext, idle/dead, waves-iterations
+        {   // lane-iterations by kind: pad[8..]: fetch, reload, init, step, trans, pos/bridge, ext, idle/dead, waves-iterations
             const int cls = (kind == K_FETCH) ? 0 : (kind == K_RELOAD) ? 1 : (kind == K_NONE) ? 7 :
-                            (mode == M_INIT) ? 2 : (mode == M_STEP) ? 3 : (mode == M_TRANS) ? 4 : (mode == M_POS) ? 5 : (mode == M_EXT) ? 6 : 7;
+                            (mode == M_INIT) ? 2 : (mode == M_STEP) ? 3 : (mode == M_TRANS) ? 4 : (mode == M_POS || mode == M_BRIDGE) ? 5 : (mode == M_EXT) ? 6 : 7;
             for (int q = 0; q < 8; q++) {
                 const unsigned long long cq = __popcll(__ballot(cls == q));
                 if (lane == 0 && cq) atomicAdd(&ws->pad[8 + q], cq);

@@ -103,6 +103,7 @@ static int g_trans_wide = [] { const char *e = getenv("SBWTGPU_TRANS_WIDE"); ret
 static int g_force_mega = 0;    // tests: store every image's block counts relative to mega[c][0] (the dense rank-only layout)
 static int g_trans_ext = -1;    // -1: adaptive per wave, 0/1: force
 static int g_path_safe = [] { const char *e = getenv("SBWTGPU_PATH_SAFE"); return e ? atoi(e) : 2; }();   // 0 off, 1 narrow rule, 2 wide
+static int g_path_lookahead = [] { const char *e = getenv("SBWTGPU_PATH_LOOKAHEAD"); return e ? atoi(e) : 8; }();   // 0: the blind rule
 static int g_path_order = [] { const char *e = getenv("SBWTGPU_PATH_ORDER"); return e ? atoi(e) : 1; }();
 static int g_sparse_depth = [] { const char *e = getenv("SBWTGPU_SPARSE_PRECALC"); return e ? atoi(e) : 31; }();
 
@@ -157,6 +158,13 @@ struct sbwtgpu_index {
     }
 };
 
+// Which path-order kernel by default: per-read segment lists (4), except on a branchy index whose paths were chosen blindly
+// ("path_lookahead" = 0) -- reads then leave their path every few k-mers and the staged writer with its wide transition
+// entries (2) is the faster one.
+static inline int auto_variant(const SbwtBlobHeader &h) {
+    return (h.path_lookahead > 0 || h.n_branch * 64 <= h.n_nodes) ? 4 : 2;
+}
+
 extern "C" {
 
 const char *sbwtgpu_version(void) { return "sbwtgpu 0.1 (gfx950)"; }
@@ -177,6 +185,7 @@ int sbwtgpu_set_tuning(const char *key, int64_t value) {
     if (!strcmp(key, "force_mega")) { g_force_mega = (int)value; return SBWTGPU_OK; }     // indexes created afterwards
     if (!strcmp(key, "trans_ext")) { g_trans_ext = (int)value; return SBWTGPU_OK; }
     if (!strcmp(key, "path_safe")) { g_path_safe = (int)value; return SBWTGPU_OK; }   // indexes created afterwards
+    if (!strcmp(key, "path_lookahead")) { g_path_lookahead = value < 0 ? 0 : value > 64 ? 64 : (int)value; return SBWTGPU_OK; }
     if (!strcmp(key, "path_order")) { g_path_order = (int)value; return SBWTGPU_OK; }   // indexes created afterwards
     if (!strcmp(key, "sparse_depth")) {      // takes effect for indexes created afterwards
         if (value < 0 || value > 31) return fail(SBWTGPU_ERR_INVALID_ARG, "sparse_depth must be in [0,31]");
@@ -344,10 +353,12 @@ int sbwtgpu_index_create(const sbwtgpu_index_desc *d, int device, sbwtgpu_index 
     }
     h.C[0] = 1;
     for (int c = 1; c < 4; c++) h.C[c] = h.C[c - 1] + tot[c - 1];
-    // Branchy index (more than one column in 64 offers a choice of successors: pan-genomes): reads leave their path every
-    // few k-mers, and what follows a transition is mostly a run of 1-4 k-mers.  Their columns go into the transition entry
-    // itself (32 instead of 16 bytes per entry, +64 bytes per column of image).
-    if (h.has_path && g_trans_wide != 0 && (g_trans_wide > 0 || tot[4] * 64 > n)) {
+    // Branchy index (more than one column in 64 offers a choice of successors: pan-genomes) with blindly chosen paths
+    // ("path_lookahead" = 0), or "trans_wide" = 1: reads leave their path every few k-mers, and what follows a transition is
+    // mostly a run of 1-4 k-mers.  Their columns go into the transition entry itself (32 instead of 16 bytes per entry,
+    // +64 bytes per column of image) for the staged-writer kernel.  With paths that follow the core neither is needed.
+    h.path_lookahead = h.has_path ? g_path_lookahead : 0;
+    if (h.has_path && g_trans_wide != 0 && (g_trans_wide > 0 || (tot[4] * 64 > n && g_path_lookahead == 0))) {
         h.trans_wide = 1;
         h.blob_bytes = align256(h.off_trans + (n + 1) * 128);
     }
@@ -463,7 +474,7 @@ int sbwtgpu_index_create(const sbwtgpu_index_desc *d, int device, sbwtgpu_index 
             int prc = sbwt_launch_build_path(v, reinterpret_cast<unsigned *>(idx->blob + h.off_col),
                                              reinterpret_cast<unsigned *>(idx->blob + h.off_pos),
                                              reinterpret_cast<uint4 *>(idx->blob + h.off_pq),
-                                             reinterpret_cast<uint4 *>(idx->blob + h.off_trans), scr, 0);
+                                             reinterpret_cast<uint4 *>(idx->blob + h.off_trans), scr, g_path_lookahead, 0);
             (void)hipFree(scr);
             if (prc != 0) { e = hipErrorUnknown; break; }
         }
@@ -543,7 +554,7 @@ int sbwtgpu_index_get_info(const sbwtgpu_index *idx, sbwtgpu_index_info *info) {
     info->image_level = idx->h.image_level;
     info->n_paths = idx->h.n_paths;
     info->n_branch = idx->h.n_branch;
-    info->default_search_variant = !idx->h.has_path ? 1 : (idx->h.n_branch * 64 <= idx->h.n_nodes ? 4 : 2);
+    info->default_search_variant = !idx->h.has_path ? 1 : auto_variant(idx->h);
     return SBWTGPU_OK;
 }
 
@@ -780,7 +791,7 @@ int sbwtgpu_search_encoded_dev(const sbwtgpu_index *idx, int64_t total_bases, co
     // in 107, config 5 one in 586), the staged writer on branchy indexes (the star pan-genome of config 3: one in 31 --
     // its reads leave their path every 3-4 k-mers, and short segments fill the lists: 146.4 vs 143.8 ms)
     int variant = g_variant_override >= 0 ? g_variant_override : tuning_variant();
-    if (variant < 0) variant = (idx->h.has_path && idx->h.n_branch * 64 <= idx->h.n_nodes) ? 4 : 2;
+    if (variant < 0) variant = idx->h.has_path ? auto_variant(idx->h) : 2;
     const int eff_streaming = (!streaming && (idx->h.has_ssup || idx->h.ssup_derived) && g_derive_ssup) ? 2 : streaming;
     // reads sorted by their place in the path order (sbwt_sort.hip): when the batch covers the index a few times
     void *sort_scratch = nullptr;

@@ -73,3 +73,21 @@ def test_config3_pangenome_k31(gpu):
     want, _ = orc.batch_search(h_bases, np.arange(sample + 1, dtype=np.int64) * L,
                                np.arange(sample + 1, dtype=np.int64) * m, 4)
     assert np.array_equal(a[: sample * m].cpu().numpy(), want)
+
+    # "path_lookahead": the paths of the default index follow the core of the pan-genome (they look 8 steps ahead and
+    # behind for branch points when they choose a successor); an index whose paths choose blindly answers with the same
+    # bits, but its reads leave their paths several times as often
+    run(True, 4)
+    trans_core = idx.workspace_stats(d_ws.data_ptr(), st)[0]
+    capi.set_tuning("path_lookahead", 0)
+    try:
+        idx0 = capi.Index.create(bits.cols[0], bits.cols[1], bits.cols[2], bits.cols[3], bits.ssup, bits.n_nodes, k,
+                                 bits.n_kmers, 8)
+    finally:
+        capi.set_tuning("path_lookahead", 8)
+    idx_core, idx = idx, idx0
+    assert torch.equal(a, run(True, 4))
+    trans_blind = idx.workspace_stats(d_ws.data_ptr(), st)[0]
+    assert torch.equal(a, run(True, 2))
+    idx = idx_core
+    assert trans_blind > 2 * trans_core, (trans_blind, trans_core)

@@ -69,11 +69,24 @@ while time.time() < t_end:
             res[(v, te)] = (a, b)
     capi.set_tuning("trans_ext", -1)
     ref = res[(0, -1)]
+
+    def explain(got, want):
+        """where two result vectors differ: the read, its text, both results around the first difference"""
+        d = int(np.flatnonzero(got != want)[0])
+        oo = np.concatenate([[0], np.cumsum(np.maximum(np.diff(off) - k + 1, 0))])
+        r = int(np.searchsorted(oo, d, side="right") - 1)
+        print(" first difference at result", d, "= k-mer", d - int(oo[r]), "of read", r, "length", int(off[r + 1] - off[r]),
+              "differences in all:", int((got != want).sum()))
+        print(" read:", bases[off[r]:off[r + 1]].tobytes().decode("latin1"))
+        print(" got :", got[oo[r]:oo[r + 1]].tolist())
+        print(" want:", want[oo[r]:oo[r + 1]].tolist())
+        print(" index: n_nodes", bits.n_nodes, "device precalc", idx.device_precalc_k, "paths", idx.n_paths, "branching", idx.n_branch)
+
     for key, (a, b) in res.items():
         if ssup and not np.array_equal(a, ref[0]):
-            print("MISMATCH streaming", key, "case", case, "k", k, "shape", shape, "ssup", ssup, "rc", rc); sys.exit(1)
+            print("MISMATCH streaming", key, "case", case, "k", k, "shape", shape, "ssup", ssup, "rc", rc); explain(a, ref[0]); sys.exit(1)
         if not np.array_equal(b, ref[1]):
-            print("MISMATCH search", key, "case", case, "k", k, "shape", shape, "ssup", ssup, "rc", rc); sys.exit(1)
+            print("MISMATCH search", key, "case", case, "k", k, "shape", shape, "ssup", ssup, "rc", rc); explain(b, ref[1]); sys.exit(1)
     if case % 10 == 1 and bits.n_nodes < 400_000:     # the oracle on a sample
         orc = OracleIndex.from_bits(bits.cols[0], bits.cols[1], bits.cols[2], bits.cols[3], bits.ssup if ssup else None,
                                     bits.n_nodes, k, bits.n_kmers, 0)
