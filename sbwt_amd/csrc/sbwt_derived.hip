@@ -498,7 +498,11 @@ __global__ void __launch_bounds__(256) k_path_head_labels(SbwtIndexView ix, u64 
     }
     hlab[t] = lab;
 }
-__global__ void __launch_bounds__(256) k_path_safe_labels(SbwtIndexView ix, unsigned *pq_words, const u64 *__restrict__ hlab) {
+// alt[u] (may be null): bit a-1 set <=> the step is safe for the one substitute ch[u] ^ a (the transition entry of that char,
+// which says "no successor", passes it on: a read with exactly that base is bridged after its transition lookup -- in a
+// pan-genome most steps have ONE real variant somewhere, and a sequencing error is usually one of the other two bases)
+__global__ void __launch_bounds__(256) k_path_safe_labels(SbwtIndexView ix, unsigned *pq_words, const u64 *__restrict__ hlab,
+                                                          unsigned char *__restrict__ alt_safe) {
     const i64 u = (i64)blockIdx.x * 256 + threadIdx.x;
     const int k = ix.k;
     if (u >= ix.n_nodes) return;
@@ -528,12 +532,14 @@ __global__ void __launch_bounds__(256) k_path_safe_labels(SbwtIndexView ix, unsi
     // S = left (k-1 chars) . ch[u] . right's other k-1 chars; window number w starts at char w, ch[u] is its char k-1-w
     const u64 Slo = left | (right << (2 * (k - 1))), Shi = right >> (64 - 2 * (k - 1));
     const u64 km = low_mask(2 * k);
-    for (int w = 0; w < k; w++) {
+    unsigned ok = 7u;                                   // substitutes not seen in any window yet
+    for (int w = 0; w < k && ok; w++) {
         const u64 key = ((Slo >> (2 * w)) | (w ? (Shi << (64 - 2 * w)) : 0ull)) & km;
         for (u64 alt = 1; alt < 4; alt++)
-            if (sp_present(ix, key ^ (alt << (2 * (k - 1 - w))))) return;
+            if (((ok >> (alt - 1)) & 1u) && sp_present(ix, key ^ (alt << (2 * (k - 1 - w))))) ok &= ~(1u << (alt - 1));
     }
-    atomicOr(&pq_words[(size_t)q * 4 + 3], 1u << s);
+    if (alt_safe) alt_safe[u] = (unsigned char)ok;
+    if (ok == 7u) atomicOr(&pq_words[(size_t)q * 4 + 3], 1u << s);
 }
 
 // transition table: entry t = four 16-byte quads, one per char c: { column of the successor of col[t] by c (or none),
@@ -541,7 +547,7 @@ __global__ void __launch_bounds__(256) k_path_safe_labels(SbwtIndexView ix, unsi
 // (built last: the path's chars and safe bits must be final)
 __global__ void __launch_bounds__(256) k_path_trans(SbwtIndexView ix, const unsigned *__restrict__ pos,
                                                     uint4 *__restrict__ trans, unsigned long long *n_branch,
-                                                    unsigned *__restrict__ only) {
+                                                    unsigned *__restrict__ only, const unsigned char *__restrict__ alt_safe) {
     const i64 v = (i64)blockIdx.x * 256 + threadIdx.x;
     if (v >= ix.n_nodes) return;
     i64 blk = v >> 6;
@@ -561,8 +567,17 @@ __global__ void __launch_bounds__(256) k_path_trans(SbwtIndexView ix, const unsi
         np[c] = (nc[c] != PATH_NONE) ? pos[nc[c]] : PATH_NONE;
     }
     const size_t t = pos[v];
+    // "no successor" entries say whether the step is substitution-safe for their char (k_path_safe_labels)
+    unsigned asafe = 0, ych = 0;
+    if (alt_safe) {
+        asafe = alt_safe[t];
+        const uint4 pqt = ix.pq[t >> 5];
+        ych = (unsigned)(quad_bits(pqt) >> (2 * (t & 31))) & 3u;
+    }
 #pragma unroll
     for (int c = 0; c < 4; c++) {
+        const unsigned a = (unsigned)c ^ ych;           // which substitute of the path's char this is (0: the char itself)
+        const unsigned flag = (nc[c] == PATH_NONE && a != 0) ? ((asafe >> (a - 1)) & 1u) : 0u;
         unsigned ext = 0;
         if (nc[c] != PATH_NONE) {
             const uint4 *q = ix.pq + (np[c] >> 5);
@@ -581,10 +596,10 @@ __global__ void __launch_bounds__(256) k_path_trans(SbwtIndexView ix, const unsi
                 nx = make_uint4(ix.col[p1 <= last ? p1 : last], ix.col[p1 + 1 <= last ? p1 + 1 : last],
                                 ix.col[p1 + 2 <= last ? p1 + 2 : last], ix.col[p1 + 3 <= last ? p1 + 3 : last]);
             }
-            trans[2 * (4 * t + c)] = make_uint4(nc[c], np[c], ext, 0u);
+            trans[2 * (4 * t + c)] = make_uint4(nc[c], np[c], ext, flag);
             trans[2 * (4 * t + c) + 1] = nx;
         } else {
-            trans[4 * t + c] = make_uint4(nc[c], np[c], ext, 0u);
+            trans[4 * t + c] = make_uint4(nc[c], np[c], ext, flag);
         }
     }
     // columns with two or more successors: how often a read that follows a path has a choice (see sbwtgpu_capi.cpp: the
@@ -740,7 +755,9 @@ long long sbwt_count_paths(const SbwtIndexView &ix, hipStream_t stream) {
     return e == hipSuccess ? (long long)h : -1;
 }
 // rule 1: 2k steps around u on one path; rule 2 (needs d_hlab, n_nodes x 8 bytes of scratch): k steps from u on
-void sbwt_launch_path_safe(const SbwtIndexView &ix, uint4 *d_pq, int rule, void *d_hlab, hipStream_t stream) {
+void sbwt_launch_path_safe(const SbwtIndexView &ix, uint4 *d_pq, int rule, void *d_hlab, unsigned char *d_alt_safe,
+                           hipStream_t stream) {
+    if (d_alt_safe) (void)hipMemsetAsync(d_alt_safe, 0, (size_t)ix.n_nodes, stream);
     if (rule < 2 || !d_hlab) {
         hipLaunchKernelGGL(k_path_safe, dim3(grid_for(ix.n_nodes)), dim3(256), 0, stream, ix, reinterpret_cast<unsigned *>(d_pq));
         return;
@@ -751,7 +768,7 @@ void sbwt_launch_path_safe(const SbwtIndexView &ix, uint4 *d_pq, int rule, void 
     else
         hipLaunchKernelGGL(k_path_head_labels<false>, dim3(grid_for(ix.n_nodes)), dim3(256), 0, stream, ix, hlab);
     hipLaunchKernelGGL(k_path_safe_labels, dim3(grid_for(ix.n_nodes)), dim3(256), 0, stream, ix,
-                       reinterpret_cast<unsigned *>(d_pq), hlab);
+                       reinterpret_cast<unsigned *>(d_pq), hlab, d_alt_safe);
 }
 
 // d_col, d_pos: n_nodes (+4 padding) u32 each; d_pq: sbwt_path_quads() quads.  Synchronises the stream.
@@ -820,7 +837,8 @@ int sbwt_launch_build_path(const SbwtIndexView &ix, unsigned *d_col, unsigned *d
 }
 // Builds the transition table, then gives the path groups their final encoding (k_path_reencode).  Returns the number
 // of columns with two or more successors (synchronises the stream), or -1.
-long long sbwt_launch_path_trans(const SbwtIndexView &ix, uint4 *d_trans, uint4 *d_pq, hipStream_t stream) {
+long long sbwt_launch_path_trans(const SbwtIndexView &ix, uint4 *d_trans, uint4 *d_pq, const unsigned char *d_alt_safe,
+                                 hipStream_t stream) {
     unsigned long long *d = nullptr, h = 0;
     unsigned *only = nullptr;
     const i64 n_quads = sbwt_path_quads(ix.n_nodes);
@@ -828,7 +846,8 @@ long long sbwt_launch_path_trans(const SbwtIndexView &ix, uint4 *d_trans, uint4 
     if (hipMalloc((void **)&only, (size_t)n_quads * 4) != hipSuccess) { (void)hipFree(d); return -1; }
     (void)hipMemsetAsync(d, 0, 8, stream);
     (void)hipMemsetAsync(only, 0, (size_t)n_quads * 4, stream);
-    hipLaunchKernelGGL(k_path_trans, dim3(grid_for(ix.n_nodes)), dim3(256), 0, stream, ix, ix.pos, d_trans, d, only);
+    hipLaunchKernelGGL(k_path_trans, dim3(grid_for(ix.n_nodes)), dim3(256), 0, stream, ix, ix.pos, d_trans, d, only,
+                       d_alt_safe);
     hipLaunchKernelGGL(k_path_reencode, dim3(grid_for(n_quads)), dim3(256), 0, stream, d_pq, n_quads, only);
     hipError_t e = hipMemcpyAsync(&h, d, 8, hipMemcpyDeviceToHost, stream);
     if (e == hipSuccess) e = hipStreamSynchronize(stream);

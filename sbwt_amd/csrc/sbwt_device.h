@@ -180,8 +180,10 @@ long long sbwt_sparse_scratch_bytes(long long n_nodes);
 long long sbwt_path_scratch_bytes(long long n_nodes);
 long long sbwt_path_quads(long long n_nodes);
 long long sbwt_count_paths(const SbwtIndexView &ix, hipStream_t stream);
-void sbwt_launch_path_safe(const SbwtIndexView &ix, uint4 *d_pq, int rule, void *d_hlab, hipStream_t stream);
-long long sbwt_launch_path_trans(const SbwtIndexView &ix, uint4 *d_trans, uint4 *d_pq, hipStream_t stream);
+void sbwt_launch_path_safe(const SbwtIndexView &ix, uint4 *d_pq, int rule, void *d_hlab, unsigned char *d_alt_safe,
+                           hipStream_t stream);
+long long sbwt_launch_path_trans(const SbwtIndexView &ix, uint4 *d_trans, uint4 *d_pq, const unsigned char *d_alt_safe,
+                                 hipStream_t stream);
 int sbwt_launch_build_path(const SbwtIndexView &ix, unsigned *d_col, unsigned *d_pos, uint4 *d_pq, uint4 *d_trans,
                            void *d_scratch, int lookahead, hipStream_t stream);
 int sbwt_launch_build_sparse(const SbwtIndexView &ix, int p_dense, int p_sparse, int log2b, uint4 *d_table,

@@ -651,7 +651,14 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
             // v1 = { successor column (SBWT.hh:562-575) or none, its path position, its path's next 8 steps, - }
             ev = EV_EMIT1;
             if (v1.x == 0xFFFFFFFFu) {
-                b = blo = i + k - 1;
+                if (ix.has_safe && (v1.w & 1u)) {
+                    // no successor, and the entry vouches for this char like a safe bit does for all three: the k-mers that hold
+                    // the base are absent if the next k-1 bases agree with the path -- M_BRIDGE looks (k_path_safe_labels)
+                    ev = EV_NONE;
+                    mode = M_BRIDGE;
+                } else {
+                    b = blo = i + k - 1;
+                }
             } else {
                 res = (pos_t)v1.x;
                 r = (pos_t)v1.y;

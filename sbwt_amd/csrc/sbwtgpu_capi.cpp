@@ -434,6 +434,7 @@ int sbwtgpu_index_create(const sbwtgpu_index_desc *d, int device, sbwtgpu_index 
                     hipGetErrorString(e));
     }
     int rc = SBWTGPU_OK;
+    unsigned char *alt_safe = nullptr;                 // per-position verdicts of the safe-bit pass, for the transition entries
     do {
         if ((e = hipMemset(idx->blob, 0, (size_t)h.blob_bytes)) != hipSuccess) break;
         {
@@ -498,8 +499,14 @@ int sbwtgpu_index_create(const sbwtgpu_index_desc *d, int device, sbwtgpu_index 
             if (h.has_path && h.p_sparse == d->k && g_path_safe) {
                 SbwtIndexView v2 = idx->view();
                 // (rule 2 keeps the path heads' labels in the transition table's room, which is filled afterwards)
+                // ... and hands the per-char verdicts to the transition entries through alt_safe (a byte per position; without
+                // it only the steps that are safe for all three substitutes bridge)
+                if (g_path_safe >= 2 && hipMalloc((void **)&alt_safe, (size_t)n) != hipSuccess) {
+                    (void)hipGetLastError();
+                    alt_safe = nullptr;
+                }
                 sbwt_launch_path_safe(v2, reinterpret_cast<uint4 *>(idx->blob + h.off_pq), g_path_safe,
-                                      idx->blob + h.off_trans, 0);
+                                      idx->blob + h.off_trans, alt_safe, 0);
                 if ((e = hipDeviceSynchronize()) != hipSuccess) break;
                 h.has_safe = 1;
             }
@@ -507,7 +514,7 @@ int sbwtgpu_index_create(const sbwtgpu_index_desc *d, int device, sbwtgpu_index 
         if (h.has_path) {                               // last: the transition entries quote the final path chars / safe bits
             SbwtIndexView v3 = idx->view();
             h.n_branch = sbwt_launch_path_trans(v3, reinterpret_cast<uint4 *>(idx->blob + h.off_trans),
-                                                reinterpret_cast<uint4 *>(idx->blob + h.off_pq), 0);
+                                                reinterpret_cast<uint4 *>(idx->blob + h.off_pq), alt_safe, 0);
             if (h.n_branch < 0) { e = hipErrorUnknown; break; }
             h.n_paths = sbwt_count_paths(idx->view(), 0);          // (reads the final encoding of the path groups)
             if (h.n_paths < 0) { e = hipErrorUnknown; break; }
@@ -515,6 +522,7 @@ int sbwtgpu_index_create(const sbwtgpu_index_desc *d, int device, sbwtgpu_index 
         if ((e = hipGetLastError()) != hipSuccess) break;
         e = hipDeviceSynchronize();
     } while (0);
+    if (alt_safe) (void)hipFree(alt_safe);
     if (e == hipErrorOutOfMemory && level < 2 && (h.has_path || h.p_sparse > 0)) {
         (void)hipGetLastError();                       // scratch of a derived structure did not fit: build without them
         (void)hipFree(idx->blob);
