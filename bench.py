@@ -260,7 +260,7 @@ def main() -> int:
                     help="reads per GPU")
     ap.add_argument("--genome-len", type=int, default=int(os.environ.get("SBWT_BENCH_GENOME", 5_000_000)))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--config", type=int, default=2, choices=[2, 3, 5],
+    ap.add_argument("--config", type=int, default=2, choices=[2, 3, 5, 6],
                     help="BASELINE.json config: 2 = coli3-like k=30 (headline, default); 3 = pan-genome-like "
                          "k=31 (65 genomes, 100 M reads unless --reads); 5 = k=63 without streaming support")
     ap.add_argument("--derived", type=int, default=64, help="config 3: number of derived genomes")
@@ -272,6 +272,8 @@ def main() -> int:
                     help="--kernel rank: columns of the four random bit vectors of the HBM-resident case (the image is "
                          "1 byte per column: the default 2 GiB defeats the 256 MB Infinity Cache); the config-2 index "
                          "(12.8 MB of blocks, cache resident) is measured beside it")
+    ap.add_argument("--hbm-genome-len", type=int, default=1_000_000_000,
+                    help="--config 6: length of the one random sequence (10^9 columns = a 139 GB image)")
     ap.add_argument("--image-level", type=int, default=0, choices=[0, 1, 2],
                     help="device image: 0 = all derived structures (default), 1 = no path order, 2 = blocks + dense table")
     ap.add_argument("--replicate", choices=["image", "rebuild"], default="image",
@@ -308,6 +310,8 @@ def main() -> int:
     elif args.config == 5:
         K = 63
         streaming = False
+    elif args.config == 6:
+        K = 31                      # SURVEY 8d "G-hbm": one uniform-random sequence, an image far beyond the Infinity Cache
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the search path has no CPU fallback")
@@ -329,7 +333,10 @@ def main() -> int:
         return rank_bench(args, rank, world, local_rank, dev)
 
     # ---- index: built once on rank 0 (host sort-based builder), replicated by one broadcast ----
-    genomes = synth.pan_like(args.derived, args.genome_len) if args.config == 3 else synth.coli3_like(args.genome_len)
+    if args.config == 6:
+        genomes = [synth.random_genome(args.hbm_genome_len, 7)]
+    else:
+        genomes = synth.pan_like(args.derived, args.genome_len) if args.config == 3 else synth.coli3_like(args.genome_len)
     t0 = time.time()
     bits = None
     if rank == 0:
@@ -476,6 +483,8 @@ def main() -> int:
             "workload": ("config %d: " % args.config) + (
                 "pan-genome-like synthetic genomes (1 + %d x %d bp, 2%% divergence)" % (args.derived, args.genome_len)
                 if args.config == 3 else
+                "G-hbm (SURVEY 8d extra): one uniform-random sequence of %d bp (seed 7)" % args.hbm_genome_len
+                if args.config == 6 else
                 "coli3-like synthetic genomes (3 x %d bp, 5%% divergence)" % args.genome_len) +
                 " k=%d plain-matrix precalc=8 %s; %d synthetic 150bp reads per GPU, 1%% substitutions; %s of every read"
                 % (K, "streaming support" if streaming else "NO streaming support", n_reads,

@@ -412,11 +412,13 @@ __global__ void __launch_bounds__(256) k_path_cut(i64 n, const unsigned *__restr
         *flag = 1;
     }
 }
+// (the last column of a path writes its length: one writer per path -- an atomicMax by every column serialises on a
+// genome that is one long path, 3.4 s for 3 x 10^8 columns)
 __global__ void __launch_bounds__(256) k_path_len(i64 n, const unsigned *__restrict__ head, const unsigned *__restrict__ dist,
-                                                  unsigned long long *len) {
+                                                  const unsigned *__restrict__ succ, unsigned long long *len) {
     const i64 v = (i64)blockIdx.x * 256 + threadIdx.x;
     if (v >= n) return;
-    atomicMax(&len[head[v]], (unsigned long long)dist[v] + 1ull);
+    if (succ[v] == PATH_NONE) len[head[v]] = (unsigned long long)dist[v] + 1ull;
 }
 __global__ void __launch_bounds__(256) k_path_place(i64 n, const unsigned *__restrict__ head, const unsigned *__restrict__ dist,
                                                     const i64 *__restrict__ base, const unsigned *__restrict__ succ,
@@ -824,7 +826,7 @@ int sbwt_launch_build_path(const SbwtIndexView &ix, unsigned *d_col, unsigned *d
         if (attempt == 2) return -2;                    // cannot happen: one cut per cycle opens every cycle
     }
     (void)hipMemsetAsync(len, 0, (size_t)np * 8, stream);
-    hipLaunchKernelGGL(k_path_len, dim3(g), dim3(256), 0, stream, n, buf[cur][0], buf[cur][1], len);
+    hipLaunchKernelGGL(k_path_len, dim3(g), dim3(256), 0, stream, n, buf[cur][0], buf[cur][1], succ, len);
     hipLaunchKernelGGL(k_scan_block_sums, dim3((unsigned)nb), dim3(256), 0, stream, reinterpret_cast<const i64 *>(len), n, bsum);
     hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, stream, bsum, nb);
     hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nb), dim3(256), 0, stream, reinterpret_cast<const i64 *>(len), n, bsum, pbase);
