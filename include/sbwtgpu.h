@@ -80,8 +80,8 @@ const char *sbwtgpu_version(void);
 const char *sbwtgpu_last_error(void);
 int         sbwtgpu_device_count(int *count);
 /* Process-wide tuning knobs for experiments (results never depend on them):
- *   "search_variant"  -1 (default) = by the index: 4 where reads can follow their paths for a while (fewer than one
- *                     column in 64 has a choice of successors), else 2; 0 = k_search (the reference's order of searches), 1 = k_search_cert on
+ *   "search_variant"  -1 (default) = by the index: 4 on an index with a path order (2 only when its paths were chosen
+ *                     blindly, "path_lookahead" = 0, and more than one column in 64 has a choice of successors); 0 = k_search (the reference's order of searches), 1 = k_search_cert on
  *                     the blocks, 2 = k_search_cert along the path order, results staged per lane and written by
  *                     descriptors, 3 = k_search_pool (reads pooled in LDS, re-assigned to lanes by state), 4 = the path
  *                     order with per-read segment lists, a read's results written by the whole wave when it ends
@@ -111,6 +111,12 @@ int         sbwtgpu_device_count(int *count);
  *                     memory runs out.  SBWTGPU_MAX_IMAGE_BYTES.
  *   "force_mega"      1: rank-only images (arbitrary bit vectors) store their block counts relative to a 64-bit base as
  *                     images whose counts pass 2^32 do (tests of that layout at small sizes); default 0
+ *   "trans_wide"      -1 (default): 32-byte transition entries (the second half = the columns of the successor's next four
+ *                     path steps, for the staged-writer kernel) only on a branchy index with blind paths; 0 never; 1 always
+ *                     (+64 bytes per column; SBWTGPU_TRANS_WIDE)
+ *   "sort_reads"      1: the path-order kernels take the reads in the order of their first k-mer's path position (a lookup
+ *                     and a radix sort per batch inside the caller's workspace; pays only when nothing upstream orders the
+ *                     reads and the index is large); default off (SBWTGPU_SORT_READS)
  *   "path_lookahead"  8 (default): how many steps ahead / behind the path order looks for branch points when it chooses
  *                     which successor a column's path takes (paths follow the core of a pan-genome); 0: blind choice
  *                     (SBWTGPU_PATH_LOOKAHEAD)
