@@ -52,6 +52,8 @@ b, o = synth.sample_reads(base, n_reads, 150, 0.01, 42)
 run("config 2: 3 strains 5% apart, 150 bp reads, 1% substitutions", idx0, b, o)
 b, o = synth.ragged_reads(base, n_reads, 80, 250, 0.01, 43)
 run("ragged read lengths 80-250", idx0, b, o)
+b, o = synth.sample_reads(base, n_reads, 250, 0.01, 48)
+run("250 bp reads, 1% substitutions", idx0, b, o)
 b, o = synth.indel_reads(base, n_reads, 150, 0.01, 0.002, 44)
 run("0.2% indels + 1% substitutions", idx0, b, o)
 b, o = synth.random_reads(n_reads, 150, 45)
