@@ -377,36 +377,30 @@ __global__ void __launch_bounds__(256) k_path_succ_weighted(SbwtIndexView ix, co
     }
 }
 __global__ void __launch_bounds__(256) k_path_keep(i64 n, unsigned *__restrict__ succ, const unsigned *__restrict__ prv,
-                                                   unsigned *__restrict__ jump, unsigned *__restrict__ dist,
-                                                   unsigned *__restrict__ mn) {
+                                                   uint4 *__restrict__ jb) {
     const i64 v = (i64)blockIdx.x * 256 + threadIdx.x;
     if (v >= n) return;
     const unsigned sv = succ[v];
     if (sv != PATH_NONE && prv[sv] != (unsigned)v) succ[v] = PATH_NONE;
     const unsigned pv = prv[v];
-    jump[v] = (pv == PATH_NONE) ? (unsigned)v : pv;     // heads point at themselves
-    dist[v] = (pv == PATH_NONE) ? 0u : 1u;
-    mn[v] = (unsigned)v;
+    // { jump (heads point at themselves), distance to it, smallest column seen, - }: one 16-byte gather per doubling step
+    jb[v] = make_uint4((pv == PATH_NONE) ? (unsigned)v : pv, (pv == PATH_NONE) ? 0u : 1u, (unsigned)v, 0u);
 }
-__global__ void __launch_bounds__(256) k_path_jump(i64 n, const unsigned *__restrict__ jin, const unsigned *__restrict__ din,
-                                                   const unsigned *__restrict__ min_, unsigned *__restrict__ jout,
-                                                   unsigned *__restrict__ dout, unsigned *__restrict__ mout) {
+__global__ void __launch_bounds__(256) k_path_jump(i64 n, const uint4 *__restrict__ in, uint4 *__restrict__ out, int *moved) {
     const i64 v = (i64)blockIdx.x * 256 + threadIdx.x;
     if (v >= n) return;
-    const unsigned j = jin[v];
-    dout[v] = din[v] + din[j];
-    const unsigned a = min_[v], bq = min_[j];
-    mout[v] = a < bq ? a : bq;
-    jout[v] = jin[j];
+    const uint4 a = in[v], b = in[a.x];
+    out[v] = make_uint4(b.x, a.y + b.y, a.z < b.z ? a.z : b.z, 0u);
+    if (b.x != a.x && moved) *moved = 1;                // (every writer stores the same value)
 }
-__global__ void __launch_bounds__(256) k_path_cut(i64 n, const unsigned *__restrict__ jump, const unsigned *__restrict__ mn,
-                                                  unsigned *prv, unsigned *succ, int *flag) {
+__global__ void __launch_bounds__(256) k_path_cut(i64 n, const uint4 *__restrict__ jb, unsigned *prv, unsigned *succ, int *flag) {
     const i64 v = (i64)blockIdx.x * 256 + threadIdx.x;
     if (v >= n) return;
+    const uint4 me = jb[v];
     // reached a head?  (a cycle's cut point may be cut by its own thread while others look: they then
     // return here, and the flag is raised by the cutting thread)
-    if (prv[jump[v]] == PATH_NONE) return;
-    if (mn[v] == (unsigned)v) {                         // the cycle's smallest column becomes a head
+    if (prv[me.x] == PATH_NONE) return;
+    if (me.z == (unsigned)v) {                          // the cycle's smallest column becomes a head
         const unsigned pv = prv[v];
         if (pv != PATH_NONE) { succ[pv] = PATH_NONE; prv[v] = PATH_NONE; }
         *flag = 1;
@@ -414,19 +408,20 @@ __global__ void __launch_bounds__(256) k_path_cut(i64 n, const unsigned *__restr
 }
 // (the last column of a path writes its length: one writer per path -- an atomicMax by every column serialises on a
 // genome that is one long path, 3.4 s for 3 x 10^8 columns)
-__global__ void __launch_bounds__(256) k_path_len(i64 n, const unsigned *__restrict__ head, const unsigned *__restrict__ dist,
-                                                  const unsigned *__restrict__ succ, unsigned long long *len) {
+__global__ void __launch_bounds__(256) k_path_len(i64 n, const uint4 *__restrict__ jb, const unsigned *__restrict__ succ,
+                                                  unsigned long long *len) {
     const i64 v = (i64)blockIdx.x * 256 + threadIdx.x;
     if (v >= n) return;
-    if (succ[v] == PATH_NONE) len[head[v]] = (unsigned long long)dist[v] + 1ull;
+    if (succ[v] == PATH_NONE) { const uint4 me = jb[v]; len[me.x] = (unsigned long long)me.y + 1ull; }
 }
-__global__ void __launch_bounds__(256) k_path_place(i64 n, const unsigned *__restrict__ head, const unsigned *__restrict__ dist,
+__global__ void __launch_bounds__(256) k_path_place(i64 n, const uint4 *__restrict__ jb,
                                                     const i64 *__restrict__ base, const unsigned *__restrict__ succ,
                                                     const unsigned char *__restrict__ sch, unsigned *__restrict__ pos,
                                                     unsigned *__restrict__ col, unsigned *pq) {
     const i64 v = (i64)blockIdx.x * 256 + threadIdx.x;
     if (v >= n) return;
-    const unsigned t = (unsigned)base[head[v]] + dist[v];
+    const uint4 me = jb[v];
+    const unsigned t = (unsigned)base[me.x] + me.y;
     pos[v] = t;
     col[t] = (unsigned)v;
     if (succ[v] != PATH_NONE) {                         // quad t>>5 = { chars lo, chars hi, go mask, - }
@@ -482,11 +477,20 @@ __global__ void __launch_bounds__(256) k_path_safe(SbwtIndexView ix, unsigned *p
 // come from the head's own label (k_path_head_labels: k backward steps, SBWT.hh:700-746) followed by the path's chars.
 // Only the k steps u .. u+k-1 must be on the path -- M_BRIDGE compares the read with exactly those, and goes on from
 // position u+k.  On genomes whose paths are ~100 columns long this makes about half as many steps again bridgeable.
-template <bool MEGA>
-__global__ void __launch_bounds__(256) k_path_head_labels(SbwtIndexView ix, u64 *__restrict__ hlab) {
+// (the heads are listed first: one position in ~100 is a head, and a wave that walks k backward steps for one or two
+// of its lanes costs as much as one that does it for 64 -- 69 -> 6 ms at 142 M columns)
+__global__ void __launch_bounds__(256) k_path_list_heads(SbwtIndexView ix, unsigned *__restrict__ list, u64 *count) {
     const i64 t = (i64)blockIdx.x * 256 + threadIdx.x;
-    if (t >= ix.n_nodes) return;
-    if (t > 0 && ((ix.pq[(t - 1) >> 5].z >> (int)((t - 1) & 31)) & 1u)) return;      // step t-1 goes on: t is not a head
+    const bool head = t < ix.n_nodes && (t == 0 || !((ix.pq[(t - 1) >> 5].z >> (int)((t - 1) & 31)) & 1u));   // step t-1 does not go on
+    const u64 slot = block_append_slot(count, head);
+    if (slot != ~0ull) list[slot] = (unsigned)t;
+}
+template <bool MEGA>
+__global__ void __launch_bounds__(256) k_path_head_labels(SbwtIndexView ix, const unsigned *__restrict__ list,
+                                                          const u64 *__restrict__ count, u64 *__restrict__ hlab) {
+    const i64 e = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (i64)*count) return;
+    const i64 t = list[e];
     const int k = ix.k;
     i64 v = ix.col[t];
     u64 lab = 0;                                        // char j of the label at bits 2j (first char lowest, as the table keys)
@@ -730,7 +734,7 @@ static inline long long path_pad(long long n) { return (n + 64 + 255) & ~255ll; 
 long long sbwt_path_scratch_bytes(long long n_nodes) {
     const long long np = path_pad(n_nodes);
     const long long nb = (n_nodes + 1023) / 1024;
-    return np * 4 * 8 + np + np * 8 * 2 + (nb + 2) * 8 + 4096;
+    return np * (8 + 32) + np + np * 8 * 2 + (nb + 2) * 8 + 4096;     // succ, prv; two arrays of { jump, dist, min, - }; ...
 }
 long long sbwt_path_quads(long long n_nodes) { return n_nodes / 32 + 4; }
 // number of paths = positions whose "path goes on" bit is clear
@@ -764,11 +768,17 @@ void sbwt_launch_path_safe(const SbwtIndexView &ix, uint4 *d_pq, int rule, void 
         hipLaunchKernelGGL(k_path_safe, dim3(grid_for(ix.n_nodes)), dim3(256), 0, stream, ix, reinterpret_cast<unsigned *>(d_pq));
         return;
     }
+    // d_hlab: [ hlab : n x 8 B ][ list of heads : n x 4 B ][ their number : 8 B ]  (inside the transition table's room)
     u64 *hlab = reinterpret_cast<u64 *>(d_hlab);
+    unsigned *list = reinterpret_cast<unsigned *>(hlab + ix.n_nodes);
+    u64 *count = reinterpret_cast<u64 *>(reinterpret_cast<char *>(d_hlab) + (((size_t)ix.n_nodes * 12 + 15) & ~(size_t)15));
+    (void)hipMemsetAsync(count, 0, 8, stream);
+    hipLaunchKernelGGL(k_path_list_heads, dim3(grid_for(ix.n_nodes)), dim3(256), 0, stream, ix, list, count);
+    // (the grid covers every position; blocks beyond the number of heads return at once)
     if (ix.n_mega > 1)
-        hipLaunchKernelGGL(k_path_head_labels<true>, dim3(grid_for(ix.n_nodes)), dim3(256), 0, stream, ix, hlab);
+        hipLaunchKernelGGL(k_path_head_labels<true>, dim3(grid_for(ix.n_nodes)), dim3(256), 0, stream, ix, list, count, hlab);
     else
-        hipLaunchKernelGGL(k_path_head_labels<false>, dim3(grid_for(ix.n_nodes)), dim3(256), 0, stream, ix, hlab);
+        hipLaunchKernelGGL(k_path_head_labels<false>, dim3(grid_for(ix.n_nodes)), dim3(256), 0, stream, ix, list, count, hlab);
     hipLaunchKernelGGL(k_path_safe_labels, dim3(grid_for(ix.n_nodes)), dim3(256), 0, stream, ix,
                        reinterpret_cast<unsigned *>(d_pq), hlab, d_alt_safe);
 }
@@ -781,12 +791,12 @@ int sbwt_launch_build_path(const SbwtIndexView &ix, unsigned *d_col, unsigned *d
     const i64 nb = (n + 1023) / 1024;
     char *base = reinterpret_cast<char *>(d_scratch);
     int *flag = reinterpret_cast<int *>(base);
+    int *moved = flag + 16;
     base += 4096;
     unsigned *succ = reinterpret_cast<unsigned *>(base); base += np * 4;
     unsigned *prv = reinterpret_cast<unsigned *>(base); base += np * 4;
-    unsigned *buf[2][3];
-    for (int a = 0; a < 2; a++)
-        for (int f = 0; f < 3; f++) { buf[a][f] = reinterpret_cast<unsigned *>(base); base += np * 4; }
+    uint4 *jb[2];
+    for (int a = 0; a < 2; a++) { jb[a] = reinterpret_cast<uint4 *>(base); base += np * 16; }
     unsigned char *sch = reinterpret_cast<unsigned char *>(base); base += np;
     unsigned long long *len = reinterpret_cast<unsigned long long *>(base); base += np * 8;
     i64 *pbase = reinterpret_cast<i64 *>(base); base += np * 8;
@@ -811,14 +821,23 @@ int sbwt_launch_build_path(const SbwtIndexView &ix, unsigned *d_col, unsigned *d
     int cur = 0;
     for (int attempt = 0; attempt < 3; attempt++) {
         cur = 0;
-        hipLaunchKernelGGL(k_path_keep, dim3(g), dim3(256), 0, stream, n, succ, prv, buf[0][0], buf[0][1], buf[0][2]);
+        hipLaunchKernelGGL(k_path_keep, dim3(g), dim3(256), 0, stream, n, succ, prv, jb[0]);
         for (int r = 0; r < rounds; r++) {
-            hipLaunchKernelGGL(k_path_jump, dim3(g), dim3(256), 0, stream, n, buf[cur][0], buf[cur][1], buf[cur][2],
-                               buf[cur ^ 1][0], buf[cur ^ 1][1], buf[cur ^ 1][2]);
+            // from the 8th round on, every other round asks whether any pointer still moved: most graphs' longest path is far
+            // shorter than 2^rounds (cycles never settle and take all rounds; k_path_cut then opens them)
+            const bool ask = r >= 7 && (r & 1);
+            if (ask) (void)hipMemsetAsync(moved, 0, 4, stream);
+            hipLaunchKernelGGL(k_path_jump, dim3(g), dim3(256), 0, stream, n, jb[cur], jb[cur ^ 1], ask ? moved : (int *)nullptr);
             cur ^= 1;
+            if (ask) {
+                int h_moved = 1;
+                if (hipMemcpyAsync(&h_moved, moved, 4, hipMemcpyDeviceToHost, stream) != hipSuccess) return -1;
+                if (hipStreamSynchronize(stream) != hipSuccess) return -1;
+                if (!h_moved) break;
+            }
         }
         (void)hipMemsetAsync(flag, 0, 4, stream);
-        hipLaunchKernelGGL(k_path_cut, dim3(g), dim3(256), 0, stream, n, buf[cur][0], buf[cur][2], prv, succ, flag);
+        hipLaunchKernelGGL(k_path_cut, dim3(g), dim3(256), 0, stream, n, jb[cur], prv, succ, flag);
         int h_flag = 0;
         if (hipMemcpyAsync(&h_flag, flag, 4, hipMemcpyDeviceToHost, stream) != hipSuccess) return -1;
         if (hipStreamSynchronize(stream) != hipSuccess) return -1;
@@ -826,12 +845,12 @@ int sbwt_launch_build_path(const SbwtIndexView &ix, unsigned *d_col, unsigned *d
         if (attempt == 2) return -2;                    // cannot happen: one cut per cycle opens every cycle
     }
     (void)hipMemsetAsync(len, 0, (size_t)np * 8, stream);
-    hipLaunchKernelGGL(k_path_len, dim3(g), dim3(256), 0, stream, n, buf[cur][0], buf[cur][1], succ, len);
+    hipLaunchKernelGGL(k_path_len, dim3(g), dim3(256), 0, stream, n, jb[cur], succ, len);
     hipLaunchKernelGGL(k_scan_block_sums, dim3((unsigned)nb), dim3(256), 0, stream, reinterpret_cast<const i64 *>(len), n, bsum);
     hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, stream, bsum, nb);
     hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nb), dim3(256), 0, stream, reinterpret_cast<const i64 *>(len), n, bsum, pbase);
     (void)hipMemsetAsync(d_pq, 0, (size_t)sbwt_path_quads(n) * 16, stream);
-    hipLaunchKernelGGL(k_path_place, dim3(g), dim3(256), 0, stream, n, buf[cur][0], buf[cur][1], pbase, succ, sch, d_pos,
+    hipLaunchKernelGGL(k_path_place, dim3(g), dim3(256), 0, stream, n, jb[cur], pbase, succ, sch, d_pos,
                        d_col, reinterpret_cast<unsigned *>(d_pq));
     if (hipStreamSynchronize(stream) != hipSuccess) return -1;
     (void)d_trans;                                      // filled by sbwt_launch_path_trans once the safe bits are final
