@@ -412,7 +412,20 @@ def main() -> int:
     d_ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
 
+    # the kernel that runs: the index's default unless SBWTGPU_SEARCH_VARIANT overrides it.  Variant 5 (fused route) is
+    # ONE call per step -- sbwtgpu_streaming_search_dev: k_check_uniform2 + k_search_fused (encodes the bases itself) + the
+    # two kernels chained behind it for reads it hands on (none here) -- and the library records HIP events around
+    # k_search_fused on the launch stream ("kernel_events"); the older variants are the two calls encode + search, with
+    # this script's events around the search call.
+    variant = (index.default_search_variant if os.environ.get("SBWTGPU_SEARCH_VARIANT") is None
+               else int(os.environ["SBWTGPU_SEARCH_VARIANT"]))
+    one_call = (variant == 5 and index.image_level == 0)
+
     def step(ev=None):
+        if one_call:
+            index.streaming_search_dev(d_bases.data_ptr(), total_bases, d_roff.data_ptr(), n_reads, d_out.data_ptr(),
+                                       d_ooff.data_ptr(), d_ws.data_ptr(), ws_bytes, stream, streaming)
+            return
         index.encode_bases_dev(d_bases.data_ptr(), total_bases, d_ws.data_ptr(), ws_bytes, stream)
         if ev is not None:
             ev[0].record()
@@ -428,6 +441,8 @@ def main() -> int:
         dist.barrier()
     events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     torch.cuda.synchronize()
+    if one_call:
+        capi.set_tuning("kernel_events", 1)
     t_start = time.perf_counter()
     for s in range(args.steps):
         step(events[s])
@@ -438,7 +453,12 @@ def main() -> int:
     if world > 1:
         elapsed = sdist.max_over_ranks(elapsed, dev)
 
-    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in events]))
+    if one_call:
+        kt = capi.kernel_times()
+        capi.set_tuning("kernel_events", 0)
+        kernel_ms = float(np.mean(kt[-args.steps:]))
+    else:
+        kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in events]))
     n_stream, n_search, n_lf, n_tab, n_ext = index.workspace_stats(d_ws.data_ptr(), stream)
     status = index.workspace_status(d_ws.data_ptr(), stream)
     if status != 0:
@@ -495,9 +515,8 @@ def main() -> int:
         },
         "roofline": {
             "bound": "hbm",
-            "kernel": {4: "k_search_cert<PATH,SEG>", 2: "k_search_cert<PATH>"}.get(
-                index.default_search_variant if os.environ.get("SBWTGPU_SEARCH_VARIANT") is None else
-                int(os.environ["SBWTGPU_SEARCH_VARIANT"]), "k_search_cert") if index.image_level == 0 else "k_search_cert",
+            "kernel": {5: "k_search_fused", 4: "k_search_cert<PATH,SEG>", 2: "k_search_cert<PATH>"}.get(
+                variant, "k_search_cert") if index.image_level == 0 else "k_search_cert",
             "achieved": alg_bytes / (kernel_ms * 1e-3) / 1e9,
             "peak": HBM_PEAK_GBPS,
             "unit": "GB/s",

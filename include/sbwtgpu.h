@@ -240,6 +240,11 @@ int  sbwtgpu_workspace_status(const void *d_workspace, void *stream, int *status
  * answered along path runs (streaming steps that needed no block access), [5] substitutions bridged by the
  * path's safe bits, [6..7] reserved (0). */
 int  sbwtgpu_workspace_stats(const void *d_workspace, void *stream, int64_t stats[8]);
+/* Measurement aid (bench.py's roofline leg): after sbwtgpu_set_tuning("kernel_events", 1), sbwtgpu_streaming_search_dev /
+ * sbwtgpu_search_dev record a pair of HIP events on their stream around the dominant kernel (k_search_fused) of every
+ * call, without synchronising; this waits for them and reports the durations in ms, oldest first (the last 256 calls
+ * since the switch was set; *n = how many). */
+int  sbwtgpu_kernel_times(double *ms, int64_t cap, int64_t *n);
 
 /* ---- output formatting on the device ---- */
 /* print_vector of src/CLI/sbwt_search.cpp:21-43 for a whole batch: one line per read, every value

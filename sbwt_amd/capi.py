@@ -37,7 +37,7 @@ EXPORTED_SYMBOLS = [
     "sbwtgpu_partial_search_batch", "sbwtgpu_get_kmer_batch", "sbwtgpu_select_batch",
     "sbwtgpu_search_workspace_bytes", "sbwtgpu_streaming_search_dev", "sbwtgpu_search_dev",
     "sbwtgpu_rank_dev", "sbwtgpu_encode_bases_dev", "sbwtgpu_search_encoded_dev",
-    "sbwtgpu_workspace_status", "sbwtgpu_workspace_stats",
+    "sbwtgpu_workspace_status", "sbwtgpu_workspace_stats", "sbwtgpu_kernel_times",
     "sbwtgpu_format_text_bound", "sbwtgpu_format_scratch_bytes", "sbwtgpu_format_results_dev",
     "sbwtgpu_search_text_batch", "sbwtgpu_free_host", "sbwtgpu_release_cached_buffers",
 ]
@@ -123,6 +123,7 @@ def lib() -> C.CDLL:
     L.sbwtgpu_encode_bases_dev.argtypes = [vp, vp, i64, vp, i64, vp]
     L.sbwtgpu_search_encoded_dev.argtypes = [vp, i64, vp, i64, vp, vp, vp, i64, ci, vp]
     L.sbwtgpu_workspace_stats.argtypes = [vp, vp, C.POINTER(i64)]
+    L.sbwtgpu_kernel_times.argtypes = [vp, i64, C.POINTER(i64)]
     L.sbwtgpu_format_text_bound.argtypes = [vp, i64, i64]
     L.sbwtgpu_format_text_bound.restype = i64
     L.sbwtgpu_format_scratch_bytes.argtypes = [i64]
@@ -393,6 +394,14 @@ class Index:
         st = C.c_int(0)
         _check(lib().sbwtgpu_workspace_status(d_ws, stream, C.byref(st)))
         return st.value
+
+
+def kernel_times() -> list:
+    """Durations (ms) of the dominant kernel of the search calls since set_tuning("kernel_events", 1)."""
+    buf = (C.c_double * 256)()
+    n = C.c_int64(0)
+    _check(lib().sbwtgpu_kernel_times(buf, 256, C.byref(n)))
+    return [float(buf[i]) for i in range(n.value)]
 
 
 def search_workspace_bytes(total_bases: int) -> int:

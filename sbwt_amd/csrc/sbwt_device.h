@@ -136,7 +136,11 @@ struct SbwtWorkHeader {
     // (u_bad == 0): read r starts at u_read0 + r*u_len, its results at u_out0 + r*u_stride -- no offset fetch needed
     unsigned long long u_bad;
     long long u_read0, u_len, u_out0, u_stride;
-    unsigned long long pad[19];
+    // the fused route (k_search_fused, sbwt_search_fused.hip): reads it handed on to the general kernel that runs behind it
+    // (a base that is not upper-case ACGT), and that kernel's own ticket counter
+    unsigned long long n_deferred;
+    unsigned long long ticket2;
+    unsigned long long pad[17];
 };
 static_assert(sizeof(SbwtWorkHeader) == 256, "workspace header is 256 bytes");
 
@@ -147,6 +151,17 @@ void sbwt_launch_search(const SbwtIndexView &ix, const uint4 *d_packed, const lo
                         const long long *d_out_off, long long *d_out, long long n_reads, SbwtWorkHeader *ws,
                         int streaming, hipStream_t stream, int variant, long long total_groups, void *d_sort_scratch,
                         long long sort_scratch_bytes, int sort_key_bits);
+// the fused route for batches of equal-length reads (sbwt_search_fused.hip): check + fused kernel + (for what it hands on)
+// selective encode + the general path kernel.  d_defer: room for one 32-bit entry per read.
+void sbwt_launch_search_fused(const SbwtIndexView &ix, const char *d_bases, long long total_bases, uint4 *d_packed,
+                              const long long *d_read_off, const long long *d_out_off, long long *d_out, long long n_reads,
+                              SbwtWorkHeader *ws, int streaming, hipStream_t stream, unsigned *d_defer,
+                              hipEvent_t ev_begin, hipEvent_t ev_end);
+void sbwt_launch_encode_chained(const char *d_bases, long long total_bases, uint4 *d_packed, SbwtWorkHeader *ws,
+                                const unsigned *d_defer, int k, hipStream_t stream);
+void sbwt_launch_search_chained(const SbwtIndexView &ix, const uint4 *d_packed, const long long *d_read_off,
+                                const long long *d_out_off, long long *d_out, long long n_reads, SbwtWorkHeader *ws,
+                                int streaming, hipStream_t stream, const unsigned *d_defer);
 long long sbwt_sort_scratch_bytes(long long n_reads, int key_bits);
 const unsigned *sbwt_launch_sort_reads(const SbwtIndexView &ix, const uint4 *d_packed, const long long *d_read_off,
                                        long long n_reads, const SbwtWorkHeader *ws, void *d_scratch, long long scratch_bytes,

@@ -93,4 +93,13 @@ __device__ __forceinline__ i64 select_in_row(const SbwtIndexView &ix, int c, i64
 }
 
 
+// The fused route (sbwt_search_fused.hip) takes a batch when all reads have one length of 32 .. 32 * SBWT_FUSED_MAXG bases
+// (k_check_uniform2 has filled in the header) that holds at least one k-mer; the kernels chained behind it ask the same
+// question to know what is left for them.
+#define SBWT_FUSED_MAXG 5
+__device__ __forceinline__ bool sbwt_fused_ok(const SbwtWorkHeader *ws, int k) {
+    const long long len = ws->u_len;
+    return ws->u_bad == 0 && len >= 32 && len <= 32 * SBWT_FUSED_MAXG && len >= k;
+}
+
 static inline unsigned grid_for(i64 n) { return (unsigned)((n + 255) / 256); }

@@ -30,12 +30,7 @@
 //   validRaw bit t set iff base itself is ACGT    (search validates the raw char: SBWT.hh:398-399,427-428)
 // Also resets the workspace header for the search launch that follows on the same stream.
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_encode(const unsigned char *__restrict__ bases, i64 total,
-                                                uint4 *__restrict__ packed, i64 n_groups,
-                                                SbwtWorkHeader *ws, int aligned16) {
-    i64 g = (i64)blockIdx.x * 256 + threadIdx.x;
-    if (g == 0) { ws->ticket = 0; ws->status = 0; ws->n_stream = 0; ws->n_search = 0; ws->n_lf = 0; ws->n_tab_hit = 0; ws->n_ext = 0; ws->n_bridge = 0; }
-    if (g >= n_groups) return;
+__device__ __forceinline__ uint4 encode_group(const unsigned char *__restrict__ bases, i64 total, i64 g, int aligned16) {
     i64 base = g * SBWT_GROUP_BASES;
     u64 codes = 0;
     unsigned vu = 0, vr = 0;
@@ -70,7 +65,36 @@ __global__ void __launch_bounds__(256) k_encode(const unsigned char *__restrict_
             }
         }
     }
-    packed[g] = make_uint4((unsigned)codes, (unsigned)(codes >> 32), vu, vr);
+    return make_uint4((unsigned)codes, (unsigned)(codes >> 32), vu, vr);
+}
+
+__global__ void __launch_bounds__(256) k_encode(const unsigned char *__restrict__ bases, i64 total,
+                                                uint4 *__restrict__ packed, i64 n_groups,
+                                                SbwtWorkHeader *ws, int aligned16) {
+    i64 g = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (g == 0) { ws->ticket = 0; ws->status = 0; ws->n_stream = 0; ws->n_search = 0; ws->n_lf = 0; ws->n_tab_hit = 0; ws->n_ext = 0; ws->n_bridge = 0; }
+    if (g >= n_groups) return;
+    packed[g] = encode_group(bases, total, g, aligned16);
+}
+
+// The encode pass of the fused route (sbwt_search_fused.hip), behind k_search_fused: every group when that kernel declined
+// the batch (reads of different lengths), else only the groups of the reads it handed on (usually none).  Leaves the
+// workspace header alone: the fused kernel's counters are in it.
+__global__ void __launch_bounds__(256) k_encode_chained(const unsigned char *__restrict__ bases, i64 total,
+                                                        uint4 *__restrict__ packed, i64 n_groups, const SbwtWorkHeader *ws,
+                                                        const unsigned *__restrict__ defer_list, int k, int aligned16) {
+    const i64 t0 = (i64)blockIdx.x * 256 + threadIdx.x, stride = (i64)gridDim.x * 256;
+    if (!sbwt_fused_ok(ws, k)) {
+        for (i64 g = t0; g < n_groups; g += stride) packed[g] = encode_group(bases, total, g, aligned16);
+        return;
+    }
+    const i64 nd = (i64)ws->n_deferred, len = ws->u_len, r0 = ws->u_read0;
+    constexpr int GP = SBWT_FUSED_MAXG + 1;                  // groups a read of <= 32 * MAXG bases can touch
+    for (i64 t = t0; t < nd * GP; t += stride) {
+        const i64 P0 = r0 + (i64)defer_list[t / GP] * len;
+        const i64 g = (P0 >> 5) + (t % GP);
+        if (g <= ((P0 + len - 1) >> 5) && g < n_groups) packed[g] = encode_group(bases, total, g, aligned16);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -356,9 +380,17 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
                                                         const i64 *__restrict__ read_off,
                                                         const i64 *__restrict__ out_off, i64 *__restrict__ out,
                                                         i64 n_reads, SbwtWorkHeader *ws, int streaming,
-                                                        const unsigned *__restrict__ perm) {
+                                                        const unsigned *__restrict__ perm,
+                                                        const unsigned *__restrict__ defer_list) {
     // perm != nullptr: ticket t is read perm[t] (the reads sorted by where they start in the path order, sbwt_sort.hip:
     // the lanes of a wave then walk the same paths and share their lines of col / pq / trans)
+    // defer_list != nullptr: this launch runs behind k_search_fused (sbwt_search_fused.hip).  If that kernel took the batch,
+    // what is left are the reads it handed on: n_deferred tickets, ticket t is read defer_list[t].
+    unsigned long long *const ticket = defer_list ? &ws->ticket2 : &ws->ticket;
+    if (defer_list && sbwt_fused_ok(ws, ix.k)) {
+        n_reads = (i64)ws->n_deferred;
+        perm = defer_list;
+    }
     typedef typename SearchTypes<WIDE>::pos_t pos_t;
     typedef typename SearchTypes<WIDE>::stage_t stage_t;
     constexpr int DEPTH = SearchTypes<WIDE>::DEPTH;
@@ -410,7 +442,7 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
         if (need) {
             if (pool_next == pool_end) {
                 u64 t = 0;
-                if (lane == 0) t = atomicAdd(&ws->ticket, 64ull);
+                if (lane == 0) t = atomicAdd(ticket, 64ull);
                 pool_next = uniform64(t);              // lane 0's value, kept in scalar registers
                 pool_end = pool_next + 64;
             }
@@ -579,9 +611,9 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
                             (mode == M_INIT) ? 2 : (mode == M_STEP) ? 3 : (mode == M_TRANS) ? 4 : (mode == M_POS || mode == M_BRIDGE) ? 5 : (mode == M_EXT) ? 6 : 7;
             for (int q = 0; q < 8; q++) {
                 const unsigned long long cq = __popcll(__ballot(cls == q));
-                if (lane == 0 && cq) atomicAdd(&ws->pad[8 + q], cq);
+                if (lane == 0 && cq) atomicAdd(&ws->pad[6 + q], cq);
             }
-            if (lane == 0) atomicAdd(&ws->pad[16], 1ull);
+            if (lane == 0) atomicAdd(&ws->pad[14], 1ull);
         }
 #endif
         c_search = uniform32(c_search + (unsigned)__popcll(__ballot(kind == K_MODE && (mode == M_INIT || (p == 0 && mode == M_STEP && j == 0)))));
@@ -802,7 +834,7 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
             }
             qshort = stopped && n < 8;
 #ifdef SBWT_STATS
-            if (!stopped && i + n != m) atomicAdd(&ws->pad[17], 1ull);      // limited by the 32-step window / descriptor size
+            if (!stopped && i + n != m) atomicAdd(&ws->pad[15], 1ull);      // limited by the 32-step window / descriptor size
 #endif
             if (i + n == m) { mode = M_IDLE; ext_absent = false; }
             else if (stopped) mode = sbit ? M_BRIDGE : M_TRANS;
@@ -1300,6 +1332,26 @@ void sbwt_launch_encode(const char *d_bases, long long total_bases, uint4 *d_pac
                        aligned);
 }
 
+void sbwt_launch_encode_chained(const char *d_bases, long long total_bases, uint4 *d_packed, SbwtWorkHeader *ws,
+                                const unsigned *d_defer, int k, hipStream_t stream) {
+    i64 n_groups = (total_bases + SBWT_GROUP_BASES - 1) / SBWT_GROUP_BASES + 2;
+    int aligned = ((uintptr_t)d_bases & 15) == 0;
+    const i64 want = (n_groups + 255) / 256;
+    hipLaunchKernelGGL(k_encode_chained, dim3((unsigned)(want < 4096 ? want : 4096)), dim3(256), 0, stream,
+                       reinterpret_cast<const unsigned char *>(d_bases), (i64)total_bases, d_packed, n_groups, ws, d_defer, k, aligned);
+}
+
+// the general path kernel behind k_search_fused: all reads when that kernel declined the batch, else the reads it handed on
+void sbwt_launch_search_chained(const SbwtIndexView &ix, const uint4 *d_packed, const long long *d_read_off,
+                                const long long *d_out_off, long long *d_out, long long n_reads, SbwtWorkHeader *ws,
+                                int streaming, hipStream_t stream, const unsigned *d_defer) {
+    const i64 want1 = (n_reads + 255) / 256;
+    const unsigned cap = (ix.debug >> 8) ? (unsigned)(ix.debug >> 8) : 1280u;
+    const unsigned g = (unsigned)(want1 < (i64)cap ? want1 : (i64)cap);
+    hipLaunchKernelGGL((k_search_cert<false, 4, true, true>), dim3(g), dim3(256), 0, stream, ix, d_packed, d_read_off,
+                       d_out_off, d_out, (i64)n_reads, ws, streaming, (const unsigned *)nullptr, d_defer);
+}
+
 void sbwt_launch_search(const SbwtIndexView &ix, const uint4 *d_packed, const long long *d_read_off,
                         const long long *d_out_off, long long *d_out, long long n_reads, SbwtWorkHeader *ws,
                         int streaming, hipStream_t stream, int variant, long long total_groups, void *d_sort_scratch,
@@ -1316,7 +1368,7 @@ void sbwt_launch_search(const SbwtIndexView &ix, const uint4 *d_packed, const lo
         unsigned g = grid1 < cap ? grid1 : cap;
         if (wide)
             hipLaunchKernelGGL((k_search_cert<true, 4, false>), dim3(g), dim3(256), 0, stream, ix, d_packed, d_read_off,
-                               d_out_off, d_out, (i64)n_reads, ws, streaming, d_perm);
+                               d_out_off, d_out, (i64)n_reads, ws, streaming, d_perm, (const unsigned *)nullptr);
         else if (variant >= 2 && ix.col && streaming) {    // path order (the default when the index has one)
             if (variant >= 4) {                             // segment lists instead of staged results (SEG)
                 if (!(ix.debug & 8))
@@ -1328,7 +1380,7 @@ void sbwt_launch_search(const SbwtIndexView &ix, const uint4 *d_packed, const lo
                     d_perm = sbwt_launch_sort_reads(ix, d_packed, d_read_off, n_reads, ws, d_sort_scratch, sort_scratch_bytes,
                                                     sort_key_bits, stream);
                 hipLaunchKernelGGL((k_search_cert<false, 4, true, true>), dim3(g), dim3(256), 0, stream, ix, d_packed, d_read_off,
-                                   d_out_off, d_out, (i64)n_reads, ws, streaming, d_perm);
+                                   d_out_off, d_out, (i64)n_reads, ws, streaming, d_perm, (const unsigned *)nullptr);
                 return;
             }
             if (variant >= 3) {                             // pooled reads: one state per wave iteration (sbwt_search_pool.hip)
@@ -1349,10 +1401,10 @@ void sbwt_launch_search(const SbwtIndexView &ix, const uint4 *d_packed, const lo
                 d_perm = sbwt_launch_sort_reads(ix, d_packed, d_read_off, n_reads, ws, d_sort_scratch, sort_scratch_bytes,
                                                 sort_key_bits, stream);
             hipLaunchKernelGGL((k_search_cert<false, 4, true>), dim3(g), dim3(256), 0, stream, ix, d_packed, d_read_off,
-                               d_out_off, d_out, (i64)n_reads, ws, streaming, d_perm);
+                               d_out_off, d_out, (i64)n_reads, ws, streaming, d_perm, (const unsigned *)nullptr);
         } else
             hipLaunchKernelGGL((k_search_cert<false, 4, false>), dim3(g), dim3(256), 0, stream, ix, d_packed, d_read_off,
-                               d_out_off, d_out, (i64)n_reads, ws, streaming, d_perm);
+                               d_out_off, d_out, (i64)n_reads, ws, streaming, d_perm, (const unsigned *)nullptr);
         return;
     }
     // persistent-style grid: enough 256-thread workgroups to fill 256 CUs x 8 workgroups, never

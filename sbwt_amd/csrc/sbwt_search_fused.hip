@@ -1,0 +1,675 @@
+// sbwt_search_fused.hip -- the streaming-search kernel for batches of equal-length reads (sequencing reads): the 2-bit
+// re-encoding of the bases is part of the search kernel, and a read lives in LDS while its lane works on it.
+//
+// Why (round-2 profile of k_search_cert<PATH,SEG>): the separate k_encode pass cost 0.3-0.4 ms and
+// 2.25 GB of traffic per 10 M reads, and the search kernel then fetched a read's packed groups again from HBM, two at a
+// time, 2.7 lines and 1.3 extra lane-iterations per read, with 12 registers and the tag / reload logic to cache them.
+// Here a wave's pool of 64 tickets is 64 CONTIGUOUS reads: when the pool runs dry every lane loads one of them (150 bytes
+// each, 1.2 lines per read, every byte of a line used), encodes it with all 64 lanes busy and parks the 2-bit codes in a
+// pool area in LDS; a lane that takes a ticket copies its read into its own LDS slot.  Bases are then LDS reads at any
+// offset: no reload state, no prefetch loads, no validity words --
+//
+// -- because this kernel only walks reads whose bases are all upper-case ACGT.  A read with any other byte (N, lower
+// case, ...) is HANDED ON: its number goes to a list, and the general kernel (k_search_cert<PATH,SEG>, sbwt_search.hip)
+// runs behind this one over that list with the reference's validity rules (SBWT.hh:398-399,427-428,565-568).  With only
+// valid bases the streaming step's and the full search's validation agree, so `streaming` 1 and 2 are the same here.
+//
+// The state machine is the one of k_search_cert<PATH,SEG> (same certificates, same path-order steps, same segment-list
+// writer; see the header comments there).  Reference semantics: SBWT::streaming_search include/sbwt/SBWT.hh:544-581,
+// SBWT::search :389-415, update_sbwt_interval :422-437.
+#include "sbwt_kernels_common.h"
+
+#define F_IDLE 0
+#define F_INIT 2
+#define F_STEP 3
+#define F_DEAD 4
+#define F_EXT 7
+#define F_TRANS 8
+#define F_POS 9
+#define F_BRIDGE 10
+#define FE_NONE 0
+#define FE_EMIT1 1
+#define FE_FAIL 2
+#define FE_END 3
+#define FE_PRES 4
+
+#define FZ_NSEG 9               // segments per lane: 256 x (9 x 4 + 9 x 1) B + 2 x 256 x 40 B of codes = 32 000 B = 5 workgroups per CU
+
+typedef unsigned fz_u32x4 __attribute__((ext_vector_type(4)));
+
+// 32 ASCII bases (8 dwords) -> 64 bits of 2-bit codes; `bad` collects bit 7 of every byte that is not one of "ACGT"
+// (exact per-byte zero detection, four bases per operation); tm[d] masks the bytes of dword d that belong to the read
+__device__ __forceinline__ u64 fz_encode32(const unsigned w[8], const unsigned tm[8], unsigned &bad) {
+    u64 codes = 0;
+#pragma unroll
+    for (int d = 0; d < 8; d++) {
+        const unsigned x = w[d];
+        const unsigned t = ((x >> 1) & 0x03030303u) ^ ((x >> 2) & 0x01010101u);          // dna_code of every byte
+        const unsigned c8 = (t * 0x01041040u) >> 24;                                     // 4 x 2 bits -> one byte
+        auto nz = [](unsigned v) { return ((v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | v; };       // bit 7 of a byte set <=> byte != 0
+        const unsigned none = nz(x ^ 0x41414141u) & nz(x ^ 0x43434343u) & nz(x ^ 0x47474747u) & nz(x ^ 0x54545454u);
+        bad |= none & tm[d];
+        codes |= (u64)c8 << (8 * d);
+    }
+    return codes;
+}
+
+__global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const unsigned char *__restrict__ bases,
+                                                          i64 total_bases, i64 *__restrict__ out, i64 n_reads,
+                                                          SbwtWorkHeader *ws, unsigned *__restrict__ defer_list) {
+    __shared__ u64 pool_codes[SBWT_FUSED_MAXG][256];        // the wave's pool of 64 tickets, encoded ([group][wave * 64 + ticket])
+    __shared__ u64 cur_codes[SBWT_FUSED_MAXG][256];         // the read this lane is working on
+    __shared__ unsigned seg_src[FZ_NSEG][256];              // segment lists: source ...
+    __shared__ unsigned char seg_at[FZ_NSEG][256];          // ... and first k-mer
+    if (!sbwt_fused_ok(ws, ix.k)) return;                   // not one length (or too long / short): the general route does it all
+    const int tid = threadIdx.x, lane = tid & 63, wbase = tid & ~63;
+    const int k = ix.k, p = ix.p_dev, L0 = ix.probe_len, ps = ix.p_sparse;
+    const int ulen = (int)ws->u_len, m = ulen - k + 1, G = (ulen + 31) >> 5;
+    const i64 u_read0 = ws->u_read0, u_out0 = ws->u_out0, u_stride = ws->u_stride;
+    const bool pfon = ix.pfil && ix.p_filter == L0 && L0 > p;
+    const u64 m2 = (k - ps >= 32) ? ~0ull : low_mask(2 * ((k - ps) & 31));   // key mask of the second-level window
+    const int pw = pfon ? L0 : p;                   // window of a range probe: the filter's when there is one
+    const int last_node = (int)(ix.n_nodes - 1);
+
+    int nseg = 0, i0 = 0, last_start = 0;           // segments listed; first result of the read not written yet
+    unsigned last_src = 0, emit_pos = 0;
+    int wk = 0;                     // how this walk starts (as in k_search_cert): 0 dense table, 1 sparse table, 2 probe filter,
+                                    // 3 range probe, 5 second-level sparse lookup
+    u64 hk = 0;                     // F_INIT: the window's key (filter: the bit positions), kept across the gather
+    int blo = -1;                   // the last failure is known to lie in [blo, b]
+    int mode = F_IDLE;
+    unsigned rd = 0;                // the read this lane works on
+    int i = 0, j = 0, b = -1, wstart = 0;
+    int l = 0, r = 0;               // walk interval; F_EXT ..: r = path position
+    unsigned c_ext = 0, c_brg = 0;  // per lane: k-mers answered along paths, substitutions bridged
+    u64 pool_next = 0, pool_end = 0, pool_bad = 0;  // wave-uniform pool of read tickets; tickets of it that are handed on
+    unsigned c_stream = 0, c_search = 0, c_lf = 0, c_tab = 0;     // wave-uniform work counters
+    unsigned c_iter = 0, c_short = 0;
+
+    for (;;) {
+        // ---- hand out reads to idle lanes from the wave's ticket pool; an empty pool is refilled with 64 encoded reads ----
+        const u64 need = __ballot(mode == F_IDLE);
+        if (need) {
+            if (pool_next == pool_end) {
+                u64 t = 0;
+                if (lane == 0) t = atomicAdd(&ws->ticket, 64ull);
+                pool_next = uniform64(t);
+                pool_end = pool_next + 64;
+                pool_bad = 0;
+                if ((i64)pool_next < n_reads) {
+                    const i64 woff = u_read0 + (i64)pool_next * ulen;                 // first byte of the pool's 64 reads
+                    i64 remain = total_bases - woff;
+                    if (remain < 0) remain = 0;
+                    if (remain > 0xFFFFFFFFll) remain = 0xFFFFFFFFll;
+                    // bounds-checked loads: bytes past the end of `bases` read as 0 (the last read's last group reaches
+                    // over its end by up to 31 bytes)
+                    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+                        const_cast<unsigned char *>(bases) + woff, (short)0, (int)(unsigned)remain, 0x00020000);
+                    const int vo = lane * ulen;
+                    unsigned bad = 0;
+#pragma unroll
+                    for (int g = 0; g < SBWT_FUSED_MAXG; g++) {
+                        if (g < G) {
+                            const fz_u32x4 x0 = __builtin_amdgcn_raw_buffer_load_b128(rs, vo + 32 * g, 0, 0);
+                            const fz_u32x4 x1 = __builtin_amdgcn_raw_buffer_load_b128(rs, vo + 32 * g + 16, 0, 0);
+                            const unsigned w[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+                            unsigned tm[8];
+#pragma unroll
+                            for (int d = 0; d < 8; d++) {
+                                const int nb = ulen - 32 * g - 4 * d;                  // bytes of this dword inside the read
+                                tm[d] = nb >= 4 ? 0x80808080u : nb <= 0 ? 0u : (0x80808080u & ((1u << (8 * nb)) - 1u));
+                            }
+                            pool_codes[g][wbase + lane] = fz_encode32(w, tm, bad);
+                        }
+                    }
+                    const bool isbad = bad != 0 && (i64)(pool_next + (u64)lane) < n_reads;
+                    pool_bad = __ballot(isbad);
+                    if (pool_bad) {                                                    // hand them on (rare)
+                        unsigned long long at = 0;
+                        if (lane == 0) at = atomicAdd(&ws->n_deferred, (unsigned long long)__popcll(pool_bad));
+                        at = uniform64(at);
+                        if (isbad) defer_list[at + (u64)__popcll(pool_bad & low_mask(lane))] = (unsigned)(pool_next + (u64)lane);
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+            const unsigned avail = (unsigned)(pool_end - pool_next);
+            const unsigned n = (unsigned)__popcll(need);
+            const unsigned rank = (unsigned)__popcll(need & low_mask(lane));
+            if (mode == F_IDLE && rank < avail) {
+                const u64 tk = pool_next + rank;
+                const int q = (int)(tk & 63ull);
+                if ((i64)tk >= n_reads) {
+                    mode = F_DEAD;
+                } else if (!((pool_bad >> q) & 1ull)) {
+                    rd = (unsigned)tk;
+#pragma unroll
+                    for (int g = 0; g < SBWT_FUSED_MAXG; g++)
+                        if (g < G) cur_codes[g][tid] = pool_codes[g][wbase + q];
+                    i = 0;
+                    nseg = 0;
+                    i0 = 0;
+                    b = -1;
+                    blo = -1;
+                    wstart = 0;
+                    j = 0;
+                    wk = (ps > 0) ? 1 : 0;
+                    if (p > 0) mode = F_INIT;
+                    else { mode = F_STEP; l = 0; r = last_node; }
+                }                                      // else: handed on -- the lane takes another ticket next time round
+            }
+            pool_next = uniform64(pool_next + ((n < avail) ? n : avail));
+        }
+        if (__ballot(mode != F_DEAD) == 0) break;
+
+        // ---- this iteration's gather: two 16-byte loads per lane, issued back to back, one wait ----
+        int ev = FE_NONE, tfail = 0, c = 0;
+        const uint4 *a1 = ix.blocks, *a2 = ix.blocks;
+        int res = -1;
+        const bool ext = (mode == F_EXT), trn = (mode == F_TRANS), brg = (mode == F_BRIDGE);
+        const bool busy = (mode != F_IDLE && mode != F_DEAD);
+        bool rknown = false, qshort = false, ext_absent = false;
+        const bool use_q = (ix.trans_ext > 0 || (ix.trans_ext < 0 && c_short >= 8u * c_iter));
+        c_iter++;
+        int tnext = F_EXT;
+        int tpos = -1;
+        int seg_n = 0;
+        unsigned seg_src_run = 0;
+        // the read's bases from position P on: three words of codes out of the lane's LDS slot
+        const int woff5 = (mode == F_INIT && wk == 5) ? ps : 0;       // the second-level window starts after the prefix
+        const int P = (ext || trn) ? (i + k - 1) : brg ? (i + k) : ((mode == F_INIT) ? (wstart + woff5) : (wstart + j));
+        const int s = P & 31, pg = busy ? (P >> 5) : 0;
+        const u64 cw0 = cur_codes[pg < SBWT_FUSED_MAXG ? pg : SBWT_FUSED_MAXG - 1][tid];
+        const u64 cw1 = cur_codes[pg + 1 < SBWT_FUSED_MAXG ? pg + 1 : SBWT_FUSED_MAXG - 1][tid];
+        const u64 cw2 = cur_codes[pg + 2 < SBWT_FUSED_MAXG ? pg + 2 : SBWT_FUSED_MAXG - 1][tid];
+        const u64 rw = s ? ((cw0 >> (2 * s)) | (cw1 << (64 - 2 * s))) : cw0;      // bases P .. P+31
+        if (mode == F_POS) {
+            a1 = reinterpret_cast<const uint4 *>(ix.pos + ((unsigned)l & ~3u));  // the aligned 16 bytes holding pos[l]
+            a2 = a1;
+        } else if (busy) {
+            const int wl = (wk == 1) ? ps : (wk == 2) ? L0 : (wk == 3) ? pw : (wk == 5) ? k - ps : p;
+            c = (int)((unsigned)rw & 3u);
+            if (ext || brg) {
+                a1 = ix.pq + (((unsigned)r + (brg ? 1u : 0u)) >> 5);   // the two quads holding path chars r (+1) .. +31
+                a2 = a1 + 1;
+            } else if (trn) {
+                a1 = ix.trans + ((4 * (size_t)(unsigned)r + (unsigned)c) << ix.trans_wide);
+                a2 = a1;
+            } else if (mode == F_INIT) {
+                (void)wl;
+                if (wk == 1) {                 // bucket (hash + j) of the sparse table: two entries
+                    const u64 key = rw & low_mask(2 * ps);
+                    hk = key;
+                    const u64 bkt = (((key * SBWT_SP_HASH) >> (64 - ix.log2b)) + (u64)j) & low_mask(ix.log2b);
+                    a1 = ix.stab + 2 * bkt;
+                    a2 = a1 + 1;
+                } else if (wk == 5) {          // second level: (prefix interval, rest of the k-mer) -> one entry
+                    hk = rw & m2;
+                    const u64 bkt = ((sp2_hash((unsigned)l, hk) >> (64 - ix.log2b2)) + (u64)j) & low_mask(ix.log2b2);
+                    a1 = ix.stab2 + 2 * bkt;
+                    a2 = a1 + 1;
+                } else if (wk == 2 || (wk == 3 && pfon)) {   // the window's block of the probe filter
+                    const u64 h = sbwt_pf_hash(rw & low_mask(2 * L0));
+                    hk = (u64)sbwt_pf_bits(h);
+                    a1 = ix.pfil + (h >> (64 - ix.log2f));
+                    a2 = a1;
+                } else {
+                    a1 = reinterpret_cast<const uint4 *>(ix.ptab + (rw & low_mask(2 * p)));
+                    a2 = a1;
+                }
+            } else {   // F_STEP
+                a1 = ix.blocks + ((((i64)l >> 6) << 2) + c);
+                a2 = ix.blocks + (((((i64)r + 1) >> 6) << 2) + c);
+            }
+        }
+        c_search = uniform32(c_search + (unsigned)__popcll(__ballot(mode == F_INIT || (p == 0 && mode == F_STEP && j == 0))));
+        c_lf = uniform32(c_lf + (unsigned)__popcll(__ballot(mode == F_STEP)));
+
+        const uint4 v1 = *a1;
+        const uint4 v2 = *a2;
+
+        // ---- consume ----
+        bool tabhit = false, do_plan = false, force = false;
+        bool imprecise = false;                        // this iteration's failure is a table-level miss
+        int burst_to = -1;                             // F_BRIDGE: k-mers i .. burst_to are certified absent
+        bool bridged = false;                          // F_BRIDGE: ... and the read goes on along the path
+        if (mode == F_POS) {
+            const unsigned sel = (unsigned)l & 3u;
+            r = (int)(sel == 0 ? v1.x : sel == 1 ? v1.y : sel == 2 ? v1.z : v1.w);
+            mode = F_EXT;
+        } else if (trn) {
+            // v1 = { successor column (SBWT.hh:562-575) or none, its path position, its path's next 8 steps, - }
+            ev = FE_EMIT1;
+            if (v1.x == 0xFFFFFFFFu) {
+                if (ix.has_safe && (v1.w & 1u)) {
+                    // no successor, and the entry vouches for this char like a safe bit does for all three (k_path_safe_labels)
+                    ev = FE_NONE;
+                    mode = F_BRIDGE;
+                } else {
+                    b = blo = i + k - 1;
+                }
+            } else {
+                res = (int)v1.x;
+                r = (int)v1.y;
+                emit_pos = v1.y;
+                rknown = true;
+                if (use_q) {
+                    // the read's next bases against the 8 steps quoted in the entry: short runs end here
+                    const unsigned rq = (unsigned)(s == 31 ? cw1 : (rw >> 2));       // bases P+1 ..
+                    const unsigned x = (rq ^ v1.z) & 0xFFFFu;
+                    const unsigned mm = (x | (x >> 1)) & 0x5555u;
+                    const int nm = mm ? ((__ffs((int)mm) - 1) >> 1) : 8;
+                    const unsigned okb = (v1.z >> 16) & 0xFFu;
+                    const int nv = __ffs((int)(~okb | 0x100u)) - 1;
+                    int n2 = nm < nv ? nm : nv;
+                    bool stop2 = n2 < 8;
+                    if (n2 > m - 1 - i) { n2 = m - 1 - i; stop2 = false; }
+                    if (n2 < 0) n2 = 0;
+                    seg_n = n2;
+                    seg_src_run = (unsigned)r + 1u;
+                    r += n2;
+                    c_ext += (unsigned)n2;
+                    if (stop2) tnext = (ix.has_safe && nm < nv && ((v1.z >> 24 >> nm) & 1u)) ? F_BRIDGE : F_TRANS;
+                    qshort = stop2;
+                }
+            }
+        } else if (brg) {
+            // k-mer i ends at the mismatching base: if the bases after it agree with the path again, every k-mer that
+            // contains the mismatching base is a one-base variant of a path k-mer, absent by the safe bit
+            const int sp = (int)(((unsigned)r + 1u) & 31u);
+            u64 pwd = quad_bits(v1) >> (2 * sp);
+            if (sp) pwd |= quad_bits(v2) << (64 - 2 * sp);
+            const u64 x = rw ^ pwd;
+            const u64 mm = (x | (x >> 1)) & 0x5555555555555555ull;
+            const int nm = mm ? ((__ffsll((i64)mm) - 1) >> 1) : 32;
+            const int needb = (k - 1 < m - 1 - i) ? (k - 1) : (m - 1 - i);
+            if (nm >= needb) {
+                ev = FE_FAIL;
+                burst_to = i + needb;
+                c_brg++;
+                bridged = needb == k - 1;              // back on the path: on with F_EXT from position r + k, no walk
+            } else {
+                ev = FE_EMIT1;                         // no bridge: a safe step has no successor by any other char
+                b = blo = i + k - 1;
+            }
+        } else if (ext) {
+            // k-mer i-1 sits at path position r.  Read bases i+k-1.. against path chars r..: while they agree (and the
+            // path goes on), k-mer i+x sits at r+1+x.
+            const int sp = (int)((unsigned)r & 31u);
+            u64 pwd = quad_bits(v1) >> (2 * sp);
+            if (sp) pwd |= quad_bits(v2) << (64 - 2 * sp);
+            // the path groups' two flag words (k_path_reencode): go = ~A | B, safe = A & B, only successor = ~A & B
+            const u64 fA = (((u64)v2.z << 32) | (u64)v1.z) >> sp, fB = (((u64)v2.w << 32) | (u64)v1.w) >> sp;
+            const u64 pgo = ~fA | fB;
+            const u64 x = rw ^ pwd;
+            const u64 mm = (x | (x >> 1)) & 0x5555555555555555ull;
+            const int nm = mm ? ((__ffsll((i64)mm) - 1) >> 1) : 32;
+            const u64 badg = ~pgo | (1ull << 32);
+            const int nv = __ffsll((i64)badg) - 1;
+            int n = nm < nv ? nm : nv;
+            bool stopped = n < 32;                     // a mismatch or the end of the path
+            int nmt = nm, nvt = nv;
+            if (!stopped) {
+                // the read's side is whole (LDS); the two path quads hold 32 - sp more chars
+                const int w2 = 32 - sp;
+                const u64 rw2 = s ? ((cw1 >> (2 * s)) | (cw2 << (64 - 2 * s))) : cw1;
+                const u64 x2 = rw2 ^ (quad_bits(v2) >> (2 * sp));
+                const u64 mm2 = (x2 | (x2 >> 1)) & 0x5555555555555555ull;
+                const int nm2 = mm2 ? ((__ffsll((i64)mm2) - 1) >> 1) : 32;
+                const u64 bad2 = ~(pgo >> 32) | (1ull << 32);
+                const int nv2 = __ffsll((i64)bad2) - 1;
+                int n2 = nm2 < nv2 ? nm2 : nv2;
+                if (n2 >= w2) n2 = w2;                 // the end of what is loaded is not a stop
+                else stopped = true;
+                n = 32 + n2;
+                nmt = 32 + nm2;
+                nvt = 32 + nv2;
+            }
+            if (n > m - i) n = m - i;
+            seg_n = n;
+            seg_src_run = (unsigned)r + 1u;
+            r += n;
+            c_ext += (unsigned)n;
+            bool sbit = false;                         // stopped at a char mismatch whose path step is substitution-safe?
+            if (stopped && nmt < nvt) {
+                const int nmq = nmt;
+                sbit = (((fA & fB) >> nmq) & 1ull) != 0;
+                // ... or a step whose char is the only successor of its column: the streaming step gives -1
+                // (SBWT.hh:572-575) without a look at the transition table
+                ext_absent = !sbit && (((~fA & fB) >> nmq) & 1ull) != 0;
+                if (sbit && nmq < 32) {
+                    // a bridge needs the next k-1 bases to agree with the path; a second difference already in this window:
+                    // skip the attempt
+                    const int after = 31 - nmq, want = (k - 1 < m - 1 - (i + nmq)) ? (k - 1) : (m - 1 - (i + nmq));
+                    const int chk = after < want ? after : want;
+                    if (chk > 0 && ((mm >> (2 * (nmq + 1))) & low_mask(2 * chk)) != 0) { sbit = false; ext_absent = true; }
+                }
+            }
+            qshort = stopped && n < 8;
+            if (i + n == m) { mode = F_IDLE; ext_absent = false; }
+            else if (stopped) mode = sbit ? F_BRIDGE : F_TRANS;
+        } else if (mode == F_INIT) {
+            int wl = p;
+            bool again = false;
+            const bool viaf = (wk == 2) || (wk == 3 && pfon);
+            if (viaf) {
+                const unsigned b1 = (unsigned)hk & 127u, b2 = ((unsigned)hk >> 7) & 127u;
+                const unsigned w1 = (b1 < 64) ? (b1 < 32 ? v1.x : v1.y) : (b1 < 96 ? v1.z : v1.w);
+                const unsigned w2 = (b2 < 64) ? (b2 < 32 ? v1.x : v1.y) : (b2 < 96 ? v1.z : v1.w);
+                wl = L0;
+                if (((w1 >> (b1 & 31u)) & (w2 >> (b2 & 31u)) & 1u) != 0) {
+                    if (wk == 3) {
+                        l = 0;                         // range probe: "perhaps present" only moves the guess
+                    } else {
+                        again = true;                  // perhaps present: the dense table walks the window exactly
+                        wk = 0;
+                    }
+                } else {
+                    l = -1;                            // read[wstart .. wstart+L0-1] is not in the index
+                }
+            } else if (wk == 5) {
+                wl = k;                                // a hit completes the k-mer; a miss: read[wstart .. wstart+k-1] is absent
+                if ((v1.w & SBWT_SP2_USED) && quad_bits(v1) == hk && v1.z == (unsigned)l) {
+                    l = (int)v2.x;
+                    r = l;
+                    tpos = (int)v2.y;
+                } else if (v1.w & SBWT_SP2_OVERFLOW) {
+                    again = true;
+                    j++;
+                } else {
+                    l = -1;
+                }
+            } else if (wk == 1) {
+                const u64 key = hk;
+                const u64 w0 = quad_bits(v1), w1 = quad_bits(v2);
+                const bool m0 = (w0 & ~SBWT_SP_OVERFLOW) == key, m1 = w1 == key;
+                wl = ps;
+                if (m0 | m1) {
+                    l = (int)(m0 ? v1.z : v2.z);
+                    if (ix.stab_pos) {                 // depth-k entries: one column, stored with its path position
+                        r = l;
+                        tpos = (int)(m0 ? v1.w : v2.w);
+                    } else {
+                        r = l + (int)(m0 ? v1.w : v2.w);
+                    }
+                } else if (w0 & SBWT_SP_OVERFLOW) {
+                    again = true;                      // a later bucket may hold the key
+                    j++;
+                } else {
+                    l = -1;                            // read[wstart .. wstart+ps-1] is not in the index
+                }
+            } else {
+                l = (int)(i64)quad_bits(v1);
+                r = (int)(i64)((u64)v1.z | ((u64)v1.w << 32));
+            }
+            if (!again) {
+                tabhit = (l != -1);
+                if (l == -1) {
+                    ev = FE_FAIL;                      // read[wstart .. wstart+wl-1] is not in the index
+                    tfail = wstart + wl - 1;
+                    imprecise = (wk != 2);             // ... but where inside the window it fails is not known
+                } else if (wk == 3) {
+                    ev = FE_PRES;
+                } else if (wk == 1 && ps < k && ix.stab2) {
+                    wk = 5;                            // the prefix is there (l = its first column): the rest in one more gather
+                    j = 0;
+                } else {
+                    j = wl;
+                    if (wstart + j == i + k) ev = FE_END;
+                    else mode = F_STEP;
+                }
+            }
+        } else if (mode == F_STEP) {
+            l = (int)v1.z + (int)__popcll(quad_bits(v1) & low_mask(l & 63));
+            r = (int)v2.z + (int)__popcll(quad_bits(v2) & low_mask((r + 1) & 63)) - 1;
+            if (l > r) {
+                ev = FE_FAIL;                          // SBWT.hh:433
+                tfail = wstart + j;
+            } else if (wstart + (++j) == i + k) {
+                ev = FE_END;
+            }
+        }
+        c_tab = uniform32(c_tab + (unsigned)__popcll(__ballot(tabhit)));
+        c_stream = uniform32(c_stream + (unsigned)__popcll(__ballot(ev == FE_EMIT1 && trn)));
+        c_short = uniform32(c_short + (unsigned)__popcll(__ballot(qshort)));
+
+        // ---- events: results, certificates, next state ----
+        int burst_hi = -1;                             // >= i: k-mers i..burst_hi are certified absent
+        if (ev == FE_END) {
+            if (wstart == i) {                         // k chars matched from i: the k-mer is there
+                res = l;
+                if (l != r) ws->status = SBWT_ERR_NOT_SINGLETON;   // SBWT.hh:410-413
+                if (tpos >= 0) { r = tpos; rknown = true; emit_pos = (unsigned)tpos; }
+                ev = FE_EMIT1;
+                b = -1;
+            } else {
+                do_plan = true;                        // probe inconclusive: the reference's own walk
+                force = true;
+            }
+        } else if (ev == FE_FAIL) {
+            // read[wstart..tfail] is not in the index: k-mers i..min(wstart, m-1) all contain it
+            burst_hi = (wstart < m - 1) ? wstart : (m - 1);
+            if (burst_to >= 0) {                       // bridged substitution: nothing is known about the next one
+                burst_hi = burst_to;
+                b = -1;
+            } else if (wk == 3) {                      // range probe: the bad base is in [wstart, b]
+                if (wstart >= b) b = -1;
+                else if (blo < wstart + 1) blo = wstart + 1;
+            } else if (imprecise && !(wstart == b && blo >= b)) {
+                blo = wstart;                          // the bad base is somewhere in [wstart, tfail]
+                b = tfail;
+            } else {
+                // a walk that started AT the known-bad position says nothing about where the next one is
+                b = (wstart == b) ? -1 : tfail;
+                blo = b;
+            }
+            if (burst_hi == i) { ev = FE_EMIT1; burst_hi = -1; }
+        }
+        if (ev == FE_PRES) {                           // no bad base in [wstart, wstart+pw-1]: shrink the range
+            const int lo = blo > i ? blo : i;
+            if (wstart > lo) b = wstart - 1;
+            else blo = wstart + pw;
+            if (blo > b) b = -1;
+            do_plan = true;
+        }
+
+        // ---- append this iteration's results to the lane's segment list (at most two segments; contiguous ones merge) ----
+        auto append = [&](int at, unsigned src) {
+            const bool merge = nseg > 0 && ((src == 0xFFFFFFFFu && last_src == 0xFFFFFFFFu) ||
+                                            (!(src >> 31) && !(last_src >> 31) && last_src + (unsigned)(at - last_start) == src));
+            if (!merge) {
+                seg_src[nseg][tid] = src;
+                seg_at[nseg][tid] = (unsigned char)at;
+                nseg++;
+                last_src = src;
+                last_start = at;
+            }
+        };
+        if (ev == FE_EMIT1) {
+            append(i, res == -1 ? 0xFFFFFFFFu : (rknown ? emit_pos : (0x80000000u | (unsigned)res)));
+            i++;
+        }
+        {
+            const int nleft = (burst_hi >= 0) ? (burst_hi - i + 1) : seg_n;
+            if (nleft > 0) {
+                append(i, (burst_hi >= 0) ? 0xFFFFFFFFu : seg_src_run);
+                i += nleft;
+            }
+            if (ext_absent) {                          // the k-mer that left the path: -1, then the certificates
+                append(i, 0xFFFFFFFFu);
+                b = blo = i + k - 1;
+                i++;
+                if (i == m) mode = F_IDLE;
+                else do_plan = true;
+            }
+        }
+        // ---- flush: the read is done, or the list could overflow in the next iteration.  Up to four reads per trip: the
+        //      col[] loads of all four are in flight before the first store ----
+        u64 fm = __ballot(nseg > 0 && (i == m || nseg > FZ_NSEG - 2));
+        while (fm) {
+            constexpr int FP = 4;
+            int fL[FP], fe[FP], fj[FP], w0[FP], w1[FP];
+            i64 fob[FP];
+            unsigned x0[FP], x1[FP];
+            bool long_read = false;
+#pragma unroll
+            for (int u = 0; u < FP; u++) {
+                fL[u] = -1; fe[u] = 0; fj[u] = 0; fob[u] = 0; x0[u] = x1[u] = 0xFFFFFFFFu; w0[u] = w1[u] = 0;
+                if (fm == 0) continue;                 // wave-uniform: unused slots cost nothing
+                const int L = __ffsll((i64)fm) - 1;
+                fm &= fm - 1;
+                const int ns = __shfl(nseg, L), a = __shfl(i0, L), e = __shfl(i, L);
+                fL[u] = L;
+                fe[u] = e;
+                fob[u] = u_out0 + (i64)uniform32((unsigned)__shfl((int)rd, L)) * u_stride;
+                long_read = long_read || (e - a > 128);
+                const int tl = wbase + L;
+                const int j0 = a + 2 * lane, j1 = j0 + 1;
+                fj[u] = j0;
+                // the segment of result j0: the last one that starts at or before it; result j1 is in the same segment or the next
+                int idx = 0;
+#pragma unroll
+                for (int step = 8; step > 0; step >>= 1) {
+                    const int t = idx + step;
+                    const int st = (int)seg_at[t < FZ_NSEG ? t : FZ_NSEG - 1][tl];
+                    if (t < ns && st <= j0) idx = t;
+                }
+                const unsigned c0s = seg_src[idx][tl];
+                const int c0a = (int)seg_at[idx][tl];
+                const int nxi = idx + 1 < FZ_NSEG ? idx + 1 : FZ_NSEG - 1;
+                const unsigned nxs = seg_src[nxi][tl];
+                const int nxa = (int)seg_at[nxi][tl];
+                const bool usenx = (idx + 1 < ns && nxa <= j1);
+                const unsigned c1s = usenx ? nxs : c0s;
+                const int c1a = usenx ? nxa : c0a;
+                x0[u] = c0s;
+                x1[u] = c1s;
+                const unsigned p0 = (j0 < e && !(c0s >> 31)) ? c0s + (unsigned)(j0 - c0a) : 0u;
+                const unsigned p1 = (j1 < e && !(c1s >> 31)) ? c1s + (unsigned)(j1 - c1a) : 0u;
+                w0[u] = (int)ix.col[p0];
+                w1[u] = (int)ix.col[p1];
+            }
+#pragma unroll
+            for (int u = 0; u < FP; u++) {
+                const int q0 = (x0[u] >> 31) ? ((x0[u] == 0xFFFFFFFFu) ? -1 : (int)(x0[u] & 0x7FFFFFFFu)) : w0[u];
+                const int q1 = (x1[u] >> 31) ? ((x1[u] == 0xFFFFFFFFu) ? -1 : (int)(x1[u] & 0x7FFFFFFFu)) : w1[u];
+                if (!(ix.debug & 1)) {
+                    if (fj[u] + 1 < fe[u]) st_stream2(out + fob[u] + fj[u], (i64)q0, (i64)q1);
+                    else if (fj[u] < fe[u]) st_stream(out + fob[u] + fj[u], (i64)q0);
+                }
+            }
+            if (long_read) {
+                // more than 128 results since the last flush (reads of up to 160 bases): the remaining pass, one read at a time
+#pragma unroll
+                for (int u = 0; u < FP; u++) {
+                    if (fL[u] < 0) continue;
+                    const int L = fL[u], ns = __shfl(nseg, L), a = __shfl(i0, L), e = fe[u];
+                    const int tl = wbase + L;
+                    for (int base = a + 128; base < e; base += 128) {
+                        const int j0 = base + 2 * lane, j1 = j0 + 1;
+                        unsigned c0s = seg_src[0][tl], c1s = c0s;
+                        int c0a = (int)seg_at[0][tl], c1a = c0a;
+                        for (int sx = 1; sx < ns; sx++) {
+                            const unsigned ss = seg_src[sx][tl];
+                            const int sa = (int)seg_at[sx][tl];
+                            if (sa <= j0) { c0s = ss; c0a = sa; }
+                            if (sa <= j1) { c1s = ss; c1a = sa; }
+                        }
+                        const unsigned p0 = (j0 < e && !(c0s >> 31)) ? c0s + (unsigned)(j0 - c0a) : 0u;
+                        const unsigned p1 = (j1 < e && !(c1s >> 31)) ? c1s + (unsigned)(j1 - c1a) : 0u;
+                        const int y0 = (int)ix.col[p0], y1 = (int)ix.col[p1];
+                        const int q0 = (c0s >> 31) ? ((c0s == 0xFFFFFFFFu) ? -1 : (int)(c0s & 0x7FFFFFFFu)) : y0;
+                        const int q1 = (c1s >> 31) ? ((c1s == 0xFFFFFFFFu) ? -1 : (int)(c1s & 0x7FFFFFFFu)) : y1;
+                        if (!(ix.debug & 1)) {
+                            if (j1 < e) st_stream2(out + fob[u] + j0, (i64)q0, (i64)q1);
+                            else if (j0 < e) st_stream(out + fob[u] + j0, (i64)q0);
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < FP; u++)
+                if (lane == fL[u]) { nseg = 0; i0 = i; }
+        }
+        if (ev == FE_EMIT1 || burst_hi >= 0) {
+            if (i == m) {
+                mode = F_IDLE;
+            } else if (ev == FE_EMIT1 && res != -1) {
+                mode = rknown ? tnext : F_POS;         // SBWT.hh:560-
+                l = res;
+            } else if (bridged) {
+                mode = F_EXT;                          // (i < m: the burst was k k-mers long)
+                r += k;
+            } else {
+                do_plan = true;                        // SBWT.hh:557-559 (with certificates)
+            }
+        }
+        if (do_plan) {
+            // where the next walk starts (see k_search_cert): at k-mer i itself, or close to the last failure position b
+            // when b lies inside k-mer i's window
+            int s0 = i, nwk = (ps > 0) ? 1 : 0;
+            if (!force && L0 > 0 && b >= i && b <= i + k - 1) {
+                const int lo = blo > i ? blo : i;
+                if (lo < b && p > 0 && k - pw >= 1) {
+                    // the bad base is somewhere in [lo, b]: halve the range with a window that starts inside it
+                    int x = lo + ((b - lo + 1) >> 1);
+                    if (x > i + k - pw) x = i + k - pw;
+                    if (x <= i) x = i + 1;
+                    s0 = x;
+                    nwk = 3;
+                } else {
+                    s0 = (b - i >= L0 - 1) ? (b - L0 + 1) : b;
+                    if (s0 + p - 1 > i + k - 1) s0 = i;
+                    if (s0 != i) nwk = (pfon && s0 + L0 - 1 <= i + k - 1) ? 2 : 0;
+                }
+            }
+            wstart = s0;
+            j = 0;
+            wk = nwk;
+            if (p > 0) mode = F_INIT;
+            else { mode = F_STEP; l = 0; r = last_node; }
+        }
+    }
+
+    {
+        u64 e = c_ext, eb = c_brg;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { e += __shfl_down(e, off); eb += __shfl_down(eb, off); }
+        if (lane == 0) { atomicAdd(&ws->n_ext, e); atomicAdd(&ws->n_bridge, eb); }
+    }
+    if (lane == 0) {   // the counters are wave-uniform
+        atomicAdd(&ws->n_stream, (u64)c_stream);
+        atomicAdd(&ws->n_search, (u64)c_search);
+        atomicAdd(&ws->n_lf, (u64)c_lf);
+        atomicAdd(&ws->n_tab_hit, (u64)c_tab);
+    }
+}
+
+// Do all reads have one length and all result ranges one stride?  Thread 0 also notes the first offsets.
+__global__ void __launch_bounds__(256) k_check_uniform2(const i64 *__restrict__ read_off, const i64 *__restrict__ out_off,
+                                                        i64 n_reads, SbwtWorkHeader *ws) {
+    const i64 t = (i64)blockIdx.x * 256 + threadIdx.x;
+    const i64 len = read_off[1] - read_off[0], stride = (n_reads > 1) ? out_off[1] - out_off[0] : 0;
+    if (t == 0) { ws->u_read0 = read_off[0]; ws->u_len = len; ws->u_out0 = out_off[0]; ws->u_stride = stride; }
+    if (t >= n_reads) return;
+    const bool bad = (read_off[t + 1] - read_off[t] != len) || (t + 1 < n_reads && out_off[t + 1] - out_off[t] != stride);
+    if (__ballot(bad) != 0 && (threadIdx.x & 63) == 0) ws->u_bad = 1ull;
+}
+
+void sbwt_launch_search_fused(const SbwtIndexView &ix, const char *d_bases, long long total_bases, uint4 *d_packed,
+                              const long long *d_read_off, const long long *d_out_off, long long *d_out, long long n_reads,
+                              SbwtWorkHeader *ws, int streaming, hipStream_t stream, unsigned *d_defer,
+                              hipEvent_t ev_begin, hipEvent_t ev_end) {
+    if (n_reads <= 0) return;
+    hipLaunchKernelGGL(k_check_uniform2, dim3(grid_for(n_reads)), dim3(256), 0, stream, d_read_off, d_out_off, (i64)n_reads, ws);
+    const i64 want = (n_reads + 255) / 256;
+    const unsigned cap = (ix.debug >> 8) ? (unsigned)(ix.debug >> 8) : 1280u;
+    const unsigned g = (unsigned)(want < (i64)cap ? want : (i64)cap);
+    if (ev_begin) (void)hipEventRecord(ev_begin, stream);
+    hipLaunchKernelGGL(k_search_fused, dim3(g), dim3(256), 0, stream, ix, reinterpret_cast<const unsigned char *>(d_bases),
+                       (i64)total_bases, d_out, (i64)n_reads, ws, d_defer);
+    if (ev_end) (void)hipEventRecord(ev_end, stream);
+    // what the fused kernel did not take: everything when the reads are not of one length, else the reads it handed on
+    sbwt_launch_encode_chained(d_bases, total_bases, d_packed, ws, d_defer, ix.k, stream);
+    sbwt_launch_search_chained(ix, d_packed, d_read_off, d_out_off, d_out, n_reads, ws, streaming, stream, d_defer);
+}

@@ -90,7 +90,8 @@ static int tuning_variant() {
     static int v = [] { const char *e = getenv("SBWTGPU_SEARCH_VARIANT"); return e ? atoi(e) : -1; }();
     return v;
 }
-static int g_variant_override = -1, g_probe_override = -1, g_debug = 0, g_derive_ssup = 1;
+static int g_variant_override = -1, g_probe_override = -1, g_debug = 0, g_derive_ssup = 1, g_kernel_events = 0;
+static int64_t g_ev_count = 0;
 // depth of the sparse (hashed) prefix table built at index creation (capped at k and at 31 = one 62-bit key)
 // debug aid for the parity tests: fill the result range with a poison pattern before every search, so that a
 // result the kernel never writes cannot inherit a correct value from an earlier launch
@@ -162,7 +163,7 @@ struct sbwtgpu_index {
 // ("path_lookahead" = 0) -- reads then leave their path every few k-mers and the staged writer with its wide transition
 // entries (2) is the faster one.
 static inline int auto_variant(const SbwtBlobHeader &h) {
-    return (h.path_lookahead > 0 || h.n_branch * 64 <= h.n_nodes) ? 4 : 2;
+    return (h.path_lookahead > 0 || h.n_branch * 64 <= h.n_nodes) ? 5 : 2;
 }
 
 extern "C" {
@@ -175,6 +176,7 @@ int sbwtgpu_set_tuning(const char *key, int64_t value) {
     if (!strcmp(key, "search_variant")) { g_variant_override = (int)value; return SBWTGPU_OK; }
     if (!strcmp(key, "probe_len")) { g_probe_override = (int)value; return SBWTGPU_OK; }
     if (!strcmp(key, "debug")) { g_debug = (int)value; return SBWTGPU_OK; }
+    if (!strcmp(key, "kernel_events")) { g_kernel_events = (int)value; if (value) g_ev_count = 0; return SBWTGPU_OK; }
     if (!strcmp(key, "derive_ssup")) { g_derive_ssup = (int)value; return SBWTGPU_OK; }
     if (!strcmp(key, "poison_results")) { g_poison = (int)value; return SBWTGPU_OK; }
     if (!strcmp(key, "probe_filter")) { g_probe_filter = (int)value; return SBWTGPU_OK; }   // indexes created afterwards
@@ -733,10 +735,12 @@ static inline int64_t ws_packed_bytes(int64_t total_bases) {
 static inline int64_t ws_sort_capacity(int64_t total_bases) {      // only when sorting is switched on ("sort_reads" = 1)
     return g_sort_reads > 0 ? total_bases / 32 + 4096 : 0;
 }
+// the fused route's list of reads handed on to the general kernel: one 32-bit entry per read, reads of >= 32 bases
+static inline int64_t ws_defer_bytes(int64_t total_bases) { return align256(total_bases / 8 + 256); }
 int64_t sbwtgpu_search_workspace_bytes(int64_t total_bases) {
     if (total_bases < 0) total_bases = 0;
     const int64_t n_cap = ws_sort_capacity(total_bases);
-    return align256(ws_packed_bytes(total_bases)) + (n_cap ? 32 * n_cap + ((int64_t)16 << 20) : 0);
+    return align256(ws_packed_bytes(total_bases)) + ws_defer_bytes(total_bases) + (n_cap ? 32 * n_cap + ((int64_t)16 << 20) : 0);
 }
 
 static const char *RANK_ONLY_MSG =
@@ -800,6 +804,7 @@ int sbwtgpu_search_encoded_dev(const sbwtgpu_index *idx, int64_t total_bases, co
     // its reads leave their path every 3-4 k-mers, and short segments fill the lists: 146.4 vs 143.8 ms)
     int variant = g_variant_override >= 0 ? g_variant_override : tuning_variant();
     if (variant < 0) variant = idx->h.has_path ? auto_variant(idx->h) : 2;
+    if (variant == 5) variant = 4;          // already-encoded bases: the fused route's general kernel
     const int eff_streaming = (!streaming && (idx->h.has_ssup || idx->h.ssup_derived) && g_derive_ssup) ? 2 : streaming;
     // reads sorted by their place in the path order (sbwt_sort.hip): when the batch covers the index a few times
     void *sort_scratch = nullptr;
@@ -814,7 +819,7 @@ int sbwtgpu_search_encoded_dev(const sbwtgpu_index *idx, int64_t total_bases, co
     const bool want_sort = path_kernel && g_sort_reads > 0;
     if (want_sort) {
         // the scratch lives in the caller's workspace, behind the packed bases (no allocation, nothing shared between calls)
-        const int64_t off = align256(ws_packed_bytes(total_bases));
+        const int64_t off = align256(ws_packed_bytes(total_bases)) + ws_defer_bytes(total_bases);
         sort_bytes = sbwt_sort_scratch_bytes(n_reads, key_bits);
         if (n_reads <= ws_sort_capacity(total_bases) && off + sort_bytes <= ws_bytes) sort_scratch = static_cast<char *>(d_ws) + off;
     }
@@ -826,12 +831,79 @@ int sbwtgpu_search_encoded_dev(const sbwtgpu_index *idx, int64_t total_bases, co
     return SBWTGPU_OK;
 }
 
+// HIP events around the dominant kernel of the search calls ("kernel_events" = 1; bench.py's roofline leg): a ring of
+// event pairs, so that a timed loop of launches needs no synchronisation in between
+static const int EV_RING = 256;
+static hipEvent_t g_ev[EV_RING][2];
+static int g_ev_made = 0;
+
+int sbwtgpu_kernel_times(double *ms, int64_t cap, int64_t *n) {
+    if (!n || (cap > 0 && !ms)) return fail(SBWTGPU_ERR_INVALID_ARG, "NULL argument");
+    const int64_t have = g_ev_count < EV_RING ? g_ev_count : EV_RING;
+    const int64_t first = g_ev_count - have;
+    int64_t w = 0;
+    for (int64_t q = first; q < g_ev_count && w < cap; q++, w++) {
+        hipEvent_t *e = g_ev[q % EV_RING];
+        HIP_TRY(hipEventSynchronize(e[1]));
+        float f = 0;
+        HIP_TRY(hipEventElapsedTime(&f, e[0], e[1]));
+        ms[w] = (double)f;
+    }
+    *n = w;
+    return SBWTGPU_OK;
+}
+
 static int search_dev_common(const sbwtgpu_index *idx, const char *d_bases, int64_t total_bases,
                              const int64_t *d_read_off, int64_t n_reads, int64_t *d_out, const int64_t *d_out_off,
                              void *d_ws, int64_t ws_bytes, void *stream, int streaming) {
     int rc = search_dev_check(idx, total_bases, n_reads, d_ws, ws_bytes, streaming);
     if (rc != SBWTGPU_OK) return rc;
     if (n_reads == 0) return SBWTGPU_OK;
+    {
+        // The fused route (sbwt_search_fused.hip; "search_variant" 5, the default on a path-order index): no separate
+        // encode pass.  It decides on the device whether the batch qualifies (reads of one length, 32 .. 160 bases) and
+        // runs the general kernel behind the fused one for everything that does not.
+        int variant = g_variant_override >= 0 ? g_variant_override : tuning_variant();
+        if (variant < 0) variant = idx->h.has_path ? auto_variant(idx->h) : 2;
+        const int eff_streaming = (!streaming && (idx->h.has_ssup || idx->h.ssup_derived) && g_derive_ssup) ? 2 : streaming;
+        const bool path_kernel = idx->h.has_path && eff_streaming && idx->h.stab_pos &&
+                                 idx->h.n_nodes < ((int64_t)1 << 31) - 128 && n_reads < ((int64_t)1 << 31) &&
+                                 total_bases / SBWT_GROUP_BASES + 2 < ((int64_t)1 << 31) - 4;
+        if (variant == 5 && path_kernel && g_sort_reads <= 0 && !(g_debug & 16)) {
+            if (!d_read_off || !d_out_off) return fail(SBWTGPU_ERR_INVALID_ARG, "NULL device pointer");
+            if (total_bases > 0 && !d_bases) return fail(SBWTGPU_ERR_INVALID_ARG, "NULL device pointer");
+            DeviceGuard guard(idx->device);
+            hipStream_t st = static_cast<hipStream_t>(stream);
+            SbwtWorkHeader *ws = static_cast<SbwtWorkHeader *>(d_ws);
+            HIP_TRY(hipMemsetAsync(ws, 0, sizeof(SbwtWorkHeader), st));
+            if (g_poison) {
+                int64_t ends[2] = {0, 0};
+                HIP_TRY(hipMemcpyAsync(&ends[0], d_out_off, 8, hipMemcpyDeviceToHost, st));
+                HIP_TRY(hipMemcpyAsync(&ends[1], d_out_off + n_reads, 8, hipMemcpyDeviceToHost, st));
+                HIP_TRY(hipStreamSynchronize(st));
+                if (ends[1] > ends[0]) HIP_TRY(hipMemsetAsync(d_out + ends[0], 0xA5, (size_t)(ends[1] - ends[0]) * 8, st));
+            }
+            uint4 *packed = reinterpret_cast<uint4 *>(static_cast<char *>(d_ws) + sizeof(SbwtWorkHeader));
+            unsigned *defer = reinterpret_cast<unsigned *>(static_cast<char *>(d_ws) + align256(ws_packed_bytes(total_bases)));
+            hipEvent_t e0 = nullptr, e1 = nullptr;
+            if (g_kernel_events) {
+                const int slot = (int)(g_ev_count % EV_RING);
+                if (slot >= g_ev_made) {
+                    HIP_TRY(hipEventCreate(&g_ev[slot][0]));
+                    HIP_TRY(hipEventCreate(&g_ev[slot][1]));
+                    g_ev_made = slot + 1;
+                }
+                e0 = g_ev[slot][0]; e1 = g_ev[slot][1];
+                g_ev_count++;
+            }
+            sbwt_launch_search_fused(idx->view(), d_bases, total_bases, packed, reinterpret_cast<const long long *>(d_read_off),
+                                     reinterpret_cast<const long long *>(d_out_off), reinterpret_cast<long long *>(d_out), n_reads,
+                                     ws, eff_streaming, st, defer, e0, e1);
+            hipError_t e = hipGetLastError();
+            if (e != hipSuccess) return fail(SBWTGPU_ERR_HIP, "kernel launch: %s", hipGetErrorString(e));
+            return SBWTGPU_OK;
+        }
+    }
     rc = sbwtgpu_encode_bases_dev(idx, d_bases, total_bases, d_ws, ws_bytes, stream);
     if (rc != SBWTGPU_OK) return rc;
     return sbwtgpu_search_encoded_dev(idx, total_bases, d_read_off, n_reads, d_out, d_out_off, d_ws, ws_bytes,

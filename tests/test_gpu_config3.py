@@ -50,9 +50,12 @@ def test_config3_pangenome_k31(gpu):
             capi.set_tuning("trans_ext", -1)
         return out
 
-    a = run(True, 3)                          # the product path (transitions decide per wave whether to run on)
+    a = run(True, 5)                          # the product path: the fused route (transitions decide per wave whether to run on)
     stats = idx.workspace_stats(d_ws.data_ptr(), st)
     assert stats[4] > 0, "the path-order kernel did not run"      # k-mers answered along path runs
+    assert torch.equal(a, run(True, 5, 1))    # transitions always run on along the quoted steps
+    assert torch.equal(a, run(True, 5, 0))    # ... never
+    assert torch.equal(a, run(True, 3))       # pooled reads (experiment, cross-check)
     assert torch.equal(a, run(True, 3, 1))    # transitions always run on along the quoted steps
     assert torch.equal(a, run(True, 3, 0))    # ... never
     assert torch.equal(a, run(True, 2))       # path order, one lane per read

@@ -46,8 +46,10 @@ def test_config2_full_size_properties(gpu):
             capi.set_tuning("search_variant", -1)
         return out
 
-    a = run(True, 3)                      # the product path: path order, pooled reads (k_search_pool)
+    a = run(True, 5)                      # the product path: the fused route (k_search_fused, sbwt_search_fused.hip)
     assert idx.workspace_stats(d_ws.data_ptr(), st)[4] > 0
+    assert torch.equal(a, run(True, 3))   # path order, pooled reads (k_search_pool: an experiment kept as a cross-check)
+    assert torch.equal(a, run(False, 5))  # the fused route under SBWT::search (internal streaming; upper-case input)
     assert torch.equal(a, run(True, 2))   # path order, one lane per read (k_search_cert<PATH>)
     assert torch.equal(a, run(True, 4))   # ... with segment lists instead of staged results
     assert torch.equal(a, run(True, 1))   # certificates on the blocks only

@@ -218,7 +218,8 @@ def test_streaming_equals_search_at_scale_properties(gpu, genome_case):
 @pytest.mark.parametrize("variant,probe", [(0, -1), (1, -1), (1, 0), (1, 9), (1, 11), (1, 12), (1, 13), (1, 20), (1, 29),
                                            (2, -1), (2, 0), (2, 9), (2, 13), (2, 29),
                                            (3, -1), (3, 0), (3, 9), (3, 12), (3, 13), (3, 29),
-                                           (4, -1), (4, 0), (4, 9), (4, 12), (4, 13), (4, 29)])
+                                           (4, -1), (4, 0), (4, 9), (4, 12), (4, 13), (4, 29),
+                                           (5, -1), (5, 0), (5, 9), (5, 12), (5, 13), (5, 29)])
 def test_results_do_not_depend_on_search_variant_or_probe_length(gpu, genome_case, variant, probe):
     # k_search (reference order), k_search_cert (absent-substring certificates) and its path-order form
     # must give the same bits for every probe length, including reads with N / lower case and all-miss reads
@@ -487,7 +488,7 @@ def test_periodic_sequences_cycles_in_the_path_order(gpu, k):
     woff = np.concatenate([[0], np.cumsum([len(g) for g in genomes])]).astype(np.int64)
     bases = np.concatenate([bases, whole])
     off = np.concatenate([off, woff[1:] + off[-1]])
-    for variant in (4, 3, 2, 1):
+    for variant in (5, 4, 3, 2, 1):
         capi.set_tuning("search_variant", variant)
         try:
             got, _ = idx.streaming_search(bases, off)
@@ -625,7 +626,7 @@ def test_sorted_reads_give_the_same_bits(gpu, genome_case, variant):
 
 
 @pytest.mark.parametrize("wide", [0, 1])
-@pytest.mark.parametrize("variant", [2, 3, 4])
+@pytest.mark.parametrize("variant", [2, 3, 4, 5])
 def test_wide_transition_entries(gpu, genome_case, variant, wide):
     # "trans_wide": transition entries that carry the columns of the successor's next four path steps (branchy
     # indexes; forced here) -- short runs after a transition are served from the entry; same bits either way, with the

@@ -59,7 +59,7 @@ while time.time() < t_end:
         bases = synth.inject(bases, int(rng.integers(0, 30)), ord("N"), int(rng.integers(1, 1 << 30)))
         bases = synth.inject(bases, int(rng.integers(0, 30)), int(rng.choice(list(b"acgtn"))), int(rng.integers(1, 1 << 30)))
     res = {}
-    for v in (0, 1, 2, 3, 4):
+    for v in (0, 1, 2, 3, 4, 5):
         capi.set_tuning("search_variant", v)
         capi.set_tuning("sort_reads", int(rng.integers(0, 2)) if v in (2, 4) else -1)
         for te in ((-1, 1) if v >= 2 else (-1,)):
