@@ -10,7 +10,10 @@ export TMPDIR=/tmp
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p $OUT
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py $ARGS > $OUT/trace_bench.json 2> $OUT/trace.err
-for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum TCC_EA0_RDREQ_128B_sum" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_WAVES" "GRBM_GUI_ACTIVE TCP_TCC_READ_REQ_sum"; do
+# PMC_GROUPS (env): '|'-separated counter groups, e.g. "SQ_INSTS_VALU SQ_INSTS_SALU|TCC_EA0_RDREQ_sum"; default = the full set
+DEFAULT_GROUPS="FETCH_SIZE|WRITE_SIZE|TCC_HIT_sum TCC_MISS_sum|TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum TCC_EA0_RDREQ_128B_sum|SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY|SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_WAVES|GRBM_GUI_ACTIVE TCP_TCC_READ_REQ_sum"
+IFS='|' read -ra GROUPS_ARR <<< "${PMC_GROUPS:-$DEFAULT_GROUPS}"
+for grp in "${GROUPS_ARR[@]}"; do
   name=$(echo $grp | tr ' ' '_')
   rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $OUT/pmc_$name -- python3 bench.py $ARGS > /dev/null 2> $OUT/pmc_$name.err || echo "pmc $grp failed" >> $OUT/errors.txt
 done
