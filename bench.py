@@ -341,8 +341,16 @@ def main() -> int:
     bits = None
     if rank == 0:
         # columns: on the GPU for k <= 32 (sbwtgpu_build_plain_matrix), host sort-based builder beyond
+        columns_on = "gpu" if K <= 32 else "host"
         if K <= 32:
-            bits = capi.build_bits_gpu([g.tobytes() for g in genomes], K, False, streaming, device=local_rank)
+            try:
+                bits = capi.build_bits_gpu([g.tobytes() for g in genomes], K, False, streaming, device=local_rank)
+            except capi.SbwtGpuError as ex:
+                if ex.code not in (capi.ERR_OOM, capi.ERR_HIP):
+                    raise
+                log(f"device builder: {ex.msg}; building the columns on the host instead")
+                columns_on = "host (device builder did not fit)"
+                bits = hostlib.build_bits([g.tobytes() for g in genomes], K, False, streaming, n_threads=effective_cores())
         else:
             bits = hostlib.build_bits([g.tobytes() for g in genomes], K, False, streaming, n_threads=effective_cores())
         t_cols = time.time() - t0
@@ -380,7 +388,7 @@ def main() -> int:
     if rank == 0:
         log(f"index: n_nodes={index.n_nodes} n_kmers={index.n_kmers} image={index.blob_bytes / 1e6:.1f} MB level={index.image_level} "
             f"device_precalc={index.device_precalc_k} (columns {t_cols:.2f} s + image {t_img:.2f} s)")
-        build_times = {"columns_s": t_cols, "image_s": t_img, "columns_on": "gpu" if K <= 32 else "host",
+        build_times = {"columns_s": t_cols, "image_s": t_img, "columns_on": columns_on,
                        "image_level": index.image_level, "image_bytes_per_column": index.blob_bytes / index.n_nodes,
                        "paths": index.n_paths, "branching_columns": index.n_branch,
                        "search_variant": index.default_search_variant}

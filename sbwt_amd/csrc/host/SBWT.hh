@@ -55,8 +55,14 @@ inline PlainMatrixBits build_plain_matrix_bits_any(const std::vector<std::string
     std::vector<int64_t> len(seqs.size());
     for (size_t i = 0; i < seqs.size(); i++) { ptr[i] = seqs[i].data(); len[i] = (int64_t)seqs[i].size(); }
     sbwtgpu_plain_matrix_bits b;
-    detail::gpu_check(sbwtgpu_build_plain_matrix(ptr.data(), len.data(), (int64_t)seqs.size(), k, add_revcomp ? 1 : 0,
-                                                 build_streaming_support ? 1 : 0, detail::default_device(), &b));
+    const int rc = sbwtgpu_build_plain_matrix(ptr.data(), len.data(), (int64_t)seqs.size(), k, add_revcomp ? 1 : 0,
+                                              build_streaming_support ? 1 : 0, detail::default_device(), &b);
+    // the device builder holds the text, its packed form, two key arrays and the sort's temporary at once; an input that
+    // does not fit (or a device that fails) is built by the host builder, as before the device builder existed.  (This is
+    // index CONSTRUCTION; queries have no host path.)
+    if (rc == SBWTGPU_ERR_OOM || rc == SBWTGPU_ERR_HIP)
+        return build_plain_matrix_bits(seqs, k, add_revcomp, build_streaming_support, n_threads);
+    detail::gpu_check(rc);
     PlainMatrixBits out;
     out.n_nodes = b.n_nodes; out.n_kmers = b.n_kmers; out.k = b.k;
     const size_t nw = (size_t)((b.n_nodes + 63) / 64);

@@ -390,6 +390,7 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
     if (defer_list && sbwt_fused_ok(ws, ix.k)) {
         n_reads = (i64)ws->n_deferred;
         perm = defer_list;
+        if (n_reads == 0) return;                      // the usual case: nothing was handed on
     }
     typedef typename SearchTypes<WIDE>::pos_t pos_t;
     typedef typename SearchTypes<WIDE>::stage_t stage_t;
@@ -1296,13 +1297,13 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
         u64 e = c_ext, eb = c_brg;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) { e += __shfl_down(e, off); eb += __shfl_down(eb, off); }
-        if (lane == 0) { atomicAdd(&ws->n_ext, e); atomicAdd(&ws->n_bridge, eb); }
+        if (lane == 0) { if (e) atomicAdd(&ws->n_ext, e); if (eb) atomicAdd(&ws->n_bridge, eb); }
     }
-    if (lane == 0) {   // the counters are wave-uniform
-        atomicAdd(&ws->n_stream, (u64)c_stream);
-        atomicAdd(&ws->n_search, (u64)c_search);
-        atomicAdd(&ws->n_lf, (u64)c_lf);
-        atomicAdd(&ws->n_tab_hit, (u64)c_tab);
+    if (lane == 0) {   // the counters are wave-uniform (a wave that found no work adds nothing: single-address atomics are slow)
+        if (c_stream) atomicAdd(&ws->n_stream, (u64)c_stream);
+        if (c_search) atomicAdd(&ws->n_search, (u64)c_search);
+        if (c_lf) atomicAdd(&ws->n_lf, (u64)c_lf);
+        if (c_tab) atomicAdd(&ws->n_tab_hit, (u64)c_tab);
     }
 }
 

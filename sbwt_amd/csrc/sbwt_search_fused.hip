@@ -255,7 +255,7 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
                 rknown = true;
                 if (use_q) {
                     // the read's next bases against the 8 steps quoted in the entry: short runs end here
-                    const unsigned rq = (unsigned)(s == 31 ? cw1 : (rw >> 2));       // bases P+1 ..
+                    const unsigned rq = (unsigned)(rw >> 2);                            // bases P+1 ..
                     const unsigned x = (rq ^ v1.z) & 0xFFFFu;
                     const unsigned mm = (x | (x >> 1)) & 0x5555u;
                     const int nm = mm ? ((__ffs((int)mm) - 1) >> 1) : 8;
@@ -635,13 +635,13 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
         u64 e = c_ext, eb = c_brg;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) { e += __shfl_down(e, off); eb += __shfl_down(eb, off); }
-        if (lane == 0) { atomicAdd(&ws->n_ext, e); atomicAdd(&ws->n_bridge, eb); }
+        if (lane == 0) { if (e) atomicAdd(&ws->n_ext, e); if (eb) atomicAdd(&ws->n_bridge, eb); }
     }
     if (lane == 0) {   // the counters are wave-uniform
-        atomicAdd(&ws->n_stream, (u64)c_stream);
-        atomicAdd(&ws->n_search, (u64)c_search);
-        atomicAdd(&ws->n_lf, (u64)c_lf);
-        atomicAdd(&ws->n_tab_hit, (u64)c_tab);
+        if (c_stream) atomicAdd(&ws->n_stream, (u64)c_stream);
+        if (c_search) atomicAdd(&ws->n_search, (u64)c_search);
+        if (c_lf) atomicAdd(&ws->n_lf, (u64)c_lf);
+        if (c_tab) atomicAdd(&ws->n_tab_hit, (u64)c_tab);
     }
 }
 

@@ -1471,6 +1471,15 @@ int sbwtgpu_build_plain_matrix(const char *const *seqs, const int64_t *seq_len, 
         int ra = sbwt_build_phase_a(text.data(), n_text, (int)k, add_revcomp ? 1 : 0, &S, 0);
         if (ra != 0) { sbwt_build_release(&S); return fail(ra == -8 ? SBWTGPU_ERR_OOM : SBWTGPU_ERR_HIP, "device builder, phase A"); }
         std::vector<char>().swap(text);
+        // the dummy prefixes are expanded on the host, k per predecessor-less k-mer at 16 bytes each: about one k-mer per
+        // input SEQUENCE, so a genome has a handful and a read set has millions.  Past 2^26 records (1 GiB) the caller's
+        // host builder (index_builder.hh) is the better tool: report it as "does not fit".
+        if ((long long)S.n_nopred * (long long)k > (1ll << 26)) {
+            sbwt_build_release(&S);
+            return fail(SBWTGPU_ERR_OOM, "device builder: %lld predecessor-less k-mers x k = %lld dummy records (limit 2^26): "
+                        "use the host builder for inputs with this many sequences", (long long)S.n_nopred,
+                        (long long)S.n_nopred * (long long)k);
+        }
         nopred.resize((size_t)S.n_nopred);
         if (sbwt_build_copy_nopred(&S, nopred.data()) != 0) { sbwt_build_release(&S); return fail(SBWTGPU_ERR_HIP, "device builder: copy"); }
         // dummy prefixes of the predecessor-less k-mers (NodeBOSSInMemoryConstructor.hh:70-79) + the root, sorted like

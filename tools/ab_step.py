@@ -1,0 +1,71 @@
+"""A/B timing of whole search STEPS (sbwtgpu_streaming_search_dev: every kernel of the route, encode included) in ONE
+process, interleaved rounds.  Env: NREADS, GLEN, ROUNDS, READLEN, K, CONFIGS = json list of [variant, debug] pairs,
+GENOMES = coli3 | pan<N> | single.  Prints per config: median / min step ms, the fused kernel's own ms (variant 5), the
+work counters, and a checksum that must be the same for every config."""
+import os, sys, json
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from sbwt_amd import capi, hostlib, synth
+import bench as B
+
+n_reads = int(os.environ.get("NREADS", 10_000_000))
+glen = int(os.environ.get("GLEN", 5_000_000))
+K = int(os.environ.get("K", 30))
+L = int(os.environ.get("READLEN", 150))
+configs = json.loads(os.environ.get("CONFIGS", "[[5,0],[4,0]]"))
+rounds = int(os.environ.get("ROUNDS", 5))
+streaming = int(os.environ.get("STREAMING", 1))
+gsel = os.environ.get("GENOMES", "coli3")
+dev = torch.device("cuda", 0)
+if gsel.startswith("pan"):
+    genomes = synth.pan_like(int(gsel[3:] or 64), glen)
+else:
+    genomes = synth.coli3_like(glen)
+    if gsel == "single":
+        genomes = genomes[:1]
+B.K, B.READ_LEN = K, L
+if K <= 32:
+    bits = capi.build_bits_gpu([g.tobytes() for g in genomes], K, False, bool(streaming))
+else:
+    bits = hostlib.build_bits([g.tobytes() for g in genomes], K, False, bool(streaming), n_threads=os.cpu_count())
+idx = capi.Index.create(bits.cols[0], bits.cols[1], bits.cols[2], bits.cols[3], bits.ssup, bits.n_nodes, K, bits.n_kmers, 8)
+print("index: n_nodes", idx.n_nodes, "image MB", idx.blob_bytes / 1e6, "B/col", idx.blob_bytes / idx.n_nodes, "paths", idx.n_paths,
+      "branching", idx.n_branch, flush=True)
+d_bases = B.gpu_reads(genomes, n_reads, 42, dev)
+m = L - K + 1
+d_roff = torch.arange(n_reads + 1, dtype=torch.int64, device=dev) * L
+d_ooff = torch.arange(n_reads + 1, dtype=torch.int64, device=dev) * m
+d_out = torch.empty(n_reads * m, dtype=torch.int64, device=dev)
+wsb = capi.search_workspace_bytes(d_bases.numel())
+d_ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+st = torch.cuda.current_stream().cuda_stream
+w = torch.arange(1, m + 1, device=dev, dtype=torch.int64)
+ref = None
+times = {tuple(c): [] for c in configs}
+ktimes = {tuple(c): [] for c in configs}
+capi.set_tuning("kernel_events", 1)
+for rnd in range(rounds + 1):
+    for c in configs:
+        capi.set_tuning("search_variant", c[0]); capi.set_tuning("debug", c[1] if len(c) > 1 else 0)
+        if rnd == 0:
+            d_out.fill_(-7)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        idx.streaming_search_dev(d_bases.data_ptr(), d_bases.numel(), d_roff.data_ptr(), n_reads, d_out.data_ptr(), d_ooff.data_ptr(),
+                                 d_ws.data_ptr(), wsb, st, bool(streaming))
+        e1.record(); torch.cuda.synchronize()
+        if rnd == 0:
+            chk = int(((d_out.view(n_reads, m) * w).sum(dim=1) * torch.arange(1, n_reads + 1, device=dev)).sum().item())
+            if ref is None: ref = chk
+            print("config", c, "checksum", chk, "same" if chk == ref else "DIFFERENT", "stats", idx.workspace_stats(d_ws.data_ptr(), st),
+                  "bridges", idx.workspace_bridges(d_ws.data_ptr(), st), flush=True)
+        else:
+            times[tuple(c)].append(e0.elapsed_time(e1))
+            if c[0] == 5:
+                ktimes[tuple(c)].append(capi.kernel_times()[-1])
+for c, v in times.items():
+    kt = ktimes[c]
+    print(f"variant={c[0]} debug={c[1] if len(c) > 1 else 0}: step median {np.median(v):.3f} ms min {min(v):.3f} ms -> "
+          f"{n_reads * m / np.median(v) / 1e6:.2f} G kmers/s" + (f"; fused kernel median {np.median(kt):.3f} ms" if kt else ""))
