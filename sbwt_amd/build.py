@@ -43,7 +43,7 @@ def _glob(d, exts):
 def build_gpu(force=False) -> str:
     os.makedirs(LIB, exist_ok=True)
     out = os.path.join(LIB, "libsbwtgpu.so")
-    srcs = [os.path.join(CSRC, f) for f in ("sbwt_search.hip", "sbwt_search_fused.hip", "sbwt_search_pool.hip", "sbwt_api_kernels.hip", "sbwt_derived.hip", "sbwt_build.hip", "sbwt_sort.hip",
+    srcs = [os.path.join(CSRC, f) for f in ("sbwt_search.hip", "sbwt_search_fused.hip", "sbwt_api_kernels.hip", "sbwt_derived.hip", "sbwt_build.hip", "sbwt_sort.hip",
                                             "sbwt_format.hip", "sbwtgpu_capi.cpp")]
     deps = srcs + [os.path.join(CSRC, f) for f in ("sbwt_device.h", "sbwt_kernels_common.h", "sbwt_scan.h")] + \
         [os.path.join(INC, "sbwtgpu.h")]

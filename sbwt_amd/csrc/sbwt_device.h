@@ -7,9 +7,10 @@
 //   [ ftab     : 4^p_file x 16 B ]   the index file's own table (only if p_file != p_dev, p_file > 0)
 //   [ mega     : 4 x n_mega x 8 B]   absolute (C[c] + rank_c) at every 2^31-column boundary
 //   [ col, pos : n_nodes x 4 B each ]  path order (see k_path_* in sbwt_derived.hip)
-//   [ pq       : (n/32+2) x 16 B ]   packed chars + go bits along the paths
-//   [ trans    : n_nodes x 64 B  ]   the four successors of every path position (column, path position, next 8 steps);
-//                                    x 128 B on branchy indexes (trans_wide): + the columns of the successor's next 4 steps
+//   [ pq       : (n/32+4) x 32 B ]   path groups of 32 positions: packed chars, GO / SAFE bits, successors off the path
+//   [ trans    : 2^log2t x 64 B  ]   transition table: one hashed entry per (position, char) with a successor off the
+//                                    path (column, path position, the next 32 steps of its path); sized once the path order
+//                                    is known -- ~2 entries per branching column + one per path end (k_trans_insert)
 //   [ pfil     : 2^log2f x 16 B  ]   probe filter (see k_pf_insert)
 //   [ stab2    : 2^log2b2 x 32 B ]   second level for 31 < k <= 63: { rest key (8 B), first column of the 31-prefix's
 //                                    interval, flags } { column, path position, -, - }
@@ -51,19 +52,15 @@ struct SbwtIndexView {
     int p_sparse;                   // its depth (0 = none)
     int log2b;                      // log2 of its number of buckets
     const unsigned *col, *pos;      // path order: column at path position t, path position of column v (nullptr = none)
-    const uint4 *pq;                // packed path chars: quad t>>5 = { 32 chars (2 bits each), A, B }: go = ~A | B, safe = A & B,
-                                    // only successor = ~A & B (k_path_reencode, sbwt_derived.hip)
-    int has_safe;                   // the safe masks are filled in (k_path_safe)
-    int trans_ext;                  // run on from a transition along the 8 steps its entry quotes: 1 always, 0 never,
-                                    // -1 (default) while most runs after a transition are shorter than that (per wave)
+    const uint4 *pq;                // path groups, two quads per 32 positions: { chars lo, chars hi, GO, SAFE } { OTH0 .. OTH3 }
+                                    // (k_path_place, k_path_safe*, k_path_oth in sbwt_derived.hip)
+    int has_safe;                   // the SAFE planes are filled in (k_path_safe*)
     const uint4 *stab2;             // second-level sparse table for 31 < k <= 63 (nullptr = none): key = (first column of the
     int log2b2;                     // 31-prefix's interval, the remaining k-31 bases) -> the k-mer's column and path position
     const uint4 *pfil;              // probe filter: blocked Bloom filter over the p_filter-mers of the index (nullptr = none)
     int p_filter, log2f;            // its depth and log2 of its number of 16-byte blocks
-    const uint4 *trans;             // transition table: 4 quads per path position, one per char: { successor column, its path
-                                    // position, its path's next 8 steps (chars | go << 16 | safe << 24), - }
-    int trans_wide;                 // transition entries are two quads: the second = the columns of the successor's next four
-                                    // path steps (branchy indexes: short runs after a transition need no look at col[])
+    const uint4 *trans;             // transition table: 2^log2t hashed 64-byte entries (k_trans_insert, sbwt_derived.hip)
+    int log2t;
     int stab_pos;                   // sparse entries are whole k-mers stored with their path position
     int debug;                      // experiments only: bit0 = skip result stores
     int force_mega;                 // one mega block whose counts do not fit 32 bits (dense rank-only images): cnt is relative
@@ -72,7 +69,7 @@ struct SbwtIndexView {
 
 // Position-independent description of a blob (what index_export_header hands out).
 struct SbwtBlobHeader {
-    uint64_t magic;                 // 'SBWTGPU1'
+    uint64_t magic;                 // 'SBWTGPU2'
     int64_t n_nodes, n_kmers, k, p_file, p_dev;
     int64_t C[4];
     int64_t n_blocks, n_mega;
@@ -91,7 +88,8 @@ struct SbwtBlobHeader {
     int32_t log2f;
     int32_t has_safe;               // pq carries the substitution-safe bits
     int32_t force_mega;             // block counts are relative to mega[c][0] although n_mega == 1 (see SbwtIndexView)
-    int64_t trans_wide;             // 1: 32-byte transition entries (see SbwtIndexView)
+    int64_t log2t;                  // transition table: log2 of its number of 64-byte entries
+    int64_t n_trans;                // ... and how many of them are in use
     int64_t n_paths;                // paths of the path order
     int64_t n_branch;               // columns with two or more successors (n_nodes / n_branch = columns between choices)
     int64_t image_level;            // 0 full, 1 no path order, 2 blocks + dense prefix table only
@@ -100,7 +98,7 @@ struct SbwtBlobHeader {
     int64_t off_stab2;
     int64_t path_lookahead;         // steps the path order looked ahead / behind when it chose successors (0: blind rule)
 };
-#define SBWT_BLOB_MAGIC 0x3155504754574253ull   // "SBWTGPU1" little endian
+#define SBWT_BLOB_MAGIC 0x3255504754574253ull   // "SBWTGPU2" little endian
 
 // Sparse prefix table entry words
 #define SBWT_SP_EMPTY (1ull << 63)              // the whole word of a free entry
@@ -166,9 +164,6 @@ long long sbwt_sort_scratch_bytes(long long n_reads, int key_bits);
 const unsigned *sbwt_launch_sort_reads(const SbwtIndexView &ix, const uint4 *d_packed, const long long *d_read_off,
                                        long long n_reads, const SbwtWorkHeader *ws, void *d_scratch, long long scratch_bytes,
                                        int key_bits, hipStream_t stream);
-void sbwt_launch_search_pool(const SbwtIndexView &ix, const uint4 *d_packed, const long long *d_read_off,
-                             const long long *d_out_off, long long *d_out, long long n_reads, SbwtWorkHeader *ws,
-                             int streaming, hipStream_t stream);
 void sbwt_launch_rank(const SbwtIndexView &ix, const long long *d_pos, const char *d_sym, long long n,
                       long long *d_out, hipStream_t stream);
 void sbwt_launch_precalc(const SbwtIndexView &ix, int p, longlong2 *d_table, hipStream_t stream);
@@ -197,8 +192,9 @@ long long sbwt_path_quads(long long n_nodes);
 long long sbwt_count_paths(const SbwtIndexView &ix, hipStream_t stream);
 void sbwt_launch_path_safe(const SbwtIndexView &ix, uint4 *d_pq, int rule, void *d_hlab, unsigned char *d_alt_safe,
                            hipStream_t stream);
-long long sbwt_launch_path_trans(const SbwtIndexView &ix, uint4 *d_trans, uint4 *d_pq, const unsigned char *d_alt_safe,
-                                 hipStream_t stream);
+long long sbwt_path_safe_scratch_bytes(long long n_nodes);
+long long sbwt_launch_path_oth(const SbwtIndexView &ix, uint4 *d_pq, long long *n_branch, hipStream_t stream);
+void sbwt_launch_trans_insert(const SbwtIndexView &ix, uint4 *d_trans, int log2t, hipStream_t stream);
 int sbwt_launch_build_path(const SbwtIndexView &ix, unsigned *d_col, unsigned *d_pos, uint4 *d_pq, uint4 *d_trans,
                            void *d_scratch, int lookahead, hipStream_t stream);
 int sbwt_launch_build_sparse(const SbwtIndexView &ix, int p_dense, int p_sparse, int log2b, uint4 *d_table,

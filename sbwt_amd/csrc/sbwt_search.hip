@@ -375,7 +375,7 @@ __device__ __forceinline__ typename SearchTypes<WIDE>::pos_t quad_rank_t(const S
 //     bytes.  One cooperative pass per read instead of one descriptor per run and iteration (the descriptor writer is
 //     53 % of this kernel's vector instructions).
 #define SBWT_NSEG 12
-template <bool WIDE, int WPS, bool PATH, bool SEG = false>
+template <bool WIDE, int WPS, bool PATH>
 __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, const uint4 *__restrict__ packed,
                                                         const i64 *__restrict__ read_off,
                                                         const i64 *__restrict__ out_off, i64 *__restrict__ out,
@@ -395,12 +395,12 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
     typedef typename SearchTypes<WIDE>::pos_t pos_t;
     typedef typename SearchTypes<WIDE>::stage_t stage_t;
     constexpr int DEPTH = SearchTypes<WIDE>::DEPTH;
-    static_assert(!SEG || (PATH && !WIDE), "segment lists: 32-bit path-order kernel only");
+    constexpr bool SEG = PATH;                      // the path-order kernel writes through per-read segment lists
+    static_assert(!PATH || !WIDE, "path order: 32-bit indexes only");
     // a third cached packed group, fetched in pairs (see the loads below).  SEG only: the descriptor-writer kernel would
     // pay for the registers with a wave per SIMD (config 3: 123 -> 150 ms)
     constexpr bool G3 = SEG;
     __shared__ stage_t stage[SEG ? 1 : DEPTH][SEG ? 1 : 256];
-    __shared__ uint4 desc[(PATH && !SEG) ? 4 : 1][(PATH && !SEG) ? 128 : 1];      // PATH: run descriptors, per wave
     __shared__ uint2 segs[SEG ? SBWT_NSEG : 1][SEG ? 256 : 1];                      // SEG: { source, first k-mer } per lane
     const int tid = threadIdx.x, lane = tid & 63;
     int nseg = 0, i0 = 0, last_start = 0;           // SEG: segments listed; first result of the read not written yet
@@ -435,7 +435,6 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
     uint4 g0 = make_uint4(0, 0, 0, 0), g1 = make_uint4(0, 0, 0, 0), g2 = make_uint4(0, 0, 0, 0);
     u64 pool_next = 0, pool_end = 0;                              // wave-uniform pool of read tickets
     unsigned c_stream = 0, c_search = 0, c_lf = 0, c_tab = 0;     // wave-uniform (scalar) work counters
-    unsigned c_iter = 0, c_short = 0;                             // PATH: iterations of this wave; runs shorter than 8 k-mers
 
     for (;;) {
         // ---- hand out reads to idle lanes from the wave's ticket pool ----
@@ -481,21 +480,14 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
         //      one (or none) load a duplicate (or the first block), so that the wave issues both
         //      loads back to back and waits once. ----
         int kind = K_NONE, ev = EV_NONE, tfail = 0, c = 0, grp = 0;
-        const uint4 *a1 = ix.blocks, *a2 = ix.blocks;
+        const uint4 *a1 = ix.blocks, *a2 = ix.blocks, *ax = nullptr, *ay = nullptr;   // ax, ay: PATH: the third / fourth quad of a path step
         pos_t res = -1;
         const bool strm = !PATH && (mode == M_STREAM || mode == M_BACK);
         const bool ext = PATH && (mode == M_EXT);
         const bool trn = PATH && (mode == M_TRANS);
         const bool brg = PATH && (mode == M_BRIDGE);
         bool rknown = false;                           // PATH: this iteration's answer came with its path position (in r)
-        bool qshort = false;                           // PATH: a run of fewer than 8 k-mers ended in this iteration
         bool ext_absent = false;                       // SEG: the k-mer after this iteration's run is absent (only-successor step)
-        int nlit = 0;                                  // trans_wide: results that came with the transition entry ...
-        uint4 lit = make_uint4(0u, 0u, 0u, 0u);        // ... the columns of the successor's next path steps
-        // run on from transitions while short runs are a sizeable part of this wave's work (one lane-iteration in
-        // eight: pan-genomes; on a few strains the saved iterations do not pay for the extra instructions)
-        const bool use_q = PATH && (ix.trans_ext > 0 || (ix.trans_ext < 0 && c_short >= 8u * c_iter));
-        c_iter++;
         int tnext = M_EXT;                             // PATH: where a transition's quoted steps already end the run
         pos_t tpos = -1;
         int seg_n = 0;                                 // PATH: k-mers i .. i+seg_n-1 are col[seg_src ..]
@@ -532,7 +524,8 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
                 g2ok = false;
                 tag = grp;
             }
-            if (grp != tag || (mode == M_INIT && s + wl > 32 && !g1ok)) {
+            // (a path step compares up to 64 bases and has no load slot left for the next group: it wants the pair cached)
+            if (grp != tag || ((mode == M_INIT ? s + wl > 32 : (PATH && (ext || trn || brg))) && !g1ok)) {
                 kind = K_RELOAD;                       // the packed group pair holding the next base(s)
                 a1 = packed + grp;
                 a2 = a1 + 1;
@@ -540,18 +533,20 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
                 kind = K_MODE;
                 const u64 codes0 = quad_bits(g0);
                 c = (int)((unsigned)(codes0 >> (2 * s)) & 3u);
-                if (ext || brg) {
-                    a1 = ix.pq + (((unsigned)r + (brg ? 1u : 0u)) >> 5);   // the two quads holding path chars r (+1) .. +31
+                if (ext) {
+                    a1 = ix.pq + 2 * (size_t)((unsigned)r >> 5);           // the two path groups holding steps r .. r+32: 64 bytes
                     a2 = a1 + 1;
+                    ax = a1 + 2;
+                    ay = a1 + 3;
+                } else if (brg) {
+                    a1 = ix.pq + 2 * (size_t)(((unsigned)r + 1u) >> 5);    // chars of steps r+1 .. : the groups' first quads
+                    a2 = a1 + 2;
                 } else if (trn) {
-                    if (((streaming == 2 ? g0.w : g0.z) >> s) & 1u) {     // validity as in M_STREAM below
-                        // the entry of this char's successor: one quad, or two on branchy indexes (trans_wide)
-                        a1 = ix.trans + ((4 * (size_t)(unsigned)r + (unsigned)c) << ix.trans_wide);
-                        a2 = a1 + ix.trans_wide;
-                    } else {
-                        ev = EV_EMIT1;
-                        b = blo = i + k - 1;
-                    }
+                    // (a base that is not ACGT never gets here: F_EXT treats it as "no successor")
+                    // the entry of (position r, char c): it exists (the OTH bit said so); j counts the slots probed
+                    a1 = ix.trans + 4 * ((sbwt_trans_slot((unsigned)r, (unsigned)c, ix.log2t) + (u64)j) & low_mask(ix.log2t));
+                    a2 = a1 + 1;
+                    ax = a1 + 2;
                 } else if (strm) {
                     // streaming == 1: SBWT::streaming_search validates the upper-cased char (SBWT.hh:565-568);
                     // streaming == 2: internal streaming inside the search loop keeps SBWT::search's raw-char
@@ -624,19 +619,20 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
         // PATH: the read's next packed group -- G3: the next TWO -- ride along when the next one is not here yet (two at a time: a group
         // fetched in a later iteration is another request to the fabric even when it lies in the same line -- the L2 turns
         // over faster than a lane comes back); a reload brings three
-        const bool pf = PATH && !g1ok && kind == K_MODE;
+        // (an iteration that gathers the four quads of a path step has no slot for them)
+        const bool pathq = PATH && ax != nullptr;
+        const bool pf = PATH && !pathq && !g1ok && kind == K_MODE;
         const bool rl3 = G3 && kind == K_RELOAD;
-        const uint4 *a3 = pf ? (packed + (tag + 1)) : rl3 ? (a1 + 2) : a1;
+        const uint4 *a3 = pathq ? ax : pf ? (packed + (tag + 1)) : rl3 ? (a1 + 2) : a1;
+        const uint4 *a4 = pathq ? (ay ? ay : a1) : pf ? (a3 + 1) : a1;
         const uint4 v1 = *a1;
         const uint4 v2 = *a2;
+        uint4 v3 = make_uint4(0u, 0u, 0u, 0u), v4 = v3;
         if (PATH) {
-            const uint4 v3 = *a3;
-            if (pf) { g1 = v3; g1ok = true; }
-            if (G3) {
-                const uint4 v4 = *(pf ? (a3 + 1) : a1);
-                if (pf) { g2 = v4; g2ok = true; }
-                if (rl3) { g2 = v3; g2ok = true; }
-            }
+            v3 = *a3;
+            v4 = *a4;
+            if (pf) { g1 = v3; g1ok = true; g2 = v4; g2ok = true; }
+            if (rl3) { g2 = v3; g2ok = true; }
         }
 
         // ---- consume ----
@@ -681,58 +677,56 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
             r = (pos_t)(sel == 0 ? v1.x : sel == 1 ? v1.y : sel == 2 ? v1.z : v1.w);
             mode = M_EXT;
         } else if (trn && have) {
-            // v1 = { successor column (SBWT.hh:562-575) or none, its path position, its path's next 8 steps, - }
-            ev = EV_EMIT1;
-            if (v1.x == 0xFFFFFFFFu) {
-                if (ix.has_safe && (v1.w & 1u)) {
-                    // no successor, and the entry vouches for this char like a safe bit does for all three: the k-mers that hold
-                    // the base are absent if the next k-1 bases agree with the path -- M_BRIDGE looks (k_path_safe_labels)
-                    ev = EV_NONE;
-                    mode = M_BRIDGE;
-                } else {
+            // v1 = { r + 1, c, successor column (SBWT.hh:562-575), its path position }, v2 / v3 = its path's next 32 steps
+            if (v1.x != (unsigned)r + 1u || v1.y != (unsigned)c) {
+                j++;                                   // another entry's slot: the next one (linear probing, always ends in a hit)
+                if (v1.x == 0u || j > 4096) {          // a free slot: the image is damaged -- report it, do not spin
+                    ws->status = SBWT_ERR_NOT_SINGLETON;
+                    ev = EV_EMIT1;
                     b = blo = i + k - 1;
                 }
             } else {
-                res = (pos_t)v1.x;
-                r = (pos_t)v1.y;
-                emit_pos = v1.y;
+                ev = EV_EMIT1;
+                res = (pos_t)v1.z;
+                r = (pos_t)v1.w;
+                emit_pos = v1.w;
                 rknown = true;
-                // the read's next bases against the 8 steps quoted in the entry: short runs (pan-genomes branch every
-                // few k-mers) end here without a separate M_EXT iteration
+                // the read's next bases against the steps quoted in the entry, as far as the cached groups reach
                 const int P1 = poff + i + k, s1 = P1 & 31;
-                if (use_q && ((s1 != 0 && (s1 <= 24 || g1ok)) || (s1 == 0 && g1ok))) {
-                    u64 rw, rv;
-                    const u64 va = (streaming == 2) ? (((u64)g1.w << 32) | (u64)g0.w) : (((u64)g1.z << 32) | (u64)g0.z);
-                    if (s1 != 0) {
-                        rw = (quad_bits(g0) >> (2 * s1)) | (quad_bits(g1) << (64 - 2 * s1));
-                        rv = va >> s1;
-                    } else {                           // the base after P starts the next group
-                        rw = quad_bits(g1);
-                        rv = va >> 32;
+                int have1 = (s1 == 0) ? (g1ok ? 32 : 0) : (32 - s1) + (g1ok ? 32 : 0);   // bases from P1 on that are cached
+                if (have1 > 31) have1 = 31;
+                u64 rq, rv;
+                const u64 va = (streaming == 2) ? (((u64)g1.w << 32) | (u64)g0.w) : (((u64)g1.z << 32) | (u64)g0.z);
+                if (s1 != 0) {
+                    rq = (quad_bits(g0) >> (2 * s1)) | (quad_bits(g1) << (64 - 2 * s1));
+                    rv = va >> s1;
+                } else {
+                    rq = quad_bits(g1);
+                    rv = va >> 32;
+                }
+                const u64 x = (rq ^ quad_bits(v2)) & low_mask(62);
+                const u64 mm = (x | (x >> 1)) & 0x5555555555555555ull;
+                const int nm = mm ? ((__ffsll((i64)mm) - 1) >> 1) : 31;
+                const int ng = __ffs((int)(~v2.z | 0x80000000u)) - 1;          // the quoted path ends
+                const int nr = __ffs((int)(~(unsigned)rv | 0x80000000u)) - 1;  // a base of the read that is not ACGT
+                const int nv = ng < nr ? ng : nr;
+                int n2 = nm < nv ? nm : nv;
+                bool stop2 = n2 < 31;
+                if (n2 >= have1) { n2 = have1; stop2 = false; }
+                if (n2 >= m - 1 - i) { n2 = m - 1 - i; stop2 = false; }
+                if (n2 < 0) n2 = 0;
+                seg_n = n2;
+                seg_src = (unsigned)r + 1u;
+                r += (pos_t)n2;
+                c_ext += (unsigned)n2;
+                if (stop2) {
+                    int kind2 = PS_ABSENT;             // a base that is not ACGT: -1 (SBWT.hh:568)
+                    if (!(nr <= nm && nr <= ng)) {
+                        const unsigned rc = (unsigned)(rq >> (2 * n2)) & 3u, aa = (unsigned)(x >> (2 * n2)) & 3u;
+                        kind2 = path_stop_kind(ng <= nm, rc, aa, v2.w, v3.x, v3.y, v3.z, v3.w, n2, ix.has_safe != 0);
                     }
-                    const unsigned x = ((unsigned)rw ^ v1.z) & 0xFFFFu;
-                    const unsigned mm = (x | (x >> 1)) & 0x5555u;
-                    const int nm = mm ? ((__ffs((int)mm) - 1) >> 1) : 8;
-                    const unsigned okb = (unsigned)rv & (v1.z >> 16) & 0xFFu;
-                    const int nv = __ffs((int)(~okb | 0x100u)) - 1;
-                    int n2 = nm < nv ? nm : nv;
-                    bool stop2 = n2 < 8;
-                    if (n2 > m - 1 - i) { n2 = m - 1 - i; stop2 = false; }
-                    if (n2 > 31 - cnt) { n2 = 31 - cnt; stop2 = false; }
-                    if (n2 < 0) n2 = 0;
-                    if (!SEG && ix.trans_wide && n2 <= 4 && cnt + 1 + n2 <= DEPTH) {
-                        // a short run right after the transition: its columns came with the entry (v2), they go straight
-                        // into the stage behind the transition's own result -- no descriptor, no look at col[]
-                        nlit = n2;
-                        lit = v2;
-                    } else {
-                        seg_n = n2;
-                        seg_src = (unsigned)r + 1u;
-                    }
-                    r += (pos_t)n2;
-                    c_ext += (unsigned)n2;
-                    if (stop2) tnext = (ix.has_safe && nm < nv && ((v1.z >> 24 >> nm) & 1u)) ? M_BRIDGE : M_TRANS;
-                    qshort = stop2;
+                    if (kind2 == PS_ABSENT) ext_absent = true;
+                    else tnext = (kind2 == PS_TRANS) ? M_TRANS : M_BRIDGE;
                 }
             }
         } else if (brg && have) {
@@ -761,36 +755,32 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
                 bridged = need == k - 1 && (~vraw & low_mask(k)) == 0;
             } else {
                 // no bridge (a second difference within k-1 bases).  The streaming step itself needs no gather either: a
-                // substitution-safe step has no successor by any other char (the k-mer that ends at the substituted base is
-                // one of the k windows the safe bit vouches for), so k-mer i is absent like after a transition that
-                // found nothing
+                // bridgeable step has no successor by the read's char
                 ev = EV_EMIT1;
                 b = blo = i + k - 1;
             }
         } else if (ext && have) {
             // k-mer i-1 sits at path position r.  Read bases i+k-1.. against path chars r..: while they agree
             // (and the read's bases are valid and the path goes on), k-mer i+x sits at r+1+x.
+            // v1 / v2 = first path group { chars, GO, SAFE } { OTH }, v3 / v4 = the second.
             const int P = poff + i + k - 1, s = P & 31, sp = (int)((unsigned)r & 31u);
             u64 rw = quad_bits(g0) >> (2 * s), pw = quad_bits(v1) >> (2 * sp);
             if (s) rw |= quad_bits(g1) << (64 - 2 * s);
-            if (sp) pw |= quad_bits(v2) << (64 - 2 * sp);
+            if (sp) pw |= quad_bits(v3) << (64 - 2 * sp);
             const u64 rv = ((streaming == 2) ? (((u64)g1.w << 32) | (u64)g0.w) : (((u64)g1.z << 32) | (u64)g0.z)) >> s;
-            // the path groups' two flag words (k_path_reencode): go = ~A | B, safe = A & B, only successor = ~A & B
-            const u64 fA = (((u64)v2.z << 32) | (u64)v1.z) >> sp, fB = (((u64)v2.w << 32) | (u64)v1.w) >> sp;
-            const u64 pg = ~fA | fB;
-            const u64 x = rw ^ pw;
+            const u64 pgo = (((u64)v3.z << 32) | (u64)v1.z) >> sp;
+            u64 x = rw ^ pw;
             const u64 mm = (x | (x >> 1)) & 0x5555555555555555ull;
-            const int nm = mm ? ((__ffsll((i64)mm) - 1) >> 1) : 32;
-            const u64 bad = ~(rv & pg) | (1ull << 32);
-            const int nv = __ffsll((i64)bad) - 1;
+            int nm = mm ? ((__ffsll((i64)mm) - 1) >> 1) : 32;
+            int ng = __ffsll((i64)(~pgo | (1ull << 32))) - 1;                 // the path ends
+            int nr = __ffsll((i64)(~rv | (1ull << 32))) - 1;                  // a base that is not ACGT
+            int nv = ng < nr ? ng : nr;
             int n = nm < nv ? nm : nv;
             bool stopped = n < 32;                     // a mismatch, an invalid base or the end of the path
-            int nmt = nm, nvt = nv;
-            if (SEG && !stopped && g1ok) {
-                // the cached group pair and the two path quads reach further than 32 steps: 32 - s more bases of the read,
-                // 32 - sp more chars of the path, and a segment list takes a run of any length (same-box A/B: -1.7 %,
-                // read lines 229 M -> 217 M per 10 M reads)
-                // (with the third cached group the read's side is whole: only the path's 32 - sp chars limit the window)
+            u64 rcw = rw;
+            if (!stopped && g1ok) {
+                // the cached group pair and the two path groups reach further than 32 steps: 32 - s more bases of the read
+                // (all 32 with the third cached group), 32 - sp more chars of the path
                 const bool r3 = g2ok && s != 0;
                 const int w2 = (r3 || s <= sp) ? 32 - sp : 32 - s;
                 u64 rw2 = quad_bits(g1) >> (2 * s);
@@ -800,45 +790,51 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
                     const u64 vb = (streaming == 2) ? (((u64)g2.w << 32) | (u64)g1.w) : (((u64)g2.z << 32) | (u64)g1.z);
                     rv2 = (vb >> s) & 0xFFFFFFFFull;
                 }
-                const u64 x2 = rw2 ^ (quad_bits(v2) >> (2 * sp));
+                const u64 x2 = rw2 ^ (quad_bits(v3) >> (2 * sp));
                 const u64 mm2 = (x2 | (x2 >> 1)) & 0x5555555555555555ull;
                 const int nm2 = mm2 ? ((__ffsll((i64)mm2) - 1) >> 1) : 32;
-                const u64 bad2 = ~(rv2 & (pg >> 32)) | (1ull << 32);
-                const int nv2 = __ffsll((i64)bad2) - 1;
+                const int ng2 = __ffsll((i64)(~(pgo >> 32) | (1ull << 32))) - 1;
+                const int nr2 = __ffsll((i64)(~rv2 | (1ull << 32))) - 1;
+                const int nv2 = ng2 < nr2 ? ng2 : nr2;
                 int n2 = nm2 < nv2 ? nm2 : nv2;
                 if (n2 >= w2) n2 = w2;                 // the end of what is cached is not a stop
                 else stopped = true;
                 n = 32 + n2;
-                nmt = 32 + nm2;
-                nvt = 32 + nv2;
+                nm = 32 + nm2;
+                ng = 32 + ng2;
+                nr = 32 + nr2;
+                rcw = rw2;
+                x = x2;
             }
-            if (n > m - i) n = m - i;
-            if (!SEG && n > 32 - cnt) { n = 32 - cnt; stopped = false; }   // staged results + run travel in one descriptor
+            if (n >= m - i) { n = m - i; stopped = false; }
             seg_n = n;
             seg_src = (unsigned)r + 1u;
-            r += (pos_t)n;
             c_ext += (unsigned)n;
-            bool sbit = false;                         // stopped at a char mismatch whose path step is substitution-safe?
-            if (stopped && nmt < nvt) {
-                const int nm = nmt;
-                sbit = (((fA & fB) >> nm) & 1ull) != 0;
-                // ... or a step whose char is the only successor of its column: the read's char has none, the streaming
-                // step gives -1 (SBWT.hh:572-575) without a look at the transition table
-                ext_absent = SEG && !sbit && (((~fA & fB) >> nm) & 1ull) != 0;
-                if (SEG && sbit && nm < 32) {
-                    // a bridge needs the next k-1 bases to agree with the path; where this window already shows a second
-                    // difference among them, skip the attempt: the safe step has no successor by the read's char either
-                    const int after = 31 - nm, want = (k - 1 < m - 1 - (i + nm)) ? (k - 1) : (m - 1 - (i + nm));
-                    const int chk = after < want ? after : want;
-                    if (chk > 0 && ((mm >> (2 * (nm + 1))) & low_mask(2 * chk)) != 0) { sbit = false; ext_absent = true; }
-                }
-            }
-            qshort = stopped && n < 8;
 #ifdef SBWT_STATS
-            if (!stopped && i + n != m) atomicAdd(&ws->pad[15], 1ull);      // limited by the 32-step window / descriptor size
+            if (!stopped && i + n != m) atomicAdd(&ws->pad[15], 1ull);      // limited by the window
 #endif
-            if (i + n == m) { mode = M_IDLE; ext_absent = false; }
-            else if (stopped) mode = sbit ? M_BRIDGE : M_TRANS;
+            if (i + n == m) {
+                mode = M_IDLE;
+            } else if (stopped) {
+                int kind2 = PS_ABSENT;                 // a base that is not ACGT: -1 (SBWT.hh:568)
+                if (!(nr <= nm && nr <= ng)) {
+                    const int o = sp + n, bit = o & 31, wn = n & 31;
+                    const bool hi = o >= 32;
+                    const unsigned rc = (unsigned)(rcw >> (2 * wn)) & 3u, aa = (unsigned)(x >> (2 * wn)) & 3u;
+                    kind2 = path_stop_kind(ng <= nm, rc, aa, hi ? v3.w : v1.w, hi ? v4.x : v2.x, hi ? v4.y : v2.y,
+                                           hi ? v4.z : v2.z, hi ? v4.w : v2.w, bit, ix.has_safe != 0);
+                    if (kind2 == PS_BRIDGE && n < 32) {
+                        // a bridge needs the next k-1 bases to agree with the path; a second difference already in this
+                        // window: skip the attempt
+                        const int after = 31 - n, want = (k - 1 < m - 1 - (i + n)) ? (k - 1) : (m - 1 - (i + n));
+                        const int chk = after < want ? after : want;
+                        if (chk > 0 && ((mm >> (2 * (n + 1))) & low_mask(2 * chk)) != 0) kind2 = PS_ABSENT;
+                    }
+                }
+                if (kind2 == PS_ABSENT) ext_absent = true;
+                else { mode = (kind2 == PS_TRANS) ? M_TRANS : M_BRIDGE; j = 0; }
+            }
+            r += (pos_t)n;
         } else if (have) {
             if (strm) {
                 const i64 blk = (mode == M_BACK) ? (i64)r : ((i64)l >> 6);
@@ -945,9 +941,6 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
         }
         c_tab = uniform32(c_tab + (unsigned)__popcll(__ballot(tabhit)));
         c_stream = uniform32(c_stream + (unsigned)__popcll(__ballot(ev == EV_EMIT1 && (strm || trn))));
-        if (PATH) {
-            c_short = uniform32(c_short + (unsigned)__popcll(__ballot(qshort)));
-        }
 
         // ---- events: results, certificates, next state ----
         int burst_hi = -1;                             // >= i: k-mers i..burst_hi are certified absent
@@ -992,14 +985,6 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
             stage[cnt][tid] = (stage_t)res;
             cnt++;
             i++;
-            if (nlit > 0) {
-                stage[cnt][tid] = (stage_t)lit.x;
-                if (nlit > 1) stage[cnt + 1][tid] = (stage_t)lit.y;
-                if (nlit > 2) stage[cnt + 2][tid] = (stage_t)lit.z;
-                if (nlit > 3) stage[cnt + 3][tid] = (stage_t)lit.w;
-                cnt += nlit;
-                i += nlit;
-            }
         }
         // ---- result writes, wave-cooperative ----
         // Staged results are those of k-mers [i-cnt, i); they leave as one run that ends on a line
@@ -1120,84 +1105,6 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
                 for (int u = 0; u < FP; u++)
                     if (lane == fL[u]) { nseg = 0; i0 = i; }
             }
-        } else if (PATH) {
-            // One writer, whole lines.  The results of a read leave in order.  What a lane has not written yet --
-            // `cnt` results staged in LDS, always starting on a 64-byte line of `out` (or at the read's first
-            // result) -- is joined with this iteration's run (a certified burst of -1, or a path run out of col[]),
-            // and the part that ends on a line boundary is written; the tail goes (back) into the lane's stage.
-            // So every store covers whole 64-byte lines except at the two ends of a read.
-            // A lane with something to write posts a 16-byte descriptor in LDS at its rank among the posting
-            // lanes; group g of 16 lanes takes descriptors g, g+4, ... and handles two results per lane
-            // (stage + run <= 32 results), PIPE descriptors per trip with their loads in flight together.
-            int nleft = (burst_hi >= 0) ? (burst_hi - i + 1) : seg_n;
-            unsigned s2 = (burst_hi >= 0) ? 0xFFFFFFFFu : seg_src;
-            uint4 *mydesc = desc[tid >> 6];
-            // lines of `out`: 16 results = 128 bytes, the largest request the fabric takes -- a random 128-byte write costs
-            // about what a 64-byte one does (tools/micro/ceilings.hip: 41 vs 51 G segments/s); debug bit 32: 64-byte lines
-            const unsigned lmask = (ix.debug & 32) ? 7u : 15u;
-            const int sub = lane & 15, grpl = lane >> 4;
-            const u64 lt = low_mask(lane);
-            for (;;) {                                 // more than one round only for bursts longer than a descriptor
-                const i64 dst0 = obase + (i - cnt);
-                const int nn = nleft < 32 - cnt ? nleft : 32 - cnt;
-                const int total = cnt + nn;
-                const bool end = (i + nn == m);
-                const int over = (int)((unsigned)(dst0 + total) & lmask);   // results past the last line boundary
-                // (a line boundary inside the staged block: reached exactly when results arrive one at a time, possibly
-                // jumped over when a transition brings up to five)
-                const bool post = nn > 0 || (cnt > 0 && (end || over < total));
-                const int w = !post ? 0 : (end ? total : (over <= total ? total - over : 0));
-                const u64 pm = __ballot(post);
-                if (pm == 0) break;
-                const int ndesc = __popcll(pm);
-                if (post)
-                    mydesc[__popcll(pm & lt)] = make_uint4((unsigned)dst0, (unsigned)((u64)dst0 >> 32),
-                                                           (unsigned)cnt | ((unsigned)total << 8) | ((unsigned)w << 16) | ((unsigned)tid << 24), s2);
-                for (int base = 0; base < ndesc; base += 4 * SBWT_COPY_PIPE) {
-                    constexpr int PIPE = SBWT_COPY_PIPE;
-                    i64 dd[PIPE];
-                    int sa[PIPE], sb[PIPE], ca[PIPE], cb[PIPE], fa[PIPE], fb[PIPE], wl[PIPE], tl[PIPE], ht[PIPE];
-#pragma unroll
-                    for (int u = 0; u < PIPE; u++) {
-                        const int idx = base + 4 * u + grpl;
-                        const bool on = idx < ndesc && !(ix.debug & 1);
-                        const uint4 ds = mydesc[idx < ndesc ? idx : 0];
-                        const int dc = (int)(ds.z & 0xFFu), dt = (int)((ds.z >> 8) & 0xFFu);
-                        const int j0 = 2 * sub;
-                        ht[u] = (int)(ds.z >> 24);
-                        wl[u] = on ? (int)((ds.z >> 16) & 0xFFu) - j0 : 0;      // results of this lane's pair that go to `out`
-                        tl[u] = on ? dt - j0 : 0;                                 // ... that exist at all
-                        dd[u] = (i64)((u64)ds.x | ((u64)ds.y << 32)) + j0;
-                        // both sources are read unconditionally (clamped addresses) and selected afterwards: loads
-                        // under divergent branches would be waited for one by one
-                        const bool isc = ds.w != 0xFFFFFFFFu && on;
-                        const int r0 = j0 < 15 ? j0 : 14;
-                        const unsigned c0 = (isc && j0 >= dc && tl[u] > 0) ? ds.w + (unsigned)(j0 - dc) : 0u;
-                        const unsigned c1 = (isc && j0 + 1 >= dc && tl[u] > 1) ? ds.w + (unsigned)(j0 + 1 - dc) : 0u;
-                        sa[u] = (int)stage[r0][ht[u]];
-                        sb[u] = (int)stage[r0 + 1][ht[u]];
-                        ca[u] = (int)ix.col[c0];
-                        cb[u] = (int)ix.col[c1];
-                        fa[u] = (j0 < dc) ? 0 : (isc ? 1 : 2);           // where the value comes from: stage, col, constant
-                        fb[u] = (j0 + 1 < dc) ? 0 : (isc ? 1 : 2);
-                    }
-#pragma unroll
-                    for (int u = 0; u < PIPE; u++) {
-                        const int va = fa[u] == 0 ? sa[u] : (fa[u] == 1 ? ca[u] : -1);
-                        const int vb = fb[u] == 0 ? sb[u] : (fb[u] == 1 ? cb[u] : -1);
-                        if (wl[u] >= 2) st_stream2(out + dd[u], (i64)va, (i64)vb);
-                        else if (wl[u] == 1) st_stream(out + dd[u], (i64)va);
-                        // the tail stays with the holder: stage slot = position past the written part
-                        if (tl[u] > 0 && wl[u] < 1) stage[-wl[u]][ht[u]] = (stage_t)va;
-                        if (tl[u] > 1 && wl[u] < 2) stage[1 - wl[u]][ht[u]] = (stage_t)vb;
-                    }
-                }
-                cnt = total - w;
-                i += nn;
-                nleft -= nn;
-                if (s2 != 0xFFFFFFFFu) s2 += (unsigned)nn;
-                if (__ballot(nleft > 0) == 0) break;
-            }
         } else
         {
             const bool fl = (cnt > 0) && (burst_hi >= 0 || seg_n > 0 || i == m || (((unsigned)obase + (unsigned)i) & (DEPTH - 1)) == 0);
@@ -1256,6 +1163,7 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
             } else if (ev == EV_EMIT1 && res != -1 && streaming) {
                 mode = PATH ? (rknown ? tnext : M_POS) : M_STREAM;   // SBWT.hh:560-
                 l = res;
+                if (PATH) j = 0;
             } else if (PATH && bridged) {
                 mode = M_EXT;                          // (i < m: the burst was k k-mers long)
                 r += (pos_t)k;
@@ -1349,7 +1257,7 @@ void sbwt_launch_search_chained(const SbwtIndexView &ix, const uint4 *d_packed, 
     const i64 want1 = (n_reads + 255) / 256;
     const unsigned cap = (ix.debug >> 8) ? (unsigned)(ix.debug >> 8) : 1280u;
     const unsigned g = (unsigned)(want1 < (i64)cap ? want1 : (i64)cap);
-    hipLaunchKernelGGL((k_search_cert<false, 4, true, true>), dim3(g), dim3(256), 0, stream, ix, d_packed, d_read_off,
+    hipLaunchKernelGGL((k_search_cert<false, 4, true>), dim3(g), dim3(256), 0, stream, ix, d_packed, d_read_off,
                        d_out_off, d_out, (i64)n_reads, ws, streaming, (const unsigned *)nullptr, d_defer);
 }
 
@@ -1371,33 +1279,11 @@ void sbwt_launch_search(const SbwtIndexView &ix, const uint4 *d_packed, const lo
             hipLaunchKernelGGL((k_search_cert<true, 4, false>), dim3(g), dim3(256), 0, stream, ix, d_packed, d_read_off,
                                d_out_off, d_out, (i64)n_reads, ws, streaming, d_perm, (const unsigned *)nullptr);
         else if (variant >= 2 && ix.col && streaming) {    // path order (the default when the index has one)
-            if (variant >= 4) {                             // segment lists instead of staged results (SEG)
-                if (!(ix.debug & 8))
-                    hipLaunchKernelGGL(k_check_uniform, dim3(grid_for(n_reads)), dim3(256), 0, stream, d_read_off, d_out_off,
-                                       (i64)n_reads, ws);
-                else
-                    (void)hipMemsetAsync(&ws->u_bad, 0xFF, 8, stream);
-                if (d_sort_scratch)
-                    d_perm = sbwt_launch_sort_reads(ix, d_packed, d_read_off, n_reads, ws, d_sort_scratch, sort_scratch_bytes,
-                                                    sort_key_bits, stream);
-                hipLaunchKernelGGL((k_search_cert<false, 4, true, true>), dim3(g), dim3(256), 0, stream, ix, d_packed, d_read_off,
-                                   d_out_off, d_out, (i64)n_reads, ws, streaming, d_perm, (const unsigned *)nullptr);
-                return;
-            }
-            if (variant >= 3) {                             // pooled reads: one state per wave iteration (sbwt_search_pool.hip)
-                if (!(ix.debug & 8))
-                    hipLaunchKernelGGL(k_check_uniform, dim3(grid_for(n_reads)), dim3(256), 0, stream, d_read_off, d_out_off,
-                                       (i64)n_reads, ws);
-                else
-                    (void)hipMemsetAsync(&ws->u_bad, 0xFF, 8, stream);
-                sbwt_launch_search_pool(ix, d_packed, d_read_off, d_out_off, d_out, n_reads, ws, streaming, stream);
-                return;
-            }
             if (!(ix.debug & 8))
                 hipLaunchKernelGGL(k_check_uniform, dim3(grid_for(n_reads)), dim3(256), 0, stream, d_read_off, d_out_off,
                                    (i64)n_reads, ws);
             else
-                (void)hipMemsetAsync(&ws->u_bad, 0xFF, 8, stream);       // experiment: the general path
+                (void)hipMemsetAsync(&ws->u_bad, 0xFF, 8, stream);       // experiment: the general offset path
             if (d_sort_scratch)
                 d_perm = sbwt_launch_sort_reads(ix, d_packed, d_read_off, n_reads, ws, d_sort_scratch, sort_scratch_bytes,
                                                 sort_key_bits, stream);
@@ -1419,4 +1305,3 @@ void sbwt_launch_search(const SbwtIndexView &ix, const uint4 *d_packed, const lo
         hipLaunchKernelGGL(k_search<false>, dim3(grid), dim3(256), 0, stream, ix, d_packed, d_read_off, d_out_off,
                            d_out, (i64)n_reads, ws, streaming == 1 ? 1 : 0);
 }
-

@@ -84,7 +84,6 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
     unsigned c_ext = 0, c_brg = 0;  // per lane: k-mers answered along paths, substitutions bridged
     u64 pool_next = 0, pool_end = 0, pool_bad = 0;  // wave-uniform pool of read tickets; tickets of it that are handed on
     unsigned c_stream = 0, c_search = 0, c_lf = 0, c_tab = 0;     // wave-uniform work counters
-    unsigned c_iter = 0, c_short = 0;
 
     for (;;) {
         // ---- hand out reads to idle lanes from the wave's ticket pool; an empty pool is refilled with 64 encoded reads ----
@@ -100,22 +99,28 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
                     const i64 woff = u_read0 + (i64)pool_next * ulen;                 // first byte of the pool's 64 reads
                     i64 remain = total_bases - woff;
                     if (remain < 0) remain = 0;
-                    if (remain > 0xFFFFFFFFll) remain = 0xFFFFFFFFll;
-                    // bounds-checked loads: bytes past the end of `bases` read as 0 (the last read's last group reaches
-                    // over its end by up to 31 bytes)
+                    if (remain > 0xFFFFFFF0ll) remain = 0xFFFFFFF0ll;
+                    // Bounds-checked loads of ALIGNED dwords (the descriptor's base is the pool's first byte rounded down to
+                    // four; a read's bytes are shifted into place afterwards): the last dword that holds a byte of `bases`
+                    // is an aligned word of memory, so nothing beyond it is touched, and dwords past it read as 0.
+                    const unsigned char *p0 = bases + woff;
+                    const unsigned delta = (unsigned)((uintptr_t)p0 & 3u);
                     __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-                        const_cast<unsigned char *>(bases) + woff, (short)0, (int)(unsigned)remain, 0x00020000);
-                    const int vo = lane * ulen;
+                        const_cast<unsigned char *>(p0 - delta), (short)0, (int)(((unsigned)remain + delta + 3u) & ~3u), 0x00020000);
+                    const unsigned vo = delta + (unsigned)lane * (unsigned)ulen;
                     unsigned bad = 0;
 #pragma unroll
                     for (int g = 0; g < SBWT_FUSED_MAXG; g++) {
                         if (g < G) {
-                            const fz_u32x4 x0 = __builtin_amdgcn_raw_buffer_load_b128(rs, vo + 32 * g, 0, 0);
-                            const fz_u32x4 x1 = __builtin_amdgcn_raw_buffer_load_b128(rs, vo + 32 * g + 16, 0, 0);
-                            const unsigned w[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
-                            unsigned tm[8];
+                            const unsigned o = vo + 32u * (unsigned)g, oa = o & ~3u, sh = o & 3u;
+                            const fz_u32x4 x0 = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)oa, 0, 0);
+                            const fz_u32x4 x1 = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)oa + 16, 0, 0);
+                            const unsigned x2 = __builtin_amdgcn_raw_buffer_load_b32(rs, (int)oa + 32, 0, 0);
+                            const unsigned raw[9] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w, x2};
+                            unsigned w[8], tm[8];
 #pragma unroll
                             for (int d = 0; d < 8; d++) {
+                                w[d] = __builtin_amdgcn_alignbyte(raw[d + 1], raw[d], sh);
                                 const int nb = ulen - 32 * g - 4 * d;                  // bytes of this dword inside the read
                                 tm[d] = nb >= 4 ? 0x80808080u : nb <= 0 ? 0u : (0x80808080u & ((1u << (8 * nb)) - 1u));
                             }
@@ -164,13 +169,11 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
 
         // ---- this iteration's gather: two 16-byte loads per lane, issued back to back, one wait ----
         int ev = FE_NONE, tfail = 0, c = 0;
-        const uint4 *a1 = ix.blocks, *a2 = ix.blocks;
+        const uint4 *a1 = ix.blocks, *a2 = ix.blocks, *a3 = nullptr, *a4 = nullptr;
         int res = -1;
         const bool ext = (mode == F_EXT), trn = (mode == F_TRANS), brg = (mode == F_BRIDGE);
         const bool busy = (mode != F_IDLE && mode != F_DEAD);
-        bool rknown = false, qshort = false, ext_absent = false;
-        const bool use_q = (ix.trans_ext > 0 || (ix.trans_ext < 0 && c_short >= 8u * c_iter));
-        c_iter++;
+        bool rknown = false, ext_absent = false;
         int tnext = F_EXT;
         int tpos = -1;
         int seg_n = 0;
@@ -189,12 +192,19 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
         } else if (busy) {
             const int wl = (wk == 1) ? ps : (wk == 2) ? L0 : (wk == 3) ? pw : (wk == 5) ? k - ps : p;
             c = (int)((unsigned)rw & 3u);
-            if (ext || brg) {
-                a1 = ix.pq + (((unsigned)r + (brg ? 1u : 0u)) >> 5);   // the two quads holding path chars r (+1) .. +31
+            if (ext) {
+                a1 = ix.pq + 2 * (size_t)((unsigned)r >> 5);           // the two path groups holding steps r .. r+32: 64 bytes
                 a2 = a1 + 1;
+                a3 = a1 + 2;
+                a4 = a1 + 3;
+            } else if (brg) {
+                a1 = ix.pq + 2 * (size_t)(((unsigned)r + 1u) >> 5);    // chars of steps r+1 .. : the groups' first quads
+                a2 = a1 + 2;
             } else if (trn) {
-                a1 = ix.trans + ((4 * (size_t)(unsigned)r + (unsigned)c) << ix.trans_wide);
-                a2 = a1;
+                // the entry of (position r, char c): it exists (the OTH bit said so); j counts the slots probed
+                a1 = ix.trans + 4 * ((sbwt_trans_slot((unsigned)r, (unsigned)c, ix.log2t) + (u64)j) & low_mask(ix.log2t));
+                a2 = a1 + 1;
+                a3 = a1 + 2;
             } else if (mode == F_INIT) {
                 (void)wl;
                 if (wk == 1) {                 // bucket (hash + j) of the sparse table: two entries
@@ -227,6 +237,8 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
 
         const uint4 v1 = *a1;
         const uint4 v2 = *a2;
+        const uint4 v3 = *(a3 ? a3 : a1);
+        const uint4 v4 = *(a4 ? a4 : a1);
 
         // ---- consume ----
         bool tabhit = false, do_plan = false, force = false;
@@ -238,39 +250,40 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
             r = (int)(sel == 0 ? v1.x : sel == 1 ? v1.y : sel == 2 ? v1.z : v1.w);
             mode = F_EXT;
         } else if (trn) {
-            // v1 = { successor column (SBWT.hh:562-575) or none, its path position, its path's next 8 steps, - }
-            ev = FE_EMIT1;
-            if (v1.x == 0xFFFFFFFFu) {
-                if (ix.has_safe && (v1.w & 1u)) {
-                    // no successor, and the entry vouches for this char like a safe bit does for all three (k_path_safe_labels)
-                    ev = FE_NONE;
-                    mode = F_BRIDGE;
-                } else {
+            // v1 = { r + 1, c, successor column (SBWT.hh:562-575), its path position }, v2 / v3 = its path's next 32 steps
+            if (v1.x != (unsigned)r + 1u || v1.y != (unsigned)c) {
+                j++;                                   // another entry's slot: the next one (linear probing, always ends in a hit)
+                if (v1.x == 0u || j > 4096) {          // a free slot: the image is damaged -- report it, do not spin
+                    ws->status = SBWT_ERR_NOT_SINGLETON;
+                    ev = FE_EMIT1;
                     b = blo = i + k - 1;
                 }
             } else {
-                res = (int)v1.x;
-                r = (int)v1.y;
-                emit_pos = v1.y;
+                ev = FE_EMIT1;
+                res = (int)v1.z;
+                r = (int)v1.w;
+                emit_pos = v1.w;
                 rknown = true;
-                if (use_q) {
-                    // the read's next bases against the 8 steps quoted in the entry: short runs end here
-                    const unsigned rq = (unsigned)(rw >> 2);                            // bases P+1 ..
-                    const unsigned x = (rq ^ v1.z) & 0xFFFFu;
-                    const unsigned mm = (x | (x >> 1)) & 0x5555u;
-                    const int nm = mm ? ((__ffs((int)mm) - 1) >> 1) : 8;
-                    const unsigned okb = (v1.z >> 16) & 0xFFu;
-                    const int nv = __ffs((int)(~okb | 0x100u)) - 1;
-                    int n2 = nm < nv ? nm : nv;
-                    bool stop2 = n2 < 8;
-                    if (n2 > m - 1 - i) { n2 = m - 1 - i; stop2 = false; }
-                    if (n2 < 0) n2 = 0;
-                    seg_n = n2;
-                    seg_src_run = (unsigned)r + 1u;
-                    r += n2;
-                    c_ext += (unsigned)n2;
-                    if (stop2) tnext = (ix.has_safe && nm < nv && ((v1.z >> 24 >> nm) & 1u)) ? F_BRIDGE : F_TRANS;
-                    qshort = stop2;
+                // the read's next bases against the steps quoted in the entry: most runs after a transition end here
+                const u64 rq = rw >> 2;                // bases P+1 .. P+31
+                const u64 x = (rq ^ quad_bits(v2)) & low_mask(62);
+                const u64 mm = (x | (x >> 1)) & 0x5555555555555555ull;
+                const int nm = mm ? ((__ffsll((i64)mm) - 1) >> 1) : 31;
+                const int nv = __ffs((int)(~v2.z | 0x80000000u)) - 1;
+                int n2 = nm < nv ? nm : nv;
+                bool stop2 = n2 < 31;
+                if (n2 >= m - 1 - i) { n2 = m - 1 - i; stop2 = false; }
+                if (n2 < 0) n2 = 0;
+                seg_n = n2;
+                seg_src_run = (unsigned)r + 1u;
+                r += n2;
+                c_ext += (unsigned)n2;
+                if (stop2) {
+                    const bool is_end = nv <= nm;
+                    const unsigned rc = (unsigned)(rq >> (2 * n2)) & 3u, aa = (unsigned)(x >> (2 * n2)) & 3u;
+                    const int kind = path_stop_kind(is_end, rc, aa, v2.w, v3.x, v3.y, v3.z, v3.w, n2, ix.has_safe != 0);
+                    if (kind == PS_ABSENT) ext_absent = true;
+                    else tnext = (kind == PS_TRANS) ? F_TRANS : F_BRIDGE;
                 }
             }
         } else if (brg) {
@@ -289,65 +302,63 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
                 c_brg++;
                 bridged = needb == k - 1;              // back on the path: on with F_EXT from position r + k, no walk
             } else {
-                ev = FE_EMIT1;                         // no bridge: a safe step has no successor by any other char
+                ev = FE_EMIT1;                         // no bridge: a bridgeable step has no successor by the read's char
                 b = blo = i + k - 1;
             }
         } else if (ext) {
             // k-mer i-1 sits at path position r.  Read bases i+k-1.. against path chars r..: while they agree (and the
-            // path goes on), k-mer i+x sits at r+1+x.
+            // path goes on), k-mer i+x sits at r+1+x.  v1 / v2 = first group { chars, GO, SAFE } { OTH }, v3 / v4 = second.
             const int sp = (int)((unsigned)r & 31u);
             u64 pwd = quad_bits(v1) >> (2 * sp);
-            if (sp) pwd |= quad_bits(v2) << (64 - 2 * sp);
-            // the path groups' two flag words (k_path_reencode): go = ~A | B, safe = A & B, only successor = ~A & B
-            const u64 fA = (((u64)v2.z << 32) | (u64)v1.z) >> sp, fB = (((u64)v2.w << 32) | (u64)v1.w) >> sp;
-            const u64 pgo = ~fA | fB;
-            const u64 x = rw ^ pwd;
+            if (sp) pwd |= quad_bits(v3) << (64 - 2 * sp);
+            const u64 pgo = (((u64)v3.z << 32) | (u64)v1.z) >> sp;
+            u64 x = rw ^ pwd;
             const u64 mm = (x | (x >> 1)) & 0x5555555555555555ull;
-            const int nm = mm ? ((__ffsll((i64)mm) - 1) >> 1) : 32;
-            const u64 badg = ~pgo | (1ull << 32);
-            const int nv = __ffsll((i64)badg) - 1;
+            int nm = mm ? ((__ffsll((i64)mm) - 1) >> 1) : 32;
+            int nv = __ffsll((i64)(~pgo | (1ull << 32))) - 1;
             int n = nm < nv ? nm : nv;
             bool stopped = n < 32;                     // a mismatch or the end of the path
-            int nmt = nm, nvt = nv;
+            u64 rcw = rw;                              // the window the stop lies in: read chars / differences from its first step
             if (!stopped) {
-                // the read's side is whole (LDS); the two path quads hold 32 - sp more chars
+                // the read's side is whole (LDS); the two path groups hold 32 - sp more steps
                 const int w2 = 32 - sp;
                 const u64 rw2 = s ? ((cw1 >> (2 * s)) | (cw2 << (64 - 2 * s))) : cw1;
-                const u64 x2 = rw2 ^ (quad_bits(v2) >> (2 * sp));
+                const u64 x2 = rw2 ^ (quad_bits(v3) >> (2 * sp));
                 const u64 mm2 = (x2 | (x2 >> 1)) & 0x5555555555555555ull;
                 const int nm2 = mm2 ? ((__ffsll((i64)mm2) - 1) >> 1) : 32;
-                const u64 bad2 = ~(pgo >> 32) | (1ull << 32);
-                const int nv2 = __ffsll((i64)bad2) - 1;
+                const int nv2 = __ffsll((i64)(~(pgo >> 32) | (1ull << 32))) - 1;
                 int n2 = nm2 < nv2 ? nm2 : nv2;
                 if (n2 >= w2) n2 = w2;                 // the end of what is loaded is not a stop
                 else stopped = true;
                 n = 32 + n2;
-                nmt = 32 + nm2;
-                nvt = 32 + nv2;
+                nm = 32 + nm2;
+                nv = 32 + nv2;
+                rcw = rw2;
+                x = x2;
             }
-            if (n > m - i) n = m - i;
+            if (n >= m - i) { n = m - i; stopped = false; }
             seg_n = n;
             seg_src_run = (unsigned)r + 1u;
-            r += n;
             c_ext += (unsigned)n;
-            bool sbit = false;                         // stopped at a char mismatch whose path step is substitution-safe?
-            if (stopped && nmt < nvt) {
-                const int nmq = nmt;
-                sbit = (((fA & fB) >> nmq) & 1ull) != 0;
-                // ... or a step whose char is the only successor of its column: the streaming step gives -1
-                // (SBWT.hh:572-575) without a look at the transition table
-                ext_absent = !sbit && (((~fA & fB) >> nmq) & 1ull) != 0;
-                if (sbit && nmq < 32) {
+            if (i + n == m) {
+                mode = F_IDLE;
+            } else if (stopped) {
+                const int o = sp + n, bit = o & 31, wn = n & 31;
+                const bool hi = o >= 32, is_end = nv <= nm;
+                const unsigned rc = (unsigned)(rcw >> (2 * wn)) & 3u, aa = (unsigned)(x >> (2 * wn)) & 3u;
+                int kind = path_stop_kind(is_end, rc, aa, hi ? v3.w : v1.w, hi ? v4.x : v2.x, hi ? v4.y : v2.y, hi ? v4.z : v2.z,
+                                          hi ? v4.w : v2.w, bit, ix.has_safe != 0);
+                if (kind == PS_BRIDGE && n < 32) {
                     // a bridge needs the next k-1 bases to agree with the path; a second difference already in this window:
-                    // skip the attempt
-                    const int after = 31 - nmq, want = (k - 1 < m - 1 - (i + nmq)) ? (k - 1) : (m - 1 - (i + nmq));
+                    // skip the attempt (the step has no successor by the read's char either way)
+                    const int after = 31 - n, want = (k - 1 < m - 1 - (i + n)) ? (k - 1) : (m - 1 - (i + n));
                     const int chk = after < want ? after : want;
-                    if (chk > 0 && ((mm >> (2 * (nmq + 1))) & low_mask(2 * chk)) != 0) { sbit = false; ext_absent = true; }
+                    if (chk > 0 && ((mm >> (2 * (n + 1))) & low_mask(2 * chk)) != 0) kind = PS_ABSENT;
                 }
+                if (kind == PS_ABSENT) ext_absent = true;
+                else { mode = (kind == PS_TRANS) ? F_TRANS : F_BRIDGE; j = 0; }
             }
-            qshort = stopped && n < 8;
-            if (i + n == m) { mode = F_IDLE; ext_absent = false; }
-            else if (stopped) mode = sbit ? F_BRIDGE : F_TRANS;
+            r += n;
         } else if (mode == F_INIT) {
             int wl = p;
             bool again = false;
@@ -431,8 +442,13 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
         }
         c_tab = uniform32(c_tab + (unsigned)__popcll(__ballot(tabhit)));
         c_stream = uniform32(c_stream + (unsigned)__popcll(__ballot(ev == FE_EMIT1 && trn)));
-        c_short = uniform32(c_short + (unsigned)__popcll(__ballot(qshort)));
 
+#ifdef SBWT_TRACE
+        if (n_reads == 1 && lane == 0 && busy)
+            printf("it: was ext%d trn%d brg%d init%d step%d | now mode %d i %d r %d l %d j %d ev %d res %d seg_n %d absent %d tnext %d wk %d wstart %d b %d | v1 %08x %08x %08x %08x v2 %08x %08x %08x %08x\n",
+                   (int)ext, (int)trn, (int)brg, 0, 0, mode, i, r, l, j, ev, res, seg_n, (int)ext_absent, tnext, wk, wstart, b,
+                   v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w);
+#endif
         // ---- events: results, certificates, next state ----
         int burst_hi = -1;                             // >= i: k-mers i..burst_hi are certified absent
         if (ev == FE_END) {
@@ -597,6 +613,7 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
             } else if (ev == FE_EMIT1 && res != -1) {
                 mode = rknown ? tnext : F_POS;         // SBWT.hh:560-
                 l = res;
+                j = 0;
             } else if (bridged) {
                 mode = F_EXT;                          // (i < m: the burst was k k-mers long)
                 r += k;

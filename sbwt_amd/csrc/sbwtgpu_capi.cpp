@@ -84,8 +84,8 @@ struct DeviceGuard {
 }  // namespace
 
 // tuning knobs (A/B experiments; defaults are the shipped configuration)
-// 0 = k_search (reference order), 1 = k_search_cert, 2 = k_search_cert along the path order (when the index has one),
-// 3 = k_search_pool: the path order with pooled reads (experiment: same bits, 18 % slower -- DESIGN.md section 3)
+// 0 = k_search (reference order), 1 = k_search_cert on the blocks, 4 = k_search_cert along the path order (two passes: encode +
+// search; 2 and 3, kernels of earlier rounds, mean 4 now), 5 = the fused route (k_search_fused + the general kernel behind it)
 static int tuning_variant() {
     static int v = [] { const char *e = getenv("SBWTGPU_SEARCH_VARIANT"); return e ? atoi(e) : -1; }();
     return v;
@@ -100,9 +100,7 @@ static int g_probe_filter = [] { const char *e = getenv("SBWTGPU_PROBE_FILTER");
 static int g_image_level = [] { const char *e = getenv("SBWTGPU_IMAGE_LEVEL"); return e ? atoi(e) : 0; }();
 static int64_t g_max_image_bytes = [] { const char *e = getenv("SBWTGPU_MAX_IMAGE_BYTES"); return e ? (int64_t)atoll(e) : (int64_t)0; }();
 static int g_sort_reads = [] { const char *e = getenv("SBWTGPU_SORT_READS"); return e ? atoi(e) : -1; }();   // -1 auto, 0 off, 1 on
-static int g_trans_wide = [] { const char *e = getenv("SBWTGPU_TRANS_WIDE"); return e ? atoi(e) : -1; }();   // -1 by the index
 static int g_force_mega = 0;    // tests: store every image's block counts relative to mega[c][0] (the dense rank-only layout)
-static int g_trans_ext = -1;    // -1: adaptive per wave, 0/1: force
 static int g_path_safe = [] { const char *e = getenv("SBWTGPU_PATH_SAFE"); return e ? atoi(e) : 2; }();   // 0 off, 1 narrow rule, 2 wide
 static int g_path_lookahead = [] { const char *e = getenv("SBWTGPU_PATH_LOOKAHEAD"); return e ? atoi(e) : 8; }();   // 0: the blind rule
 static int g_path_order = [] { const char *e = getenv("SBWTGPU_PATH_ORDER"); return e ? atoi(e) : 1; }();
@@ -145,11 +143,10 @@ struct sbwtgpu_index {
         v.col = h.has_path ? reinterpret_cast<const unsigned *>(blob + h.off_col) : nullptr;
         v.pos = h.has_path ? reinterpret_cast<const unsigned *>(blob + h.off_pos) : nullptr;
         v.pq = h.has_path ? reinterpret_cast<const uint4 *>(blob + h.off_pq) : nullptr;
-        v.trans = h.has_path ? reinterpret_cast<const uint4 *>(blob + h.off_trans) : nullptr;
+        v.trans = (h.has_path && h.log2t > 0) ? reinterpret_cast<const uint4 *>(blob + h.off_trans) : nullptr;
         v.stab_pos = h.stab_pos;
-        v.trans_wide = (int)h.trans_wide;
+        v.log2t = (int)h.log2t;
         v.has_safe = h.has_safe;
-        v.trans_ext = g_trans_ext;
         v.stab2 = h.log2b2 > 0 ? reinterpret_cast<const uint4 *>(blob + h.off_stab2) : nullptr;
         v.log2b2 = (int)h.log2b2;
         v.pfil = h.p_filter > 0 ? reinterpret_cast<const uint4 *>(blob + h.off_pfil) : nullptr;
@@ -159,12 +156,9 @@ struct sbwtgpu_index {
     }
 };
 
-// Which path-order kernel by default: per-read segment lists (4), except on a branchy index whose paths were chosen blindly
-// ("path_lookahead" = 0) -- reads then leave their path every few k-mers and the staged writer with its wide transition
-// entries (2) is the faster one.
-static inline int auto_variant(const SbwtBlobHeader &h) {
-    return (h.path_lookahead > 0 || h.n_branch * 64 <= h.n_nodes) ? 5 : 2;
-}
+// Which path-order route by default: the fused one (equal-length batches in one kernel, everything else through the
+// general kernel behind it).
+static inline int auto_variant(const SbwtBlobHeader &) { return 5; }
 
 extern "C" {
 
@@ -183,9 +177,9 @@ int sbwtgpu_set_tuning(const char *key, int64_t value) {
     if (!strcmp(key, "image_level")) { g_image_level = (int)value; return SBWTGPU_OK; }          // indexes created afterwards
     if (!strcmp(key, "max_image_bytes")) { g_max_image_bytes = value; return SBWTGPU_OK; }     // indexes created afterwards
     if (!strcmp(key, "sort_reads")) { g_sort_reads = (int)value; return SBWTGPU_OK; }
-    if (!strcmp(key, "trans_wide")) { g_trans_wide = (int)value; return SBWTGPU_OK; }     // indexes created afterwards
+    if (!strcmp(key, "trans_wide")) return SBWTGPU_OK;     // (round 2: wide transition entries; the table is sparse now)
     if (!strcmp(key, "force_mega")) { g_force_mega = (int)value; return SBWTGPU_OK; }     // indexes created afterwards
-    if (!strcmp(key, "trans_ext")) { g_trans_ext = (int)value; return SBWTGPU_OK; }
+    if (!strcmp(key, "trans_ext")) return SBWTGPU_OK;      // (round 2: transitions always run on along their quoted steps now)
     if (!strcmp(key, "path_safe")) { g_path_safe = (int)value; return SBWTGPU_OK; }   // indexes created afterwards
     if (!strcmp(key, "path_lookahead")) { g_path_lookahead = value < 0 ? 0 : value > 64 ? 64 : (int)value; return SBWTGPU_OK; }
     if (!strcmp(key, "path_order")) { g_path_order = (int)value; return SBWTGPU_OK; }   // indexes created afterwards
@@ -325,7 +319,7 @@ int sbwtgpu_index_create(const sbwtgpu_index_desc *d, int device, sbwtgpu_index 
         h.off_pos = align256(h.off_col + (n + 4) * 4);
         h.off_pq = align256(h.off_pos + (n + 4) * 4);
         h.off_trans = align256(h.off_pq + sbwt_path_quads(n) * 16);
-        h.blob_bytes = align256(h.off_trans + (n + 1) * 64);          // (n + 1) x 128 on branchy indexes: revised below
+        h.blob_bytes = h.off_trans;        // the transition table follows once the path order has said how many entries it needs
     }
     idx->device = device;
 
@@ -355,15 +349,7 @@ int sbwtgpu_index_create(const sbwtgpu_index_desc *d, int device, sbwtgpu_index 
     }
     h.C[0] = 1;
     for (int c = 1; c < 4; c++) h.C[c] = h.C[c - 1] + tot[c - 1];
-    // Branchy index (more than one column in 64 offers a choice of successors: pan-genomes) with blindly chosen paths
-    // ("path_lookahead" = 0), or "trans_wide" = 1: reads leave their path every few k-mers, and what follows a transition is
-    // mostly a run of 1-4 k-mers.  Their columns go into the transition entry itself (32 instead of 16 bytes per entry,
-    // +64 bytes per column of image) for the staged-writer kernel.  With paths that follow the core neither is needed.
     h.path_lookahead = h.has_path ? g_path_lookahead : 0;
-    if (h.has_path && g_trans_wide != 0 && (g_trans_wide > 0 || (tot[4] * 64 > n && g_path_lookahead == 0))) {
-        h.trans_wide = 1;
-        h.blob_bytes = align256(h.off_trans + (n + 1) * 128);
-    }
     // In an SBWT every column except the root has exactly one incoming edge, so the matrix holds
     // n_nodes - 1 set bits and every LF step stays inside [0, n_nodes).  Arbitrary bit vectors (the
     // stand-alone SubsetMatrixRank use) are still served, but only by rank(): walking them would
@@ -389,7 +375,6 @@ int sbwtgpu_index_create(const sbwtgpu_index_desc *d, int device, sbwtgpu_index 
         h.log2b2 = 0;
         h.p_filter = 0;
         h.has_path = 0;
-        h.trans_wide = 0;
     }
     if (d->precalc && p_file > 0) {
         const int64_t np = (int64_t)1 << (2 * p_file);
@@ -436,7 +421,6 @@ int sbwtgpu_index_create(const sbwtgpu_index_desc *d, int device, sbwtgpu_index 
                     hipGetErrorString(e));
     }
     int rc = SBWTGPU_OK;
-    unsigned char *alt_safe = nullptr;                 // per-position verdicts of the safe-bit pass, for the transition entries
     do {
         if ((e = hipMemset(idx->blob, 0, (size_t)h.blob_bytes)) != hipSuccess) break;
         {
@@ -500,31 +484,48 @@ int sbwtgpu_index_create(const sbwtgpu_index_desc *d, int device, sbwtgpu_index 
             // substitution-safe bits of the path: need the whole k-mers in the sparse table
             if (h.has_path && h.p_sparse == d->k && g_path_safe) {
                 SbwtIndexView v2 = idx->view();
-                // (rule 2 keeps the path heads' labels in the transition table's room, which is filled afterwards)
-                // ... and hands the per-char verdicts to the transition entries through alt_safe (a byte per position; without
-                // it only the steps that are safe for all three substitutes bridge)
-                if (g_path_safe >= 2 && hipMalloc((void **)&alt_safe, (size_t)n) != hipSuccess) {
+                // (rule 2 keeps the path heads' labels and their list in scratch)
+                void *hscr = nullptr;
+                if (g_path_safe >= 2 && hipMalloc(&hscr, (size_t)sbwt_path_safe_scratch_bytes(n)) != hipSuccess) {
                     (void)hipGetLastError();
-                    alt_safe = nullptr;
+                    hscr = nullptr;                     // no room for rule 2: the narrow rule needs none
                 }
-                sbwt_launch_path_safe(v2, reinterpret_cast<uint4 *>(idx->blob + h.off_pq), g_path_safe,
-                                      idx->blob + h.off_trans, alt_safe, 0);
-                if ((e = hipDeviceSynchronize()) != hipSuccess) break;
+                sbwt_launch_path_safe(v2, reinterpret_cast<uint4 *>(idx->blob + h.off_pq), hscr ? g_path_safe : 1, hscr, nullptr, 0);
+                e = hipDeviceSynchronize();
+                if (hscr) (void)hipFree(hscr);
+                if (e != hipSuccess) break;
                 h.has_safe = 1;
             }
         }
-        if (h.has_path) {                               // last: the transition entries quote the final path chars / safe bits
+        if (h.has_path) {
+            // Last: where reads can leave their paths (the OTH planes), and the transition table.  Its size is known only
+            // now -- about two entries per branching column and one per path end -- so the image moves once into an
+            // allocation of its final size (device-to-device, ~1 ms per GB).
             SbwtIndexView v3 = idx->view();
-            h.n_branch = sbwt_launch_path_trans(v3, reinterpret_cast<uint4 *>(idx->blob + h.off_trans),
-                                                reinterpret_cast<uint4 *>(idx->blob + h.off_pq), alt_safe, 0);
-            if (h.n_branch < 0) { e = hipErrorUnknown; break; }
-            h.n_paths = sbwt_count_paths(idx->view(), 0);          // (reads the final encoding of the path groups)
+            long long nb = 0;
+            const long long n_ent = sbwt_launch_path_oth(v3, reinterpret_cast<uint4 *>(idx->blob + h.off_pq), &nb, 0);
+            if (n_ent < 0) { e = hipErrorUnknown; break; }
+            h.n_branch = nb;
+            h.n_trans = n_ent;
+            int lt = 4;
+            while (((int64_t)1 << lt) < 2 * n_ent) lt++;                    // load factor 0.25 .. 0.5
+            h.log2t = lt;
+            const int64_t full = align256(h.off_trans + ((int64_t)64 << lt));
+            if (g_max_image_bytes > 0 && full > g_max_image_bytes && level < 2) { e = hipErrorOutOfMemory; break; }
+            char *nblob = nullptr;
+            if ((e = hipMalloc((void **)&nblob, (size_t)full)) != hipSuccess) break;
+            if ((e = hipMemcpy(nblob, idx->blob, (size_t)h.blob_bytes, hipMemcpyDeviceToDevice)) != hipSuccess) { (void)hipFree(nblob); break; }
+            (void)hipFree(idx->blob);
+            idx->blob = nblob;
+            h.blob_bytes = full;
+            sbwt_launch_trans_insert(idx->view(), reinterpret_cast<uint4 *>(idx->blob + h.off_trans), lt, 0);
+            if ((e = hipDeviceSynchronize()) != hipSuccess) break;
+            h.n_paths = sbwt_count_paths(idx->view(), 0);
             if (h.n_paths < 0) { e = hipErrorUnknown; break; }
         }
         if ((e = hipGetLastError()) != hipSuccess) break;
         e = hipDeviceSynchronize();
     } while (0);
-    if (alt_safe) (void)hipFree(alt_safe);
     if (e == hipErrorOutOfMemory && level < 2 && (h.has_path || h.p_sparse > 0)) {
         (void)hipGetLastError();                       // scratch of a derived structure did not fit: build without them
         (void)hipFree(idx->blob);
@@ -804,14 +805,14 @@ int sbwtgpu_search_encoded_dev(const sbwtgpu_index *idx, int64_t total_bases, co
     // its reads leave their path every 3-4 k-mers, and short segments fill the lists: 146.4 vs 143.8 ms)
     int variant = g_variant_override >= 0 ? g_variant_override : tuning_variant();
     if (variant < 0) variant = idx->h.has_path ? auto_variant(idx->h) : 2;
-    if (variant == 5) variant = 4;          // already-encoded bases: the fused route's general kernel
+    if (variant == 5 || variant == 2 || variant == 3) variant = 4;   // already-encoded bases: the general path kernel
     const int eff_streaming = (!streaming && (idx->h.has_ssup || idx->h.ssup_derived) && g_derive_ssup) ? 2 : streaming;
     // reads sorted by their place in the path order (sbwt_sort.hip): when the batch covers the index a few times
     void *sort_scratch = nullptr;
     long long sort_bytes = 0;
     int key_bits = 1;
     while (key_bits < 32 && ((int64_t)1 << key_bits) <= idx->h.n_nodes) key_bits++;
-    const bool path_kernel = (variant == 2 || variant == 4) && idx->h.has_path && eff_streaming && idx->h.stab_pos &&
+    const bool path_kernel = variant == 4 && idx->h.has_path && eff_streaming && idx->h.stab_pos &&
                              idx->h.n_nodes < ((int64_t)1 << 31) - 128 && n_reads < ((int64_t)1 << 31);
     // Off unless asked for ("sort_reads" = 1): the path order numbers its paths in column order, not along the genome, so
     // reads sorted by path position share lines only within one path (kernel 6.45 -> 6.16 ms on config 2) and the

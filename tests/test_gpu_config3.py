@@ -36,10 +36,9 @@ def test_config3_pangenome_k31(gpu):
     d_ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
     st = torch.cuda.current_stream().cuda_stream
 
-    def run(streaming, variant, trans_ext=-1):
+    def run(streaming, variant):
         out = torch.full((n_reads * m,), -9, dtype=torch.int64, device=dev)
         capi.set_tuning("search_variant", variant)
-        capi.set_tuning("trans_ext", trans_ext)
         try:
             idx.streaming_search_dev(d_bases.data_ptr(), d_bases.numel(), d_roff.data_ptr(), n_reads, out.data_ptr(),
                                      d_ooff.data_ptr(), d_ws.data_ptr(), wsb, st, streaming)
@@ -47,25 +46,15 @@ def test_config3_pangenome_k31(gpu):
             assert idx.workspace_status(d_ws.data_ptr(), st) == 0
         finally:
             capi.set_tuning("search_variant", -1)
-            capi.set_tuning("trans_ext", -1)
         return out
 
-    a = run(True, 5)                          # the product path: the fused route (transitions decide per wave whether to run on)
+    a = run(True, 5)                          # the product path: the fused route
     stats = idx.workspace_stats(d_ws.data_ptr(), st)
     assert stats[4] > 0, "the path-order kernel did not run"      # k-mers answered along path runs
-    assert torch.equal(a, run(True, 5, 1))    # transitions always run on along the quoted steps
-    assert torch.equal(a, run(True, 5, 0))    # ... never
-    assert torch.equal(a, run(True, 3))       # pooled reads (experiment, cross-check)
-    assert torch.equal(a, run(True, 3, 1))    # transitions always run on along the quoted steps
-    assert torch.equal(a, run(True, 3, 0))    # ... never
-    assert torch.equal(a, run(True, 2))       # path order, one lane per read
-    assert torch.equal(a, run(True, 4))       # ... with segment lists
-    assert torch.equal(a, run(True, 4, 1))
-    assert torch.equal(a, run(True, 2, 1))
-    assert torch.equal(a, run(True, 2, 0))
+    assert torch.equal(a, run(True, 4))       # the general path kernel over all reads (two passes)
     assert torch.equal(a, run(True, 1))       # certificates on the blocks only
     assert torch.equal(a, run(True, 0))       # the reference's order of searches
-    assert torch.equal(a, run(False, 3))      # per-k-mer search loop == streaming (upper-case input)
+    assert torch.equal(a, run(False, 5))      # per-k-mer search loop == streaming (upper-case input)
     assert int(a.min()) == -1 and int(a.max()) < bits.n_nodes
     hit = (a >= 0).double().mean().item()
     assert 0.68 < hit < 0.80                  # 0.99^31 = 0.73 of the k-mers avoid every substituted base
@@ -91,6 +80,6 @@ def test_config3_pangenome_k31(gpu):
     idx_core, idx = idx, idx0
     assert torch.equal(a, run(True, 4))
     trans_blind = idx.workspace_stats(d_ws.data_ptr(), st)[0]
-    assert torch.equal(a, run(True, 2))
+    assert torch.equal(a, run(True, 5))
     idx = idx_core
     assert trans_blind > 2 * trans_core, (trans_blind, trans_core)

@@ -48,14 +48,11 @@ def test_config2_full_size_properties(gpu):
 
     a = run(True, 5)                      # the product path: the fused route (k_search_fused, sbwt_search_fused.hip)
     assert idx.workspace_stats(d_ws.data_ptr(), st)[4] > 0
-    assert torch.equal(a, run(True, 3))   # path order, pooled reads (k_search_pool: an experiment kept as a cross-check)
     assert torch.equal(a, run(False, 5))  # the fused route under SBWT::search (internal streaming; upper-case input)
-    assert torch.equal(a, run(True, 2))   # path order, one lane per read (k_search_cert<PATH>)
-    assert torch.equal(a, run(True, 4))   # ... with segment lists instead of staged results
+    assert torch.equal(a, run(True, 4))   # the general path kernel over all reads (two passes: k_encode + k_search_cert<PATH>)
     assert torch.equal(a, run(True, 1))   # certificates on the blocks only
     assert torch.equal(a, run(True, 0))   # the reference's order of searches
-    assert torch.equal(a, run(False, 3))  # per-k-mer search loop (internal streaming) == streaming (upper-case input)
-    assert torch.equal(a, run(False, 2))
+    assert torch.equal(a, run(False, 4))  # per-k-mer search loop (internal streaming) == streaming (upper-case input)
     assert torch.equal(a, run(False, 1))  # per-k-mer search loop == streaming (upper-case input)
     assert torch.equal(a, run(True, 1))   # deterministic
     assert int(a.min()) == -1 and int(a.max()) < bits.n_nodes

@@ -216,8 +216,6 @@ def test_streaming_equals_search_at_scale_properties(gpu, genome_case):
 
 
 @pytest.mark.parametrize("variant,probe", [(0, -1), (1, -1), (1, 0), (1, 9), (1, 11), (1, 12), (1, 13), (1, 20), (1, 29),
-                                           (2, -1), (2, 0), (2, 9), (2, 13), (2, 29),
-                                           (3, -1), (3, 0), (3, 9), (3, 12), (3, 13), (3, 29),
                                            (4, -1), (4, 0), (4, 9), (4, 12), (4, 13), (4, 29),
                                            (5, -1), (5, 0), (5, 9), (5, 12), (5, 13), (5, 29)])
 def test_results_do_not_depend_on_search_variant_or_probe_length(gpu, genome_case, variant, probe):
@@ -488,7 +486,7 @@ def test_periodic_sequences_cycles_in_the_path_order(gpu, k):
     woff = np.concatenate([[0], np.cumsum([len(g) for g in genomes])]).astype(np.int64)
     bases = np.concatenate([bases, whole])
     off = np.concatenate([off, woff[1:] + off[-1]])
-    for variant in (5, 4, 3, 2, 1):
+    for variant in (5, 4, 1):
         capi.set_tuning("search_variant", variant)
         try:
             got, _ = idx.streaming_search(bases, off)
@@ -577,26 +575,7 @@ def test_many_short_reads_of_mixed_lengths(gpu, genome_case):
     assert np.array_equal(got2, oracle_batch(orc, bases, off, False))
 
 
-@pytest.mark.parametrize("mode", [0, 1])
-def test_transition_quoted_steps_on_and_off(gpu, genome_case, mode):
-    # the 8 path steps quoted in a transition entry let short runs end in the transition's own iteration; the
-    # kernel decides per wave, here both settings are forced
-    genomes, orc = genome_case
-    idx = gpu_index_from_oracle(orc)
-    bases, off = synth.sample_reads(genomes, 3000, 150, 0.02, 123)
-    bases = synth.inject(bases, 50, ord("N"), 6)
-    bases = synth.inject(bases, 50, ord("c"), 7)
-    capi.set_tuning("trans_ext", mode)
-    try:
-        got, _ = idx.streaming_search(bases, off)
-        got2, _ = idx.search(bases, off)
-    finally:
-        capi.set_tuning("trans_ext", -1)
-    assert np.array_equal(got, oracle_batch(orc, bases, off, True))
-    assert np.array_equal(got2, oracle_batch(orc, bases, off, False))
-
-
-@pytest.mark.parametrize("variant", [2, 4])
+@pytest.mark.parametrize("variant", [4])
 def test_sorted_reads_give_the_same_bits(gpu, genome_case, variant):
     # "sort_reads": the path-order kernels take the reads in the order of their first k-mer's path position (a radix
     # sort before the search); every result still lands at its own place.  Fixed-length and ragged batches, reads
@@ -625,19 +604,12 @@ def test_sorted_reads_give_the_same_bits(gpu, genome_case, variant):
         capi.set_tuning("sort_reads", -1)
 
 
-@pytest.mark.parametrize("wide", [0, 1])
-@pytest.mark.parametrize("variant", [2, 3, 4, 5])
-def test_wide_transition_entries(gpu, genome_case, variant, wide):
-    # "trans_wide": transition entries that carry the columns of the successor's next four path steps (branchy
-    # indexes; forced here) -- short runs after a transition are served from the entry; same bits either way, with the
-    # transitions running on along their quoted steps (trans_ext = 1) or deciding per wave
+@pytest.mark.parametrize("variant", [4, 5])
+def test_reads_that_hop_between_strains(gpu, genome_case, variant):
+    # reads that hop between the strains every few bases leave their path all the time: transition entries (hashed on
+    # (path position, char), probed linearly), runs that end inside the 32 steps an entry quotes, path ends
     genomes, orc = genome_case
-    capi.set_tuning("trans_wide", wide)
-    try:
-        idx = gpu_index_from_oracle(orc)
-    finally:
-        capi.set_tuning("trans_wide", -1)
-    # reads that hop between the strains every few bases leave their path all the time
+    idx = gpu_index_from_oracle(orc)
     rng = np.random.default_rng(4)
     n, L = 3000, 150
     start = rng.integers(0, len(genomes[0]) - L, size=n)
@@ -651,10 +623,10 @@ def test_wide_transition_entries(gpu, genome_case, variant, wide):
     want = oracle_batch(orc, bases, off, True)
     capi.set_tuning("search_variant", variant)
     try:
-        for te in (1, -1, 0):
-            capi.set_tuning("trans_ext", te)
-            got, _ = idx.streaming_search(bases, off)
-            assert np.array_equal(got, want), (variant, wide, te)
+        got, _ = idx.streaming_search(bases, off)
+        assert np.array_equal(got, want), variant
+        bases2 = synth.inject(synth.inject(bases, 200, ord("N"), 3), 200, ord("t"), 4)      # ... with bases the fused kernel hands on
+        got, _ = idx.streaming_search(bases2, off)
+        assert np.array_equal(got, oracle_batch(orc, bases2, off, True)), variant
     finally:
         capi.set_tuning("search_variant", -1)
-        capi.set_tuning("trans_ext", -1)

@@ -34,7 +34,10 @@ while time.time() < t_end:
     ssup = bool(rng.integers(0, 2))
     rc = bool(rng.integers(0, 2))
     bits = hostlib.build_bits([g.tobytes() for g in genomes], k, rc, ssup, n_threads=4)
-    capi.set_tuning("trans_wide", int(rng.integers(-1, 2)))
+    # knobs that must not change results: how the paths are chosen, which safe rule, the image level
+    capi.set_tuning("path_lookahead", int(rng.choice([0, 1, 8])))
+    capi.set_tuning("path_safe", int(rng.choice([0, 1, 2, 2])))
+    capi.set_tuning("image_level", int(rng.choice([0, 0, 0, 1, 2])))
     idx = capi.Index.create(bits.cols[0], bits.cols[1], bits.cols[2], bits.cols[3], bits.ssup if ssup else None,
                             bits.n_nodes, k, bits.n_kmers, int(rng.choice([0, 0, 2, min(k, 8)])))
     # reads
@@ -59,15 +62,12 @@ while time.time() < t_end:
         bases = synth.inject(bases, int(rng.integers(0, 30)), ord("N"), int(rng.integers(1, 1 << 30)))
         bases = synth.inject(bases, int(rng.integers(0, 30)), int(rng.choice(list(b"acgtn"))), int(rng.integers(1, 1 << 30)))
     res = {}
-    for v in (0, 1, 2, 3, 4, 5):
+    for v in (0, 1, 4, 5):
         capi.set_tuning("search_variant", v)
-        capi.set_tuning("sort_reads", int(rng.integers(0, 2)) if v in (2, 4) else -1)
-        for te in ((-1, 1) if v >= 2 else (-1,)):
-            capi.set_tuning("trans_ext", te)
-            a = idx.streaming_search(bases, off)[0] if ssup else None
-            b = idx.search(bases, off)[0]
-            res[(v, te)] = (a, b)
-    capi.set_tuning("trans_ext", -1)
+        capi.set_tuning("sort_reads", int(rng.integers(0, 2)) if v == 4 else -1)
+        a = idx.streaming_search(bases, off)[0] if ssup else None
+        b = idx.search(bases, off)[0]
+        res[(v, -1)] = (a, b)
     ref = res[(0, -1)]
 
     def explain(got, want):
@@ -99,4 +99,5 @@ while time.time() < t_end:
                 print("MISMATCH vs oracle case", case, "read", r); sys.exit(1)
 capi.set_tuning("search_variant", -1)
 capi.set_tuning("sort_reads", -1)
+capi.set_tuning("path_lookahead", 8); capi.set_tuning("path_safe", 2); capi.set_tuning("image_level", 0)
 print("fuzz ok:", case, "cases")
