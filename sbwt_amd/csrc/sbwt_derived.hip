@@ -424,8 +424,8 @@ __global__ void __launch_bounds__(256) k_path_place(i64 n, const uint4 *__restri
     const unsigned t = (unsigned)base[me.x] + me.y;
     pos[v] = t;
     col[t] = (unsigned)v;
-    if (succ[v] != PATH_NONE) {                         // group t>>5, first quad = { chars lo, chars hi, GO, SAFE }
-        unsigned *quad = pq + (size_t)(t >> 5) * 8;
+    if (succ[v] != PATH_NONE) {                         // quad t>>5 = { chars lo, chars hi, go mask, - }
+        unsigned *quad = pq + (size_t)(t >> 5) * 4;
         const unsigned s = t & 31u;
         if (sch[v]) atomicOr(&quad[s >> 4], (unsigned)sch[v] << (2 * (s & 15u)));
         atomicOr(&quad[2], 1u << s);
@@ -452,8 +452,8 @@ __global__ void __launch_bounds__(256) k_path_safe(SbwtIndexView ix, unsigned *p
     const int k = ix.k;
     if (u < k || u + k > ix.n_nodes) return;
     const i64 lo = u - k;                               // steps lo .. lo+2k-1 must all be kept
-    const uint4 *q = ix.pq + 2 * (lo >> 5);
-    const uint4 a = q[0], b = q[2], c = q[4];
+    const uint4 *q = ix.pq + (lo >> 5);
+    const uint4 a = q[0], b = q[1], c = q[2];
     const int s = (int)(lo & 31);
     const u64 A = quad_bits(a), B = quad_bits(b), C = quad_bits(c);
     const u64 w0 = s ? ((A >> (2 * s)) | (B << (64 - 2 * s))) : A;       // chars lo .. lo+31
@@ -469,7 +469,7 @@ __global__ void __launch_bounds__(256) k_path_safe(SbwtIndexView ix, unsigned *p
         for (u64 alt = 1; alt < 4; alt++)
             if (sp_present(ix, key ^ (alt << (2 * w)))) return;
     }
-    atomicOr(&pq_words[(size_t)(u >> 5) * 8 + 3], 1u << (int)(u & 31));
+    atomicOr(&pq_words[(size_t)(u >> 5) * 4 + 3], 1u << (int)(u & 31));
 }
 
 // The same bit by a wider rule (the default): the k-1 steps BEFORE u need not lie on u's path.  What the k windows hold
@@ -481,7 +481,7 @@ __global__ void __launch_bounds__(256) k_path_safe(SbwtIndexView ix, unsigned *p
 // of its lanes costs as much as one that does it for 64 -- 69 -> 6 ms at 142 M columns)
 __global__ void __launch_bounds__(256) k_path_list_heads(SbwtIndexView ix, unsigned *__restrict__ list, u64 *count) {
     const i64 t = (i64)blockIdx.x * 256 + threadIdx.x;
-    const bool head = t < ix.n_nodes && (t == 0 || !((ix.pq[2 * ((t - 1) >> 5)].z >> (int)((t - 1) & 31)) & 1u));   // step t-1 does not go on
+    const bool head = t < ix.n_nodes && (t == 0 || !((ix.pq[(t - 1) >> 5].z >> (int)((t - 1) & 31)) & 1u));   // step t-1 does not go on
     const u64 slot = block_append_slot(count, head);
     if (slot != ~0ull) list[slot] = (unsigned)t;
 }
@@ -516,7 +516,7 @@ __global__ void __launch_bounds__(256) k_path_safe_labels(SbwtIndexView ix, unsi
     const i64 q = u >> 5;
     const int s = (int)(u & 31), o = 32 + s;
     const uint4 zero = make_uint4(0u, 0u, 0u, 0u);
-    const uint4 qa = q > 0 ? ix.pq[2 * (q - 1)] : zero, qb = ix.pq[2 * q], qc = ix.pq[2 * (q + 1)];
+    const uint4 qa = q > 0 ? ix.pq[q - 1] : zero, qb = ix.pq[q], qc = ix.pq[q + 1];
     const u64 A = quad_bits(qa), B = quad_bits(qb), C = quad_bits(qc);
     // the k steps u .. u+k-1 and their chars
     const u64 gr = ((((u64)qc.z << 32) | (u64)qb.z) >> s) & low_mask(k);
@@ -538,48 +538,38 @@ __global__ void __launch_bounds__(256) k_path_safe_labels(SbwtIndexView ix, unsi
     // S = left (k-1 chars) . ch[u] . right's other k-1 chars; window number w starts at char w, ch[u] is its char k-1-w
     const u64 Slo = left | (right << (2 * (k - 1))), Shi = right >> (64 - 2 * (k - 1));
     const u64 km = low_mask(2 * k);
-    // A substitute by which the column HAS a successor needs no verdict: a read with that base takes the transition
-    // (the OTH bits, k_path_oth).  The SAFE bit speaks for the others: every substitute WITHOUT a successor is absent from
-    // all k windows -- in a pan-genome most steps have one real variant, and a sequencing error is one of the other two.
-    const PathGroup pgv = path_group(ix, (i64)ix.col[u]);
-    const unsigned ych = (unsigned)(B >> (2 * s)) & 3u;
     unsigned ok = 7u;                                   // substitutes not seen in any window yet
-    for (unsigned alt = 1; alt < 4; alt++)
-        if (pgv.target[ych ^ alt] != PATH_NONE) ok &= ~(1u << (alt - 1));
-    const unsigned need = ok;                           // the substitutes the bit has to vouch for
-    for (int w = 0; w < k && ok == need; w++) {
+    for (int w = 0; w < k && ok; w++) {
         const u64 key = ((Slo >> (2 * w)) | (w ? (Shi << (64 - 2 * w)) : 0ull)) & km;
         for (u64 alt = 1; alt < 4; alt++)
             if (((ok >> (alt - 1)) & 1u) && sp_present(ix, key ^ (alt << (2 * (k - 1 - w))))) ok &= ~(1u << (alt - 1));
     }
-    (void)alt_safe;
-    if (ok == need && need != 0u) atomicOr(&pq_words[(size_t)q * 8 + 3], 1u << s);
+    if (alt_safe) alt_safe[u] = (unsigned char)ok;
+    if (ok == 7u) atomicOr(&pq_words[(size_t)q * 4 + 3], 1u << s);
 }
 
-// Where a read can leave its path.  Position t (column v = col[t]) offers the successors of v's suffix group; the path itself
-// takes one of them (char y, GO bit set).  Second quad of the path group = four planes OTH0..OTH3:
-//   GO = 1: OTHa (a = 1..3) set <=> v has a successor by char y ^ a       (OTH0 unused)
-//   GO = 0: OTHc (c = 0..3) set <=> v has a successor by char c           (the path ends here; its char bits are 0)
-// A read that differs from the path at t looks at its bit: clear -> the streaming step's answer is -1 without any gather
-// (SBWT.hh:572-575: no column of the group carries that char), or a bridge where the SAFE bit vouches for it; set -> ONE
-// gather of the transition entry (k_trans_insert), which always exists.  Also counts those entries and the columns with
-// two or more successors.
-__global__ void __launch_bounds__(256) k_path_oth(SbwtIndexView ix, unsigned *__restrict__ pq_words,
+// Where a read can leave its path, and the transition table.  Position t (column v = col[t]) offers the successors of v's
+// suffix group; the path itself takes one of them (char y).  ONLY[t]: y is the only one -- a read that differs from the path
+// there gets -1 without any gather (SBWT.hh:572-575: no column of the group carries its char), or a bridge where the SAFE bit
+// vouches for the step.  Every other way off a path is ONE gather of a 32-byte entry of the transition table, hashed on
+// (t, c) with linear probing:
+//   quad 0 = { t + 1 (0 = free slot), c | flags, successor column (the streaming step's answer, SBWT.hh:562-575), its path position p }
+//   quad 1 = the successor's path from p on, steps p .. p+31, in the path groups' own encoding { chars lo, chars hi, A, B }
+//            (pre-shifted: a read that takes the transition runs on along them without a look at pq)
+// Entries exist for (i) every successor of a column whose path ends there (a char without one finds a free slot: -1), and
+// (ii) at a step with two or more successors, for ALL three substitutes of the path's char: a successor, or a NEGATIVE entry
+// (flag 0x100) that says "none" and whether the step is substitution-safe for exactly this char (0x200, k_path_safe_labels:
+// in a pan-genome most branching steps have ONE real variant, and a sequencing error is one of the other two bases).
+__global__ void __launch_bounds__(256) k_path_oth(SbwtIndexView ix, unsigned *__restrict__ only,
                                                   unsigned long long *__restrict__ counters) {
     const i64 t = (i64)blockIdx.x * 256 + threadIdx.x;
     int n_ent = 0, branch = 0;
     if (t < ix.n_nodes) {
         const PathGroup pg = path_group(ix, (i64)ix.col[t]);
-        const uint4 A = ix.pq[2 * (t >> 5)];
-        const int s = (int)(t & 31);
-        const bool go = (A.z >> s) & 1u;
-        const unsigned y = go ? ((unsigned)(quad_bits(A) >> (2 * s)) & 3u) : 0u;
-#pragma unroll
-        for (unsigned c = 0; c < 4; c++) {
-            if (pg.target[c] == PATH_NONE || (go && c == y)) continue;
-            atomicOr(&pq_words[(size_t)(t >> 5) * 8 + 4 + (c ^ y)], 1u << s);
-            n_ent++;
-        }
+        const bool go = (ix.pq[t >> 5].z >> (int)(t & 31)) & 1u;        // (build-time layout: z = GO, w = SAFE)
+        if (!go) n_ent = pg.deg;
+        else if (pg.deg >= 2) n_ent = 3;
+        else atomicOr(&only[t >> 5], 1u << (unsigned)(t & 31));         // exactly one successor: where the path goes on
         branch = pg.deg >= 2;
     }
 #pragma unroll
@@ -589,50 +579,65 @@ __global__ void __launch_bounds__(256) k_path_oth(SbwtIndexView ix, unsigned *__
         if (branch) atomicAdd(&counters[1], (unsigned long long)branch);
     }
 }
-// The transition table: one 64-byte entry per (position t, char c) that has a successor off the path, hashed on (t, c)
-// with linear probing (lookups always hit, so no overflow marks):
-//   quad 0 = { t + 1 (0 = free), c, successor column (the streaming step's answer, SBWT.hh:562-575), its path position p }
-//   quad 1 = the successor's path from p on, steps p .. p+31: { chars lo, chars hi, GO, SAFE }      (pre-shifted: a read that
-//   quad 2 = ... { OTH0, OTH1, OTH2, OTH3 }                                                           takes the transition
-//   quad 3 = -                                                                                       runs on without a look at pq)
-__global__ void __launch_bounds__(256) k_trans_insert(SbwtIndexView ix, unsigned *__restrict__ table, int log2t) {
+// (runs on the FINAL encoding of the path groups, k_path_reencode: go = ~A | B)
+__global__ void __launch_bounds__(256) k_trans_insert(SbwtIndexView ix, unsigned *__restrict__ table, int log2t,
+                                                      const unsigned char *__restrict__ alt_safe) {
     const i64 t = (i64)blockIdx.x * 256 + threadIdx.x;
     if (t >= ix.n_nodes) return;
-    const uint4 A = ix.pq[2 * (t >> 5)];
+    const uint4 Q = ix.pq[t >> 5];
     const int s = (int)(t & 31);
-    const bool go = (A.z >> s) & 1u;
-    const unsigned y = go ? ((unsigned)(quad_bits(A) >> (2 * s)) & 3u) : 0u;
-    const uint4 Bq = ix.pq[2 * (t >> 5) + 1];
-    const unsigned oth[4] = {Bq.x, Bq.y, Bq.z, Bq.w};
-    bool any = false;
-#pragma unroll
-    for (unsigned a = 0; a < 4; a++) any = any || ((oth[a] >> s) & 1u);
-    if (!any) return;
+    const bool go = ((~Q.z | Q.w) >> s) & 1u, only = ((~Q.z & Q.w) >> s) & 1u;
+    if (go && only) return;
     const PathGroup pg = path_group(ix, (i64)ix.col[t]);
+    if (go && pg.deg < 2) return;
+    const unsigned y = go ? ((unsigned)(quad_bits(Q) >> (2 * s)) & 3u) : 0u;
+    const unsigned asafe = (go && alt_safe) ? alt_safe[t] : 0u;
 #pragma unroll
     for (unsigned c = 0; c < 4; c++) {
-        if (!((oth[c ^ y] >> s) & 1u)) continue;
-        const unsigned nc = pg.target[c], np = ix.pos[nc];
-        // the successor's path from np on: 32 steps out of two path groups
-        const uint4 *q = ix.pq + 2 * (size_t)(np >> 5);
-        const uint4 a0 = q[0], b0 = q[1], a1 = q[2], b1 = q[3];
-        const int sp = (int)(np & 31u);
-        const u64 ch = (quad_bits(a0) >> (2 * sp)) | (sp ? (quad_bits(a1) << (64 - 2 * sp)) : 0ull);
-        auto pl = [&](unsigned lo, unsigned hi) { return (unsigned)((((u64)hi << 32) | (u64)lo) >> sp); };
-        const uint4 e1 = make_uint4((unsigned)ch, (unsigned)(ch >> 32), pl(a0.z, a1.z), pl(a0.w, a1.w));
-        const uint4 e2 = make_uint4(pl(b0.x, b1.x), pl(b0.y, b1.y), pl(b0.z, b1.z), pl(b0.w, b1.w));
+        if (go ? (c == y) : (pg.target[c] == PATH_NONE)) continue;
+        uint4 e0, e1 = make_uint4(0u, 0u, 0u, 0u);
+        if (pg.target[c] == PATH_NONE) {
+            const unsigned a = c ^ y;
+            e0 = make_uint4((unsigned)t + 1u, c | SBWT_TRANS_NEG | (((asafe >> (a - 1)) & 1u) ? SBWT_TRANS_NEG_SAFE : 0u), PATH_NONE, 0u);
+        } else {
+            const unsigned nc = pg.target[c], np = ix.pos[nc];
+            const uint4 *q = ix.pq + (np >> 5);         // the successor's path from np on: 32 steps out of two path groups
+            const uint4 a0 = q[0], a1 = q[1];
+            const int sp = (int)(np & 31u);
+            const u64 ch = (quad_bits(a0) >> (2 * sp)) | (sp ? (quad_bits(a1) << (64 - 2 * sp)) : 0ull);
+            e0 = make_uint4((unsigned)t + 1u, c, nc, np);
+            e1 = make_uint4((unsigned)ch, (unsigned)(ch >> 32), (unsigned)((((u64)a1.z << 32) | (u64)a0.z) >> sp),
+                            (unsigned)((((u64)a1.w << 32) | (u64)a0.w) >> sp));
+        }
         u64 slot = sbwt_trans_slot((unsigned)t, c, log2t);
         for (;;) {
-            if (atomicCAS(&table[slot * 16], 0u, (unsigned)t + 1u) == 0u) break;
+            if (atomicCAS(&table[slot * 8], 0u, e0.x) == 0u) break;
             slot = (slot + 1) & low_mask(log2t);
         }
-        uint4 *e = reinterpret_cast<uint4 *>(table + slot * 16);
-        e[1] = e1;
-        e[2] = e2;
-        table[slot * 16 + 1] = c;
-        table[slot * 16 + 2] = nc;
-        table[slot * 16 + 3] = np;
+        table[slot * 8 + 1] = e0.y;
+        table[slot * 8 + 2] = e0.z;
+        table[slot * 8 + 3] = e0.w;
+        reinterpret_cast<uint4 *>(table + slot * 8)[1] = e1;
     }
+}
+
+// Final form of the path groups.  While the path order is built, quad t>>5 = { chars lo, chars hi, GO, SAFE }.  The search
+// kernels want a third bit per position (ONLY: the path's char is the only successor) in the same 16 bytes, and a
+// substitution-safe step is necessarily an only-successor step, so two words encode the four states of a position:
+//     A B
+//     0 0   the path goes on                        A = SAFE | ~GO
+//     0 1   ... and its char is the only successor   B = SAFE | (ONLY & GO)
+//     1 1   ... and the step is substitution-safe
+//     1 0   the path ends here
+// decoded by the kernels as  go = ~A | B,  safe = A & B,  only = ~A & B.
+__global__ void __launch_bounds__(256) k_path_reencode(uint4 *__restrict__ pq, i64 n_quads, const unsigned *__restrict__ only) {
+    const i64 q = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (q >= n_quads) return;
+    uint4 v = pq[q];
+    const unsigned go = v.z, safe = v.w, on = only[q];
+    v.z = safe | ~go;
+    v.w = safe | (on & go);
+    pq[q] = v;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -734,7 +739,7 @@ long long sbwt_path_scratch_bytes(long long n_nodes) {
     const long long nb = (n_nodes + 1023) / 1024;
     return np * (8 + 32) + np + np * 8 * 2 + (nb + 2) * 8 + 4096;     // succ, prv; two arrays of { jump, dist, min, - }; ...
 }
-long long sbwt_path_quads(long long n_nodes) { return 2 * (n_nodes / 32 + 4); }   // 16-byte quads: two per group of 32 positions
+long long sbwt_path_quads(long long n_nodes) { return n_nodes / 32 + 4; }
 // number of paths = positions whose "path goes on" bit is clear
 __global__ void __launch_bounds__(256) k_path_count_ends(const uint4 *__restrict__ pq, i64 n, unsigned long long *counter) {
     const i64 q = (i64)blockIdx.x * 256 + threadIdx.x;
@@ -742,7 +747,7 @@ __global__ void __launch_bounds__(256) k_path_count_ends(const uint4 *__restrict
     if (q * 32 < n) {
         const i64 left = n - q * 32;
         const unsigned valid = left >= 32 ? 0xFFFFFFFFu : ((1u << (int)left) - 1u);
-        ends = (unsigned)__popc(~pq[2 * q].z & valid);            // GO clear: the path ends
+        ends = (unsigned)__popc(pq[q].z & ~pq[q].w & valid);      // A & ~B: the path ends (final encoding, k_path_reencode)
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) ends += __shfl_down(ends, off);
@@ -848,29 +853,38 @@ int sbwt_launch_build_path(const SbwtIndexView &ix, unsigned *d_col, unsigned *d
     hipLaunchKernelGGL(k_scan_block_sums, dim3((unsigned)nb), dim3(256), 0, stream, reinterpret_cast<const i64 *>(len), n, bsum);
     hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, stream, bsum, nb);
     hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nb), dim3(256), 0, stream, reinterpret_cast<const i64 *>(len), n, bsum, pbase);
-    (void)hipMemsetAsync(d_pq, 0, (size_t)sbwt_path_quads(n) * 16, stream);   // (the last groups stay zero: GO clear)
+    (void)hipMemsetAsync(d_pq, 0, (size_t)sbwt_path_quads(n) * 16, stream);
     hipLaunchKernelGGL(k_path_place, dim3(g), dim3(256), 0, stream, n, jb[cur], pbase, succ, sch, d_pos,
                        d_col, reinterpret_cast<unsigned *>(d_pq));
     if (hipStreamSynchronize(stream) != hipSuccess) return -1;
     (void)d_trans;                                      // filled by sbwt_launch_path_trans once the safe bits are final
     return 0;
 }
-// The OTH planes of the path groups; returns the number of transition entries (*n_branch: columns with two or more
-// successors).  Synchronises the stream.  -1 on error.
+// The ONLY bits, then the path groups' final encoding (k_path_reencode); returns the number of transition entries
+// (*n_branch: columns with two or more successors).  Synchronises the stream.  -1 on error.
 long long sbwt_launch_path_oth(const SbwtIndexView &ix, uint4 *d_pq, long long *n_branch, hipStream_t stream) {
     unsigned long long *d = nullptr, h[2] = {0, 0};
+    unsigned *only = nullptr;
+    const i64 n_quads = sbwt_path_quads(ix.n_nodes);
     if (hipMalloc((void **)&d, 16) != hipSuccess) return -1;
+    if (hipMalloc((void **)&only, (size_t)n_quads * 4) != hipSuccess) { (void)hipFree(d); return -1; }
     (void)hipMemsetAsync(d, 0, 16, stream);
-    hipLaunchKernelGGL(k_path_oth, dim3(grid_for(ix.n_nodes)), dim3(256), 0, stream, ix, reinterpret_cast<unsigned *>(d_pq), d);
+    (void)hipMemsetAsync(only, 0, (size_t)n_quads * 4, stream);
+    hipLaunchKernelGGL(k_path_oth, dim3(grid_for(ix.n_nodes)), dim3(256), 0, stream, ix, only, d);
+    hipLaunchKernelGGL(k_path_reencode, dim3(grid_for(n_quads)), dim3(256), 0, stream, d_pq, n_quads, only);
     hipError_t e = hipMemcpyAsync(h, d, 16, hipMemcpyDeviceToHost, stream);
     if (e == hipSuccess) e = hipStreamSynchronize(stream);
     (void)hipFree(d);
+    (void)hipFree(only);
     if (e != hipSuccess) return -1;
     if (n_branch) *n_branch = (long long)h[1];
     return (long long)h[0];
 }
-// Fills the (zeroed) transition table of 2^log2t 64-byte entries.
-void sbwt_launch_trans_insert(const SbwtIndexView &ix, uint4 *d_trans, int log2t, hipStream_t stream) {
-    (void)hipMemsetAsync(d_trans, 0, (size_t)64 << log2t, stream);
-    hipLaunchKernelGGL(k_trans_insert, dim3(grid_for(ix.n_nodes)), dim3(256), 0, stream, ix, reinterpret_cast<unsigned *>(d_trans), log2t);
+// Fills the transition table of 2^log2t 32-byte entries (zeroed here).  d_alt_safe: the per-substitute verdicts of
+// k_path_safe_labels (a byte per position), or nullptr.
+void sbwt_launch_trans_insert(const SbwtIndexView &ix, uint4 *d_trans, int log2t, const unsigned char *d_alt_safe,
+                              hipStream_t stream) {
+    (void)hipMemsetAsync(d_trans, 0, (size_t)32 << log2t, stream);
+    hipLaunchKernelGGL(k_trans_insert, dim3(grid_for(ix.n_nodes)), dim3(256), 0, stream, ix, reinterpret_cast<unsigned *>(d_trans), log2t,
+                       d_alt_safe);
 }

@@ -93,21 +93,19 @@ __device__ __forceinline__ i64 select_in_row(const SbwtIndexView &ix, int c, i64
 }
 
 
-// What a read meets at the path step it does not follow (path groups: sbwt_device.h, k_path_oth).  `is_end`: the path ends at
-// that step (GO clear) and rc is the read's char; else a = rc ^ the path's char (1..3).  safe_w / o0..o3: the SAFE and OTH
-// words that hold the step, `bit` its bit there.
+// What a read meets at the path step it does not follow.  sA, sB: the step's two state bits (k_path_reencode): go = ~A | B,
+// safe = A & B, only successor = ~A & B.  `mismatch`: the path goes on there with another char than the read's (else the
+// path ends at the step).
 #define PS_NONE 0               // nothing: the window was used up
-#define PS_TRANS 1              // a successor off the path: one gather of the transition entry
-#define PS_BRIDGE 2             // no successor, and the SAFE bit vouches for the substitute: compare the next k-1 bases
-#define PS_ABSENT 3             // no successor: the streaming step's answer is -1 (SBWT.hh:572-575), no gather
-__device__ __forceinline__ int path_stop_kind(bool is_end, unsigned rc, unsigned a, unsigned safe_w, unsigned o0, unsigned o1,
-                                              unsigned o2, unsigned o3, int bit, bool has_safe) {
-    const unsigned sel = is_end ? rc : a;
-    const unsigned ow = sel == 0 ? o0 : sel == 1 ? o1 : sel == 2 ? o2 : o3;
-    if ((ow >> bit) & 1u) return PS_TRANS;
-    if (!is_end && has_safe && ((safe_w >> bit) & 1u)) return PS_BRIDGE;
-    return PS_ABSENT;
+#define PS_TRANS 1              // a lookup in the transition table (k_trans_insert): a successor, a verdict, or a free slot
+#define PS_BRIDGE 2             // no other successor, and the step is substitution-safe: compare the next k-1 bases
+#define PS_ABSENT 3             // no other successor: the streaming step's answer is -1 (SBWT.hh:572-575), no gather
+__device__ __forceinline__ int path_stop_kind(bool mismatch, unsigned sA, unsigned sB, bool has_safe) {
+    if (!mismatch || !sB) return PS_TRANS;              // the path ends, or the step has other successors
+    return (sA && has_safe) ? PS_BRIDGE : PS_ABSENT;
 }
+#define SBWT_TRANS_NEG 0x100u          // transition entry: (t, c) has no successor ...
+#define SBWT_TRANS_NEG_SAFE 0x200u     // ... and the step is substitution-safe for exactly this char
 // home slot of (path position t, char c) in the transition table of 2^log2t entries
 __device__ __forceinline__ u64 sbwt_trans_slot(unsigned t, unsigned c, int log2t) {
     return (((u64)t * 4ull + c) * SBWT_SP_HASH) >> (64 - log2t);

@@ -480,7 +480,7 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
         //      one (or none) load a duplicate (or the first block), so that the wave issues both
         //      loads back to back and waits once. ----
         int kind = K_NONE, ev = EV_NONE, tfail = 0, c = 0, grp = 0;
-        const uint4 *a1 = ix.blocks, *a2 = ix.blocks, *ax = nullptr, *ay = nullptr;   // ax, ay: PATH: the third / fourth quad of a path step
+        const uint4 *a1 = ix.blocks, *a2 = ix.blocks;
         pos_t res = -1;
         const bool strm = !PATH && (mode == M_STREAM || mode == M_BACK);
         const bool ext = PATH && (mode == M_EXT);
@@ -524,8 +524,7 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
                 g2ok = false;
                 tag = grp;
             }
-            // (a path step compares up to 64 bases and has no load slot left for the next group: it wants the pair cached)
-            if (grp != tag || ((mode == M_INIT ? s + wl > 32 : (PATH && (ext || trn || brg))) && !g1ok)) {
+            if (grp != tag || (mode == M_INIT && s + wl > 32 && !g1ok)) {
                 kind = K_RELOAD;                       // the packed group pair holding the next base(s)
                 a1 = packed + grp;
                 a2 = a1 + 1;
@@ -533,20 +532,14 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
                 kind = K_MODE;
                 const u64 codes0 = quad_bits(g0);
                 c = (int)((unsigned)(codes0 >> (2 * s)) & 3u);
-                if (ext) {
-                    a1 = ix.pq + 2 * (size_t)((unsigned)r >> 5);           // the two path groups holding steps r .. r+32: 64 bytes
+                if (ext || brg) {
+                    a1 = ix.pq + (((unsigned)r + (brg ? 1u : 0u)) >> 5);   // the two quads holding path chars r (+1) .. +31
                     a2 = a1 + 1;
-                    ax = a1 + 2;
-                    ay = a1 + 3;
-                } else if (brg) {
-                    a1 = ix.pq + 2 * (size_t)(((unsigned)r + 1u) >> 5);    // chars of steps r+1 .. : the groups' first quads
-                    a2 = a1 + 2;
                 } else if (trn) {
-                    // (a base that is not ACGT never gets here: F_EXT treats it as "no successor")
-                    // the entry of (position r, char c): it exists (the OTH bit said so); j counts the slots probed
-                    a1 = ix.trans + 4 * ((sbwt_trans_slot((unsigned)r, (unsigned)c, ix.log2t) + (u64)j) & low_mask(ix.log2t));
+                    // (a base that is not ACGT never gets here: M_EXT treats it as "no successor")
+                    // the entry of (position r, char c); j counts the slots probed
+                    a1 = ix.trans + 2 * ((sbwt_trans_slot((unsigned)r, (unsigned)c, ix.log2t) + (u64)j) & low_mask(ix.log2t));
                     a2 = a1 + 1;
-                    ax = a1 + 2;
                 } else if (strm) {
                     // streaming == 1: SBWT::streaming_search validates the upper-cased char (SBWT.hh:565-568);
                     // streaming == 2: internal streaming inside the search loop keeps SBWT::search's raw-char
@@ -619,20 +612,19 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
         // PATH: the read's next packed group -- G3: the next TWO -- ride along when the next one is not here yet (two at a time: a group
         // fetched in a later iteration is another request to the fabric even when it lies in the same line -- the L2 turns
         // over faster than a lane comes back); a reload brings three
-        // (an iteration that gathers the four quads of a path step has no slot for them)
-        const bool pathq = PATH && ax != nullptr;
-        const bool pf = PATH && !pathq && !g1ok && kind == K_MODE;
+        const bool pf = PATH && !g1ok && kind == K_MODE;
         const bool rl3 = G3 && kind == K_RELOAD;
-        const uint4 *a3 = pathq ? ax : pf ? (packed + (tag + 1)) : rl3 ? (a1 + 2) : a1;
-        const uint4 *a4 = pathq ? (ay ? ay : a1) : pf ? (a3 + 1) : a1;
+        const uint4 *a3 = pf ? (packed + (tag + 1)) : rl3 ? (a1 + 2) : a1;
         const uint4 v1 = *a1;
         const uint4 v2 = *a2;
-        uint4 v3 = make_uint4(0u, 0u, 0u, 0u), v4 = v3;
         if (PATH) {
-            v3 = *a3;
-            v4 = *a4;
-            if (pf) { g1 = v3; g1ok = true; g2 = v4; g2ok = true; }
-            if (rl3) { g2 = v3; g2ok = true; }
+            const uint4 v3 = *a3;
+            if (pf) { g1 = v3; g1ok = true; }
+            if (G3) {
+                const uint4 v4 = *(pf ? (a3 + 1) : a1);
+                if (pf) { g2 = v4; g2ok = true; }
+                if (rl3) { g2 = v3; g2ok = true; }
+            }
         }
 
         // ---- consume ----
@@ -677,11 +669,18 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
             r = (pos_t)(sel == 0 ? v1.x : sel == 1 ? v1.y : sel == 2 ? v1.z : v1.w);
             mode = M_EXT;
         } else if (trn && have) {
-            // v1 = { r + 1, c, successor column (SBWT.hh:562-575), its path position }, v2 / v3 = its path's next 32 steps
-            if (v1.x != (unsigned)r + 1u || v1.y != (unsigned)c) {
-                j++;                                   // another entry's slot: the next one (linear probing, always ends in a hit)
-                if (v1.x == 0u || j > 4096) {          // a free slot: the image is damaged -- report it, do not spin
-                    ws->status = SBWT_ERR_NOT_SINGLETON;
+            // v1 = { r + 1, c | flags, successor column (SBWT.hh:562-575), its path position }, v2 = its path's next 32 steps
+            if (v1.x == 0u) {
+                ev = EV_EMIT1;                         // a free slot: (r, c) has no entry -- a path's last column without a
+                b = blo = i + k - 1;                   // successor by c: -1
+            } else if (v1.x != (unsigned)r + 1u || (v1.y & 3u) != (unsigned)c) {
+                j++;                                   // another entry's slot: the next one (linear probing)
+                if (j > 4096) { ws->status = SBWT_ERR_NOT_SINGLETON; ev = EV_EMIT1; b = blo = i + k - 1; }   // damaged image
+            } else if (v1.y & SBWT_TRANS_NEG) {
+                // no successor by this char at a step that has others; the entry says whether the step is safe for it
+                if (ix.has_safe && (v1.y & SBWT_TRANS_NEG_SAFE)) {
+                    mode = M_BRIDGE;
+                } else {
                     ev = EV_EMIT1;
                     b = blo = i + k - 1;
                 }
@@ -707,8 +706,8 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
                 const u64 x = (rq ^ quad_bits(v2)) & low_mask(62);
                 const u64 mm = (x | (x >> 1)) & 0x5555555555555555ull;
                 const int nm = mm ? ((__ffsll((i64)mm) - 1) >> 1) : 31;
-                const int ng = __ffs((int)(~v2.z | 0x80000000u)) - 1;          // the quoted path ends
-                const int nr = __ffs((int)(~(unsigned)rv | 0x80000000u)) - 1;  // a base of the read that is not ACGT
+                const int ng = __ffs((int)((v2.z & ~v2.w) | 0x80000000u)) - 1;  // the quoted path ends: A & ~B
+                const int nr = __ffs((int)(~(unsigned)rv | 0x80000000u)) - 1;   // a base of the read that is not ACGT
                 const int nv = ng < nr ? ng : nr;
                 int n2 = nm < nv ? nm : nv;
                 bool stop2 = n2 < 31;
@@ -721,10 +720,8 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
                 c_ext += (unsigned)n2;
                 if (stop2) {
                     int kind2 = PS_ABSENT;             // a base that is not ACGT: -1 (SBWT.hh:568)
-                    if (!(nr <= nm && nr <= ng)) {
-                        const unsigned rc = (unsigned)(rq >> (2 * n2)) & 3u, aa = (unsigned)(x >> (2 * n2)) & 3u;
-                        kind2 = path_stop_kind(ng <= nm, rc, aa, v2.w, v3.x, v3.y, v3.z, v3.w, n2, ix.has_safe != 0);
-                    }
+                    if (!(nr <= nm && nr <= ng))
+                        kind2 = path_stop_kind(nm < ng, (v2.z >> n2) & 1u, (v2.w >> n2) & 1u, ix.has_safe != 0);
                     if (kind2 == PS_ABSENT) ext_absent = true;
                     else tnext = (kind2 == PS_TRANS) ? M_TRANS : M_BRIDGE;
                 }
@@ -762,14 +759,15 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
         } else if (ext && have) {
             // k-mer i-1 sits at path position r.  Read bases i+k-1.. against path chars r..: while they agree
             // (and the read's bases are valid and the path goes on), k-mer i+x sits at r+1+x.
-            // v1 / v2 = first path group { chars, GO, SAFE } { OTH }, v3 / v4 = the second.
             const int P = poff + i + k - 1, s = P & 31, sp = (int)((unsigned)r & 31u);
             u64 rw = quad_bits(g0) >> (2 * s), pw = quad_bits(v1) >> (2 * sp);
             if (s) rw |= quad_bits(g1) << (64 - 2 * s);
-            if (sp) pw |= quad_bits(v3) << (64 - 2 * sp);
+            if (sp) pw |= quad_bits(v2) << (64 - 2 * sp);
             const u64 rv = ((streaming == 2) ? (((u64)g1.w << 32) | (u64)g0.w) : (((u64)g1.z << 32) | (u64)g0.z)) >> s;
-            const u64 pgo = (((u64)v3.z << 32) | (u64)v1.z) >> sp;
-            u64 x = rw ^ pw;
+            // the path groups' two state words (k_path_reencode): go = ~A | B, safe = A & B, only successor = ~A & B
+            const u64 fA = (((u64)v2.z << 32) | (u64)v1.z) >> sp, fB = (((u64)v2.w << 32) | (u64)v1.w) >> sp;
+            const u64 pgo = ~fA | fB;
+            const u64 x = rw ^ pw;
             const u64 mm = (x | (x >> 1)) & 0x5555555555555555ull;
             int nm = mm ? ((__ffsll((i64)mm) - 1) >> 1) : 32;
             int ng = __ffsll((i64)(~pgo | (1ull << 32))) - 1;                 // the path ends
@@ -777,9 +775,8 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
             int nv = ng < nr ? ng : nr;
             int n = nm < nv ? nm : nv;
             bool stopped = n < 32;                     // a mismatch, an invalid base or the end of the path
-            u64 rcw = rw;
             if (!stopped && g1ok) {
-                // the cached group pair and the two path groups reach further than 32 steps: 32 - s more bases of the read
+                // the cached group pair and the two path quads reach further than 32 steps: 32 - s more bases of the read
                 // (all 32 with the third cached group), 32 - sp more chars of the path
                 const bool r3 = g2ok && s != 0;
                 const int w2 = (r3 || s <= sp) ? 32 - sp : 32 - s;
@@ -790,7 +787,7 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
                     const u64 vb = (streaming == 2) ? (((u64)g2.w << 32) | (u64)g1.w) : (((u64)g2.z << 32) | (u64)g1.z);
                     rv2 = (vb >> s) & 0xFFFFFFFFull;
                 }
-                const u64 x2 = rw2 ^ (quad_bits(v3) >> (2 * sp));
+                const u64 x2 = rw2 ^ (quad_bits(v2) >> (2 * sp));
                 const u64 mm2 = (x2 | (x2 >> 1)) & 0x5555555555555555ull;
                 const int nm2 = mm2 ? ((__ffsll((i64)mm2) - 1) >> 1) : 32;
                 const int ng2 = __ffsll((i64)(~(pgo >> 32) | (1ull << 32))) - 1;
@@ -803,8 +800,6 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
                 nm = 32 + nm2;
                 ng = 32 + ng2;
                 nr = 32 + nr2;
-                rcw = rw2;
-                x = x2;
             }
             if (n >= m - i) { n = m - i; stopped = false; }
             seg_n = n;
@@ -818,11 +813,7 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
             } else if (stopped) {
                 int kind2 = PS_ABSENT;                 // a base that is not ACGT: -1 (SBWT.hh:568)
                 if (!(nr <= nm && nr <= ng)) {
-                    const int o = sp + n, bit = o & 31, wn = n & 31;
-                    const bool hi = o >= 32;
-                    const unsigned rc = (unsigned)(rcw >> (2 * wn)) & 3u, aa = (unsigned)(x >> (2 * wn)) & 3u;
-                    kind2 = path_stop_kind(ng <= nm, rc, aa, hi ? v3.w : v1.w, hi ? v4.x : v2.x, hi ? v4.y : v2.y,
-                                           hi ? v4.z : v2.z, hi ? v4.w : v2.w, bit, ix.has_safe != 0);
+                    kind2 = path_stop_kind(nm < ng, (unsigned)(fA >> n) & 1u, (unsigned)(fB >> n) & 1u, ix.has_safe != 0);
                     if (kind2 == PS_BRIDGE && n < 32) {
                         // a bridge needs the next k-1 bases to agree with the path; a second difference already in this
                         // window: skip the attempt

@@ -169,7 +169,7 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
 
         // ---- this iteration's gather: two 16-byte loads per lane, issued back to back, one wait ----
         int ev = FE_NONE, tfail = 0, c = 0;
-        const uint4 *a1 = ix.blocks, *a2 = ix.blocks, *a3 = nullptr, *a4 = nullptr;
+        const uint4 *a1 = ix.blocks, *a2 = ix.blocks;
         int res = -1;
         const bool ext = (mode == F_EXT), trn = (mode == F_TRANS), brg = (mode == F_BRIDGE);
         const bool busy = (mode != F_IDLE && mode != F_DEAD);
@@ -192,19 +192,13 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
         } else if (busy) {
             const int wl = (wk == 1) ? ps : (wk == 2) ? L0 : (wk == 3) ? pw : (wk == 5) ? k - ps : p;
             c = (int)((unsigned)rw & 3u);
-            if (ext) {
-                a1 = ix.pq + 2 * (size_t)((unsigned)r >> 5);           // the two path groups holding steps r .. r+32: 64 bytes
+            if (ext || brg) {
+                a1 = ix.pq + (((unsigned)r + (brg ? 1u : 0u)) >> 5);   // the two quads holding path chars r (+1) .. +31
                 a2 = a1 + 1;
-                a3 = a1 + 2;
-                a4 = a1 + 3;
-            } else if (brg) {
-                a1 = ix.pq + 2 * (size_t)(((unsigned)r + 1u) >> 5);    // chars of steps r+1 .. : the groups' first quads
-                a2 = a1 + 2;
             } else if (trn) {
-                // the entry of (position r, char c): it exists (the OTH bit said so); j counts the slots probed
-                a1 = ix.trans + 4 * ((sbwt_trans_slot((unsigned)r, (unsigned)c, ix.log2t) + (u64)j) & low_mask(ix.log2t));
+                // the entry of (position r, char c); j counts the slots probed
+                a1 = ix.trans + 2 * ((sbwt_trans_slot((unsigned)r, (unsigned)c, ix.log2t) + (u64)j) & low_mask(ix.log2t));
                 a2 = a1 + 1;
-                a3 = a1 + 2;
             } else if (mode == F_INIT) {
                 (void)wl;
                 if (wk == 1) {                 // bucket (hash + j) of the sparse table: two entries
@@ -232,13 +226,23 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
                 a2 = ix.blocks + (((((i64)r + 1) >> 6) << 2) + c);
             }
         }
+#ifdef SBWT_STATS
+        {   // lane-iterations by kind: pad[0..]: sparse lookup, filter probe, dense table, second level, interval update, path run,
+            // transition, bridge, pos, idle/dead; pad[10] = wave-iterations
+            const int cls = !busy ? 9 : mode == F_INIT ? (wk == 1 ? 0 : (wk == 2 || (wk == 3 && pfon)) ? 1 : wk == 5 ? 3 : 2) :
+                            mode == F_STEP ? 4 : ext ? 5 : trn ? 6 : brg ? 7 : 8;
+            for (int q = 0; q < 10; q++) {
+                const unsigned long long cq = __popcll(__ballot(cls == q));
+                if (lane == 0 && cq) atomicAdd(&ws->pad[q], cq);
+            }
+            if (lane == 0) atomicAdd(&ws->pad[10], 1ull);
+        }
+#endif
         c_search = uniform32(c_search + (unsigned)__popcll(__ballot(mode == F_INIT || (p == 0 && mode == F_STEP && j == 0))));
         c_lf = uniform32(c_lf + (unsigned)__popcll(__ballot(mode == F_STEP)));
 
         const uint4 v1 = *a1;
         const uint4 v2 = *a2;
-        const uint4 v3 = *(a3 ? a3 : a1);
-        const uint4 v4 = *(a4 ? a4 : a1);
 
         // ---- consume ----
         bool tabhit = false, do_plan = false, force = false;
@@ -250,11 +254,18 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
             r = (int)(sel == 0 ? v1.x : sel == 1 ? v1.y : sel == 2 ? v1.z : v1.w);
             mode = F_EXT;
         } else if (trn) {
-            // v1 = { r + 1, c, successor column (SBWT.hh:562-575), its path position }, v2 / v3 = its path's next 32 steps
-            if (v1.x != (unsigned)r + 1u || v1.y != (unsigned)c) {
-                j++;                                   // another entry's slot: the next one (linear probing, always ends in a hit)
-                if (v1.x == 0u || j > 4096) {          // a free slot: the image is damaged -- report it, do not spin
-                    ws->status = SBWT_ERR_NOT_SINGLETON;
+            // v1 = { r + 1, c | flags, successor column (SBWT.hh:562-575), its path position }, v2 = its path's next 32 steps
+            if (v1.x == 0u) {
+                ev = FE_EMIT1;                         // a free slot: (r, c) has no entry -- a path's last column without a
+                b = blo = i + k - 1;                   // successor by c: -1
+            } else if (v1.x != (unsigned)r + 1u || (v1.y & 3u) != (unsigned)c) {
+                j++;                                   // another entry's slot: the next one (linear probing)
+                if (j > 4096) { ws->status = SBWT_ERR_NOT_SINGLETON; ev = FE_EMIT1; b = blo = i + k - 1; }   // damaged image
+            } else if (v1.y & SBWT_TRANS_NEG) {
+                // no successor by this char at a step that has others; the entry says whether the step is safe for it
+                if (ix.has_safe && (v1.y & SBWT_TRANS_NEG_SAFE)) {
+                    mode = F_BRIDGE;
+                } else {
                     ev = FE_EMIT1;
                     b = blo = i + k - 1;
                 }
@@ -269,7 +280,7 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
                 const u64 x = (rq ^ quad_bits(v2)) & low_mask(62);
                 const u64 mm = (x | (x >> 1)) & 0x5555555555555555ull;
                 const int nm = mm ? ((__ffsll((i64)mm) - 1) >> 1) : 31;
-                const int nv = __ffs((int)(~v2.z | 0x80000000u)) - 1;
+                const int nv = __ffs((int)((v2.z & ~v2.w) | 0x80000000u)) - 1;      // the quoted path ends: A & ~B
                 int n2 = nm < nv ? nm : nv;
                 bool stop2 = n2 < 31;
                 if (n2 >= m - 1 - i) { n2 = m - 1 - i; stop2 = false; }
@@ -279,9 +290,7 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
                 r += n2;
                 c_ext += (unsigned)n2;
                 if (stop2) {
-                    const bool is_end = nv <= nm;
-                    const unsigned rc = (unsigned)(rq >> (2 * n2)) & 3u, aa = (unsigned)(x >> (2 * n2)) & 3u;
-                    const int kind = path_stop_kind(is_end, rc, aa, v2.w, v3.x, v3.y, v3.z, v3.w, n2, ix.has_safe != 0);
+                    const int kind = path_stop_kind(nm < nv, (v2.z >> n2) & 1u, (v2.w >> n2) & 1u, ix.has_safe != 0);
                     if (kind == PS_ABSENT) ext_absent = true;
                     else tnext = (kind == PS_TRANS) ? F_TRANS : F_BRIDGE;
                 }
@@ -307,23 +316,24 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
             }
         } else if (ext) {
             // k-mer i-1 sits at path position r.  Read bases i+k-1.. against path chars r..: while they agree (and the
-            // path goes on), k-mer i+x sits at r+1+x.  v1 / v2 = first group { chars, GO, SAFE } { OTH }, v3 / v4 = second.
+            // path goes on), k-mer i+x sits at r+1+x.
             const int sp = (int)((unsigned)r & 31u);
             u64 pwd = quad_bits(v1) >> (2 * sp);
-            if (sp) pwd |= quad_bits(v3) << (64 - 2 * sp);
-            const u64 pgo = (((u64)v3.z << 32) | (u64)v1.z) >> sp;
-            u64 x = rw ^ pwd;
+            if (sp) pwd |= quad_bits(v2) << (64 - 2 * sp);
+            // the path groups' two state words (k_path_reencode): go = ~A | B, safe = A & B, only successor = ~A & B
+            const u64 fA = (((u64)v2.z << 32) | (u64)v1.z) >> sp, fB = (((u64)v2.w << 32) | (u64)v1.w) >> sp;
+            const u64 pgo = ~fA | fB;
+            const u64 x = rw ^ pwd;
             const u64 mm = (x | (x >> 1)) & 0x5555555555555555ull;
             int nm = mm ? ((__ffsll((i64)mm) - 1) >> 1) : 32;
             int nv = __ffsll((i64)(~pgo | (1ull << 32))) - 1;
             int n = nm < nv ? nm : nv;
             bool stopped = n < 32;                     // a mismatch or the end of the path
-            u64 rcw = rw;                              // the window the stop lies in: read chars / differences from its first step
             if (!stopped) {
-                // the read's side is whole (LDS); the two path groups hold 32 - sp more steps
+                // the read's side is whole (LDS); the two path quads hold 32 - sp more steps
                 const int w2 = 32 - sp;
                 const u64 rw2 = s ? ((cw1 >> (2 * s)) | (cw2 << (64 - 2 * s))) : cw1;
-                const u64 x2 = rw2 ^ (quad_bits(v3) >> (2 * sp));
+                const u64 x2 = rw2 ^ (quad_bits(v2) >> (2 * sp));
                 const u64 mm2 = (x2 | (x2 >> 1)) & 0x5555555555555555ull;
                 const int nm2 = mm2 ? ((__ffsll((i64)mm2) - 1) >> 1) : 32;
                 const int nv2 = __ffsll((i64)(~(pgo >> 32) | (1ull << 32))) - 1;
@@ -333,8 +343,6 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
                 n = 32 + n2;
                 nm = 32 + nm2;
                 nv = 32 + nv2;
-                rcw = rw2;
-                x = x2;
             }
             if (n >= m - i) { n = m - i; stopped = false; }
             seg_n = n;
@@ -343,11 +351,7 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
             if (i + n == m) {
                 mode = F_IDLE;
             } else if (stopped) {
-                const int o = sp + n, bit = o & 31, wn = n & 31;
-                const bool hi = o >= 32, is_end = nv <= nm;
-                const unsigned rc = (unsigned)(rcw >> (2 * wn)) & 3u, aa = (unsigned)(x >> (2 * wn)) & 3u;
-                int kind = path_stop_kind(is_end, rc, aa, hi ? v3.w : v1.w, hi ? v4.x : v2.x, hi ? v4.y : v2.y, hi ? v4.z : v2.z,
-                                          hi ? v4.w : v2.w, bit, ix.has_safe != 0);
+                int kind = path_stop_kind(nm < nv, (unsigned)(fA >> n) & 1u, (unsigned)(fB >> n) & 1u, ix.has_safe != 0);
                 if (kind == PS_BRIDGE && n < 32) {
                     // a bridge needs the next k-1 bases to agree with the path; a second difference already in this window:
                     // skip the attempt (the step has no successor by the read's char either way)

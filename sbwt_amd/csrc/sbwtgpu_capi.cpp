@@ -421,6 +421,7 @@ int sbwtgpu_index_create(const sbwtgpu_index_desc *d, int device, sbwtgpu_index 
                     hipGetErrorString(e));
     }
     int rc = SBWTGPU_OK;
+    unsigned char *alt_safe = nullptr;                 // per-position verdicts of the safe-bit pass, for the transition table
     do {
         if ((e = hipMemset(idx->blob, 0, (size_t)h.blob_bytes)) != hipSuccess) break;
         {
@@ -490,7 +491,13 @@ int sbwtgpu_index_create(const sbwtgpu_index_desc *d, int device, sbwtgpu_index 
                     (void)hipGetLastError();
                     hscr = nullptr;                     // no room for rule 2: the narrow rule needs none
                 }
-                sbwt_launch_path_safe(v2, reinterpret_cast<uint4 *>(idx->blob + h.off_pq), hscr ? g_path_safe : 1, hscr, nullptr, 0);
+                // ... and hands the per-substitute verdicts to the transition table's negative entries through alt_safe (a byte
+                // per position; without it only the steps that are safe for all three substitutes bridge)
+                if (hscr && hipMalloc((void **)&alt_safe, (size_t)n) != hipSuccess) {
+                    (void)hipGetLastError();
+                    alt_safe = nullptr;
+                }
+                sbwt_launch_path_safe(v2, reinterpret_cast<uint4 *>(idx->blob + h.off_pq), hscr ? g_path_safe : 1, hscr, alt_safe, 0);
                 e = hipDeviceSynchronize();
                 if (hscr) (void)hipFree(hscr);
                 if (e != hipSuccess) break;
@@ -498,9 +505,9 @@ int sbwtgpu_index_create(const sbwtgpu_index_desc *d, int device, sbwtgpu_index 
             }
         }
         if (h.has_path) {
-            // Last: where reads can leave their paths (the OTH planes), and the transition table.  Its size is known only
-            // now -- about two entries per branching column and one per path end -- so the image moves once into an
-            // allocation of its final size (device-to-device, ~1 ms per GB).
+            // Last: the only-successor bits, the path groups' final encoding, and the transition table.  Its size is known
+            // only now -- three entries per branching column and one per successor of a path's last column -- so the image
+            // moves once into an allocation of its final size (device-to-device, ~1 ms per GB).
             SbwtIndexView v3 = idx->view();
             long long nb = 0;
             const long long n_ent = sbwt_launch_path_oth(v3, reinterpret_cast<uint4 *>(idx->blob + h.off_pq), &nb, 0);
@@ -510,7 +517,7 @@ int sbwtgpu_index_create(const sbwtgpu_index_desc *d, int device, sbwtgpu_index 
             int lt = 4;
             while (((int64_t)1 << lt) < 2 * n_ent) lt++;                    // load factor 0.25 .. 0.5
             h.log2t = lt;
-            const int64_t full = align256(h.off_trans + ((int64_t)64 << lt));
+            const int64_t full = align256(h.off_trans + ((int64_t)32 << lt));
             if (g_max_image_bytes > 0 && full > g_max_image_bytes && level < 2) { e = hipErrorOutOfMemory; break; }
             char *nblob = nullptr;
             if ((e = hipMalloc((void **)&nblob, (size_t)full)) != hipSuccess) break;
@@ -518,7 +525,7 @@ int sbwtgpu_index_create(const sbwtgpu_index_desc *d, int device, sbwtgpu_index 
             (void)hipFree(idx->blob);
             idx->blob = nblob;
             h.blob_bytes = full;
-            sbwt_launch_trans_insert(idx->view(), reinterpret_cast<uint4 *>(idx->blob + h.off_trans), lt, 0);
+            sbwt_launch_trans_insert(idx->view(), reinterpret_cast<uint4 *>(idx->blob + h.off_trans), lt, alt_safe, 0);
             if ((e = hipDeviceSynchronize()) != hipSuccess) break;
             h.n_paths = sbwt_count_paths(idx->view(), 0);
             if (h.n_paths < 0) { e = hipErrorUnknown; break; }
@@ -526,6 +533,7 @@ int sbwtgpu_index_create(const sbwtgpu_index_desc *d, int device, sbwtgpu_index 
         if ((e = hipGetLastError()) != hipSuccess) break;
         e = hipDeviceSynchronize();
     } while (0);
+    if (alt_safe) (void)hipFree(alt_safe);
     if (e == hipErrorOutOfMemory && level < 2 && (h.has_path || h.p_sparse > 0)) {
         (void)hipGetLastError();                       // scratch of a derived structure did not fit: build without them
         (void)hipFree(idx->blob);

@@ -1,0 +1,5 @@
+#!/bin/bash
+# libsbwtgpu with the lane-iteration counters compiled in (-DSBWT_STATS): sbwt_amd/lib/lib_stats.so
+cd "$(dirname "$0")/.." && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -DSBWT_STATS -o sbwt_amd/lib/lib_stats.so \
+  sbwt_amd/csrc/sbwt_search.hip sbwt_amd/csrc/sbwt_search_fused.hip sbwt_amd/csrc/sbwt_api_kernels.hip sbwt_amd/csrc/sbwt_derived.hip \
+  sbwt_amd/csrc/sbwt_build.hip sbwt_amd/csrc/sbwt_sort.hip sbwt_amd/csrc/sbwt_format.hip sbwt_amd/csrc/sbwtgpu_capi.cpp -ldl

@@ -1,0 +1,16 @@
+"""Lane-iterations of k_search_fused by kind.  Needs a library built with -DSBWT_STATS (tools/build_stats_lib.sh):
+  SBWTGPU_LIB=$PWD/sbwt_amd/lib/lib_stats.so python tools/lane_stats_fused.py        (env of tools/ab_step.py applies)"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("CONFIGS", "[[5,0]]"); os.environ.setdefault("ROUNDS", "0")
+import tools.ab_step as ab
+hdr = ab.d_ws[:256].cpu().numpy().view("uint64")
+names = ["sparse lookup", "filter probe", "dense table", "second level", "interval update", "path run", "transition", "bridge", "pos",
+         "idle"]
+base = 15        # pad[0] is the 16th 8-byte word of the header
+vals = [int(hdr[base + q]) for q in range(10)]
+tot = sum(vals)
+nr = ab.n_reads
+print({n: round(v / nr, 3) for n, v in zip(names, vals)})
+print("lane-iterations per read", round(tot / nr, 2), "wave-iterations", int(hdr[base + 10]), "lanes busy per iteration",
+      round((tot - vals[9]) / max(1, int(hdr[base + 10])), 1))
