@@ -98,15 +98,16 @@ def gpu_reads(genomes, n_reads: int, seed: int, dev: torch.device) -> torch.Tens
     return out
 
 
-KERNEL_SOURCES = ("sbwt_search.hip", "sbwt_api_kernels.hip", "sbwt_kernels_common.h", "sbwt_device.h")
-
-
 def kernel_source_sha16() -> str:
-    """Identifies the kernels a profile was taken on: sha256 of the kernel sources, first 16 hex digits."""
+    """Identifies the code a profile was taken on: sha256 of every source of libsbwtgpu (kernels, the derived
+    structures that decide their traffic, the C ABI with its defaults), first 16 hex digits."""
     import hashlib
     h = hashlib.sha256()
-    for f in KERNEL_SOURCES:
-        h.update(open(os.path.join(ROOT, "sbwt_amd", "csrc", f), "rb").read())
+    d = os.path.join(ROOT, "sbwt_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h", ".cpp")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]
 
 
@@ -260,6 +261,9 @@ def main() -> int:
                     help="reads per GPU")
     ap.add_argument("--genome-len", type=int, default=int(os.environ.get("SBWT_BENCH_GENOME", 5_000_000)))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-end-to-end", action="store_true",
+                    help="skip the end-to-end leg (host buffers over PCIe, and the `sbwt search` CLI on a FASTQ file)")
+    ap.add_argument("--e2e-reads", type=int, default=2_000_000, help="reads of the end-to-end leg")
     ap.add_argument("--config", type=int, default=2, choices=[2, 3, 5, 6],
                     help="BASELINE.json config: 2 = coli3-like k=30 (headline, default); 3 = pan-genome-like "
                          "k=31 (65 genomes, 100 M reads unless --reads); 5 = k=63 without streaming support")
@@ -635,12 +639,97 @@ def main() -> int:
             print(json.dumps(result))
             raise SystemExit("PARITY FAILURE: GPU output differs from the oracle on the baseline sample")
 
+    # ---- end to end (SURVEY 8d "Timing"; sbwt_search.cpp:54-56,145,255-256): rank 0 at N=1 only ----
+    if rank == 0 and world == 1 and not args.no_end_to_end and args.config in (2, 5):
+        try:
+            result["end_to_end"] = end_to_end_leg(args, index, genomes, d_bases, m, streaming, dev)
+        except Exception as ex:      # the headline must not die with its side measurement
+            result["end_to_end"] = {"error": repr(ex)}
+
     if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
     return 0
+
+
+def end_to_end_leg(args, index, genomes, d_bases, m, streaming, dev):
+    """What a caller with HOST buffers gets, PCIe included: (1) sbwtgpu_streaming_search_batch / sbwtgpu_search_batch on
+    pinned host reads -> int64 results in pinned host memory (median of 3; chunks pipelined over two streams inside the
+    library), beside the rate PCIe allows (8 bytes of results per k-mer at the measured device-to-host copy rate); (2) the
+    `sbwt search` command on a FASTQ file of the same reads, index file -> output text file, wall clock (best of 2)."""
+    import ctypes as C
+    import shutil
+    import subprocess
+    import tempfile
+    E = min(args.e2e_reads, args.reads)
+    n_k = E * m
+    h_bases = torch.empty(E * READ_LEN, dtype=torch.uint8, pin_memory=True)
+    h_bases.copy_(d_bases[: E * READ_LEN])
+    h_out = torch.empty(n_k, dtype=torch.int64, pin_memory=True)
+    roff = np.arange(E + 1, dtype=np.int64) * READ_LEN
+    ooff = np.arange(E + 1, dtype=np.int64) * m
+    fn = capi.lib().sbwtgpu_streaming_search_batch if streaming else capi.lib().sbwtgpu_search_batch
+    times = []
+    for _ in range(4):
+        t0 = time.perf_counter()
+        capi._check(fn(index.handle, h_bases.data_ptr(), roff.ctypes.data, E, h_out.data_ptr(), ooff.ctypes.data))
+        times.append(time.perf_counter() - t0)
+    host_rate = n_k / float(np.median(times[1:]))
+    # the copy rate PCIe gives this box, device -> pinned host, 1 GiB
+    probe = torch.empty(1 << 30, dtype=torch.uint8, device=dev)
+    hprobe = torch.empty(1 << 30, dtype=torch.uint8, pin_memory=True)
+    best = None
+    for _ in range(3):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        hprobe.copy_(probe, non_blocking=True)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    d2h = (1 << 30) / best
+    del probe, hprobe
+    out = {"batch_reads": E, "host_buffers_kmers_per_s": host_rate, "host_buffers_s": float(np.median(times[1:])),
+           "d2h_GBps": d2h / 1e9, "pcie_bound_kmers_per_s": d2h / 8.0,
+           "host_buffers_frac_of_pcie_bound": host_rate / (d2h / 8.0),
+           "host_buffers": "pinned bases + pinned int64 results, offsets pageable; median of 3 after one warm-up call"}
+    # the CLI: index file, FASTQ file, output text file
+    sbwt = os.path.join(ROOT, "sbwt_amd", "bin", "sbwt")
+    d = tempfile.mkdtemp(prefix="sbwt_e2e_", dir=os.environ.get("TMPDIR", "/tmp"))
+    try:
+        with open(d + "/g.fna", "wb") as f:
+            for i, g in enumerate(genomes):
+                f.write(b">g%d\n" % i + g.tobytes() + b"\n")
+        cmd = [sbwt, "build", "-i", d + "/g.fna", "-o", d + "/i.sbwt", "-k", str(K), "-t", str(effective_cores())]
+        if not streaming:
+            cmd.append("--no-streaming-support")
+        subprocess.run(cmd, check=True, capture_output=True)
+        rows = h_bases.numpy().reshape(E, READ_LEN)
+        rec = np.empty((E, 4 + READ_LEN + 3 + READ_LEN + 1), dtype=np.uint8)       # "@r\n" seq "\n+\n" qual "\n"
+        rec[:, 0:3] = np.frombuffer(b"@r\n", dtype=np.uint8)
+        rec[:, 3:3 + READ_LEN] = rows
+        rec[:, 3 + READ_LEN:6 + READ_LEN] = np.frombuffer(b"\n+\n", dtype=np.uint8)
+        rec[:, 6 + READ_LEN:6 + 2 * READ_LEN] = ord("I")
+        rec[:, 6 + 2 * READ_LEN:] = ord("\n")
+        rec = rec[:, :7 + 2 * READ_LEN]
+        rec.tofile(d + "/r.fastq")
+        best = None
+        for _ in range(2):
+            t0 = time.perf_counter()
+            p = subprocess.run([sbwt, "search", "-i", d + "/i.sbwt", "-q", d + "/r.fastq", "-o", d + "/out.txt"], capture_output=True)
+            dt = time.perf_counter() - t0
+            if p.returncode != 0:
+                raise RuntimeError("sbwt search failed: " + p.stderr.decode(errors="replace")[-300:])
+            best = dt if best is None else min(best, dt)
+        logs = [l.split("us/query")[1].strip() for l in p.stderr.decode().splitlines() if "us/query" in l]
+        out.update({"cli_kmers_per_s": n_k / best, "cli_wall_s": best, "cli_us_per_query_lines": logs,
+                    "cli_fastq_bytes": os.path.getsize(d + "/r.fastq"), "cli_output_bytes": os.path.getsize(d + "/out.txt"),
+                    "cli": "sbwt search -i index -q reads.fastq -o out.txt, process start to exit (index load, parse, search, "
+                           "format on the GPU, write), best of 2"})
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+    return out
 
 
 if __name__ == "__main__":

@@ -265,6 +265,13 @@ int  sbwtgpu_format_results_dev(const sbwtgpu_index *idx, const int64_t *d_value
 int  sbwtgpu_search_text_batch(const sbwtgpu_index *idx, const char *bases, const int64_t *read_off,
                                int64_t n_reads, int streaming, char **text, int64_t *text_bytes,
                                int64_t *n_queries);
+/* The same, streamed: `sink` is called from the calling thread with consecutive pieces of the output text, in order, each
+ * straight out of a pinned staging buffer that is only valid during the call (what `sbwt search` writes to its output
+ * file: no copy of the whole text is ever made).  A non-zero return of the sink aborts the call. */
+typedef int (*sbwtgpu_text_sink)(void *ctx, const char *text, int64_t bytes);
+int  sbwtgpu_search_text_stream(const sbwtgpu_index *idx, const char *bases, const int64_t *read_off,
+                                int64_t n_reads, int streaming, sbwtgpu_text_sink sink, void *sink_ctx,
+                                int64_t *n_queries);
 void sbwtgpu_free_host(void *p);
 /* sbwtgpu_search_text_batch keeps its pinned staging and device buffers for the next call, and every host thread
  * keeps one small (1 MiB) pinned + device buffer pair and a stream per device for small host-buffer calls (the

@@ -39,7 +39,7 @@ EXPORTED_SYMBOLS = [
     "sbwtgpu_rank_dev", "sbwtgpu_encode_bases_dev", "sbwtgpu_search_encoded_dev",
     "sbwtgpu_workspace_status", "sbwtgpu_workspace_stats", "sbwtgpu_kernel_times",
     "sbwtgpu_format_text_bound", "sbwtgpu_format_scratch_bytes", "sbwtgpu_format_results_dev",
-    "sbwtgpu_search_text_batch", "sbwtgpu_free_host", "sbwtgpu_release_cached_buffers",
+    "sbwtgpu_search_text_batch", "sbwtgpu_search_text_stream", "sbwtgpu_free_host", "sbwtgpu_release_cached_buffers",
 ]
 
 

@@ -309,6 +309,27 @@ public:
         }
         return total;
     }
+    // The same on one device, streamed: `sink(text, bytes)` receives consecutive pieces of the output text in order, each
+    // straight out of a pinned staging buffer that is valid only during the call.  Returns the number of k-mers searched.
+    template <typename Sink>
+    int64_t search_text_stream(const char *bases, const int64_t *read_off, int64_t n_reads, Sink &&sink) const {
+        const sbwtgpu_index *root = need_device();
+        struct Ctx { Sink *s; std::exception_ptr err; } ctx{&sink, nullptr};
+        int64_t nq = 0;
+        const int rc = sbwtgpu_search_text_stream(
+            root, bases, read_off, n_reads, has_streaming_query_support() ? 1 : 0,
+            [](void *c, const char *text, int64_t bytes) -> int {
+                Ctx *x = static_cast<Ctx *>(c);
+                try { (*x->s)(text, bytes); } catch (...) { x->err = std::current_exception(); return 1; }
+                return 0;
+            },
+            &ctx, &nq);
+        if (ctx.err) std::rethrow_exception(ctx.err);
+        bug_exit(rc);
+        detail::gpu_check(rc);
+        return nq;
+    }
+    int number_of_devices_in_use() const { return number_of_devices(); }
     // Replicates the device image onto the listed HIP devices (one RCCL broadcast over xGMI);
     // the first entry should be the device the index was created on.  Listing a device twice is allowed
     // (two host threads share it) and is how the sharding is tested on a single-GPU box.

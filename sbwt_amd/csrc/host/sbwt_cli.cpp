@@ -24,6 +24,8 @@
 #include <mutex>
 #include <string>
 #include <thread>
+#include <unistd.h>
+#include <functional>
 #include <vector>
 
 #include "SBWT.hh"
@@ -131,7 +133,10 @@ public:
     }
     bool pop(T &out) {   // false when closed and drained
         std::unique_lock<std::mutex> lk(m_);
+        waiting_ = true;
+        cv_.notify_all();
         cv_.wait(lk, [&] { return !q_.empty() || closed_; });
+        waiting_ = false;
         if (q_.empty()) return false;
         out = std::move(q_.front());
         q_.pop_front();
@@ -143,13 +148,18 @@ public:
         closed_ = true;
         cv_.notify_all();
     }
+    // blocks until every item pushed so far has been popped AND its consumer has come back for the next one
+    void drain() {
+        std::unique_lock<std::mutex> lk(m_);
+        cv_.wait(lk, [&] { return q_.empty() && waiting_; });
+    }
 
 private:
     std::mutex m_;
     std::condition_variable cv_;
     std::deque<T> q_;
     size_t cap_;
-    bool closed_ = false;
+    bool closed_ = false, waiting_ = false;
 };
 
 struct ReadBatch {
@@ -164,32 +174,27 @@ struct TextBatch {
 // run_file + run_queries_streaming / run_queries_not_streaming (sbwt_search.cpp:46-105), batched and
 // pipelined: a reader thread parses the next batch and a writer thread writes the previous one while
 // the GPU searches the current one.  The output is written strictly in input order.
-QueryStats run_file(const string &infile, const string &outfile, const plain_matrix_sbwt_t &index, bool gzip_output,
-                    int64_t batch_bases, bool host_format) {
+// (get_index: the index, waited for at the first use -- while it loads, the reader thread already parses the input)
+QueryStats run_file(const string &infile, const string &outfile, const std::function<const plain_matrix_sbwt_t &()> &get_index,
+                    bool gzip_output, int64_t batch_bases, bool host_format) {
     seq_io::Reader reader(infile);
     seq_io::Buffered_ofstream writer(outfile, gzip_output);
-    const bool streaming = index.has_streaming_query_support();
-    write_log(string("Running ") + (streaming ? "streaming" : "non-streaming") + " queries from input file " + infile +
-                  " to output file " + outfile,
-              LogLevel::MAJOR);
-    const int64_t k = index.get_k();
     QueryStats st;
     Channel<ReadBatch> to_search(2);
     Channel<TextBatch> to_write(2);
     std::exception_ptr reader_err, writer_err;
 
+    const bool timing = getenv("SBWT_CLI_TIMING") != nullptr;       // stage times on stderr (tools/e2e_bench.py)
+    int64_t t_parse = 0, t_write = 0;
     std::thread reader_thread([&] {
         try {
-            bool eof = false;
-            while (!eof) {
+            bool more = true;
+            while (more) {
                 ReadBatch rb;
-                while ((int64_t)rb.bases.size() < batch_bases) {
-                    int64_t len = reader.get_next_read_to_buffer();
-                    if (len == 0) { eof = true; break; }
-                    rb.bases.insert(rb.bases.end(), reader.read_buf, reader.read_buf + len);
-                    rb.read_off.push_back((int64_t)rb.bases.size());
-                    rb.out_off.push_back(rb.out_off.back() + std::max<int64_t>(0, len - k + 1));
-                }
+                rb.bases.reserve((size_t)batch_bases + 4096);
+                const int64_t p0 = cur_time_micros();
+                more = reader.read_batch(rb.bases, rb.read_off, batch_bases);
+                t_parse += cur_time_micros() - p0;
                 if (rb.read_off.size() > 1) to_search.push(std::move(rb));
             }
         } catch (...) {
@@ -216,10 +221,19 @@ QueryStats run_file(const string &infile, const string &outfile, const plain_mat
 
     std::exception_ptr search_err;
     try {
+        const plain_matrix_sbwt_t &index = get_index();
+        const bool streaming = index.has_streaming_query_support();
+        write_log(string("Running ") + (streaming ? "streaming" : "non-streaming") + " queries from input file " + infile +
+                      " to output file " + outfile,
+                  LogLevel::MAJOR);
+        const int64_t k = index.get_k();
         ReadBatch rb;
         vector<int64_t> out;
         while (to_search.pop(rb)) {
             const int64_t n_reads = (int64_t)rb.read_off.size() - 1;
+            rb.out_off.resize(rb.read_off.size());
+            for (size_t r = 1; r < rb.read_off.size(); r++)
+                rb.out_off[r] = rb.out_off[r - 1] + std::max<int64_t>(0, rb.read_off[r] - rb.read_off[r - 1] - k + 1);
             TextBatch tb;
             if (host_format) {
                 // reference-style: raw ranks back to the host, print_vector on the CPU
@@ -231,8 +245,24 @@ QueryStats run_file(const string &infile, const string &outfile, const plain_mat
                 st.queries += rb.out_off.back();
                 for (int64_t r = 0; r < n_reads; r++)
                     print_vector(out.data() + rb.out_off[(size_t)r], rb.out_off[(size_t)r + 1] - rb.out_off[(size_t)r], tb.host_text);
+            } else if (index.number_of_devices_in_use() <= 1 && !gzip_output) {
+                // default: search + print_vector on the GPU, pipelined over PCIe; the text goes from the
+                // pinned staging buffers straight into the output file (one copy, into the page cache), in order, while
+                // the next chunk is on the GPU.  Batches before this one must be on disk first.
+                to_write.push(std::move(tb));
+                to_write.drain();
+                int64_t t0 = cur_time_micros(), t_sink = 0;
+                st.queries += index.search_text_stream(rb.bases.data(), rb.read_off.data(), n_reads,
+                                                       [&](const char *text, int64_t bytes) {
+                                                           const int64_t w0 = cur_time_micros();
+                                                           writer.write(text, bytes);
+                                                           t_sink += cur_time_micros() - w0;
+                                                       });
+                st.micros += cur_time_micros() - t0 - t_sink;
+                t_write += t_sink;
+                continue;
             } else {
-                // default: search + print_vector on the GPU, pipelined over PCIe
+                // several devices (every device's text is a piece of its own), or compressed output (a writer thread)
                 int64_t t0 = cur_time_micros();
                 st.queries += index.search_text_batch(rb.bases.data(), rb.read_off.data(), n_reads, tb.pieces);
                 st.micros += cur_time_micros() - t0;
@@ -252,6 +282,9 @@ QueryStats run_file(const string &infile, const string &outfile, const plain_mat
     if (writer_err) std::rethrow_exception(writer_err);
     write_log("us/query: " + std::to_string((double)st.micros / (double)st.queries) + " (excluding I/O etc)",
               LogLevel::MAJOR);
+    if (timing)
+        std::cerr << "timing: parse " << t_parse / 1e6 << " s, search (GPU + PCIe) " << st.micros / 1e6 << " s, write "
+                  << t_write / 1e6 << " s" << std::endl;
     return st;
 }
 
@@ -327,20 +360,45 @@ int search_main(int argc, char **argv) {
     if (variant != "plain-matrix")
         throw std::runtime_error("Error: only the plain-matrix variant is supported by the GPU search path (got " +
                                  variant + ")");
-    plain_matrix_sbwt_t index;
-    index.load(in);
-    if (devices.size() > 1) {
-        index.use_devices(devices);
-        write_log("Index replicated onto " + std::to_string(devices.size()) + " GPU contexts", LogLevel::MAJOR);
-    }
-
     if (input_files.size() != output_files.size())   // run_queries, sbwt_search.cpp:111-115
         throw std::runtime_error("Number of input and output files does not match (" +
                                  std::to_string(input_files.size()) + " vs " + std::to_string(output_files.size()) + ")");
+    // The index loads (file, HIP start-up, device image: a few tenths of a second) on a thread of its own while the first
+    // input file is already being parsed; the search waits for it.
+    plain_matrix_sbwt_t index;
+    std::exception_ptr load_err;
+    std::thread loader([&] {
+        try {
+            const int64_t load0 = cur_time_micros();
+            index.load(in);
+            if (getenv("SBWT_CLI_TIMING"))
+                std::cerr << "timing: index load + device image " << (cur_time_micros() - load0) / 1e6 << " s" << std::endl;
+            if (devices.size() > 1) {
+                index.use_devices(devices);
+                write_log("Index replicated onto " + std::to_string(devices.size()) + " GPU contexts", LogLevel::MAJOR);
+            }
+        } catch (...) {
+            load_err = std::current_exception();
+        }
+    });
+    bool joined = false;
+    std::mutex join_mutex;
+    const std::function<const plain_matrix_sbwt_t &()> get_index = [&]() -> const plain_matrix_sbwt_t & {
+        std::lock_guard<std::mutex> lk(join_mutex);
+        if (!joined) { loader.join(); joined = true; }
+        if (load_err) std::rethrow_exception(load_err);
+        return index;
+    };
     int64_t number_of_queries = 0;
-    for (size_t i = 0; i < input_files.size(); i++)
-        number_of_queries += run_file(input_files[i], output_files[i], index, gzip_output, batch_bases,
-                                      opts.count("host-format")).queries;
+    try {
+        for (size_t i = 0; i < input_files.size(); i++)
+            number_of_queries += run_file(input_files[i], output_files[i], get_index, gzip_output, batch_bases,
+                                          opts.count("host-format")).queries;
+    } catch (...) {
+        if (!joined) { loader.join(); joined = true; }
+        throw;
+    }
+    if (!joined) { loader.join(); joined = true; }
 
     int64_t total_micros = cur_time_micros() - micros_start;
     write_log("us/query end-to-end: " + std::to_string((double)total_micros / (double)number_of_queries), LogLevel::MAJOR);
@@ -437,7 +495,15 @@ int main(int argc, char **argv) {   // sbwt.cpp:19-57
     argc--;
     try {
         if (command == "build") return build_main(argc, argv);
-        else if (command == "search") return search_main(argc, argv);
+        else if (command == "search") {
+            const int rc = search_main(argc, argv);
+            // every output file is closed: leave without the HIP runtime's teardown and the freeing of the index (a tenth
+            // of a second of a sub-second run)
+            std::cout.flush();
+            std::cerr.flush();
+            fflush(nullptr);
+            _exit(rc);
+        }
         else throw std::runtime_error("Invalid command: " + command);
     } catch (const std::runtime_error &e) {
         std::cerr << "Runtime error: " << e.what() << '\n';

@@ -580,7 +580,7 @@ __global__ void __launch_bounds__(256) k_path_oth(SbwtIndexView ix, unsigned *__
     }
 }
 // (runs on the FINAL encoding of the path groups, k_path_reencode: go = ~A | B)
-__global__ void __launch_bounds__(256) k_trans_insert(SbwtIndexView ix, unsigned *__restrict__ table, int log2t,
+__global__ void __launch_bounds__(256) k_trans_insert(SbwtIndexView ix, unsigned *__restrict__ table, unsigned n_slots,
                                                       const unsigned char *__restrict__ alt_safe) {
     const i64 t = (i64)blockIdx.x * 256 + threadIdx.x;
     if (t >= ix.n_nodes) return;
@@ -609,10 +609,10 @@ __global__ void __launch_bounds__(256) k_trans_insert(SbwtIndexView ix, unsigned
             e1 = make_uint4((unsigned)ch, (unsigned)(ch >> 32), (unsigned)((((u64)a1.z << 32) | (u64)a0.z) >> sp),
                             (unsigned)((((u64)a1.w << 32) | (u64)a0.w) >> sp));
         }
-        u64 slot = sbwt_trans_slot((unsigned)t, c, log2t);
+        size_t slot = sbwt_trans_slot((unsigned)t, c, n_slots, 0u);
         for (;;) {
             if (atomicCAS(&table[slot * 8], 0u, e0.x) == 0u) break;
-            slot = (slot + 1) & low_mask(log2t);
+            slot = slot + 1 < n_slots ? slot + 1 : 0;
         }
         table[slot * 8 + 1] = e0.y;
         table[slot * 8 + 2] = e0.z;
@@ -880,11 +880,11 @@ long long sbwt_launch_path_oth(const SbwtIndexView &ix, uint4 *d_pq, long long *
     if (n_branch) *n_branch = (long long)h[1];
     return (long long)h[0];
 }
-// Fills the transition table of 2^log2t 32-byte entries (zeroed here).  d_alt_safe: the per-substitute verdicts of
+// Fills the transition table of n_slots 32-byte entries (zeroed here).  d_alt_safe: the per-substitute verdicts of
 // k_path_safe_labels (a byte per position), or nullptr.
-void sbwt_launch_trans_insert(const SbwtIndexView &ix, uint4 *d_trans, int log2t, const unsigned char *d_alt_safe,
+void sbwt_launch_trans_insert(const SbwtIndexView &ix, uint4 *d_trans, long long n_slots, const unsigned char *d_alt_safe,
                               hipStream_t stream) {
-    (void)hipMemsetAsync(d_trans, 0, (size_t)32 << log2t, stream);
-    hipLaunchKernelGGL(k_trans_insert, dim3(grid_for(ix.n_nodes)), dim3(256), 0, stream, ix, reinterpret_cast<unsigned *>(d_trans), log2t,
+    (void)hipMemsetAsync(d_trans, 0, (size_t)32 * (size_t)n_slots, stream);
+    hipLaunchKernelGGL(k_trans_insert, dim3(grid_for(ix.n_nodes)), dim3(256), 0, stream, ix, reinterpret_cast<unsigned *>(d_trans), (unsigned)n_slots,
                        d_alt_safe);
 }

@@ -8,7 +8,7 @@
 //   [ mega     : 4 x n_mega x 8 B]   absolute (C[c] + rank_c) at every 2^31-column boundary
 //   [ col, pos : n_nodes x 4 B each ]  path order (see k_path_* in sbwt_derived.hip)
 //   [ pq       : (n/32+4) x 16 B ]   path groups of 32 positions: packed chars + two state bits per position
-//   [ trans    : 2^log2t x 32 B  ]   transition table: one hashed entry per way off a path -- (position, char) -> column,
+//   [ trans    : n_tslots x 32 B ]   transition table: one hashed entry per way off a path -- (position, char) -> column,
 //                                    path position and the next 32 steps of its path; sized once the path order is known:
 //                                    3 entries per branching column + the successors of every path's last column
 //   [ pfil     : 2^log2f x 16 B  ]   probe filter (see k_pf_insert)
@@ -59,8 +59,8 @@ struct SbwtIndexView {
     int log2b2;                     // 31-prefix's interval, the remaining k-31 bases) -> the k-mer's column and path position
     const uint4 *pfil;              // probe filter: blocked Bloom filter over the p_filter-mers of the index (nullptr = none)
     int p_filter, log2f;            // its depth and log2 of its number of 16-byte blocks
-    const uint4 *trans;             // transition table: 2^log2t hashed 32-byte entries (k_trans_insert, sbwt_derived.hip)
-    int log2t;
+    const uint4 *trans;             // transition table: hashed 32-byte entries (k_trans_insert, sbwt_derived.hip)
+    unsigned n_tslots;              // ... and their number (any: the hash is scaled to it)
     int stab_pos;                   // sparse entries are whole k-mers stored with their path position
     int debug;                      // experiments only: bit0 = skip result stores
     int force_mega;                 // one mega block whose counts do not fit 32 bits (dense rank-only images): cnt is relative
@@ -88,7 +88,7 @@ struct SbwtBlobHeader {
     int32_t log2f;
     int32_t has_safe;               // pq carries the substitution-safe bits
     int32_t force_mega;             // block counts are relative to mega[c][0] although n_mega == 1 (see SbwtIndexView)
-    int64_t log2t;                  // transition table: log2 of its number of 32-byte entries
+    int64_t n_tslots;               // transition table: its number of 32-byte slots
     int64_t n_trans;                // ... and how many of them are in use
     int64_t n_paths;                // paths of the path order
     int64_t n_branch;               // columns with two or more successors (n_nodes / n_branch = columns between choices)
@@ -194,7 +194,7 @@ void sbwt_launch_path_safe(const SbwtIndexView &ix, uint4 *d_pq, int rule, void 
                            hipStream_t stream);
 long long sbwt_path_safe_scratch_bytes(long long n_nodes);
 long long sbwt_launch_path_oth(const SbwtIndexView &ix, uint4 *d_pq, long long *n_branch, hipStream_t stream);
-void sbwt_launch_trans_insert(const SbwtIndexView &ix, uint4 *d_trans, int log2t, const unsigned char *d_alt_safe,
+void sbwt_launch_trans_insert(const SbwtIndexView &ix, uint4 *d_trans, long long n_slots, const unsigned char *d_alt_safe,
                               hipStream_t stream);
 int sbwt_launch_build_path(const SbwtIndexView &ix, unsigned *d_col, unsigned *d_pos, uint4 *d_pq, uint4 *d_trans,
                            void *d_scratch, int lookahead, hipStream_t stream);

@@ -106,9 +106,13 @@ __device__ __forceinline__ int path_stop_kind(bool mismatch, unsigned sA, unsign
 }
 #define SBWT_TRANS_NEG 0x100u          // transition entry: (t, c) has no successor ...
 #define SBWT_TRANS_NEG_SAFE 0x200u     // ... and the step is substitution-safe for exactly this char
-// home slot of (path position t, char c) in the transition table of 2^log2t entries
-__device__ __forceinline__ u64 sbwt_trans_slot(unsigned t, unsigned c, int log2t) {
-    return (((u64)t * 4ull + c) * SBWT_SP_HASH) >> (64 - log2t);
+// slot of (path position t, char c) in the transition table of n_slots entries (any number: the hash is scaled, not masked),
+// j slots past its home
+__device__ __forceinline__ unsigned sbwt_trans_slot(unsigned t, unsigned c, unsigned n_slots, unsigned j) {
+    const u64 h = ((u64)t * 4ull + c) * SBWT_SP_HASH;
+    unsigned s = (unsigned)__umul64hi(h, (u64)n_slots) + j;
+    while (s >= n_slots) s -= n_slots;
+    return s;
 }
 
 // The fused route (sbwt_search_fused.hip) takes a batch when all reads have one length of 32 .. 32 * SBWT_FUSED_MAXG bases

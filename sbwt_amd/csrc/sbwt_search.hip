@@ -538,7 +538,7 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
                 } else if (trn) {
                     // (a base that is not ACGT never gets here: M_EXT treats it as "no successor")
                     // the entry of (position r, char c); j counts the slots probed
-                    a1 = ix.trans + 2 * ((sbwt_trans_slot((unsigned)r, (unsigned)c, ix.log2t) + (u64)j) & low_mask(ix.log2t));
+                    a1 = ix.trans + 2 * (size_t)sbwt_trans_slot((unsigned)r, (unsigned)c, ix.n_tslots, (unsigned)j);
                     a2 = a1 + 1;
                 } else if (strm) {
                     // streaming == 1: SBWT::streaming_search validates the upper-cased char (SBWT.hh:565-568);

@@ -197,7 +197,7 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
                 a2 = a1 + 1;
             } else if (trn) {
                 // the entry of (position r, char c); j counts the slots probed
-                a1 = ix.trans + 2 * ((sbwt_trans_slot((unsigned)r, (unsigned)c, ix.log2t) + (u64)j) & low_mask(ix.log2t));
+                a1 = ix.trans + 2 * (size_t)sbwt_trans_slot((unsigned)r, (unsigned)c, ix.n_tslots, (unsigned)j);
                 a2 = a1 + 1;
             } else if (mode == F_INIT) {
                 (void)wl;

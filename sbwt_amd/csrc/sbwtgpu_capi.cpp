@@ -14,6 +14,7 @@
 #include <cstring>
 #include <new>
 #include <vector>
+#include <thread>
 
 #include "../../include/sbwtgpu.h"
 #include "sbwt_device.h"
@@ -143,9 +144,9 @@ struct sbwtgpu_index {
         v.col = h.has_path ? reinterpret_cast<const unsigned *>(blob + h.off_col) : nullptr;
         v.pos = h.has_path ? reinterpret_cast<const unsigned *>(blob + h.off_pos) : nullptr;
         v.pq = h.has_path ? reinterpret_cast<const uint4 *>(blob + h.off_pq) : nullptr;
-        v.trans = (h.has_path && h.log2t > 0) ? reinterpret_cast<const uint4 *>(blob + h.off_trans) : nullptr;
+        v.trans = (h.has_path && h.n_tslots > 0) ? reinterpret_cast<const uint4 *>(blob + h.off_trans) : nullptr;
         v.stab_pos = h.stab_pos;
-        v.log2t = (int)h.log2t;
+        v.n_tslots = (unsigned)h.n_tslots;
         v.has_safe = h.has_safe;
         v.stab2 = h.log2b2 > 0 ? reinterpret_cast<const uint4 *>(blob + h.off_stab2) : nullptr;
         v.log2b2 = (int)h.log2b2;
@@ -204,6 +205,7 @@ int sbwtgpu_device_count(int *count) {
 }
 
 static inline int64_t align256(int64_t x) { return (x + 255) & ~(int64_t)255; }
+static inline int64_t a256(int64_t x) { return align256(x); }
 
 // set while sbwtgpu_index_create retries without the derived structures after running out of device memory
 // Image levels: 0 = everything (path order, transition table, sparse table, probe filter: 139-168 bytes per column),
@@ -514,10 +516,10 @@ int sbwtgpu_index_create(const sbwtgpu_index_desc *d, int device, sbwtgpu_index 
             if (n_ent < 0) { e = hipErrorUnknown; break; }
             h.n_branch = nb;
             h.n_trans = n_ent;
-            int lt = 4;
-            while (((int64_t)1 << lt) < 2 * n_ent) lt++;                    // load factor 0.25 .. 0.5
-            h.log2t = lt;
-            const int64_t full = align256(h.off_trans + ((int64_t)32 << lt));
+            const int64_t n_slots = 3 * n_ent + 64;                         // load factor 1/3: ~1.25 probes per lookup
+            if (n_slots >= ((int64_t)1 << 32)) { e = hipErrorOutOfMemory; break; }
+            h.n_tslots = n_slots;
+            const int64_t full = align256(h.off_trans + 32 * n_slots);
             if (g_max_image_bytes > 0 && full > g_max_image_bytes && level < 2) { e = hipErrorOutOfMemory; break; }
             char *nblob = nullptr;
             if ((e = hipMalloc((void **)&nblob, (size_t)full)) != hipSuccess) break;
@@ -525,7 +527,7 @@ int sbwtgpu_index_create(const sbwtgpu_index_desc *d, int device, sbwtgpu_index 
             (void)hipFree(idx->blob);
             idx->blob = nblob;
             h.blob_bytes = full;
-            sbwt_launch_trans_insert(idx->view(), reinterpret_cast<uint4 *>(idx->blob + h.off_trans), lt, alt_safe, 0);
+            sbwt_launch_trans_insert(idx->view(), reinterpret_cast<uint4 *>(idx->blob + h.off_trans), n_slots, alt_safe, 0);
             if ((e = hipDeviceSynchronize()) != hipSuccess) break;
             h.n_paths = sbwt_count_paths(idx->view(), 0);
             if (h.n_paths < 0) { e = hipErrorUnknown; break; }
@@ -1092,6 +1094,180 @@ static inline int64_t pieces_bases_bound(int64_t len, int64_t k) {   // bytes ap
     return len + (m / PIECE + 2) * (k - 1);
 }
 
+// ---- large host batches: chunks pipelined over two streams ------------------------------------------------------
+// A batch whose results exceed PIPE_MIN bytes is cut into chunks of reads; chunk c+1's bases go up and its kernels run
+// while chunk c's results come down (H2D and D2H use different DMA engines, the kernels are ~30x faster than either).
+// Buffers of the caller that are pinned (hipHostMalloc / hipHostRegister / torch pin_memory: hipPointerGetAttributes says
+// so) are the DMA's source and target themselves; pageable ones go through pinned staging buffers, copied by a few host
+// threads.  The rate is then PCIe's: 8 bytes of results per k-mer.
+namespace {
+struct PipeSlot {
+    hipStream_t st = nullptr;
+    char *h_in = nullptr, *h_out = nullptr;     // pinned staging: bases | offsets; results (only for pageable callers)
+    int *h_status = nullptr;
+    char *d_mem = nullptr;
+    int64_t cap_in = 0, cap_out = 0, cap_dev = 0;
+    void release() {
+        if (st) (void)hipStreamDestroy(st);
+        if (h_in) (void)hipHostFree(h_in);
+        if (h_out) (void)hipHostFree(h_out);
+        if (h_status) (void)hipHostFree(h_status);
+        if (d_mem) (void)hipFree(d_mem);
+        *this = PipeSlot();
+    }
+};
+std::mutex g_pipe_mutex;
+struct ParkedPipe { int device; PipeSlot s[2]; };
+std::vector<ParkedPipe> g_pipe_parked;
+bool is_pinned(const void *p) {
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return a.type == hipMemoryTypeHost;
+}
+void parallel_memcpy(char *dst, const char *src, size_t n) {
+    const int T = n >= ((size_t)8 << 20) ? 4 : 1;
+    if (T == 1) { memcpy(dst, src, n); return; }
+    std::vector<std::thread> th;
+    const size_t per = (n / T + 4095) & ~(size_t)4095;
+    for (int t = 0; t < T; t++) {
+        const size_t lo = std::min(n, per * (size_t)t), hi = std::min(n, lo + per);
+        if (hi > lo) th.emplace_back([=] { memcpy(dst + lo, src + lo, hi - lo); });
+    }
+    for (auto &x : th) x.join();
+}
+const int64_t PIPE_MIN = (int64_t)64 << 20;
+}  // namespace
+
+// ro / oo: offsets rebased to 0 (nv + 1 entries); src_bases: the bases of the batch; out: where result 0 goes
+static int search_host_pipelined(const sbwtgpu_index *idx, const char *src_bases, const int64_t *ro, const int64_t *oo,
+                                 int64_t nv, int64_t *out, int streaming) {
+    const bool pin_in = is_pinned(src_bases), pin_out = is_pinned(out);
+    // chunks: results <= 512 MiB when they land in the caller's pinned memory, <= 128 MiB when they are staged
+    const int64_t CH_OUT = (pin_out ? (int64_t)512 : (int64_t)128) << 20;
+    std::vector<int64_t> cuts{0};
+    int64_t max_bases = 0, max_reads = 0, max_vals = 0;
+    for (int64_t lo = 0; lo < nv;) {
+        int64_t hi = lo + 1;
+        // (offsets are non-decreasing: bisect for the last read whose results still fit)
+        int64_t a = lo + 1, b = nv;
+        while (a < b) {
+            const int64_t mid = a + (b - a + 1) / 2;
+            if ((oo[mid] - oo[lo]) * 8 <= CH_OUT && ro[mid] - ro[lo] <= ((int64_t)1 << 30)) a = mid; else b = mid - 1;
+        }
+        hi = a;
+        cuts.push_back(hi);
+        max_bases = std::max(max_bases, ro[hi] - ro[lo]);
+        max_reads = std::max(max_reads, hi - lo);
+        max_vals = std::max(max_vals, oo[hi] - oo[lo]);
+        lo = hi;
+    }
+    const int64_t n_chunks = (int64_t)cuts.size() - 1;
+    const int64_t ws_bytes = sbwtgpu_search_workspace_bytes(max_bases);
+    const int64_t need_in = a256(max_bases + 16) + 2 * a256((max_reads + 1) * 8);
+    const int64_t need_out = pin_out ? 0 : a256(max_vals * 8 + 8);
+    const int64_t need_dev = a256(max_bases + 16) + 2 * a256((max_reads + 1) * 8) + a256(max_vals * 8 + 8) + a256(ws_bytes);
+    DeviceGuard guard(idx->device);
+    PipeSlot S[2];
+    {
+        std::lock_guard<std::mutex> lock(g_pipe_mutex);
+        for (size_t i = 0; i < g_pipe_parked.size(); i++)
+            if (g_pipe_parked[i].device == idx->device) {
+                S[0] = g_pipe_parked[i].s[0];
+                S[1] = g_pipe_parked[i].s[1];
+                g_pipe_parked.erase(g_pipe_parked.begin() + (long)i);
+                break;
+            }
+    }
+    int rc = SBWTGPU_OK;
+    auto cleanup = [&]() { S[0].release(); S[1].release(); };
+    for (int q = 0; q < 2 && rc == SBWTGPU_OK; q++) {
+        PipeSlot &P = S[q];
+        hipError_t e = hipSuccess;
+        if (!P.st) e = hipStreamCreateWithFlags(&P.st, hipStreamNonBlocking);
+        if (e == hipSuccess && !P.h_status) e = hipHostMalloc((void **)&P.h_status, 64, hipHostMallocDefault);
+        if (e == hipSuccess && P.cap_in < need_in) {
+            if (P.h_in) (void)hipHostFree(P.h_in);
+            P.h_in = nullptr; P.cap_in = 0;
+            if ((e = hipHostMalloc((void **)&P.h_in, (size_t)need_in, hipHostMallocDefault)) == hipSuccess) P.cap_in = need_in;
+        }
+        if (e == hipSuccess && P.cap_out < need_out) {
+            if (P.h_out) (void)hipHostFree(P.h_out);
+            P.h_out = nullptr; P.cap_out = 0;
+            if ((e = hipHostMalloc((void **)&P.h_out, (size_t)need_out, hipHostMallocDefault)) == hipSuccess) P.cap_out = need_out;
+        }
+        if (e == hipSuccess && P.cap_dev < need_dev) {
+            if (P.d_mem) (void)hipFree(P.d_mem);
+            P.d_mem = nullptr; P.cap_dev = 0;
+            if ((e = hipMalloc((void **)&P.d_mem, (size_t)need_dev)) == hipSuccess) P.cap_dev = need_dev;
+        }
+        if (e != hipSuccess)
+            rc = fail(e == hipErrorOutOfMemory ? SBWTGPU_ERR_OOM : SBWTGPU_ERR_HIP, "pipeline buffers: %s", hipGetErrorString(e));
+    }
+    if (rc != SBWTGPU_OK) { (void)hipGetLastError(); cleanup(); return rc; }
+    bool bug = false;
+    struct Carve { char *bases; int64_t *roff, *ooff, *out; char *ws; };
+    auto carve = [&](PipeSlot &P) {
+        Carve c;
+        char *p = P.d_mem;
+        c.bases = p; p += a256(max_bases + 16);
+        c.roff = (int64_t *)p; p += a256((max_reads + 1) * 8);
+        c.ooff = (int64_t *)p; p += a256((max_reads + 1) * 8);
+        c.out = (int64_t *)p; p += a256(max_vals * 8 + 8);
+        c.ws = p;
+        return c;
+    };
+    auto submit = [&](int64_t c) -> int {
+        PipeSlot &P = S[c & 1];
+        const Carve d = carve(P);
+        const int64_t lo = cuts[(size_t)c], hi = cuts[(size_t)c + 1], nr = hi - lo, nb = ro[hi] - ro[lo], nvals = oo[hi] - oo[lo];
+        int64_t *hro = (int64_t *)(P.h_in + a256(max_bases + 16)), *hoo = (int64_t *)((char *)hro + a256((max_reads + 1) * 8));
+        for (int64_t r = 0; r <= nr; r++) { hro[r] = ro[lo + r] - ro[lo]; hoo[r] = oo[lo + r] - oo[lo]; }
+        const char *hb = src_bases + ro[lo];
+        if (!pin_in) { memcpy(P.h_in, hb, (size_t)nb); hb = P.h_in; }
+        hipError_t e;
+        if ((e = hipMemcpyAsync(d.bases, hb, (size_t)nb, hipMemcpyHostToDevice, P.st)) != hipSuccess ||
+            (e = hipMemcpyAsync(d.roff, hro, (size_t)(nr + 1) * 8, hipMemcpyHostToDevice, P.st)) != hipSuccess ||
+            (e = hipMemcpyAsync(d.ooff, hoo, (size_t)(nr + 1) * 8, hipMemcpyHostToDevice, P.st)) != hipSuccess)
+            return fail(SBWTGPU_ERR_HIP, "H2D copy: %s", hipGetErrorString(e));
+        int r2 = search_dev_common(idx, d.bases, nb, d.roff, nr, d.out, d.ooff, d.ws, ws_bytes, P.st, streaming);
+        if (r2 != SBWTGPU_OK) return r2;
+        char *target = pin_out ? (char *)(out + oo[lo]) : P.h_out;
+        if ((e = hipMemcpyAsync(target, d.out, (size_t)nvals * 8, hipMemcpyDeviceToHost, P.st)) != hipSuccess ||
+            (e = hipMemcpyAsync(P.h_status, d.ws + offsetof(SbwtWorkHeader, status), 4, hipMemcpyDeviceToHost, P.st)) != hipSuccess)
+            return fail(SBWTGPU_ERR_HIP, "D2H copy: %s", hipGetErrorString(e));
+        return SBWTGPU_OK;
+    };
+    auto collect = [&](int64_t c) -> int {
+        PipeSlot &P = S[c & 1];
+        hipError_t e = hipStreamSynchronize(P.st);
+        if (e != hipSuccess) return fail(SBWTGPU_ERR_HIP, "stream synchronize: %s", hipGetErrorString(e));
+        if (P.h_status[0] != 0) bug = true;
+        const int64_t lo = cuts[(size_t)c], hi = cuts[(size_t)c + 1];
+        if (!pin_out) parallel_memcpy((char *)(out + oo[lo]), P.h_out, (size_t)(oo[hi] - oo[lo]) * 8);
+        return SBWTGPU_OK;
+    };
+    for (int64_t c = 0; c < n_chunks && rc == SBWTGPU_OK; c++) {
+        if (c >= 2) rc = collect(c - 2);
+        if (rc == SBWTGPU_OK) rc = submit(c);
+    }
+    for (int64_t c = std::max<int64_t>(0, n_chunks - 2); c < n_chunks && rc == SBWTGPU_OK; c++) rc = collect(c);
+    if (rc != SBWTGPU_OK) {
+        (void)hipDeviceSynchronize();
+        cleanup();
+        return rc;
+    }
+    {
+        std::lock_guard<std::mutex> lock(g_pipe_mutex);
+        ParkedPipe pp;
+        pp.device = idx->device;
+        pp.s[0] = S[0];
+        pp.s[1] = S[1];
+        g_pipe_parked.push_back(pp);
+    }
+    if (bug) return fail(SBWTGPU_ERR_NOT_SINGLETON, "Bug: k-mer search did not give a singleton interval");
+    return SBWTGPU_OK;
+}
+
 static int search_host_common(const sbwtgpu_index *idx, const char *bases, const int64_t *read_off, int64_t n_reads,
                               int64_t *out, const int64_t *out_off, int streaming) {
     if (!idx) return fail(SBWTGPU_ERR_INVALID_ARG, "idx is NULL");
@@ -1140,6 +1316,8 @@ static int search_host_common(const sbwtgpu_index *idx, const char *bases, const
     } catch (const std::bad_alloc &) {
         return fail(SBWTGPU_ERR_OOM, "out of host memory");
     }
+    if (n_out * 8 >= PIPE_MIN)
+        return search_host_pipelined(idx, src_bases, ro.data(), oo.data(), nv, out + out0, streaming);
     DeviceGuard guard(idx->device);
     const int64_t ws_bytes = sbwtgpu_search_workspace_bytes(vtotal);
     {   // small call: layout [roff][ooff][bases] (in) | [out][workspace] (the D2H copy ends with the workspace header)
@@ -1600,7 +1778,6 @@ struct Slot {
         *this = Slot();
     }
 };
-inline int64_t a256(int64_t x) { return (x + 255) & ~(int64_t)255; }
 
 // Pinned + device buffers are expensive to create (page pinning), so finished calls park their slots
 // here and later calls on the same device reuse them when they are large enough.
@@ -1630,6 +1807,11 @@ void park(int device, Slot &S) {
 }  // namespace
 
 void sbwtgpu_release_cached_buffers(void) {
+    {
+        std::lock_guard<std::mutex> lock(g_pipe_mutex);
+        for (auto &pp : g_pipe_parked) { DeviceGuard guard(pp.device); pp.s[0].release(); pp.s[1].release(); }
+        g_pipe_parked.clear();
+    }
     std::lock_guard<std::mutex> lock(g_slot_mutex);
     for (auto &ps : g_parked) {
         int prev = -1;
@@ -1643,11 +1825,9 @@ void sbwtgpu_release_cached_buffers(void) {
     t_slots.v.clear();
 }
 
-int sbwtgpu_search_text_batch(const sbwtgpu_index *idx, const char *bases, const int64_t *read_off, int64_t n_reads,
-                              int streaming, char **text, int64_t *text_bytes, int64_t *n_queries) {
-    if (!idx || !text || !text_bytes) return fail(SBWTGPU_ERR_INVALID_ARG, "NULL argument");
-    *text = nullptr;
-    *text_bytes = 0;
+int sbwtgpu_search_text_stream(const sbwtgpu_index *idx, const char *bases, const int64_t *read_off, int64_t n_reads,
+                               int streaming, sbwtgpu_text_sink sink, void *sink_ctx, int64_t *n_queries) {
+    if (!idx || !sink) return fail(SBWTGPU_ERR_INVALID_ARG, "NULL argument");
     if (n_queries) *n_queries = 0;
     if (streaming && !idx->h.has_ssup)
         return fail(SBWTGPU_ERR_NO_STREAMING, "Error: streaming search support not built");
@@ -1690,22 +1870,11 @@ int sbwtgpu_search_text_batch(const sbwtgpu_index *idx, const char *bases, const
         }
     }
     const int64_t n_chunks = (int64_t)cuts.size() - 1;
-    if (n_chunks == 0) {
-        *text = (char *)malloc(1);
-        return *text ? SBWTGPU_OK : fail(SBWTGPU_ERR_OOM, "out of host memory");
-    }
+    if (n_chunks == 0) return SBWTGPU_OK;
     DeviceGuard guard(idx->device);
-    Slot slots[2];
+    Slot slots[3];
     int rc = SBWTGPU_OK;
-    auto cleanup = [&]() { slots[0].release(); slots[1].release(); };
-    // the output buffer is sized by the bound of the whole batch (untouched pages cost nothing) and
-    // shrunk at the end, so every chunk's text is copied exactly once
-    int64_t all_vals = 0;
-    for (int64_t r = 0; r < n_reads; r++) all_vals += std::max<int64_t>(0, read_off[r + 1] - read_off[r] - k + 1);
-    const int64_t result_cap = sbwtgpu_format_text_bound(idx, all_vals, n_reads);
-    char *result = (char *)malloc((size_t)result_cap);
-    if (!result) return fail(SBWTGPU_ERR_OOM, "out of host memory");
-    int64_t result_len = 0;
+    auto cleanup = [&]() { slots[0].release(); slots[1].release(); slots[2].release(); };
 #define PIPE_TRY(expr)                                                                                     \
     do {                                                                                                   \
         hipError_t e_ = (expr);                                                                            \
@@ -1713,11 +1882,10 @@ int sbwtgpu_search_text_batch(const sbwtgpu_index *idx, const char *bases, const
             rc = fail(e_ == hipErrorOutOfMemory ? SBWTGPU_ERR_OOM : SBWTGPU_ERR_HIP, "%s failed: %s", #expr, \
                       hipGetErrorString(e_));                                                              \
             cleanup();                                                                                     \
-            free(result);                                                                                  \
             return rc;                                                                                     \
         }                                                                                                  \
     } while (0)
-    const int n_slots = n_chunks > 1 ? 2 : 1;
+    const int n_slots = n_chunks > 2 ? 3 : (int)n_chunks;
     for (int s = 0; s < n_slots; s++) {
         Slot &S = slots[s];
         if (take_parked(idx->device, max_bases, max_reads, max_vals, sbwtgpu_format_text_bound(idx, max_vals, max_reads), &S) &&
@@ -1757,19 +1925,39 @@ int sbwtgpu_search_text_batch(const sbwtgpu_index *idx, const char *bases, const
         int64_t *hro = (int64_t *)(S.h_in + a256(S.cap_bases + 16));                    // pieces: base offsets
         int64_t *hvo = (int64_t *)((char *)hro + a256((S.cap_vreads + 1) * 8));         // pieces: result offsets
         int64_t *hoo = (int64_t *)((char *)hvo + a256((S.cap_vreads + 1) * 8));         // reads: result offsets
-        std::vector<int64_t> vro{0}, voo{0};
-        int64_t nb = 0, acc = 0;
+        int64_t nb = 0, acc = 0, nv = 0;
         hoo[0] = 0;
-        for (int64_t r = 0; r < nr; r++) {
-            const int64_t len = read_off[lo + r + 1] - read_off[lo + r];
-            nb += append_pieces(bases + read_off[lo + r], len, k, hb + nb, vro, voo);
-            acc += std::max<int64_t>(0, len - k + 1);
-            hoo[r + 1] = acc;
+        bool any_long = false;
+        for (int64_t r = 0; r < nr && !any_long; r++) any_long = (read_off[lo + r + 1] - read_off[lo + r] - k + 1) > 2 * PIECE;
+        if (!any_long) {
+            // the usual chunk: no read long enough to be cut, pieces = reads -- one copy of the bases, offsets by a loop
+            const int64_t b0 = read_off[lo];
+            nb = read_off[hi] - b0;
+            if (nb > S.cap_bases || nr > S.cap_vreads) return fail(SBWTGPU_ERR_HIP, "internal: piece bound exceeded");
+            if (nb > 0) memcpy(hb, bases + b0, (size_t)nb);
+            hro[0] = 0;
+            hvo[0] = 0;
+            for (int64_t r = 0; r < nr; r++) {
+                const int64_t len = read_off[lo + r + 1] - read_off[lo + r];
+                acc += std::max<int64_t>(0, len - k + 1);
+                hro[r + 1] = read_off[lo + r + 1] - b0;
+                hvo[r + 1] = acc;
+                hoo[r + 1] = acc;
+            }
+            nv = nr;
+        } else {
+            std::vector<int64_t> vro{0}, voo{0};
+            for (int64_t r = 0; r < nr; r++) {
+                const int64_t len = read_off[lo + r + 1] - read_off[lo + r];
+                nb += append_pieces(bases + read_off[lo + r], len, k, hb + nb, vro, voo);
+                acc += std::max<int64_t>(0, len - k + 1);
+                hoo[r + 1] = acc;
+            }
+            nv = (int64_t)vro.size() - 1;
+            if (nv > S.cap_vreads || nb > S.cap_bases) return fail(SBWTGPU_ERR_HIP, "internal: piece bound exceeded");
+            memcpy(hro, vro.data(), (size_t)(nv + 1) * 8);
+            memcpy(hvo, voo.data(), (size_t)(nv + 1) * 8);
         }
-        const int64_t nv = (int64_t)vro.size() - 1;
-        if (nv > S.cap_vreads || nb > S.cap_bases) return fail(SBWTGPU_ERR_HIP, "internal: piece bound exceeded");
-        memcpy(hro, vro.data(), (size_t)(nv + 1) * 8);
-        memcpy(hvo, voo.data(), (size_t)(nv + 1) * 8);
         S.n_reads = nr;
         S.n_vals = acc;
         total_queries += acc;
@@ -1802,42 +1990,66 @@ int sbwtgpu_search_text_batch(const sbwtgpu_index *idx, const char *bases, const
         if (e != hipSuccess) return fail(SBWTGPU_ERR_HIP, "D2H copy: %s", hipGetErrorString(e));
         return SBWTGPU_OK;
     };
-    // wait for chunk c's text and append it
+    // wait for chunk c's text and hand it to the sink (straight out of the pinned staging buffer)
     auto collect = [&](int64_t c) -> int {
         Slot &S = slots[c % n_slots];
         hipError_t e = hipStreamSynchronize(S.st);
         if (e != hipSuccess) return fail(SBWTGPU_ERR_HIP, "stream synchronize: %s", hipGetErrorString(e));
-        if (result_len + S.text_len > result_cap) return fail(SBWTGPU_ERR_HIP, "formatted text overflows its bound");
-        memcpy(result + result_len, S.h_text, (size_t)S.text_len);
-        result_len += S.text_len;
+        if (S.text_len > 0 && sink(sink_ctx, S.h_text, S.text_len) != 0) return fail(SBWTGPU_ERR_INVALID_ARG, "the text sink reported an error");
         S.busy = false;
         return SBWTGPU_OK;
     };
-    // chunk c+1 is submitted (other slot) before chunk c is fetched, so its H2D and kernels overlap
-    // chunk c's D2H and host append
+    // Three slots: while the sink has chunk c-2's text (a write to a file takes several times longer than the GPU needs
+    // for a chunk), chunk c is on the GPU and chunk c-1's text is on its way down.
     for (int64_t c = 0; c < n_chunks && rc == SBWTGPU_OK; c++) {
-        if (c >= n_slots) rc = collect(c - n_slots);              // frees this chunk's slot
-        if (rc == SBWTGPU_OK) rc = submit(c);
+        rc = submit(c);                                            // its slot was freed by collect(c - 3) in the last round
         if (rc == SBWTGPU_OK && c >= 1) rc = fetch(c - 1);
+        if (rc == SBWTGPU_OK && c >= 2) rc = collect(c - 2);
     }
     if (rc == SBWTGPU_OK) rc = fetch(n_chunks - 1);
-    for (int64_t c = std::max<int64_t>(0, n_chunks - n_slots); c < n_chunks && rc == SBWTGPU_OK; c++) rc = collect(c);
+    for (int64_t c = std::max<int64_t>(0, n_chunks - 2); c < n_chunks && rc == SBWTGPU_OK; c++) rc = collect(c);
 #undef PIPE_TRY
     if (rc != SBWTGPU_OK) {
         (void)hipDeviceSynchronize();
         cleanup();
-        free(result);
         return rc;
     }
     for (int s2 = 0; s2 < n_slots; s2++) park(idx->device, slots[s2]);
-    if (bug) {
-        free(result);
-        return fail(SBWTGPU_ERR_NOT_SINGLETON, "Bug: k-mer search did not give a singleton interval");
-    }
-    char *shrunk = (char *)realloc(result, (size_t)(result_len ? result_len : 1));
-    *text = shrunk ? shrunk : result;
-    *text_bytes = result_len;
+    if (bug) return fail(SBWTGPU_ERR_NOT_SINGLETON, "Bug: k-mer search did not give a singleton interval");
     if (n_queries) *n_queries = total_queries;
+    return SBWTGPU_OK;
+}
+
+// The same with the whole text in one malloc'ed buffer: sized by the bound of the batch (untouched pages cost nothing)
+// and shrunk at the end, so every chunk's text is copied exactly once.
+namespace {
+struct TextAcc { char *buf; int64_t len, cap; };
+int text_acc_sink(void *ctx, const char *text, int64_t bytes) {
+    TextAcc *a = static_cast<TextAcc *>(ctx);
+    if (a->len + bytes > a->cap) return 1;
+    memcpy(a->buf + a->len, text, (size_t)bytes);
+    a->len += bytes;
+    return 0;
+}
+}  // namespace
+int sbwtgpu_search_text_batch(const sbwtgpu_index *idx, const char *bases, const int64_t *read_off, int64_t n_reads,
+                              int streaming, char **text, int64_t *text_bytes, int64_t *n_queries) {
+    if (!idx || !text || !text_bytes) return fail(SBWTGPU_ERR_INVALID_ARG, "NULL argument");
+    *text = nullptr;
+    *text_bytes = 0;
+    if (n_queries) *n_queries = 0;
+    if (n_reads < 0) return fail(SBWTGPU_ERR_INVALID_ARG, "negative n_reads");
+    if (n_reads > 0 && !read_off) return fail(SBWTGPU_ERR_INVALID_ARG, "NULL input");
+    int64_t all_vals = 0;
+    for (int64_t r = 0; r < n_reads; r++) all_vals += std::max<int64_t>(0, read_off[r + 1] - read_off[r] - idx->h.k + 1);
+    TextAcc acc{nullptr, 0, sbwtgpu_format_text_bound(idx, all_vals, n_reads) + 1};
+    acc.buf = (char *)malloc((size_t)acc.cap);
+    if (!acc.buf) return fail(SBWTGPU_ERR_OOM, "out of host memory");
+    const int rc = sbwtgpu_search_text_stream(idx, bases, read_off, n_reads, streaming, text_acc_sink, &acc, n_queries);
+    if (rc != SBWTGPU_OK) { free(acc.buf); return rc; }
+    char *shrunk = (char *)realloc(acc.buf, (size_t)(acc.len ? acc.len : 1));
+    *text = shrunk ? shrunk : acc.buf;
+    *text_bytes = acc.len;
     return SBWTGPU_OK;
 }
 

@@ -25,9 +25,11 @@ with open(d + "/r.fastq", "wb") as f:
     f.write(b"".join(chunk))
 print("fastq written s", time.time() - t, os.path.getsize(d + "/r.fastq") / 1e6, "MB", flush=True)
 n_kmers = n_reads * 121
-for extra in ([], ["--host-format"]):
+for extra in ([], [], ["--batch-bases", "268435456"]):
     t = time.time()
-    p = subprocess.run([SBWT, "search", "-i", d + "/i.sbwt", "-q", d + "/r.fastq", "-o", d + "/out.txt"] + extra, capture_output=True)
+    p = subprocess.run([SBWT, "search", "-i", d + "/i.sbwt", "-q", d + "/r.fastq", "-o", d + "/out.txt"] + extra, capture_output=True,
+                       env=dict(os.environ, SBWT_CLI_TIMING="1"))
+    print("\n".join(l for l in p.stderr.decode().splitlines() if l.startswith("timing")))
     dt = time.time() - t
     logs = [l for l in p.stderr.decode().splitlines() if "us/query" in l]
     print("CLI", extra, "wall s %.2f -> %.1f M k-mers/s end to end;" % (dt, n_kmers / dt / 1e6), logs, "out MB", os.path.getsize(d + "/out.txt") / 1e6, flush=True)

@@ -2,7 +2,7 @@
   SBWTGPU_LIB=$PWD/sbwt_amd/lib/lib_stats.so python tools/lane_stats_fused.py        (env of tools/ab_step.py applies)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ.setdefault("CONFIGS", "[[5,0]]"); os.environ.setdefault("ROUNDS", "0")
+os.environ.setdefault("CONFIGS", "[[5,0]]"); os.environ.setdefault("ROUNDS", "1")
 import tools.ab_step as ab
 hdr = ab.d_ws[:256].cpu().numpy().view("uint64")
 names = ["sparse lookup", "filter probe", "dense table", "second level", "interval update", "path run", "transition", "bridge", "pos",
