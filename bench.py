@@ -283,6 +283,10 @@ def main() -> int:
     ap.add_argument("--replicate", choices=["image", "rebuild"], default="image",
                     help="N > 1: broadcast the finished device image (default), or broadcast the five bit vectors "
                          "(0.7 bytes per column) and let every rank derive its own image")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak (default): --reads reads per GPU; strong: ONE set of --reads reads, cut into contiguous shards "
+                         "balanced by bases (sbwt_amd/dist.py::contiguous_shard), rank r searches shard r -- the concatenation "
+                         "of the ranks' outputs in rank order is the output of the whole set (checked with --check-ranks)")
     ap.add_argument("--check-ranks", action="store_true",
                     help="every rank's first 2000 reads are compared with the oracle on rank 0 (rank_parity in the JSON "
                          "line); used by the N > 1 tests")
@@ -400,8 +404,7 @@ def main() -> int:
         hdr, blob = None, None
         if rank == 0:
             hdr = index.export_header()
-            blob = torch.empty(index.blob_bytes, dtype=torch.uint8, device=dev)
-            index.copy_blob(blob.data_ptr(), blob.numel(), torch.cuda.current_stream().cuda_stream)
+            blob = index.blob_tensor()           # the image itself (an alias, no second copy on the root)
         torch.cuda.synchronize()
         dist.barrier()
         tb = time.time()
@@ -412,10 +415,20 @@ def main() -> int:
             index = capi.Index.adopt(hdr, blob.data_ptr(), blob.numel(), local_rank, keepalive=blob)
 
     # ---- this rank's reads, resident in HBM ----
-    n_reads = args.reads
-    d_bases = gpu_reads(genomes, n_reads, 42 + rank, dev)
-    total_bases = d_bases.numel()
     m = READ_LEN - K + 1
+    strong = args.scaling == "strong" and world >= 1
+    d_all = None
+    if args.scaling == "strong":
+        # one read set (the same bytes on every rank: same seed), cut into contiguous shards balanced by bases
+        d_all = gpu_reads(genomes, args.reads, 42, dev)
+        lo, hi = sdist.contiguous_shard(np.arange(args.reads + 1, dtype=np.int64) * READ_LEN, rank, world)
+        n_reads = hi - lo
+        d_bases = d_all[lo * READ_LEN:hi * READ_LEN]
+        shard_lo = lo
+    else:
+        n_reads = args.reads
+        d_bases = gpu_reads(genomes, n_reads, 42 + rank, dev)
+    total_bases = d_bases.numel()
     n_kmers = n_reads * m
     d_roff = torch.arange(n_reads + 1, dtype=torch.int64, device=dev) * READ_LEN
     d_ooff = torch.arange(n_reads + 1, dtype=torch.int64, device=dev) * m
@@ -495,7 +508,11 @@ def main() -> int:
     n_full = n_kmers - n_streamed
     nominal_bytes = B_STREAM * n_streamed + (K + 16 + 8 + B_LF * (K - PRECALC)) * n_full
 
-    total_kmers = n_kmers * world
+    if world > 1:
+        total_kmers = int(sdist.sum_over_ranks([n_kmers], dev)[0])
+        rank_kernel_ms = [float(x) for x in sdist.gather_floats(kernel_ms, dev)]
+    else:
+        total_kmers, rank_kernel_ms = n_kmers, [kernel_ms]
     value = total_kmers * args.steps / elapsed
     result = {
         "metric": "k-mers/sec (whole node), plain-matrix k=%d %s" % (K, "streaming search" if streaming else
@@ -507,10 +524,11 @@ def main() -> int:
         "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": args.scaling,
         "vs_baseline": None,
         "dtype": "u64",
         "data": "synthetic",
+        "rank_kernel_ms": rank_kernel_ms,
         "config": {
             "workload": ("config %d: " % args.config) + (
                 "pan-genome-like synthetic genomes (1 + %d x %d bp, 2%% divergence)" % (args.derived, args.genome_len)
@@ -551,6 +569,8 @@ def main() -> int:
     if t_bcast is not None:
         result["index_broadcast_s"] = t_bcast
         result["index_replication"] = args.replicate
+        if args.replicate == "image":
+            result["index_broadcast_GBps"] = index.blob_bytes / max(t_bcast, 1e-9) / 1e9
     if rank == 0:
         result["index_build"] = build_times
     # HBM-side bytes per launch from the PMC counters: measured by tools/profile.sh in separate rocprofv3 passes (a
@@ -564,6 +584,29 @@ def main() -> int:
         result["roofline"]["traffic_GBps"] = tj.get("hbm_bytes_per_launch") / (kernel_ms * 1e-3) / 1e9
         result["roofline"]["traffic_frac_of_peak"] = result["roofline"]["traffic_GBps"] / HBM_PEAK_GBPS
     result["roofline"]["kernel_source_sha16"] = kernel_source_sha16()
+
+    # ---- strong scaling: the ranks' outputs, concatenated in rank order, are the output of the whole set ----
+    if args.check_ranks and args.scaling == "strong":
+        counts = sdist.gather_floats(float(n_kmers), dev) if world > 1 else [float(n_kmers)]
+        if world > 1:
+            mx = int(max(counts))
+            pad = torch.full((mx,), -7, dtype=torch.int64, device=dev)
+            pad[:n_kmers] = d_out
+            parts = [torch.empty_like(pad) for _ in range(world)]
+            dist.all_gather(parts, pad)
+        else:
+            parts = [d_out]
+        if rank == 0:
+            whole = torch.cat([parts[r][: int(counts[r])] for r in range(world)])
+            ref = torch.empty(args.reads * m, dtype=torch.int64, device=dev)
+            ws1 = torch.empty(capi.search_workspace_bytes(d_all.numel()), dtype=torch.uint8, device=dev)
+            ro1 = torch.arange(args.reads + 1, dtype=torch.int64, device=dev) * READ_LEN
+            oo1 = torch.arange(args.reads + 1, dtype=torch.int64, device=dev) * m
+            index.streaming_search_dev(d_all.data_ptr(), d_all.numel(), ro1.data_ptr(), args.reads, ref.data_ptr(), oo1.data_ptr(),
+                                       ws1.data_ptr(), ws1.numel(), stream, streaming)
+            torch.cuda.synchronize()
+            result["strong_concat_equals_single"] = bool(whole.numel() == ref.numel() and torch.equal(whole, ref))
+            del ref, ws1, whole
 
     # ---- N > 1 tests: every rank's first reads against the oracle (rank 0 holds the bits) ----
     if args.check_ranks:

@@ -267,6 +267,18 @@ class Index:
         _check(lib().sbwtgpu_index_blob(self._h, C.byref(p), C.byref(n)))
         return p.value, n.value
 
+    def blob_tensor(self):
+        """The device image as a uint8 torch tensor that ALIASES it (no copy): what rank 0 hands to the broadcast.  The
+        tensor is valid while this Index is."""
+        import torch
+        ptr, n = self.blob()
+
+        class _Alias:
+            __cuda_array_interface__ = {"shape": (n,), "typestr": "|u1", "data": (ptr, False), "version": 3, "strides": None}
+        t = torch.as_tensor(_Alias(), device=torch.device("cuda", self.device))
+        t._sbwt_owner = self          # keeps the image alive as long as the tensor
+        return t
+
     def copy_blob(self, dst_dev_ptr: int, nbytes: int, stream: int = 0) -> None:
         _check(lib().sbwtgpu_index_copy_blob(self._h, dst_dev_ptr, nbytes, stream))
 

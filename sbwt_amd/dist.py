@@ -61,3 +61,11 @@ def sum_over_ranks(values, device: torch.device):
     t = torch.tensor(list(values), dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return [float(x) for x in t.tolist()]
+
+
+def gather_floats(value: float, device: torch.device):
+    """value of every rank, in rank order (on every rank)."""
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    out = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [float(x.item()) for x in out]

@@ -41,6 +41,7 @@ def _worker(rank, world, port, q):
     mine = int(off[hi] - off[lo])
     tot = sdist.sum_over_ranks([mine, hi - lo], dev)
     mx = sdist.max_over_ranks(1.0 + rank, dev)
+    ok = ok and sdist.gather_floats(10.0 + rank, dev) == [10.0, 11.0]          # per-rank values in rank order
     q.put((rank, ok, lo, hi, mine, tot, mx, int(off[-1])))
     dist.barrier()
     dist.destroy_process_group()

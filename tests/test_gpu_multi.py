@@ -45,6 +45,37 @@ def test_bench_gpus2_launches_two_ranks(gpu, replicate):
     assert res["value"] > 0 and res["index_broadcast_s"] >= 0 and res["index_replication"] == replicate
 
 
+def _run_bench(args, n_dev):
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py")] + args
+    p = subprocess.run(cmd, env=_bench_env(n_dev), capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    return json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+
+
+def test_bench_gpus2_config4_index_type(gpu):
+    # BASELINE config 4's KIND of index at N = 2: k = 31 pan-genome (a core + derived genomes: core-following paths,
+    # branching columns, negative transition entries), image broadcast + adopt, every rank against the oracle
+    res = _run_bench(["--gpus", "2", "--config", "3", "--derived", "4", "--genome-len", "300000", "--reads", "200000",
+                      "--steps", "2", "--warmup", "1", "--check-ranks"], capi.device_count())
+    assert res["n_gpus"] == 2 and res["config"]["k"] == 31
+    assert res["rank_parity"] == [True, True], res.get("rank_parity")
+    assert res["rank_reads_differ"] is True
+    assert len(res["rank_kernel_ms"]) == 2 and min(res["rank_kernel_ms"]) > 0
+    assert res["index_broadcast_GBps"] > 0
+    assert res["roofline"]["work_per_launch"]["stream_steps"] > 0          # reads did leave their paths
+
+
+def test_bench_strong_scaling_preserves_order(gpu):
+    # north_star: "reads sharded ... preserving order": ONE read set cut into contiguous shards, rank r searches shard r;
+    # the ranks' outputs concatenated in rank order are bit for bit the output of the whole set on one GPU
+    res = _run_bench(["--gpus", "2", "--scaling", "strong", "--reads", "300001", "--genome-len", "300000", "--steps", "2",
+                      "--warmup", "1", "--check-ranks"], capi.device_count())
+    assert res["n_gpus"] == 2 and res["scaling"] == "strong"
+    assert res["strong_concat_equals_single"] is True
+    assert res["rank_parity"] == [True, True]
+    assert res["config"]["kmers_per_gpu"] in (150000 * 121, 150001 * 121)
+
+
 def test_bench_rejects_world_mismatch(gpu):
     env = _bench_env(1)
     env["RANK"], env["WORLD_SIZE"], env["LOCAL_RANK"] = "0", "1", "0"
