@@ -180,12 +180,11 @@ __global__ void __launch_bounds__(256) k_pf_insert(const SpItem *__restrict__ it
 }
 // pos != nullptr: the items are whole k-mers (one column each); the second payload word is the column's path position
 __global__ void __launch_bounds__(256) k_sp_insert(const SpItem *__restrict__ items, const u64 *n, uint4 *table,
-                                                   int log2b, const unsigned *__restrict__ pos) {
+                                                   unsigned n_buckets, const unsigned *__restrict__ pos) {
     u64 t = (u64)blockIdx.x * 256 + threadIdx.x;
     if (t >= *n) return;
     const SpItem it = items[t];
-    const u64 mask = (1ull << log2b) - 1ull;
-    u64 bkt = (it.key * SBWT_SP_HASH) >> (64 - log2b);
+    size_t bkt = sbwt_sp_bucket(it.key, n_buckets, 0u);
     for (;;) {
         for (int e = 0; e < 2; e++) {
             u64 *word = reinterpret_cast<u64 *>(&table[2 * bkt + e]);
@@ -198,7 +197,7 @@ __global__ void __launch_bounds__(256) k_sp_insert(const SpItem *__restrict__ it
             }
         }
         atomicOr(reinterpret_cast<u64 *>(&table[2 * bkt]), SBWT_SP_OVERFLOW);   // both entries taken: mark and move on
-        bkt = (bkt + 1) & mask;
+        bkt = bkt + 1 < n_buckets ? bkt + 1 : 0;
     }
 }
 
@@ -438,13 +437,13 @@ __global__ void __launch_bounds__(256) k_path_place(i64 n, const uint4 *__restri
 // A read that follows the path, differs from it in exactly the base at u and agrees again on the next k-1 bases
 // therefore has -1 for all k k-mers that contain that base -- no probe needed (M_BRIDGE).
 __device__ __forceinline__ bool sp_present(const SbwtIndexView &ix, u64 key) {
-    u64 bkt = (key * SBWT_SP_HASH) >> (64 - ix.log2b);
+    size_t bkt = sbwt_sp_bucket(key, ix.n_sb, 0u);
     for (;;) {
         const uint4 e0 = ix.stab[2 * bkt], e1 = ix.stab[2 * bkt + 1];
         const u64 w0 = quad_bits(e0), w1 = quad_bits(e1);
         if ((w0 & ~SBWT_SP_OVERFLOW) == key || w1 == key) return true;
         if (!(w0 & SBWT_SP_OVERFLOW)) return false;
-        bkt = (bkt + 1) & low_mask(ix.log2b);
+        bkt = bkt + 1 < ix.n_sb ? bkt + 1 : 0;
     }
 }
 __global__ void __launch_bounds__(256) k_path_safe(SbwtIndexView ix, unsigned *pq_words) {
@@ -668,14 +667,14 @@ long long sbwt_sparse_scratch_bytes(long long n_nodes) { return 2 * (n_nodes + 6
 
 // d_pos: path positions to store with depth-k entries (nullptr = none).  Returns 1 if they were stored,
 // 0 if not (no d_pos, p_sparse < k, or some k-mer's interval is wider than one column), < 0 on error.
-int sbwt_launch_build_sparse(const SbwtIndexView &ix, int p_dense, int p_sparse, int log2b, uint4 *d_table,
+int sbwt_launch_build_sparse(const SbwtIndexView &ix, int p_dense, int p_sparse, long long n_buckets, uint4 *d_table,
                              void *d_scratch, const unsigned *d_pos, int p_filter, int log2f, uint4 *d_filter,
                              int log2b2, uint4 *d_table2, hipStream_t stream) {
     u64 *counters = reinterpret_cast<u64 *>(d_scratch);                    // [0], [1]: list lengths
     SpItem *listA = reinterpret_cast<SpItem *>(reinterpret_cast<char *>(d_scratch) + 256);
     SpItem *listB = listA + (ix.n_nodes + 64);
     (void)hipMemsetAsync(counters, 0, 256, stream);
-    hipLaunchKernelGGL(k_sp_clear, dim3(grid_for((i64)2 << log2b)), dim3(256), 0, stream, d_table, (u64)2 << log2b);
+    hipLaunchKernelGGL(k_sp_clear, dim3(grid_for((i64)2 * n_buckets)), dim3(256), 0, stream, d_table, (u64)2 * (u64)n_buckets);
     const u64 n_dense = 1ull << (2 * p_dense);
     hipLaunchKernelGGL(k_sp_collect, dim3(grid_for((i64)n_dense)), dim3(256), 0, stream, ix.ptab, n_dense, listA,
                        counters + 0);
@@ -708,7 +707,7 @@ int sbwt_launch_build_sparse(const SbwtIndexView &ix, int p_dense, int p_sparse,
         with_pos = h_flag ? 0 : 1;
     }
     hipLaunchKernelGGL(k_sp_insert, dim3(grid_for(ix.n_nodes + 64)), dim3(256), 0, stream, in, counters + ci, d_table,
-                       log2b, with_pos ? d_pos : (const unsigned *)nullptr);
+                       (unsigned)n_buckets, with_pos ? d_pos : (const unsigned *)nullptr);
     if (d_table2 && ix.k > p_sparse) {
         // second level: carry every depth-p_sparse prefix on to depth k, remembering where it started
         (void)hipMemsetAsync(d_table2, 0, (size_t)32 << log2b2, stream);

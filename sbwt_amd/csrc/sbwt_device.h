@@ -14,7 +14,7 @@
 //   [ pfil     : 2^log2f x 16 B  ]   probe filter (see k_pf_insert)
 //   [ stab2    : 2^log2b2 x 32 B ]   second level for 31 < k <= 63: { rest key (8 B), first column of the 31-prefix's
 //                                    interval, flags } { column, path position, -, - }
-//   [ stab     : 2^log2b x 32 B  ]   sparse prefix table at depth p_sparse (only non-empty prefixes), hashed:
+//   [ stab     : n_sb x 32 B     ]   sparse prefix table at depth p_sparse (only non-empty prefixes), hashed:
 //                                    bucket = two 16-byte entries { key | flags (u64), first (u32), second-first (u32) }
 //
 // One 64-byte block covers 64 consecutive columns and carries everything both query kinds need,
@@ -50,7 +50,7 @@ struct SbwtIndexView {
     int probe_len;                  // length of the certificate probes of k_search_cert (0 = off)
     const uint4 *stab;              // sparse prefix table (nullptr if p_sparse == 0)
     int p_sparse;                   // its depth (0 = none)
-    int log2b;                      // log2 of its number of buckets
+    unsigned n_sb;                  // its number of buckets (any: the hash is scaled to it)
     const unsigned *col, *pos;      // path order: column at path position t, path position of column v (nullptr = none)
     const uint4 *pq;                // packed path chars: quad t>>5 = { 32 chars (2 bits each), A, B }: go = ~A | B, safe = A & B,
                                     // only successor = ~A & B (k_path_reencode, sbwt_derived.hip)
@@ -79,7 +79,7 @@ struct SbwtBlobHeader {
     int32_t ssup_derived;           // no suffix_group_starts given: marks derived on the device (internal use)
     int32_t p_sparse;               // depth of the sparse prefix table (0 = none)
     int64_t off_stab;
-    int32_t log2b;
+    int32_t log2b_unused;
     int32_t has_path;               // path order present (col, pos, pq)
     int64_t off_col, off_pos, off_pq, off_trans;
     int32_t stab_pos;
@@ -89,6 +89,7 @@ struct SbwtBlobHeader {
     int32_t has_safe;               // pq carries the substitution-safe bits
     int32_t force_mega;             // block counts are relative to mega[c][0] although n_mega == 1 (see SbwtIndexView)
     int64_t n_tslots;               // transition table: its number of 32-byte slots
+    int64_t n_sb;                   // sparse prefix table: its number of 32-byte buckets
     int64_t n_trans;                // ... and how many of them are in use
     int64_t n_paths;                // paths of the path order
     int64_t n_branch;               // columns with two or more successors (n_nodes / n_branch = columns between choices)
@@ -198,7 +199,7 @@ void sbwt_launch_trans_insert(const SbwtIndexView &ix, uint4 *d_trans, long long
                               hipStream_t stream);
 int sbwt_launch_build_path(const SbwtIndexView &ix, unsigned *d_col, unsigned *d_pos, uint4 *d_pq, uint4 *d_trans,
                            void *d_scratch, int lookahead, hipStream_t stream);
-int sbwt_launch_build_sparse(const SbwtIndexView &ix, int p_dense, int p_sparse, int log2b, uint4 *d_table,
+int sbwt_launch_build_sparse(const SbwtIndexView &ix, int p_dense, int p_sparse, long long n_buckets, uint4 *d_table,
                              void *d_scratch, const unsigned *d_pos, int p_filter, int log2f, uint4 *d_filter,
                              int log2b2, uint4 *d_table2, hipStream_t stream);
 

@@ -106,6 +106,13 @@ __device__ __forceinline__ int path_stop_kind(bool mismatch, unsigned sA, unsign
 }
 #define SBWT_TRANS_NEG 0x100u          // transition entry: (t, c) has no successor ...
 #define SBWT_TRANS_NEG_SAFE 0x200u     // ... and the step is substitution-safe for exactly this char
+// bucket of a key in the sparse prefix table of n_buckets 32-byte buckets (any number: the hash is scaled, not masked),
+// j buckets past its home
+__device__ __forceinline__ unsigned sbwt_sp_bucket(u64 key, unsigned n_buckets, unsigned j) {
+    unsigned b = (unsigned)__umul64hi(key * SBWT_SP_HASH, (u64)n_buckets) + j;
+    while (b >= n_buckets) b -= n_buckets;
+    return b;
+}
 // slot of (path position t, char c) in the transition table of n_slots entries (any number: the hash is scaled, not masked),
 // j slots past its home
 __device__ __forceinline__ unsigned sbwt_trans_slot(unsigned t, unsigned c, unsigned n_slots, unsigned j) {

@@ -204,7 +204,7 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
                 if (wk == 1) {                 // bucket (hash + j) of the sparse table: two entries
                     const u64 key = rw & low_mask(2 * ps);
                     hk = key;
-                    const u64 bkt = (((key * SBWT_SP_HASH) >> (64 - ix.log2b)) + (u64)j) & low_mask(ix.log2b);
+                    const size_t bkt = sbwt_sp_bucket(key, ix.n_sb, (unsigned)j);
                     a1 = ix.stab + 2 * bkt;
                     a2 = a1 + 1;
                 } else if (wk == 5) {          // second level: (prefix interval, rest of the k-mer) -> one entry

@@ -32,7 +32,7 @@ __global__ void __launch_bounds__(256) k_anchor(SbwtIndexView ix, const uint4 *_
         const u64 vm = low_mask(k);
         if ((vr & vm) != vm) continue;                     // a non-ACGT base in the window
         const u64 key = w & low_mask(2 * k);
-        u64 bkt = (key * SBWT_SP_HASH) >> (64 - ix.log2b);
+        size_t bkt = sbwt_sp_bucket(key, ix.n_sb, 0u);
         bool found = false;
         for (int tries = 0; tries < 64; tries++) {         // buckets a key had to skip carry the overflow flag
             const uint4 e0 = ix.stab[2 * bkt], e1 = ix.stab[2 * bkt + 1];
@@ -40,7 +40,7 @@ __global__ void __launch_bounds__(256) k_anchor(SbwtIndexView ix, const uint4 *_
             if ((w0 & ~SBWT_SP_OVERFLOW) == key) { key_out = e0.w; found = true; break; }
             if (w1 == key) { key_out = e1.w; found = true; break; }
             if (!(w0 & SBWT_SP_OVERFLOW)) break;
-            bkt = (bkt + 1) & low_mask(ix.log2b);
+            bkt = bkt + 1 < ix.n_sb ? bkt + 1 : 0;
         }
         if (found) break;
     }

@@ -139,7 +139,7 @@ struct sbwtgpu_index {
         v.debug = g_debug;
         v.force_mega = h.force_mega;
         v.p_sparse = (int)h.p_sparse;
-        v.log2b = (int)h.log2b;
+        v.n_sb = (unsigned)h.n_sb;
         v.stab = h.p_sparse > 0 ? reinterpret_cast<const uint4 *>(blob + h.off_stab) : nullptr;
         v.col = h.has_path ? reinterpret_cast<const unsigned *>(blob + h.off_col) : nullptr;
         v.pos = h.has_path ? reinterpret_cast<const unsigned *>(blob + h.off_pos) : nullptr;
@@ -288,12 +288,10 @@ int sbwtgpu_index_create(const sbwtgpu_index_desc *d, int device, sbwtgpu_index 
     if (p_sparse > SBWT_SP_MAX_DEPTH) p_sparse = SBWT_SP_MAX_DEPTH;
     if (p_sparse <= p_dev || p_dev <= 0 || n >= ((int64_t)1 << 32) || n_mega > 1) p_sparse = 0;
     if (p_sparse > 0) {
-        int lb = 6;
-        while (((int64_t)1 << lb) < n) lb++;
         h.p_sparse = (int32_t)p_sparse;
-        h.log2b = lb;
+        h.n_sb = n + n / 4 + 64;            // 1.25 two-entry buckets per column: 40 % of the entry slots in use, ~6 % of the keys overflow
         h.off_stab = h.blob_bytes;
-        h.blob_bytes = align256(h.off_stab + ((int64_t)32 << lb));
+        h.blob_bytes = align256(h.off_stab + 32 * h.n_sb);
         // second level for 31 < k <= 63 (the remaining k-31 bases fit one 64-bit key): two entries' worth of space per column
         if (p_sparse == SBWT_SP_MAX_DEPTH && d->k > p_sparse && d->k - p_sparse <= 32) {
             int lb2 = 6;
@@ -397,7 +395,7 @@ int sbwtgpu_index_create(const sbwtgpu_index_desc *d, int device, sbwtgpu_index 
         h.off_mega = h.off_ptab;
         h.blob_bytes = align256(h.off_mega + 4 * n_mega * 8);
         h.off_stab = 0;
-        h.log2b = 0;
+        h.n_sb = 0;
         h.off_col = h.off_pos = h.off_pq = h.off_trans = 0;
     }
     h.image_level = (h.has_path ? 0 : h.p_sparse > 0 ? 1 : 2);
@@ -471,7 +469,7 @@ int sbwtgpu_index_create(const sbwtgpu_index_desc *d, int device, sbwtgpu_index 
         if (h.p_sparse > 0) {
             void *scr = nullptr;
             if ((e = hipMalloc(&scr, (size_t)sbwt_sparse_scratch_bytes(n))) != hipSuccess) break;
-            int src = sbwt_launch_build_sparse(v, (int)p_dev, (int)h.p_sparse, (int)h.log2b,
+            int src = sbwt_launch_build_sparse(v, (int)p_dev, (int)h.p_sparse, (long long)h.n_sb,
                                                reinterpret_cast<uint4 *>(idx->blob + h.off_stab), scr,
                                                h.has_path ? reinterpret_cast<const unsigned *>(idx->blob + h.off_pos) : nullptr,
                                                (int)h.p_filter, (int)h.log2f,
@@ -877,7 +875,7 @@ static int search_dev_common(const sbwtgpu_index *idx, const char *d_bases, int6
         int variant = g_variant_override >= 0 ? g_variant_override : tuning_variant();
         if (variant < 0) variant = idx->h.has_path ? auto_variant(idx->h) : 2;
         const int eff_streaming = (!streaming && (idx->h.has_ssup || idx->h.ssup_derived) && g_derive_ssup) ? 2 : streaming;
-        const bool path_kernel = idx->h.has_path && eff_streaming && idx->h.stab_pos &&
+        const bool path_kernel = idx->h.has_path && eff_streaming &&
                                  idx->h.n_nodes < ((int64_t)1 << 31) - 128 && n_reads < ((int64_t)1 << 31) &&
                                  total_bases / SBWT_GROUP_BASES + 2 < ((int64_t)1 << 31) - 4;
         if (variant == 5 && path_kernel && g_sort_reads <= 0 && !(g_debug & 16)) {
