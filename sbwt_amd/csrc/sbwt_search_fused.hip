@@ -33,6 +33,7 @@
 #define FE_END 3
 #define FE_PRES 4
 
+#define FZ_SPLIT_MIN 16         // the tail: a lane gives away half of its remaining k-mers when it has at least this many left
 #define FZ_NSEG 9               // segments per lane: 256 x (9 x 4 + 9 x 1) B + 2 x 256 x 40 B of codes = 32 000 B = 5 workgroups per CU
 
 typedef unsigned fz_u32x4 __attribute__((ext_vector_type(4)));
@@ -80,6 +81,8 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
     int mode = F_IDLE;
     unsigned rd = 0;                // the read this lane works on
     int i = 0, j = 0, b = -1, wstart = 0;
+    int mend = 0;                   // this lane answers k-mers [i, mend) of its read (mend = m unless the read was split, below)
+    bool drained = false;           // wave-uniform: the ticket counter has run past the last read
     int l = 0, r = 0;               // walk interval; F_EXT ..: r = path position
     unsigned c_ext = 0, c_brg = 0;  // per lane: k-mers answered along paths, substitutions bridged
     u64 pool_next = 0, pool_end = 0, pool_bad = 0;  // wave-uniform pool of read tickets; tickets of it that are handed on
@@ -88,7 +91,7 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
     for (;;) {
         // ---- hand out reads to idle lanes from the wave's ticket pool; an empty pool is refilled with 64 encoded reads ----
         const u64 need = __ballot(mode == F_IDLE);
-        if (need) {
+        if (need && !drained) {
             if (pool_next == pool_end) {
                 u64 t = 0;
                 if (lane == 0) t = atomicAdd(&ws->ticket, 64ull);
@@ -135,6 +138,9 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
                         at = uniform64(at);
                         if (isbad) defer_list[at + (u64)__popcll(pool_bad & low_mask(lane))] = (unsigned)(pool_next + (u64)lane);
                     }
+                } else {
+                    drained = true;                    // no read left anywhere: from now on idle lanes help busy ones (below)
+                    pool_end = pool_next;
                 }
                 __builtin_amdgcn_wave_barrier();
             }
@@ -144,14 +150,13 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
             if (mode == F_IDLE && rank < avail) {
                 const u64 tk = pool_next + rank;
                 const int q = (int)(tk & 63ull);
-                if ((i64)tk >= n_reads) {
-                    mode = F_DEAD;
-                } else if (!((pool_bad >> q) & 1ull)) {
+                if ((i64)tk < n_reads && !((pool_bad >> q) & 1ull)) {
                     rd = (unsigned)tk;
 #pragma unroll
                     for (int g = 0; g < SBWT_FUSED_MAXG; g++)
                         if (g < G) cur_codes[g][tid] = pool_codes[g][wbase + q];
                     i = 0;
+                    mend = m;
                     nseg = 0;
                     i0 = 0;
                     b = -1;
@@ -161,11 +166,59 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
                     wk = (ps > 0) ? 1 : 0;
                     if (p > 0) mode = F_INIT;
                     else { mode = F_STEP; l = 0; r = last_node; }
-                }                                      // else: handed on -- the lane takes another ticket next time round
+                }                                      // else: past the last read, or handed on -- the lane stays idle
             }
             pool_next = uniform64(pool_next + ((n < avail) ? n : avail));
         }
-        if (__ballot(mode != F_DEAD) == 0) break;
+        if (drained) {
+            // ---- the tail of the batch: one lane per read means a wave waits for its slowest read.  An idle lane takes over
+            //      the second half of what a busy lane still has to answer.  Exact: this kernel only walks reads of upper-case
+            //      ACGT, where a k-mer's result does not depend on what came before it (streaming step and full search agree,
+            //      tests/test_large.hh:104-115), so the taker starts with a full search at its first k-mer.
+            const u64 idle = __ballot(mode == F_IDLE);
+            const u64 busy_m = __ballot(mode != F_IDLE);
+            if (busy_m == 0) break;                    // everything this wave took is answered and written
+            u64 donors = __ballot(mode != F_IDLE && mend - i >= FZ_SPLIT_MIN);
+            if (idle && donors) {
+                const int n_pairs = min(__popcll(idle), __popcll(donors));
+                const int my_idle_rank = __popcll(idle & low_mask(lane)), my_donor_rank = __popcll(donors & low_mask(lane));
+                const bool giving = ((donors >> lane) & 1ull) && my_donor_rank < n_pairs;
+                const bool taking = ((idle >> lane) & 1ull) && my_idle_rank < n_pairs;
+                // the lane number of the donor of rank q, for every taker
+                int src = 0;
+                {
+                    u64 dm = donors;
+                    for (int q = 0; q < my_idle_rank && taking; q++) dm &= dm - 1;
+                    src = taking ? (__ffsll((i64)dm) - 1) : lane;
+                }
+                const int d_i = __shfl(i, src), d_end = __shfl(mend, src);
+                const unsigned d_rd = (unsigned)__shfl((int)rd, src);
+                const int mid = d_i + ((d_end - d_i + 1) >> 1);
+                if (giving) mend = i + ((mend - i + 1) >> 1);                        // (the same mid its taker computed)
+#ifdef SBWT_STATS
+                if (lane == 0) atomicAdd(&ws->pad[13], (unsigned long long)n_pairs);
+#endif
+                if (taking) {
+#pragma unroll
+                    for (int g = 0; g < SBWT_FUSED_MAXG; g++)
+                        if (g < G) cur_codes[g][tid] = cur_codes[g][wbase + src];
+                    rd = d_rd;
+                    i = mid;
+                    mend = d_end;
+                    nseg = 0;
+                    i0 = mid;
+                    b = -1;
+                    blo = -1;
+                    wstart = mid;
+                    j = 0;
+                    wk = (ps > 0) ? 1 : 0;
+                    if (p > 0) mode = F_INIT;
+                    else { mode = F_STEP; l = 0; r = last_node; }
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+
 
         // ---- this iteration's gather: two 16-byte loads per lane, issued back to back, one wait ----
         int ev = FE_NONE, tfail = 0, c = 0;
@@ -236,6 +289,12 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
                 if (lane == 0 && cq) atomicAdd(&ws->pad[q], cq);
             }
             if (lane == 0) atomicAdd(&ws->pad[10], 1ull);
+            // the tail: wave-iterations and idle lane-iterations after the tickets ran out; k-mers still open then
+            if (drained) {
+                const unsigned long long idl = __popcll(__ballot(!busy));
+                const unsigned long long dn = __popcll(__ballot(busy && mend - i >= FZ_SPLIT_MIN));
+                if (lane == 0) { atomicAdd(&ws->pad[11], 1ull); atomicAdd(&ws->pad[12], idl); atomicAdd(&ws->pad[14], dn); }
+            }
         }
 #endif
         c_search = uniform32(c_search + (unsigned)__popcll(__ballot(mode == F_INIT || (p == 0 && mode == F_STEP && j == 0))));
@@ -283,7 +342,7 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
                 const int nv = __ffs((int)((v2.z & ~v2.w) | 0x80000000u)) - 1;      // the quoted path ends: A & ~B
                 int n2 = nm < nv ? nm : nv;
                 bool stop2 = n2 < 31;
-                if (n2 >= m - 1 - i) { n2 = m - 1 - i; stop2 = false; }
+                if (n2 >= mend - 1 - i) { n2 = mend - 1 - i; stop2 = false; }
                 if (n2 < 0) n2 = 0;
                 seg_n = n2;
                 seg_src_run = (unsigned)r + 1u;
@@ -304,7 +363,7 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
             const u64 x = rw ^ pwd;
             const u64 mm = (x | (x >> 1)) & 0x5555555555555555ull;
             const int nm = mm ? ((__ffsll((i64)mm) - 1) >> 1) : 32;
-            const int needb = (k - 1 < m - 1 - i) ? (k - 1) : (m - 1 - i);
+            const int needb = (k - 1 < mend - 1 - i) ? (k - 1) : (mend - 1 - i);
             if (nm >= needb) {
                 ev = FE_FAIL;
                 burst_to = i + needb;
@@ -344,18 +403,18 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
                 nm = 32 + nm2;
                 nv = 32 + nv2;
             }
-            if (n >= m - i) { n = m - i; stopped = false; }
+            if (n >= mend - i) { n = mend - i; stopped = false; }
             seg_n = n;
             seg_src_run = (unsigned)r + 1u;
             c_ext += (unsigned)n;
-            if (i + n == m) {
+            if (i + n == mend) {
                 mode = F_IDLE;
             } else if (stopped) {
                 int kind = path_stop_kind(nm < nv, (unsigned)(fA >> n) & 1u, (unsigned)(fB >> n) & 1u, ix.has_safe != 0);
                 if (kind == PS_BRIDGE && n < 32) {
                     // a bridge needs the next k-1 bases to agree with the path; a second difference already in this window:
                     // skip the attempt (the step has no successor by the read's char either way)
-                    const int after = 31 - n, want = (k - 1 < m - 1 - (i + n)) ? (k - 1) : (m - 1 - (i + n));
+                    const int after = 31 - n, want = (k - 1 < mend - 1 - (i + n)) ? (k - 1) : (mend - 1 - (i + n));
                     const int chk = after < want ? after : want;
                     if (chk > 0 && ((mm >> (2 * (n + 1))) & low_mask(2 * chk)) != 0) kind = PS_ABSENT;
                 }
@@ -468,7 +527,7 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
             }
         } else if (ev == FE_FAIL) {
             // read[wstart..tfail] is not in the index: k-mers i..min(wstart, m-1) all contain it
-            burst_hi = (wstart < m - 1) ? wstart : (m - 1);
+            burst_hi = (wstart < mend - 1) ? wstart : (mend - 1);
             if (burst_to >= 0) {                       // bridged substitution: nothing is known about the next one
                 burst_hi = burst_to;
                 b = -1;
@@ -519,13 +578,13 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
                 append(i, 0xFFFFFFFFu);
                 b = blo = i + k - 1;
                 i++;
-                if (i == m) mode = F_IDLE;
+                if (i == mend) mode = F_IDLE;
                 else do_plan = true;
             }
         }
         // ---- flush: the read is done, or the list could overflow in the next iteration.  Up to four reads per trip: the
         //      col[] loads of all four are in flight before the first store ----
-        u64 fm = __ballot(nseg > 0 && (i == m || nseg > FZ_NSEG - 2));
+        u64 fm = __ballot(nseg > 0 && (i == mend || nseg > FZ_NSEG - 2));
         while (fm) {
             constexpr int FP = 4;
             int fL[FP], fe[FP], fj[FP], w0[FP], w1[FP];
@@ -612,7 +671,7 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
                 if (lane == fL[u]) { nseg = 0; i0 = i; }
         }
         if (ev == FE_EMIT1 || burst_hi >= 0) {
-            if (i == m) {
+            if (i == mend) {
                 mode = F_IDLE;
             } else if (ev == FE_EMIT1 && res != -1) {
                 mode = rknown ? tnext : F_POS;         // SBWT.hh:560-

@@ -14,3 +14,6 @@ nr = ab.n_reads
 print({n: round(v / nr, 3) for n, v in zip(names, vals)})
 print("lane-iterations per read", round(tot / nr, 2), "wave-iterations", int(hdr[base + 10]), "lanes busy per iteration",
       round((tot - vals[9]) / max(1, int(hdr[base + 10])), 1))
+print("after the tickets ran out: wave-iterations", int(hdr[base + 11]), "(per wave %.1f)" % (int(hdr[base + 11]) / 5120), "idle lane-iterations",
+      int(hdr[base + 12]), "= %.2f per read" % (int(hdr[base + 12]) / nr))
+print("splits", int(hdr[base + 13]), "donor-capable lane-iterations in the tail", int(hdr[base + 14]))
