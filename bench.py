@@ -98,16 +98,24 @@ def gpu_reads(genomes, n_reads: int, seed: int, dev: torch.device) -> torch.Tens
     return out
 
 
+SEARCH_SOURCES = ("sbwt_search_fused.hip", "sbwt_search.hip", "sbwt_derived.hip", "sbwt_sort.hip", "sbwt_kernels_common.h",
+                  "sbwt_device.h", "sbwtgpu_capi.cpp")
+
+
 def kernel_source_sha16() -> str:
-    """Identifies the code a profile was taken on: sha256 of every source of libsbwtgpu (kernels, the derived
-    structures that decide their traffic, the C ABI with its defaults), first 16 hex digits."""
+    """Identifies the code a search profile was taken on: sha256 of the sources that decide the search kernels' traffic --
+    the kernels, the derived structures (path order, transition table, sparse table), the read sorting, and the C ABI with
+    its defaults (which kernel, which image) -- plus the tuning overrides in the environment; first 16 hex digits.  (The
+    builder, the rank / API kernels and the formatter do not take part in a search step.)"""
     import hashlib
     h = hashlib.sha256()
     d = os.path.join(ROOT, "sbwt_amd", "csrc")
-    for f in sorted(os.listdir(d)):
-        if f.endswith((".hip", ".h", ".cpp")):
-            h.update(f.encode())
-            h.update(open(os.path.join(d, f), "rb").read())
+    for f in SEARCH_SOURCES:
+        h.update(f.encode())
+        h.update(open(os.path.join(d, f), "rb").read())
+    for key in sorted(os.environ):
+        if key.startswith("SBWTGPU_") and key != "SBWTGPU_LIB":
+            h.update(("%s=%s" % (key, os.environ[key])).encode())
     return h.hexdigest()[:16]
 
 

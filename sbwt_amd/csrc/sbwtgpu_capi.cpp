@@ -240,7 +240,12 @@ int sbwtgpu_index_create(const sbwtgpu_index_desc *d, int device, sbwtgpu_index 
     int64_t p_file = d->precalc_k;
     const int level = t_image_level >= 0 ? t_image_level : (g_image_level < 0 ? 0 : g_image_level > 2 ? 2 : g_image_level);
     const bool t_minimal_image = level >= 2;
+    DevBuf d_bits, d_bscr;                             // the uploaded bit vectors and the block builder's scratch (below)
     auto retry_next_level = [&]() {
+        // (this frame's device buffers first: the retry uploads its own, and holding both could push a level that fits down
+        // another level)
+        if (d_bits.p) { (void)hipFree(d_bits.p); d_bits.p = nullptr; }
+        if (d_bscr.p) { (void)hipFree(d_bscr.p); d_bscr.p = nullptr; }
         t_image_level = level + 1;
         const int rc2 = sbwtgpu_index_create(d, device, out);
         t_image_level = -1;
@@ -326,7 +331,6 @@ int sbwtgpu_index_create(const sbwtgpu_index_desc *d, int device, sbwtgpu_index 
     // The bit vectors go to the device once; counting, the per-block prefix counts and the interleaving all happen
     // there (sbwt_build.hip) -- 142 M columns took seconds in host loops.
     const uint64_t *cols[4] = {d->A_bits, d->C_bits, d->G_bits, d->T_bits};
-    DevBuf d_bits, d_bscr;
     {
         hipError_t eb = d_bits.alloc((size_t)(5 * nw) * 8);
         if (eb == hipSuccess) eb = d_bscr.alloc((size_t)sbwt_blocks_scratch_bytes(n));
@@ -400,7 +404,9 @@ int sbwtgpu_index_create(const sbwtgpu_index_desc *d, int device, sbwtgpu_index 
     }
     h.image_level = (h.has_path ? 0 : h.p_sparse > 0 ? 1 : 2);
     if (g_max_image_bytes > 0 && h.blob_bytes > g_max_image_bytes) {
-        if (level < 2 && (h.has_path || h.p_sparse > 0)) {          // the derived structures are optional
+        // the derived structures are optional, and at level 2 the dense table shrinks until the image fits: an index without
+        // path order or sparse table (k <= 16, or both switched off) still has that last resort
+        if (level < 2) {
             delete idx;
             return retry_next_level();
         }

@@ -1,5 +1,5 @@
 """Adds one workload's entry to profiles/traffic.json from a tools/profile.sh summary: HBM-side bytes per k_search
-launch from the PMC counters FETCH_SIZE and WRITE_SIZE (separate rocprofv3 passes, kernel-trace only).
+launch (k_search_fused where the fused route ran) from the PMC counters FETCH_SIZE and WRITE_SIZE (separate rocprofv3 passes, kernel-trace only).
 
 Correction (MI355X_MICROARCH.md, HBM section; re-measured here): FETCH_SIZE = TCC_EA0_RDREQ x 64 B, but on gfx950 every
 L2 read miss is a 128-byte fabric request -- TCC_EA0_RDREQ_128B equals TCC_EA0_RDREQ for this kernel (gpurun pmc_reqsize)
@@ -12,9 +12,12 @@ sys.path.insert(0, ROOT)
 import bench
 summary, config, reads = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
 tag = sys.argv[4] if len(sys.argv) > 4 else os.path.basename(summary)
+# the dominant kernel of the run: the fused kernel when it appears in the summary, else the general search kernel
+text = open(summary).read()
+KERNEL = r"k_search_fused" if "k_search_fused" in text else r"void k_search\S*"
 vals = {}
 for line in open(summary):
-    m = re.match(r"void k_search\S*.*\s(FETCH_SIZE|WRITE_SIZE|TCC_EA0_RDREQ_sum|TCC_EA0_WRREQ_sum|TCC_HIT_sum|TCC_MISS_sum|SQ_INSTS_VALU|SQ_INSTS_SALU)\s+n=\s*\d+ avg=([0-9.e+]+)", line)
+    m = re.match(KERNEL + r".*\s(FETCH_SIZE|WRITE_SIZE|TCC_EA0_RDREQ_sum|TCC_EA0_WRREQ_sum|TCC_HIT_sum|TCC_MISS_sum|SQ_INSTS_VALU|SQ_INSTS_SALU)\s+n=\s*\d+ avg=([0-9.e+]+)", line)
     if m:
         vals[m.group(1)] = float(m.group(2))
 path = os.path.join(ROOT, "profiles", "traffic.json")

@@ -17,7 +17,7 @@ for f in find("trace/**/*kernel_trace.csv"):
         print(f"{name[:90]:90s} n={len(v):4d} total={sum(v):10.3f} avg={sum(v)/len(v):9.4f} min={min(v):9.4f} max={max(v):9.4f}")
     rows = list(csv.DictReader(open(f)))
     if rows:
-        r = [x for x in rows if "k_search" in x.get("Kernel_Name", "")]
+        r = [x for x in rows if "k_search_fused" in x.get("Kernel_Name", "")] or [x for x in rows if "k_search" in x.get("Kernel_Name", "")]
         if r:
             x = r[-1]
             print("k_search resources:", {k: x[k] for k in x if k in ("VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Scratch_Size", "Workgroup_Size", "Grid_Size")})
