@@ -357,8 +357,8 @@ def main() -> int:
     bits = None
     if rank == 0:
         # columns: on the GPU for k <= 32 (sbwtgpu_build_plain_matrix), host sort-based builder beyond
-        columns_on = "gpu" if K <= 32 else "host"
-        if K <= 32:
+        columns_on = "gpu" if K <= 64 else "host"
+        if K <= 64:
             try:
                 bits = capi.build_bits_gpu([g.tobytes() for g in genomes], K, False, streaming, device=local_rank)
             except capi.SbwtGpuError as ex:

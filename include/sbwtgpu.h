@@ -139,7 +139,7 @@ int  sbwtgpu_index_get_precalc(const sbwtgpu_index *idx, int64_t *out_pairs);
  * (build_nodeboss_in_memory, include/sbwt/NodeBOSSInMemoryConstructor.hh:98-213; the KMC-based SBWT(config) ctor,
  * SBWT.hh:300-332, gives the same bits): the four rows A, C, G, T and suffix_group_starts as sdsl-ordered words.
  * k-mers with anything but upper-case ACGT are skipped (:156-159); add_revcomp adds every reverse complement
- * (src/CLI/sbwt_build.cpp:108-123).  2 <= k <= 32 (a k-mer is packed into 64 bits); for longer k the C++ host
+ * (src/CLI/sbwt_build.cpp:108-123).  2 <= k <= 64 (a k-mer is packed into 64 or 128 bits); for longer k the C++ host
  * mirror (sbwt::build_plain_matrix_bits) builds on the CPU.  Release with sbwtgpu_free_plain_matrix(). */
 typedef struct {
     int64_t   n_nodes, n_kmers, k;

@@ -183,7 +183,7 @@ class BuiltBits:
 
 def build_bits_gpu(seqs: Sequence[bytes], k: int, add_revcomp: bool = False, streaming_support: bool = True,
                    device: int = 0) -> BuiltBits:
-    """sbwtgpu_build_plain_matrix: the plain-matrix SBWT columns of `seqs`, built on the GPU (2 <= k <= 32)."""
+    """sbwtgpu_build_plain_matrix: the plain-matrix SBWT columns of `seqs`, built on the GPU (2 <= k <= 64)."""
     arr = (C.c_char_p * len(seqs))(*[bytes(s) for s in seqs])
     lens = np.array([len(s) for s in seqs], dtype=np.int64)
     out = PlainMatrixBitsC()

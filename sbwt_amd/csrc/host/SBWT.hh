@@ -45,12 +45,12 @@ struct DeviceIndex {
 // Selects the HIP device new indexes are placed on (default 0).
 inline void set_default_device(int device) { detail::default_device() = device; }
 
-// The plain-matrix columns of a set of sequences: on the GPU for k <= 32 (sbwtgpu_build_plain_matrix: radix sort of the
+// The plain-matrix columns of a set of sequences: on the GPU for k <= 64 (sbwtgpu_build_plain_matrix: radix sort of the
 // packed k-mers and searches in the sorted array), with the multi-threaded host builder (index_builder.hh) for longer
 // k-mers.  Both give the reference constructors' bits (NodeBOSSInMemoryConstructor.hh:98-213).
 inline PlainMatrixBits build_plain_matrix_bits_any(const std::vector<std::string> &seqs, int k, bool add_revcomp,
                                                    bool build_streaming_support, int n_threads) {
-    if (k < 2 || k > 32) return build_plain_matrix_bits(seqs, k, add_revcomp, build_streaming_support, n_threads);
+    if (k < 2 || k > 64) return build_plain_matrix_bits(seqs, k, add_revcomp, build_streaming_support, n_threads);
     std::vector<const char *> ptr(seqs.size());
     std::vector<int64_t> len(seqs.size());
     for (size_t i = 0; i < seqs.size(); i++) { ptr[i] = seqs[i].data(); len[i] = (int64_t)seqs[i].size(); }

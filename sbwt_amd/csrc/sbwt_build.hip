@@ -2,7 +2,7 @@
 //   (1) the interleaved 64-column blocks of the device image from the four bit vectors (+ suffix_group_starts):
 //       what SubsetMatrixRank's constructor does with sdsl::util::init_support (SubsetMatrixRank.hh:52-58) and
 //       SBWT's constructor with the C array (SBWT.hh:344-349), for this layout;
-//   (2) the plain-matrix SBWT columns themselves from sequences, k <= 32: every k-mer packed so that integer order is
+//   (2) the plain-matrix SBWT columns themselves from sequences, k <= 64: every k-mer packed so that integer order is
 //       the colexicographic order (Kmer.hh:108-123), radix sort (rocPRIM), predecessors / edges / suffix groups by
 //       searches in the sorted array, dummy prefixes of the predecessor-less k-mers, merged emission of the columns --
 //       the node and edge rules of NodeBOSSInMemoryConstructor.hh:98-213 (edges only on suffix-group starts; k-mers
@@ -98,12 +98,18 @@ void sbwt_blocks_fill(const unsigned long long *d_bits, const unsigned long long
 }
 
 // ---------------------------------------------------------------------------------------------
-// (2) plain-matrix SBWT columns from sequences, k <= 32
+// (2) plain-matrix SBWT columns from sequences, k <= 64
 // ---------------------------------------------------------------------------------------------
 // packed text: the k_encode format (sbwt_search.hip): group = { codes lo, codes hi, validU, validRaw }, 32 bases per
 // 16 bytes; validRaw = upper-case ACGT, which is what the reference's constructors accept
 // (NodeBOSSInMemoryConstructor.hh:156-159).  Sequences are separated by one non-ACGT byte by the caller, so a k-mer
 // window that crosses a boundary is invalid like one that holds an N.
+// Keys: char i of the k-mer at bits 2i, so that integer order = colexicographic order (Kmer.hh:108-123); one 64-bit
+// word for k <= 32, __uint128_t for 32 < k <= 64 (the kernels are templates on the key type; rocPRIM sorts both).
+typedef __uint128_t u128;
+template <typename KT> __host__ __device__ __forceinline__ KT key_mask(int bits) {       // bits in [0, 8 * sizeof(KT)]
+    return bits >= (int)(8 * sizeof(KT)) ? ~(KT)0 : (((KT)1 << bits) - (KT)1);
+}
 __device__ __forceinline__ u64 rev2(u64 x) {               // reverses the order of the 32 two-bit groups
     x = ((x >> 2) & 0x3333333333333333ull) | ((x & 0x3333333333333333ull) << 2);
     x = ((x >> 4) & 0x0F0F0F0F0F0F0F0Full) | ((x & 0x0F0F0F0F0F0F0F0Full) << 4);
@@ -111,22 +117,40 @@ __device__ __forceinline__ u64 rev2(u64 x) {               // reverses the order
     x = ((x >> 16) & 0x0000FFFF0000FFFFull) | ((x & 0x0000FFFF0000FFFFull) << 16);
     return (x >> 32) | (x << 32);
 }
-// every valid k-mer start p -> key (char i of the k-mer at bits 2i: integer order = colex order); with rc also the
-// reverse complement's key.  Output slots from a wave-aggregated counter (the order does not matter: they get sorted).
+__device__ __forceinline__ u64 revcomp_key(u64 key, int k) { return (~rev2(key)) >> (64 - 2 * k); }   // complement = 3 - code
+__device__ __forceinline__ u128 revcomp_key(u128 key, int k) {
+    const u128 r = ((u128)rev2((u64)key) << 64) | (u128)rev2((u64)(key >> 64));
+    return (~r) >> (128 - 2 * k);
+}
+// every valid k-mer start p -> key; with rc also the reverse complement's key.  Output slots from a wave-aggregated
+// counter (the order does not matter: they get sorted).
+template <typename KT>
 __global__ void __launch_bounds__(256) k_bld_extract(const uint4 *__restrict__ packed, i64 n_pos, int k, int rc,
-                                                     u64 *__restrict__ keys, unsigned long long *__restrict__ counter) {
+                                                     KT *__restrict__ keys, unsigned long long *__restrict__ counter) {
     const i64 p = (i64)blockIdx.x * 256 + threadIdx.x;
     bool ok = false;
-    u64 key = 0;
+    KT key = 0;
     if (p < n_pos) {
         const uint4 g0 = packed[p >> 5], g1 = packed[(p >> 5) + 1];
         const int s = (int)(p & 31);
-        u64 w = quad_bits(g0) >> (2 * s);
-        if (s) w |= quad_bits(g1) << (64 - 2 * s);
-        const u64 vr = (((u64)g1.w << 32) | (u64)g0.w) >> s;
-        const u64 vm = (k >= 64) ? ~0ull : low_mask(k);
-        ok = (vr & vm) == vm;
-        key = (k == 32) ? w : (w & low_mask(2 * k));
+        if (sizeof(KT) == 8) {
+            u64 w = quad_bits(g0) >> (2 * s);
+            if (s) w |= quad_bits(g1) << (64 - 2 * s);
+            const u64 vr = (((u64)g1.w << 32) | (u64)g0.w) >> s;
+            const u64 vm = low_mask(k >= 64 ? 63 : k) | (k >= 64 ? (1ull << 63) : 0ull);
+            ok = (vr & vm) == vm;
+            key = (KT)((k == 32) ? w : (w & low_mask(2 * k)));
+        } else {
+            const uint4 g2 = packed[(p >> 5) + 2];          // (the text is padded: three groups from any position)
+            const u128 lo = (u128)quad_bits(g0) | ((u128)quad_bits(g1) << 64);
+            u128 w = lo >> (2 * s);
+            if (s) w |= (u128)quad_bits(g2) << (128 - 2 * s);
+            const u128 va = (u128)g0.w | ((u128)g1.w << 32) | ((u128)g2.w << 64);
+            const u128 vr = va >> s;
+            const u128 vm = key_mask<u128>(k);
+            ok = (vr & vm) == vm;
+            key = (KT)(w & key_mask<u128>(2 * k));
+        }
     }
     const u64 m = __ballot(ok);
     if (m == 0) return;
@@ -137,42 +161,47 @@ __global__ void __launch_bounds__(256) k_bld_extract(const uint4 *__restrict__ p
     if (ok) {
         const i64 at = (i64)base + (i64)__popcll(m & low_mask(lane)) * per;
         keys[at] = key;
-        if (rc) keys[at + 1] = (~rev2(key)) >> (64 - 2 * k);      // complement = 3 - code, order reversed
+        if (rc) keys[at + 1] = revcomp_key(key, k);
     }
 }
 // flag[i] = first of its run of equal values (shifted right by `shift`: 0 = distinct k-mers, 2 = suffix groups)
-__global__ void __launch_bounds__(256) k_bld_flag_first(const u64 *__restrict__ v, i64 n, int shift, i64 *__restrict__ flag) {
+template <typename KT>
+__global__ void __launch_bounds__(256) k_bld_flag_first(const KT *__restrict__ v, i64 n, int shift, i64 *__restrict__ flag) {
     const i64 i = (i64)blockIdx.x * 256 + threadIdx.x;
     if (i < n) flag[i] = (i == 0 || (v[i] >> shift) != (v[i - 1] >> shift)) ? 1 : 0;
 }
-__global__ void __launch_bounds__(256) k_bld_compact(const u64 *__restrict__ v, const i64 *__restrict__ flag,
-                                                     const i64 *__restrict__ pos, i64 n, u64 *__restrict__ out) {
+template <typename KT>
+__global__ void __launch_bounds__(256) k_bld_compact(const KT *__restrict__ v, const i64 *__restrict__ flag,
+                                                     const i64 *__restrict__ pos, i64 n, KT *__restrict__ out) {
     const i64 i = (i64)blockIdx.x * 256 + threadIdx.x;
     if (i < n && flag[i]) out[pos[i]] = v[i];
 }
 // group starts: gstart[g] = index of the first k-mer of suffix group g, gsuf[g] = its (k-1)-suffix
-__global__ void __launch_bounds__(256) k_bld_groups(const u64 *__restrict__ km, const i64 *__restrict__ flag,
+template <typename KT>
+__global__ void __launch_bounds__(256) k_bld_groups(const KT *__restrict__ km, const i64 *__restrict__ flag,
                                                     const i64 *__restrict__ pos, i64 n, i64 *__restrict__ gstart,
-                                                    u64 *__restrict__ gsuf) {
+                                                    KT *__restrict__ gsuf) {
     const i64 i = (i64)blockIdx.x * 256 + threadIdx.x;
     if (i < n && flag[i]) { gstart[pos[i]] = i; gsuf[pos[i]] = km[i] >> 2; }
 }
-__device__ __forceinline__ i64 lower_bound_u64(const u64 *__restrict__ a, i64 n, u64 x) {   // first index with a[i] >= x
+template <typename KT>
+__device__ __forceinline__ i64 lower_bound_key(const KT *__restrict__ a, i64 n, KT x) {   // first index with a[i] >= x
     i64 lo = 0, hi = n;
     while (lo < hi) { const i64 mid = (lo + hi) >> 1; if (a[mid] < x) lo = mid + 1; else hi = mid; }
     return lo;
 }
 // predecessor join (NodeBOSSInMemoryConstructor.hh:113-147): k-mer z = y c has an edge from the suffix group of x iff x's
 // (k-1)-suffix equals z's (k-1)-prefix y; otherwise z has no predecessor (nopred[z] = 1)
-__global__ void __launch_bounds__(256) k_bld_pred(const u64 *__restrict__ km, i64 nk, int k, const i64 *__restrict__ gstart,
-                                                  const u64 *__restrict__ gsuf, i64 ng, unsigned *__restrict__ edges,
+template <typename KT>
+__global__ void __launch_bounds__(256) k_bld_pred(const KT *__restrict__ km, i64 nk, int k, const i64 *__restrict__ gstart,
+                                                  const KT *__restrict__ gsuf, i64 ng, unsigned *__restrict__ edges,
                                                   i64 *__restrict__ nopred) {
     const i64 z = (i64)blockIdx.x * 256 + threadIdx.x;
     if (z >= nk) return;
-    const u64 key = km[z];
-    const int c = (int)(key >> (2 * k - 2));
-    const u64 pre = (k > 1) ? (key & low_mask(2 * k - 2)) : 0;
-    const i64 g = lower_bound_u64(gsuf, ng, pre);
+    const KT key = km[z];
+    const int c = (int)(key >> (2 * k - 2)) & 3;
+    const KT pre = (k > 1) ? (key & key_mask<KT>(2 * k - 2)) : (KT)0;
+    const i64 g = lower_bound_key<KT>(gsuf, ng, pre);
     if (g < ng && gsuf[g] == pre) {
         atomicOr(&edges[gstart[g]], 1u << c);
         nopred[z] = 0;
@@ -189,23 +218,25 @@ __device__ __forceinline__ void put_column(u64 *__restrict__ rows, i64 nw, i64 c
         if (e & (1u << c)) atomicOr(reinterpret_cast<unsigned long long *>(rows + (i64)c * nw + (col >> 6)), (unsigned long long)bit);
     if (ssup && start) atomicOr(reinterpret_cast<unsigned long long *>(rows + 4 * nw + (col >> 6)), (unsigned long long)bit);
 }
-__global__ void __launch_bounds__(256) k_bld_emit_kmers(const u64 *__restrict__ km, i64 nk, const unsigned *__restrict__ edges,
-                                                        const u64 *__restrict__ ddata, i64 nd, u64 *__restrict__ rows, i64 nw,
+template <typename KT>
+__global__ void __launch_bounds__(256) k_bld_emit_kmers(const KT *__restrict__ km, i64 nk, const unsigned *__restrict__ edges,
+                                                        const KT *__restrict__ ddata, i64 nd, u64 *__restrict__ rows, i64 nw,
                                                         int ssup) {
     const i64 i = (i64)blockIdx.x * 256 + threadIdx.x;
     if (i >= nk) return;
-    const u64 key = km[i];
+    const KT key = km[i];
     i64 lo = 0, hi = nd;                                   // dummies with label <= key
     while (lo < hi) { const i64 mid = (lo + hi) >> 1; if (ddata[mid] <= key) lo = mid + 1; else hi = mid; }
     const bool start = (i == 0) || ((key >> 2) != (km[i - 1] >> 2));
     put_column(rows, nw, i + lo, edges[i], start, ssup);
 }
-__global__ void __launch_bounds__(256) k_bld_emit_dummies(const u64 *__restrict__ ddata, const unsigned *__restrict__ dedges,
-                                                          i64 nd, const u64 *__restrict__ km, i64 nk, u64 *__restrict__ rows,
+template <typename KT>
+__global__ void __launch_bounds__(256) k_bld_emit_dummies(const KT *__restrict__ ddata, const unsigned *__restrict__ dedges,
+                                                          i64 nd, const KT *__restrict__ km, i64 nk, u64 *__restrict__ rows,
                                                           i64 nw, int ssup) {
     const i64 d = (i64)blockIdx.x * 256 + threadIdx.x;
     if (d >= nd) return;
-    put_column(rows, nw, d + lower_bound_u64(km, nk, ddata[d]), dedges[d], true, ssup);   // a dummy is its own group
+    put_column(rows, nw, d + lower_bound_key<KT>(km, nk, ddata[d]), dedges[d], true, ssup);   // a dummy is its own group
 }
 
 static void scan_i64(const i64 *in, i64 n, i64 *out, i64 *bsum, hipStream_t st) {
@@ -220,14 +251,15 @@ static void scan_i64(const i64 *in, i64 n, i64 *out, i64 *bsum, hipStream_t st) 
 // the columns.  All device memory is owned by SbwtBuildState.
 #define BLD_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { err = e_; goto fail; } } while (0)
 
-int sbwt_build_phase_a(const char *h_text, long long n_text, int k, int rc, SbwtBuildState *S, hipStream_t st) {
+template <typename KT>
+static int build_phase_a(const char *h_text, long long n_text, int k, int rc, SbwtBuildState *S, hipStream_t st) {
     hipError_t err = hipSuccess;
     S->k = k; S->rc = rc; S->n_text = n_text;
-    const i64 n_groups = (n_text + 31) / 32 + 2;
+    const i64 n_groups = (n_text + 31) / 32 + 4;
     const i64 n_pos = n_text;                              // windows that run past the end meet zero validity bits
     const i64 cap = (rc ? 2 : 1) * n_text;
-    char *d_text = nullptr; uint4 *d_packed = nullptr; u64 *keys = nullptr, *keys2 = nullptr; unsigned long long *d_cnt = nullptr;
-    i64 *flag = nullptr, *pos = nullptr, *bsum = nullptr, *gstart = nullptr; u64 *gsuf = nullptr;
+    char *d_text = nullptr; uint4 *d_packed = nullptr; KT *keys = nullptr, *keys2 = nullptr; unsigned long long *d_cnt = nullptr;
+    i64 *flag = nullptr, *pos = nullptr, *bsum = nullptr, *gstart = nullptr; KT *gsuf = nullptr;
     void *tmp = nullptr; size_t tmp_bytes = 0;
     SbwtWorkHeader *ws = nullptr;
     unsigned long long h_cnt = 0;
@@ -238,16 +270,17 @@ int sbwt_build_phase_a(const char *h_text, long long n_text, int k, int rc, Sbwt
     BLD_TRY(hipMalloc((void **)&d_cnt, 8));
     BLD_TRY(hipMemcpyAsync(d_text, h_text, (size_t)n_text, hipMemcpyHostToDevice, st));
     BLD_TRY(hipMemsetAsync(d_cnt, 0, 8, st));
+    BLD_TRY(hipMemsetAsync(d_packed, 0, (size_t)n_groups * 16, st));     // (the groups past the text: no valid base)
     sbwt_launch_encode(d_text, n_text, d_packed, ws, st);
-    BLD_TRY(hipMalloc((void **)&keys, (size_t)(cap + 1) * 8));
-    hipLaunchKernelGGL(k_bld_extract, dim3(grid_for(n_pos)), dim3(256), 0, st, d_packed, n_pos, k, rc, keys, d_cnt);
+    BLD_TRY(hipMalloc((void **)&keys, (size_t)(cap + 1) * sizeof(KT)));
+    hipLaunchKernelGGL(k_bld_extract<KT>, dim3(grid_for(n_pos)), dim3(256), 0, st, d_packed, n_pos, k, rc, keys, d_cnt);
     BLD_TRY(hipMemcpyAsync(&h_cnt, d_cnt, 8, hipMemcpyDeviceToHost, st));
     BLD_TRY(hipStreamSynchronize(st));
     (void)hipFree(d_text); d_text = nullptr;
     (void)hipFree(d_packed); d_packed = nullptr;
     nv = (i64)h_cnt;
     if (nv > 0) {
-        BLD_TRY(hipMalloc((void **)&keys2, (size_t)nv * 8));
+        BLD_TRY(hipMalloc((void **)&keys2, (size_t)nv * sizeof(KT)));
         BLD_TRY(rocprim::radix_sort_keys(nullptr, tmp_bytes, keys, keys2, (size_t)nv, 0, 2 * k, st));
         BLD_TRY(hipMalloc(&tmp, tmp_bytes + 16));
         BLD_TRY(rocprim::radix_sort_keys(tmp, tmp_bytes, keys, keys2, (size_t)nv, 0, 2 * k, st));
@@ -258,32 +291,36 @@ int sbwt_build_phase_a(const char *h_text, long long n_text, int k, int rc, Sbwt
         BLD_TRY(hipMalloc((void **)&flag, (size_t)(nv + 1) * 8));
         BLD_TRY(hipMalloc((void **)&pos, (size_t)(nv + 2) * 8));
         BLD_TRY(hipMalloc((void **)&bsum, (size_t)((nv + 1023) / 1024 + 2) * 8));
-        hipLaunchKernelGGL(k_bld_flag_first, dim3(grid_for(nv)), dim3(256), 0, st, keys2, nv, 0, flag);
+        hipLaunchKernelGGL(k_bld_flag_first<KT>, dim3(grid_for(nv)), dim3(256), 0, st, keys2, nv, 0, flag);
         scan_i64(flag, nv, pos, bsum, st);
         BLD_TRY(hipMemcpyAsync(&nk, pos + nv, 8, hipMemcpyDeviceToHost, st));
         BLD_TRY(hipStreamSynchronize(st));
-        BLD_TRY(hipMalloc((void **)&S->km, (size_t)nk * 8));
-        hipLaunchKernelGGL(k_bld_compact, dim3(grid_for(nv)), dim3(256), 0, st, keys2, flag, pos, nv, S->km);
+        KT *km = nullptr;
+        BLD_TRY(hipMalloc((void **)&km, (size_t)nk * sizeof(KT)));
+        S->km = km;
+        hipLaunchKernelGGL(k_bld_compact<KT>, dim3(grid_for(nv)), dim3(256), 0, st, keys2, flag, pos, nv, km);
         BLD_TRY(hipStreamSynchronize(st));
         (void)hipFree(keys2); keys2 = nullptr;
         // suffix groups
-        hipLaunchKernelGGL(k_bld_flag_first, dim3(grid_for(nk)), dim3(256), 0, st, S->km, nk, 2, flag);
+        hipLaunchKernelGGL(k_bld_flag_first<KT>, dim3(grid_for(nk)), dim3(256), 0, st, km, nk, 2, flag);
         scan_i64(flag, nk, pos, bsum, st);
         BLD_TRY(hipMemcpyAsync(&ng, pos + nk, 8, hipMemcpyDeviceToHost, st));
         BLD_TRY(hipStreamSynchronize(st));
         BLD_TRY(hipMalloc((void **)&gstart, (size_t)ng * 8));
-        BLD_TRY(hipMalloc((void **)&gsuf, (size_t)ng * 8));
-        hipLaunchKernelGGL(k_bld_groups, dim3(grid_for(nk)), dim3(256), 0, st, S->km, flag, pos, nk, gstart, gsuf);
+        BLD_TRY(hipMalloc((void **)&gsuf, (size_t)ng * sizeof(KT)));
+        hipLaunchKernelGGL(k_bld_groups<KT>, dim3(grid_for(nk)), dim3(256), 0, st, km, flag, pos, nk, gstart, gsuf);
         // predecessors and edges
         BLD_TRY(hipMalloc((void **)&S->edges, (size_t)nk * 4));
         BLD_TRY(hipMemsetAsync(S->edges, 0, (size_t)nk * 4, st));
-        hipLaunchKernelGGL(k_bld_pred, dim3(grid_for(nk)), dim3(256), 0, st, S->km, nk, k, gstart, gsuf, ng, S->edges, flag);
+        hipLaunchKernelGGL(k_bld_pred<KT>, dim3(grid_for(nk)), dim3(256), 0, st, km, nk, k, gstart, gsuf, ng, S->edges, flag);
         scan_i64(flag, nk, pos, bsum, st);
         BLD_TRY(hipMemcpyAsync(&nn, pos + nk, 8, hipMemcpyDeviceToHost, st));
         BLD_TRY(hipStreamSynchronize(st));
         if (nn > 0) {
-            BLD_TRY(hipMalloc((void **)&S->nopred_keys, (size_t)nn * 8));
-            hipLaunchKernelGGL(k_bld_compact, dim3(grid_for(nk)), dim3(256), 0, st, S->km, flag, pos, nk, S->nopred_keys);
+            KT *np = nullptr;
+            BLD_TRY(hipMalloc((void **)&np, (size_t)nn * sizeof(KT)));
+            S->nopred_keys = np;
+            hipLaunchKernelGGL(k_bld_compact<KT>, dim3(grid_for(nk)), dim3(256), 0, st, km, flag, pos, nk, np);
         }
         BLD_TRY(hipStreamSynchronize(st));
     }
@@ -294,35 +331,46 @@ fail:
     if (err != hipSuccess) { (void)hipGetLastError(); return err == hipErrorOutOfMemory ? -8 : -3; }
     return 0;
 }
+int sbwt_build_phase_a(const char *h_text, long long n_text, int k, int rc, SbwtBuildState *S, hipStream_t st) {
+    S->key_bytes = k <= 32 ? 8 : 16;
+    return k <= 32 ? build_phase_a<u64>(h_text, n_text, k, rc, S, st) : build_phase_a<u128>(h_text, n_text, k, rc, S, st);
+}
 
-int sbwt_build_copy_nopred(const SbwtBuildState *S, unsigned long long *h_keys) {
+int sbwt_build_copy_nopred(const SbwtBuildState *S, void *h_keys) {
     if (S->n_nopred == 0) return 0;
-    return hipMemcpy(h_keys, S->nopred_keys, (size_t)S->n_nopred * 8, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -3;
+    return hipMemcpy(h_keys, S->nopred_keys, (size_t)S->n_nopred * (size_t)S->key_bytes, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -3;
 }
 
 // Phase B: dummies (sorted by (label, length), edges merged; label top-aligned in 2k bits) + k-mers -> the five rows
 // (A, C, G, T, suffix_group_starts; nw words each) in host memory.
-int sbwt_build_phase_b(SbwtBuildState *S, const unsigned long long *h_ddata, const unsigned *h_dedges, long long nd, int ssup,
-                       unsigned long long *h_rows, hipStream_t st) {
+template <typename KT>
+static int build_phase_b(SbwtBuildState *S, const void *h_ddata, const unsigned *h_dedges, long long nd, int ssup,
+                         unsigned long long *h_rows, hipStream_t st) {
     hipError_t err = hipSuccess;
     const i64 n = S->nk + nd, nw = (n + 63) / 64;
-    u64 *ddata = nullptr, *rows = nullptr; unsigned *dedges = nullptr;
-    BLD_TRY(hipMalloc((void **)&ddata, (size_t)(nd + 1) * 8));
+    KT *ddata = nullptr; u64 *rows = nullptr; unsigned *dedges = nullptr;
+    const KT *km = static_cast<const KT *>(S->km);
+    BLD_TRY(hipMalloc((void **)&ddata, (size_t)(nd + 1) * sizeof(KT)));
     BLD_TRY(hipMalloc((void **)&dedges, (size_t)(nd + 1) * 4));
     BLD_TRY(hipMalloc((void **)&rows, (size_t)(5 * nw + 1) * 8));
-    BLD_TRY(hipMemcpyAsync(ddata, h_ddata, (size_t)nd * 8, hipMemcpyHostToDevice, st));
+    BLD_TRY(hipMemcpyAsync(ddata, h_ddata, (size_t)nd * sizeof(KT), hipMemcpyHostToDevice, st));
     BLD_TRY(hipMemcpyAsync(dedges, h_dedges, (size_t)nd * 4, hipMemcpyHostToDevice, st));
     BLD_TRY(hipMemsetAsync(rows, 0, (size_t)(5 * nw) * 8, st));
     if (S->nk > 0)
-        hipLaunchKernelGGL(k_bld_emit_kmers, dim3(grid_for(S->nk)), dim3(256), 0, st, S->km, S->nk, S->edges, ddata, (i64)nd, rows,
+        hipLaunchKernelGGL(k_bld_emit_kmers<KT>, dim3(grid_for(S->nk)), dim3(256), 0, st, km, S->nk, S->edges, ddata, (i64)nd, rows,
                            nw, ssup);
-    hipLaunchKernelGGL(k_bld_emit_dummies, dim3(grid_for(nd)), dim3(256), 0, st, ddata, dedges, (i64)nd, S->km, S->nk, rows, nw, ssup);
+    hipLaunchKernelGGL(k_bld_emit_dummies<KT>, dim3(grid_for(nd)), dim3(256), 0, st, ddata, dedges, (i64)nd, km, S->nk, rows, nw, ssup);
     BLD_TRY(hipMemcpyAsync(h_rows, rows, (size_t)(5 * nw) * 8, hipMemcpyDeviceToHost, st));
     BLD_TRY(hipStreamSynchronize(st));
 fail:
     (void)hipFree(ddata); (void)hipFree(dedges); (void)hipFree(rows);
     if (err != hipSuccess) { (void)hipGetLastError(); return err == hipErrorOutOfMemory ? -8 : -3; }
     return 0;
+}
+int sbwt_build_phase_b(SbwtBuildState *S, const void *h_ddata, const unsigned *h_dedges, long long nd, int ssup,
+                       unsigned long long *h_rows, hipStream_t st) {
+    return S->key_bytes == 8 ? build_phase_b<u64>(S, h_ddata, h_dedges, nd, ssup, h_rows, st)
+                             : build_phase_b<u128>(S, h_ddata, h_dedges, nd, ssup, h_rows, st);
 }
 
 void sbwt_build_release(SbwtBuildState *S) {

@@ -207,13 +207,14 @@ int sbwt_launch_build_sparse(const SbwtIndexView &ix, int p_dense, int p_sparse,
 // dummies + k-mers -> the five rows in host memory
 struct SbwtBuildState {
     int k = 0, rc = 0, ssup = 0;
+    int key_bytes = 8;                           // 8: k <= 32 (one 64-bit word per k-mer), 16: 32 < k <= 64 (__uint128_t)
     long long n_text = 0, nk = 0, ng = 0, n_nopred = 0;
-    unsigned long long *km = nullptr;            // sorted distinct k-mers
+    void *km = nullptr;                          // sorted distinct k-mers (key_bytes each)
     unsigned *edges = nullptr;                   // per k-mer (set on suffix-group starts)
-    unsigned long long *nopred_keys = nullptr;   // the k-mers without a predecessor
+    void *nopred_keys = nullptr;                 // the k-mers without a predecessor
 };
 int sbwt_build_phase_a(const char *h_text, long long n_text, int k, int rc, SbwtBuildState *S, hipStream_t st);
-int sbwt_build_copy_nopred(const SbwtBuildState *S, unsigned long long *h_keys);
-int sbwt_build_phase_b(SbwtBuildState *S, const unsigned long long *h_ddata, const unsigned *h_dedges, long long nd, int ssup,
+int sbwt_build_copy_nopred(const SbwtBuildState *S, void *h_keys);
+int sbwt_build_phase_b(SbwtBuildState *S, const void *h_ddata, const unsigned *h_dedges, long long nd, int ssup,
                        unsigned long long *h_rows, hipStream_t st);
 void sbwt_build_release(SbwtBuildState *S);

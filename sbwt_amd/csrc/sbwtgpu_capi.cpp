@@ -1629,12 +1629,67 @@ int sbwtgpu_select_batch(const sbwtgpu_index *idx, const int64_t *j, const char 
 }
 
 // ---- construction on the device ---------------------------------------------------
+}  // extern "C"
+namespace {
+// The host part between the builder's two device phases: the dummy prefixes of the predecessor-less k-mers
+// (NodeBOSSInMemoryConstructor.hh:70-79) + the root, sorted like Kmer::operator< (label, then length), equal nodes merged.
+// KT = the key type of the device builder: uint64_t for k <= 32, unsigned __int128 for 32 < k <= 64.
+template <typename KT>
+int build_columns_t(SbwtBuildState &S, int64_t k, int build_streaming_support, sbwtgpu_plain_matrix_bits *out) {
+    std::vector<KT> nopred, ddata;
+    std::vector<unsigned long long> rows;
+    std::vector<unsigned> dedges;
+    nopred.resize((size_t)S.n_nopred);
+    if (sbwt_build_copy_nopred(&S, nopred.data()) != 0) { sbwt_build_release(&S); return fail(SBWTGPU_ERR_HIP, "device builder: copy"); }
+    struct Dm { KT data; unsigned len, edges; };
+    std::vector<Dm> dm;
+    dm.reserve((size_t)S.n_nopred * (size_t)k + 1);
+    dm.push_back(Dm{(KT)0, 0, 0});
+    const int kbits = 2 * (int)k;
+    for (KT zk : nopred)
+        for (int j = 0; j < (int)k; j++) {
+            KT label = (j == 0) ? (KT)0 : (KT)((zk & ((((KT)1) << (2 * j)) - (KT)1)) << (kbits - 2 * j));
+            dm.push_back(Dm{label, (unsigned)j, 1u << (unsigned)((unsigned)(zk >> (2 * j)) & 3u)});
+        }
+    std::sort(dm.begin(), dm.end(), [](const Dm &a, const Dm &b) { return a.data != b.data ? a.data < b.data : a.len < b.len; });
+    size_t wd = 0;
+    for (size_t i = 0; i < dm.size(); i++) {
+        if (wd > 0 && dm[wd - 1].data == dm[i].data && dm[wd - 1].len == dm[i].len) dm[wd - 1].edges |= dm[i].edges;
+        else dm[wd++] = dm[i];
+    }
+    dm.resize(wd);
+    ddata.resize(wd);
+    dedges.resize(wd);
+    for (size_t i = 0; i < wd; i++) { ddata[i] = dm[i].data; dedges[i] = dm[i].edges; }
+    const int64_t n = S.nk + (int64_t)wd, nw = (n + 63) / 64;
+    rows.resize((size_t)(5 * nw));
+    int rb = sbwt_build_phase_b(&S, ddata.data(), dedges.data(), (long long)wd, build_streaming_support ? 1 : 0, rows.data(), 0);
+    const int64_t nk = S.nk;
+    sbwt_build_release(&S);
+    if (rb != 0) return fail(rb == -8 ? SBWTGPU_ERR_OOM : SBWTGPU_ERR_HIP, "device builder, phase B");
+    uint64_t *mem = static_cast<uint64_t *>(malloc((size_t)(5 * nw) * 8 + 8));
+    if (!mem) return fail(SBWTGPU_ERR_OOM, "out of host memory");
+    memcpy(mem, rows.data(), (size_t)(5 * nw) * 8);
+    out->n_nodes = n;
+    out->n_kmers = nk;
+    out->k = k;
+    out->A_bits = mem;
+    out->C_bits = mem + nw;
+    out->G_bits = mem + 2 * nw;
+    out->T_bits = mem + 3 * nw;
+    out->suffix_group_starts = build_streaming_support ? mem + 4 * nw : nullptr;
+    return SBWTGPU_OK;
+}
+}  // namespace
+extern "C" {
+
 int sbwtgpu_build_plain_matrix(const char *const *seqs, const int64_t *seq_len, int64_t n_seqs, int64_t k, int add_revcomp,
                                int build_streaming_support, int device, sbwtgpu_plain_matrix_bits *out) {
     if (!out) return fail(SBWTGPU_ERR_INVALID_ARG, "out is NULL");
     memset(out, 0, sizeof(*out));
     if (n_seqs < 0 || (n_seqs > 0 && (!seqs || !seq_len))) return fail(SBWTGPU_ERR_INVALID_ARG, "bad sequence list");
-    if (k < 2 || k > 32) return fail(SBWTGPU_ERR_INVALID_ARG, "the device builder packs a k-mer into 64 bits: 2 <= k <= 32");
+    if (k < 2 || k > 64)
+        return fail(SBWTGPU_ERR_INVALID_ARG, "the device builder packs a k-mer into 64 or 128 bits: 2 <= k <= 64");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(SBWTGPU_ERR_NO_DEVICE, "no HIP device");
     if (device < 0 || device >= ndev) return fail(SBWTGPU_ERR_NO_DEVICE, "device %d out of range", device);
@@ -1647,8 +1702,6 @@ int sbwtgpu_build_plain_matrix(const char *const *seqs, const int64_t *seq_len, 
         n_text += seq_len[i] + 1;
     }
     std::vector<char> text;
-    std::vector<unsigned long long> nopred, ddata, rows;
-    std::vector<unsigned> dedges;
     SbwtBuildState S;
     int rc = SBWTGPU_OK;
     try {
@@ -1662,55 +1715,17 @@ int sbwtgpu_build_plain_matrix(const char *const *seqs, const int64_t *seq_len, 
         int ra = sbwt_build_phase_a(text.data(), n_text, (int)k, add_revcomp ? 1 : 0, &S, 0);
         if (ra != 0) { sbwt_build_release(&S); return fail(ra == -8 ? SBWTGPU_ERR_OOM : SBWTGPU_ERR_HIP, "device builder, phase A"); }
         std::vector<char>().swap(text);
-        // the dummy prefixes are expanded on the host, k per predecessor-less k-mer at 16 bytes each: about one k-mer per
-        // input SEQUENCE, so a genome has a handful and a read set has millions.  Past 2^26 records (1 GiB) the caller's
-        // host builder (index_builder.hh) is the better tool: report it as "does not fit".
+        // the dummy prefixes are expanded on the host, k per predecessor-less k-mer at 16-32 bytes each: about one k-mer per
+        // input SEQUENCE, so a genome has a handful and a read set has millions.  Past 2^26 records the caller's host
+        // builder (index_builder.hh) is the better tool: report it as "does not fit".
         if ((long long)S.n_nopred * (long long)k > (1ll << 26)) {
             sbwt_build_release(&S);
             return fail(SBWTGPU_ERR_OOM, "device builder: %lld predecessor-less k-mers x k = %lld dummy records (limit 2^26): "
                         "use the host builder for inputs with this many sequences", (long long)S.n_nopred,
                         (long long)S.n_nopred * (long long)k);
         }
-        nopred.resize((size_t)S.n_nopred);
-        if (sbwt_build_copy_nopred(&S, nopred.data()) != 0) { sbwt_build_release(&S); return fail(SBWTGPU_ERR_HIP, "device builder: copy"); }
-        // dummy prefixes of the predecessor-less k-mers (NodeBOSSInMemoryConstructor.hh:70-79) + the root, sorted like
-        // Kmer::operator< (label, then length), equal nodes merged.  These are few (about one k-mer per input sequence).
-        struct Dm { unsigned long long data; unsigned len, edges; };
-        std::vector<Dm> dm;
-        dm.reserve((size_t)S.n_nopred * (size_t)k + 1);
-        dm.push_back(Dm{0, 0, 0});
-        const int kbits = 2 * (int)k;
-        for (unsigned long long zk : nopred)
-            for (int j = 0; j < (int)k; j++) {
-                unsigned long long label = (j == 0) ? 0ull : ((zk & ((1ull << (2 * j)) - 1ull)) << (kbits - 2 * j));
-                dm.push_back(Dm{label, (unsigned)j, 1u << (unsigned)((zk >> (2 * j)) & 3ull)});
-            }
-        std::sort(dm.begin(), dm.end(), [](const Dm &a, const Dm &b) { return a.data != b.data ? a.data < b.data : a.len < b.len; });
-        size_t wd = 0;
-        for (size_t i = 0; i < dm.size(); i++) {
-            if (wd > 0 && dm[wd - 1].data == dm[i].data && dm[wd - 1].len == dm[i].len) dm[wd - 1].edges |= dm[i].edges;
-            else dm[wd++] = dm[i];
-        }
-        dm.resize(wd);
-        ddata.resize(wd);
-        dedges.resize(wd);
-        for (size_t i = 0; i < wd; i++) { ddata[i] = dm[i].data; dedges[i] = dm[i].edges; }
-        const int64_t n = S.nk + (int64_t)wd, nw = (n + 63) / 64;
-        rows.resize((size_t)(5 * nw));
-        int rb = sbwt_build_phase_b(&S, ddata.data(), dedges.data(), (long long)wd, build_streaming_support ? 1 : 0, rows.data(), 0);
-        sbwt_build_release(&S);
-        if (rb != 0) return fail(rb == -8 ? SBWTGPU_ERR_OOM : SBWTGPU_ERR_HIP, "device builder, phase B");
-        uint64_t *mem = static_cast<uint64_t *>(malloc((size_t)(5 * nw) * 8 + 8));
-        if (!mem) return fail(SBWTGPU_ERR_OOM, "out of host memory");
-        memcpy(mem, rows.data(), (size_t)(5 * nw) * 8);
-        out->n_nodes = n;
-        out->n_kmers = S.nk;
-        out->k = k;
-        out->A_bits = mem;
-        out->C_bits = mem + nw;
-        out->G_bits = mem + 2 * nw;
-        out->T_bits = mem + 3 * nw;
-        out->suffix_group_starts = build_streaming_support ? mem + 4 * nw : nullptr;
+        rc = (k <= 32) ? build_columns_t<unsigned long long>(S, k, build_streaming_support, out)
+                       : build_columns_t<unsigned __int128>(S, k, build_streaming_support, out);
     } catch (const std::bad_alloc &) {
         sbwt_build_release(&S);
         rc = fail(SBWTGPU_ERR_OOM, "out of host memory");

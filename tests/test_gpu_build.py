@@ -41,7 +41,7 @@ def test_reference_known_answers(gpu):
         same_bits(got, orc.columns(), orc.ssup_words(), orc.n_nodes)
 
 
-@pytest.mark.parametrize("k", [2, 3, 7, 16, 21, 30, 31, 32])
+@pytest.mark.parametrize("k", [2, 3, 7, 16, 21, 30, 31, 32, 33, 48, 63, 64])
 @pytest.mark.parametrize("rc", [False, True])
 def test_random_inputs_equal_oracle_constructor(gpu, k, rc):
     rng = np.random.default_rng(100 * k + rc)
@@ -68,7 +68,19 @@ def test_empty_input_is_the_root_alone(gpu):
     assert got.n_nodes == 1 and got.n_kmers == 0 and int(got.ssup[0]) == 1
     assert all(int(c[0]) == 0 for c in got.cols)
     with pytest.raises(capi.SbwtGpuError):
-        capi.build_bits_gpu([b"ACGT"], 33, False, True)
+        capi.build_bits_gpu([b"ACGT"], 65, False, True)     # 128-bit keys end at k = 64; the C++ host builder goes on
+
+
+@pytest.mark.parametrize("k", [33, 63])
+def test_long_kmers_equal_host_builder(gpu, k):
+    # 32 < k <= 64: 128-bit keys (config 5's index is k = 63); the threaded host builder is the second opinion
+    genomes = synth.coli3_like(300_000)
+    seqs = [g.tobytes() for g in genomes] + [b"ACGT" * 30, synth.random_genome(k + 3, 4).tobytes()]
+    for rc in (False, True):
+        got = capi.build_bits_gpu(seqs, k, rc, True)
+        host = hostlib.build_bits(seqs, k, rc, True, n_threads=8)
+        assert (got.n_nodes, got.n_kmers) == (host.n_nodes, host.n_kmers)
+        same_bits(got, host.cols, host.ssup, host.n_nodes)
 
 
 def test_genome_scale_equals_host_builder_and_searches(gpu):

@@ -26,7 +26,7 @@ else:
     if gsel == "single":
         genomes = genomes[:1]
 B.K, B.READ_LEN = K, L
-if K <= 32:
+if K <= 64:
     bits = capi.build_bits_gpu([g.tobytes() for g in genomes], K, False, bool(streaming))
 else:
     bits = hostlib.build_bits([g.tobytes() for g in genomes], K, False, bool(streaming), n_threads=os.cpu_count())
