@@ -117,13 +117,12 @@ __global__ void __launch_bounds__(256) k_sp2_expand(SbwtIndexView ix, const SpIt
     if (slot != ~0ull) out[slot] = SpItem2{it.key2 | ((u64)c << (2 * d2)), it.origin, (unsigned)l, (unsigned)r, 0u};
 }
 __global__ void __launch_bounds__(256) k_sp2_insert(const SpItem2 *__restrict__ items, const u64 *n, uint4 *table,
-                                                    int log2b2, const unsigned *__restrict__ pos, int *wide_flag) {
+                                                    unsigned n_entries, const unsigned *__restrict__ pos, int *wide_flag) {
     u64 t = (u64)blockIdx.x * 256 + threadIdx.x;
     if (t >= *n) return;
     const SpItem2 it = items[t];
     if (it.l != it.r) *wide_flag = 1;                  // a k-mer's interval is one column in an SBWT
-    const u64 mask = (1ull << log2b2) - 1ull;
-    u64 bkt = sp2_hash(it.origin, it.key2) >> (64 - log2b2);
+    size_t bkt = sbwt_sp2_entry(it.origin, it.key2, n_entries, 0u);
     for (;;) {
         unsigned *e = reinterpret_cast<unsigned *>(&table[2 * bkt]);
         if (atomicCAS(&e[3], 0u, SBWT_SP2_USED) == 0u) {     // keys are distinct: an empty entry is simply taken
@@ -135,7 +134,7 @@ __global__ void __launch_bounds__(256) k_sp2_insert(const SpItem2 *__restrict__ 
             return;
         }
         atomicOr(&e[3], SBWT_SP2_OVERFLOW);
-        bkt = (bkt + 1) & mask;
+        bkt = bkt + 1 < n_entries ? bkt + 1 : 0;
     }
 }
 __global__ void __launch_bounds__(256) k_sp_wide(const SpItem *__restrict__ items, const u64 *n, int *flag) {
@@ -669,7 +668,7 @@ long long sbwt_sparse_scratch_bytes(long long n_nodes) { return 2 * (n_nodes + 6
 // 0 if not (no d_pos, p_sparse < k, or some k-mer's interval is wider than one column), < 0 on error.
 int sbwt_launch_build_sparse(const SbwtIndexView &ix, int p_dense, int p_sparse, long long n_buckets, uint4 *d_table,
                              void *d_scratch, const unsigned *d_pos, int p_filter, int log2f, uint4 *d_filter,
-                             int log2b2, uint4 *d_table2, hipStream_t stream) {
+                             long long n_entries2, uint4 *d_table2, hipStream_t stream) {
     u64 *counters = reinterpret_cast<u64 *>(d_scratch);                    // [0], [1]: list lengths
     SpItem *listA = reinterpret_cast<SpItem *>(reinterpret_cast<char *>(d_scratch) + 256);
     SpItem *listB = listA + (ix.n_nodes + 64);
@@ -710,7 +709,7 @@ int sbwt_launch_build_sparse(const SbwtIndexView &ix, int p_dense, int p_sparse,
                        (unsigned)n_buckets, with_pos ? d_pos : (const unsigned *)nullptr);
     if (d_table2 && ix.k > p_sparse) {
         // second level: carry every depth-p_sparse prefix on to depth k, remembering where it started
-        (void)hipMemsetAsync(d_table2, 0, (size_t)32 << log2b2, stream);
+        (void)hipMemsetAsync(d_table2, 0, (size_t)32 * (size_t)n_entries2, stream);
         hipLaunchKernelGGL(k_sp2_seed, dim3(grid_for(ix.n_nodes + 64)), dim3(256), 0, stream, in, counters + ci);
         SpItem2 *in2 = reinterpret_cast<SpItem2 *>(in), *out2 = reinterpret_cast<SpItem2 *>(outl);
         for (int d = p_sparse; d < ix.k; d++) {
@@ -722,7 +721,7 @@ int sbwt_launch_build_sparse(const SbwtIndexView &ix, int p_dense, int p_sparse,
         }
         int *flag = reinterpret_cast<int *>(counters + 9);
         hipLaunchKernelGGL(k_sp2_insert, dim3(grid_for(ix.n_nodes + 64)), dim3(256), 0, stream, in2, counters + ci, d_table2,
-                           log2b2, d_pos, flag);
+                           (unsigned)n_entries2, d_pos, flag);
         int h_flag = 1;
         if (hipMemcpyAsync(&h_flag, flag, 4, hipMemcpyDeviceToHost, stream) != hipSuccess) return -1;
         if (hipStreamSynchronize(stream) != hipSuccess) return -1;

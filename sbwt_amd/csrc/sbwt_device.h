@@ -12,7 +12,7 @@
 //                                    path position and the next 32 steps of its path; sized once the path order is known:
 //                                    3 entries per branching column + the successors of every path's last column
 //   [ pfil     : 2^log2f x 16 B  ]   probe filter (see k_pf_insert)
-//   [ stab2    : 2^log2b2 x 32 B ]   second level for 31 < k <= 63: { rest key (8 B), first column of the 31-prefix's
+//   [ stab2    : n_sb2 x 32 B    ]   second level for 31 < k <= 63: { rest key (8 B), first column of the 31-prefix's
 //                                    interval, flags } { column, path position, -, - }
 //   [ stab     : n_sb x 32 B     ]   sparse prefix table at depth p_sparse (only non-empty prefixes), hashed:
 //                                    bucket = two 16-byte entries { key | flags (u64), first (u32), second-first (u32) }
@@ -56,7 +56,7 @@ struct SbwtIndexView {
                                     // only successor = ~A & B (k_path_reencode, sbwt_derived.hip)
     int has_safe;                   // the safe states are filled in (k_path_safe*)
     const uint4 *stab2;             // second-level sparse table for 31 < k <= 63 (nullptr = none): key = (first column of the
-    int log2b2;                     // 31-prefix's interval, the remaining k-31 bases) -> the k-mer's column and path position
+    unsigned n_sb2;                 // 31-prefix's interval, the remaining k-31 bases) -> the k-mer's column and path position; its entries
     const uint4 *pfil;              // probe filter: blocked Bloom filter over the p_filter-mers of the index (nullptr = none)
     int p_filter, log2f;            // its depth and log2 of its number of 16-byte blocks
     const uint4 *trans;             // transition table: hashed 32-byte entries (k_trans_insert, sbwt_derived.hip)
@@ -95,7 +95,8 @@ struct SbwtBlobHeader {
     int64_t n_branch;               // columns with two or more successors (n_nodes / n_branch = columns between choices)
     int64_t image_level;            // 0 full, 1 no path order, 2 blocks + dense prefix table only
     int64_t row_ones[4];            // set bits of the rows A, C, G, T (select: valid j are 1 .. row_ones[c])
-    int32_t log2b2;                 // second-level sparse table: log2 of its number of 32-byte entries (0 = none)
+    int32_t log2b2_unused;
+    int64_t n_sb2;                  // second-level sparse table: its number of 32-byte entries (0 = none)
     int64_t off_stab2;
     int64_t path_lookahead;         // steps the path order looked ahead / behind when it chose successors (0: blind rule)
 };
@@ -201,7 +202,7 @@ int sbwt_launch_build_path(const SbwtIndexView &ix, unsigned *d_col, unsigned *d
                            void *d_scratch, int lookahead, hipStream_t stream);
 int sbwt_launch_build_sparse(const SbwtIndexView &ix, int p_dense, int p_sparse, long long n_buckets, uint4 *d_table,
                              void *d_scratch, const unsigned *d_pos, int p_filter, int log2f, uint4 *d_filter,
-                             int log2b2, uint4 *d_table2, hipStream_t stream);
+                             long long n_entries2, uint4 *d_table2, hipStream_t stream);
 
 // device builder (sbwt_build.hip): phase A = text -> sorted distinct k-mers, edges, predecessor-less k-mers; phase B =
 // dummies + k-mers -> the five rows in host memory

@@ -262,7 +262,7 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
                     a2 = a1 + 1;
                 } else if (wk == 5) {          // second level: (prefix interval, rest of the k-mer) -> one entry
                     hk = rw & m2;
-                    const u64 bkt = ((sp2_hash((unsigned)l, hk) >> (64 - ix.log2b2)) + (u64)j) & low_mask(ix.log2b2);
+                    const size_t bkt = sbwt_sp2_entry((unsigned)l, hk, ix.n_sb2, (unsigned)j);
                     a1 = ix.stab2 + 2 * bkt;
                     a2 = a1 + 1;
                 } else if (wk == 2 || (wk == 3 && pfon)) {   // the window's block of the probe filter

@@ -148,8 +148,8 @@ struct sbwtgpu_index {
         v.stab_pos = h.stab_pos;
         v.n_tslots = (unsigned)h.n_tslots;
         v.has_safe = h.has_safe;
-        v.stab2 = h.log2b2 > 0 ? reinterpret_cast<const uint4 *>(blob + h.off_stab2) : nullptr;
-        v.log2b2 = (int)h.log2b2;
+        v.stab2 = h.n_sb2 > 0 ? reinterpret_cast<const uint4 *>(blob + h.off_stab2) : nullptr;
+        v.n_sb2 = (unsigned)h.n_sb2;
         v.pfil = h.p_filter > 0 ? reinterpret_cast<const uint4 *>(blob + h.off_pfil) : nullptr;
         v.p_filter = (int)h.p_filter;
         v.log2f = (int)h.log2f;
@@ -299,11 +299,9 @@ int sbwtgpu_index_create(const sbwtgpu_index_desc *d, int device, sbwtgpu_index 
         h.blob_bytes = align256(h.off_stab + 32 * h.n_sb);
         // second level for 31 < k <= 63 (the remaining k-31 bases fit one 64-bit key): two entries' worth of space per column
         if (p_sparse == SBWT_SP_MAX_DEPTH && d->k > p_sparse && d->k - p_sparse <= 32) {
-            int lb2 = 6;
-            while (((int64_t)1 << lb2) < 2 * n) lb2++;
-            h.log2b2 = lb2;
+            h.n_sb2 = 2 * n + 64;           // one entry per k-mer at load 0.5
             h.off_stab2 = h.blob_bytes;
-            h.blob_bytes = align256(h.off_stab2 + ((int64_t)32 << lb2));
+            h.blob_bytes = align256(h.off_stab2 + 32 * h.n_sb2);
         }
         // probe filter at the certificate probes' length: 128-bit blocks, about 16 bits per column
         const int L0 = idx->probe_len(false);
@@ -376,7 +374,7 @@ int sbwtgpu_index_create(const sbwtgpu_index_desc *d, int device, sbwtgpu_index 
         h.p_dev = 0;
         h.has_ssup = 0;
         h.p_sparse = 0;
-        h.log2b2 = 0;
+        h.n_sb2 = 0;
         h.p_filter = 0;
         h.has_path = 0;
     }
@@ -480,11 +478,11 @@ int sbwtgpu_index_create(const sbwtgpu_index_desc *d, int device, sbwtgpu_index 
                                                h.has_path ? reinterpret_cast<const unsigned *>(idx->blob + h.off_pos) : nullptr,
                                                (int)h.p_filter, (int)h.log2f,
                                                h.p_filter > 0 ? reinterpret_cast<uint4 *>(idx->blob + h.off_pfil) : nullptr,
-                                               (int)h.log2b2,
-                                               h.log2b2 > 0 ? reinterpret_cast<uint4 *>(idx->blob + h.off_stab2) : nullptr, 0);
+                                               (long long)h.n_sb2,
+                                               h.n_sb2 > 0 ? reinterpret_cast<uint4 *>(idx->blob + h.off_stab2) : nullptr, 0);
             e = hipDeviceSynchronize();
             (void)hipFree(scr);
-            if (src == -3) { h.log2b2 = 0; src = 0; }   // some k-mer spans several columns: no second level
+            if (src == -3) { h.n_sb2 = 0; src = 0; }   // some k-mer spans several columns: no second level
             if (src < 0 && e == hipSuccess) e = hipErrorUnknown;
             if (e != hipSuccess) break;
             h.stab_pos = src > 0 ? 1 : 0;
