@@ -78,6 +78,7 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
                                     // 3 range probe, 5 second-level sparse lookup
     u64 hk = 0;                     // F_INIT: the window's key (filter: the bit positions), kept across the gather
     int blo = -1;                   // the last failure is known to lie in [blo, b]
+    int bnext = -1;                 // a hint: the read's next difference from its path after b (a failed bridge's compare saw it)
     int mode = F_IDLE;
     unsigned rd = 0;                // the read this lane works on
     int i = 0, j = 0, b = -1, wstart = 0;
@@ -161,6 +162,7 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
                     i0 = 0;
                     b = -1;
                     blo = -1;
+                    bnext = -1;
                     wstart = 0;
                     j = 0;
                     wk = (ps > 0) ? 1 : 0;
@@ -209,6 +211,7 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
                     i0 = mid;
                     b = -1;
                     blo = -1;
+                    bnext = -1;
                     wstart = mid;
                     j = 0;
                     wk = (ps > 0) ? 1 : 0;
@@ -243,7 +246,7 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
             a1 = reinterpret_cast<const uint4 *>(ix.pos + ((unsigned)l & ~3u));  // the aligned 16 bytes holding pos[l]
             a2 = a1;
         } else if (busy) {
-            const int wl = (wk == 1) ? ps : (wk == 2) ? L0 : (wk == 3) ? pw : (wk == 5) ? k - ps : p;
+            const int wl = (wk == 1) ? ps : (wk == 2 || wk == 6) ? L0 : (wk == 3) ? pw : (wk == 5) ? k - ps : p;
             c = (int)((unsigned)rw & 3u);
             if (ext || brg) {
                 a1 = ix.pq + (((unsigned)r + (brg ? 1u : 0u)) >> 5);   // the two quads holding path chars r (+1) .. +31
@@ -265,7 +268,7 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
                     const size_t bkt = sbwt_sp2_entry((unsigned)l, hk, ix.n_sb2, (unsigned)j);
                     a1 = ix.stab2 + 2 * bkt;
                     a2 = a1 + 1;
-                } else if (wk == 2 || (wk == 3 && pfon)) {   // the window's block of the probe filter
+                } else if (wk == 2 || wk == 6 || (wk == 3 && pfon)) {   // the window's block of the probe filter
                     const u64 h = sbwt_pf_hash(rw & low_mask(2 * L0));
                     hk = (u64)sbwt_pf_bits(h);
                     a1 = ix.pfil + (h >> (64 - ix.log2f));
@@ -282,7 +285,7 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
 #ifdef SBWT_STATS
         {   // lane-iterations by kind: pad[0..]: sparse lookup, filter probe, dense table, second level, interval update, path run,
             // transition, bridge, pos, idle/dead; pad[10] = wave-iterations
-            const int cls = !busy ? 9 : mode == F_INIT ? (wk == 1 ? 0 : (wk == 2 || (wk == 3 && pfon)) ? 1 : wk == 5 ? 3 : 2) :
+            const int cls = !busy ? 9 : mode == F_INIT ? (wk == 1 ? 0 : (wk == 2 || wk == 6 || (wk == 3 && pfon)) ? 1 : wk == 5 ? 3 : 2) :
                             mode == F_STEP ? 4 : ext ? 5 : trn ? 6 : brg ? 7 : 8;
             for (int q = 0; q < 10; q++) {
                 const unsigned long long cq = __popcll(__ballot(cls == q));
@@ -372,6 +375,7 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
             } else {
                 ev = FE_EMIT1;                         // no bridge: a bridgeable step has no successor by the read's char
                 b = blo = i + k - 1;
+                bnext = i + k + nm;                    // ... and the compare has seen where the read differs next
             }
         } else if (ext) {
             // k-mer i-1 sits at path position r.  Read bases i+k-1.. against path chars r..: while they agree (and the
@@ -416,7 +420,11 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
                     // skip the attempt (the step has no successor by the read's char either way)
                     const int after = 31 - n, want = (k - 1 < mend - 1 - (i + n)) ? (k - 1) : (mend - 1 - (i + n));
                     const int chk = after < want ? after : want;
-                    if (chk > 0 && ((mm >> (2 * (n + 1))) & low_mask(2 * chk)) != 0) kind = PS_ABSENT;
+                    const u64 m2nd = chk > 0 ? ((mm >> (2 * (n + 1))) & low_mask(2 * chk)) : 0ull;
+                    if (m2nd) {
+                        kind = PS_ABSENT;
+                        bnext = (i + k - 1) + n + 1 + ((__ffsll((i64)m2nd) - 1) >> 1);     // the second difference
+                    }
                 }
                 if (kind == PS_ABSENT) ext_absent = true;
                 else { mode = (kind == PS_TRANS) ? F_TRANS : F_BRIDGE; j = 0; }
@@ -425,15 +433,15 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
         } else if (mode == F_INIT) {
             int wl = p;
             bool again = false;
-            const bool viaf = (wk == 2) || (wk == 3 && pfon);
+            const bool viaf = (wk == 2) || (wk == 6) || (wk == 3 && pfon);
             if (viaf) {
                 const unsigned b1 = (unsigned)hk & 127u, b2 = ((unsigned)hk >> 7) & 127u;
                 const unsigned w1 = (b1 < 64) ? (b1 < 32 ? v1.x : v1.y) : (b1 < 96 ? v1.z : v1.w);
                 const unsigned w2 = (b2 < 64) ? (b2 < 32 ? v1.x : v1.y) : (b2 < 96 ? v1.z : v1.w);
                 wl = L0;
                 if (((w1 >> (b1 & 31u)) & (w2 >> (b2 & 31u)) & 1u) != 0) {
-                    if (wk == 3) {
-                        l = 0;                         // range probe: "perhaps present" only moves the guess
+                    if (wk == 3 || wk == 6) {
+                        l = 0;                         // range probe / hinted probe: "perhaps present" only moves the guess
                     } else {
                         again = true;                  // perhaps present: the dense table walks the window exactly
                         wk = 0;
@@ -481,8 +489,8 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
                 if (l == -1) {
                     ev = FE_FAIL;                      // read[wstart .. wstart+wl-1] is not in the index
                     tfail = wstart + wl - 1;
-                    imprecise = (wk != 2);             // ... but where inside the window it fails is not known
-                } else if (wk == 3) {
+                    imprecise = (wk != 2 && wk != 6);  // ... but where inside the window it fails is not known
+                } else if (wk == 3 || wk == 6) {
                     ev = FE_PRES;
                 } else if (wk == 1 && ps < k && ix.stab2) {
                     wk = 5;                            // the prefix is there (l = its first column): the rest in one more gather
@@ -546,7 +554,8 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
         }
         if (ev == FE_PRES) {                           // no bad base in [wstart, wstart+pw-1]: shrink the range
             const int lo = blo > i ? blo : i;
-            if (wstart > lo) b = wstart - 1;
+            if (wk == 6) b = -1;                       // (the hint was no substitution -- a variant the index knows: forget it)
+            else if (wstart > lo) b = wstart - 1;
             else blo = wstart + pw;
             if (blo > b) b = -1;
             do_plan = true;
@@ -688,6 +697,11 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
             // where the next walk starts (see k_search_cert): at k-mer i itself, or close to the last failure position b
             // when b lies inside k-mer i's window
             int s0 = i, nwk = (ps > 0) ? 1 : 0;
+            // nothing known about k-mer i's window, but a bridge compare has seen the read's next difference inside it: two
+            // substitutions within k-1 bases -- start the certificates there instead of bisecting for it (a hint like b
+            // itself: the probes prove what they prove wherever they start)
+            bool hinted = false;
+            if (!force && pfon && !(b >= i && b <= i + k - 1) && bnext >= i && bnext <= i + k - 1) { b = blo = bnext; bnext = -1; hinted = true; }
             if (!force && L0 > 0 && b >= i && b <= i + k - 1) {
                 const int lo = blo > i ? blo : i;
                 if (lo < b && p > 0 && k - pw >= 1) {
@@ -701,6 +715,8 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
                     s0 = (b - i >= L0 - 1) ? (b - L0 + 1) : b;
                     if (s0 + p - 1 > i + k - 1) s0 = i;
                     if (s0 != i) nwk = (pfon && s0 + L0 - 1 <= i + k - 1) ? 2 : 0;
+                    // a hinted probe that finds its window in the index gives up the hint instead of walking the window
+                    if (hinted) { if (nwk == 2) nwk = 6; else { s0 = i; nwk = (ps > 0) ? 1 : 0; b = -1; } }
                 }
             }
             wstart = s0;

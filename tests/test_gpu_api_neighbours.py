@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 from oracle import OracleIndex
-from sbwt_amd import capi, synth
+from sbwt_amd import capi, hostlib, synth
 
 pytestmark = pytest.mark.gpu
 
@@ -184,3 +184,55 @@ def test_image_levels_and_memory_cap(gpu, case):
         assert ei.value.code == capi.ERR_OOM
     finally:
         capi.set_tuning("max_image_bytes", 0)
+
+
+def test_text_stream_pieces_and_kernel_events(gpu):
+    """sbwtgpu_search_text_stream hands out the text of sbwtgpu_search_text_batch piece by piece, in order; the library's
+    kernel events time the fused kernel of every device-pointer call (what bench.py reports as roofline.kernel_ms)."""
+    import ctypes as C
+    import torch
+    genomes = synth.coli3_like(200_000)
+    bits = hostlib.build_bits([g.tobytes() for g in genomes], 30, False, True, n_threads=8)
+    idx = capi.Index.create(bits.cols[0], bits.cols[1], bits.cols[2], bits.cols[3], bits.ssup, bits.n_nodes, 30, bits.n_kmers, 8)
+    bases, off = synth.sample_reads(genomes, 300_000, 100, 0.01, 11)        # 30 M bases: several pipeline chunks
+    bases = synth.inject(bases, 500, ord("N"), 3)
+    want, nq = idx.search_text(bases, off, True)
+    pieces = []
+    SINK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64)
+
+    def sink(_ctx, text, n):
+        pieces.append(C.string_at(text, n))
+        return 0
+    cb = SINK(sink)
+    n_q = C.c_int64(0)
+    L = capi.lib()
+    L.sbwtgpu_search_text_stream.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, SINK, C.c_void_p,
+                                             C.POINTER(C.c_int64)]
+    capi._check(L.sbwtgpu_search_text_stream(idx.handle, bases.ctypes.data, off.ctypes.data, len(off) - 1, 1, cb, None,
+                                             C.byref(n_q)))
+    assert len(pieces) >= 3 and b"".join(pieces) == want and n_q.value == nq
+    # a sink that gives up ends the call with an error instead of going on
+    bad = SINK(lambda _c, _t, _n: 1)
+    assert L.sbwtgpu_search_text_stream(idx.handle, bases.ctypes.data, off.ctypes.data, len(off) - 1, 1, bad, None,
+                                        C.byref(n_q)) != 0
+    # kernel events
+    dev = torch.device("cuda:0")
+    n = 200_000
+    d_b = torch.from_numpy(bases[: n * 100].copy()).to(dev)
+    d_ro = torch.arange(n + 1, dtype=torch.int64, device=dev) * 100
+    d_oo = torch.arange(n + 1, dtype=torch.int64, device=dev) * 71
+    d_out = torch.empty(n * 71, dtype=torch.int64, device=dev)
+    wsb = capi.search_workspace_bytes(d_b.numel())
+    d_ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    capi.set_tuning("kernel_events", 1)
+    try:
+        for _ in range(3):
+            idx.streaming_search_dev(d_b.data_ptr(), d_b.numel(), d_ro.data_ptr(), n, d_out.data_ptr(), d_oo.data_ptr(),
+                                     d_ws.data_ptr(), wsb, st, True)
+        kt = capi.kernel_times()
+    finally:
+        capi.set_tuning("kernel_events", 0)
+    assert len(kt) == 3 and all(0 < t < 1000 for t in kt)
+    ref, _ = idx.streaming_search(bases[: n * 100], off[: n + 1])
+    assert np.array_equal(d_out.cpu().numpy(), ref)
