@@ -356,7 +356,7 @@ def main() -> int:
     t0 = time.time()
     bits = None
     if rank == 0:
-        # columns: on the GPU for k <= 32 (sbwtgpu_build_plain_matrix), host sort-based builder beyond
+        # columns: on the GPU for k <= 64 (sbwtgpu_build_plain_matrix), host sort-based builder beyond
         columns_on = "gpu" if K <= 64 else "host"
         if K <= 64:
             try:
