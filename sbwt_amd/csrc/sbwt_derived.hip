@@ -430,6 +430,173 @@ __global__ void __launch_bounds__(256) k_path_place(i64 n, const uint4 *__restri
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Stitched paths.  Vertex-disjoint paths end wherever two strains merge: the shared stretch belongs to ONE path, the other
+// strain's path stops at the merge and a new one starts where the strains part again -- a read of that strain makes two
+// transitions per shared stretch (config 2: 21 % of the k-mers are shared, 1.4 transitions per read), and its path pieces
+// are too short for most substitution-safe bits.  So the path ORDER may repeat columns: behind the last column e of a path
+// comes a COPY of the stretch of the other path that e's successor lies on, up to a column that has another way out onto
+// the head of a third path, and that path follows -- path, copied stretch, path: one chain, numbered consecutively.
+// Nothing about a position changes: col[t+1] is still the successor of col[t] by the position's char, a column's state bits
+// and transitions are its own wherever it stands; pos[v] names the position in v's own path.  Which head a tail is
+// joined to is a guess (the first free one within ST_MAXCOPY steps, smallest path number first where several tails want
+// one head); a wrong guess costs the transition it would have cost anyway.  The copies are bounded to a fifth of the columns; a graph that would need more keeps its disjoint paths.
+// Works on the positions of the disjoint layout (k_path_place), where a path is a run of positions: GO ... GO, end.
+// ---------------------------------------------------------------------------------------------
+#define ST_MAXCOPY 256
+struct StLink { int next; unsigned t0, len, chars; };          // next path (-1: none), first copied position, copy length, c_in | c_out << 2
+__device__ __forceinline__ bool st_go(const uint4 *__restrict__ pq, i64 t) { return (pq[t >> 5].z >> (int)(t & 31)) & 1u; }
+__device__ __forceinline__ unsigned st_char(const uint4 *__restrict__ pq, i64 t) {
+    return (unsigned)(quad_bits(pq[t >> 5]) >> (2 * (int)(t & 31))) & 3u;
+}
+__global__ void __launch_bounds__(256) k_st_flags(const uint4 *__restrict__ pq, i64 n, i64 *__restrict__ flag) {
+    const i64 t = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (t < n) flag[t] = (t == 0 || !st_go(pq, t - 1)) ? 1 : 0;
+}
+__global__ void __launch_bounds__(256) k_st_paths(const i64 *__restrict__ flag, const i64 *__restrict__ pex, i64 n,
+                                                  unsigned *__restrict__ start, unsigned *__restrict__ pid_of) {
+    const i64 t = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n) return;
+    if (flag[t]) start[pex[t]] = (unsigned)t;
+    pid_of[t] = (unsigned)(pex[t] + flag[t] - 1);
+    if (t == n - 1) start[pex[n]] = (unsigned)n;              // sentinel: the end of the last path
+}
+// One round of joining tails to heads.  Every path whose tail is still free looks, along the path its column's successor
+// lies on, for the first column with a way out onto the head of a third path that nobody holds yet, and PROPOSES to that
+// head (atomicMin on the proposer's number); k_st_accept gives every head to its smallest proposer.  Rounds repeat until
+// nobody proposes: the outcome does not depend on the order the threads ran in.
+// cand[p] = { head's path, first copied position, copy length, c_in | c_out << 2 | branching columns copied << 4 }
+__global__ void __launch_bounds__(256) k_st_propose(SbwtIndexView ix, const unsigned *__restrict__ col, const unsigned *__restrict__ pos,
+                                                    const uint4 *__restrict__ pq, const unsigned *__restrict__ pid_of,
+                                                    const unsigned *__restrict__ start, i64 np, i64 n, const int *__restrict__ claim,
+                                                    const StLink *__restrict__ link, unsigned char *__restrict__ spent,
+                                                    unsigned *__restrict__ prop, uint4 *__restrict__ cand, int min_copy, int *any) {
+    const i64 p = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (p >= np) return;
+    cand[p] = make_uint4(0xFFFFFFFFu, 0u, 0u, 0u);
+    if (link[p].next >= 0 || spent[p]) return;
+    const i64 end = (i64)start[p + 1] - 1;
+    const PathGroup pg = path_group(ix, (i64)col[end]);
+    for (unsigned c0 = 0; c0 < 4; c0++) {                       // where the tail's column goes on (usually one way: a merge)
+        if (pg.target[c0] == PATH_NONE) continue;
+        const i64 t0 = pos[pg.target[c0]];
+        const unsigned q0 = pid_of[t0];
+        if ((i64)q0 == p) break;
+        unsigned nbr = 0;
+        for (int j = 0; j < ST_MAXCOPY; j++) {
+            const i64 t = t0 + j;
+            if (t >= n || pid_of[t] != q0) break;              // the other path ended first
+            const PathGroup pv = path_group(ix, (i64)col[t]);
+            nbr += pv.deg >= 2;
+            if (j + 1 < min_copy) continue;
+            const bool go = st_go(pq, t);
+            const unsigned y = st_char(pq, t);
+            for (unsigned c = 0; c < 4; c++) {
+                const unsigned h = pv.target[c];
+                if (h == PATH_NONE || (go && c == y)) continue;
+                const i64 th = pos[h];
+                const unsigned q1 = pid_of[th];
+                if (th != (i64)start[q1] || (i64)q1 == p || q1 == q0 || claim[q1] != -1) continue;   // not a free head of a third path
+                atomicMin(&prop[q1], (unsigned)p);
+                cand[p] = make_uint4(q1, (unsigned)t0, (unsigned)(j + 1), c0 | (c << 2) | (nbr << 4));
+                *any = 1;
+                return;
+            }
+        }
+        break;                                                 // (the first way on only)
+    }
+    spent[p] = 1;                                              // nothing within reach
+}
+__global__ void __launch_bounds__(256) k_st_accept(i64 np, const unsigned *__restrict__ prop, const uint4 *__restrict__ cand,
+                                                   int *__restrict__ claim, StLink *__restrict__ link,
+                                                   unsigned long long *__restrict__ totals) {
+    const i64 p = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (p >= np) return;
+    const uint4 c = cand[p];
+    if (c.x == 0xFFFFFFFFu || prop[c.x] != (unsigned)p) return;
+    claim[c.x] = (int)p;
+    link[p] = StLink{(int)c.x, c.y, c.z, c.w & 15u};
+    atomicAdd(&totals[0], (unsigned long long)c.z);            // positions copied
+    atomicAdd(&totals[1], (unsigned long long)(c.w >> 4));     // ... of them columns with two or more successors
+}
+__global__ void __launch_bounds__(256) k_st_link_init(i64 np, StLink *__restrict__ link) {
+    const i64 p = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (p < np) link[p] = StLink{-1, 0u, 0u, 0u};
+}
+// list ranking over the paths of a chain: { jump towards the chain's first path, positions before this path, smallest path seen }
+__global__ void __launch_bounds__(256) k_st_rank_init(const int *__restrict__ claim, const StLink *__restrict__ link,
+                                                      const unsigned *__restrict__ start, i64 np, uint4 *__restrict__ R) {
+    const i64 p = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (p >= np) return;
+    const int prev = claim[p];
+    unsigned before = 0;
+    if (prev >= 0) before = (start[prev + 1] - start[prev]) + link[prev].len;
+    R[p] = make_uint4(prev >= 0 ? (unsigned)prev : (unsigned)p, before, (unsigned)p, 0u);
+}
+__global__ void __launch_bounds__(256) k_st_rank_jump(i64 np, const uint4 *__restrict__ in, uint4 *__restrict__ out, int *moved) {
+    const i64 p = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (p >= np) return;
+    const uint4 a = in[p], b = in[a.x];
+    out[p] = make_uint4(b.x, a.y + b.y, a.z < b.z ? a.z : b.z, 0u);
+    if (b.x != a.x) *moved = 1;
+}
+__global__ void __launch_bounds__(256) k_st_rank_cut(i64 np, const uint4 *__restrict__ R, int *__restrict__ claim,
+                                                     StLink *__restrict__ link, int *flag) {
+    const i64 p = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (p >= np) return;
+    const uint4 me = R[p];
+    if (claim[me.x] == -1) return;                             // reached a chain's first path
+    if (me.z == (unsigned)p) {                                 // a cycle of paths: its smallest member becomes a first path
+        const int prev = claim[p];
+        if (prev >= 0) { link[prev].next = -1; link[prev].len = 0; claim[p] = -1; }
+        *flag = 1;
+    }
+}
+__global__ void __launch_bounds__(256) k_st_chainlen(i64 np, const uint4 *__restrict__ R, const StLink *__restrict__ link,
+                                                     const unsigned *__restrict__ start, i64 *__restrict__ chainlen) {
+    const i64 p = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (p >= np) return;
+    const i64 seg = (i64)(start[p + 1] - start[p]) + (link[p].next >= 0 ? (i64)link[p].len : 0);
+    atomicAdd(reinterpret_cast<unsigned long long *>(&chainlen[R[p].x]), (unsigned long long)seg);
+}
+__device__ __forceinline__ void st_put(unsigned *__restrict__ pq_words, i64 t, unsigned ch) {     // chars + GO of a step that goes on
+    unsigned *quad = pq_words + (size_t)(t >> 5) * 4;
+    const unsigned s = (unsigned)(t & 31);
+    if (ch) atomicOr(&quad[s >> 4], ch << (2 * (s & 15u)));
+    atomicOr(&quad[2], 1u << s);
+}
+__global__ void __launch_bounds__(256) k_st_place(i64 n, const unsigned *__restrict__ col_old, const uint4 *__restrict__ pq_old,
+                                                  const unsigned *__restrict__ pid_of, const unsigned *__restrict__ start,
+                                                  const uint4 *__restrict__ R, const i64 *__restrict__ cbase,
+                                                  const StLink *__restrict__ link, unsigned *__restrict__ col,
+                                                  unsigned *__restrict__ pos, unsigned *__restrict__ pq_words) {
+    const i64 t = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n) return;
+    const unsigned p = pid_of[t];
+    const uint4 r = R[p];
+    const i64 nt = cbase[r.x] + (i64)r.y + (t - (i64)start[p]);
+    const unsigned v = col_old[t];
+    col[nt] = v;
+    pos[v] = (unsigned)nt;
+    if (st_go(pq_old, t)) st_put(pq_words, nt, st_char(pq_old, t));
+    else if (link[p].next >= 0) st_put(pq_words, nt, link[p].chars & 3u);        // the tail's step into the copied stretch
+}
+__global__ void __launch_bounds__(256) k_st_copy(i64 np, const unsigned *__restrict__ col_old, const uint4 *__restrict__ pq_old,
+                                                 const unsigned *__restrict__ start, const uint4 *__restrict__ R,
+                                                 const i64 *__restrict__ cbase, const StLink *__restrict__ link,
+                                                 unsigned *__restrict__ col, unsigned *__restrict__ pq_words) {
+    const i64 p = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (p >= np) return;
+    const StLink lk = link[p];
+    if (lk.next < 0) return;
+    const uint4 r = R[p];
+    const i64 first = cbase[r.x] + (i64)r.y + (i64)(start[p + 1] - start[p]);     // behind the path's own positions
+    for (unsigned j = 0; j < lk.len; j++) {
+        col[first + j] = col_old[lk.t0 + j];
+        st_put(pq_words, first + j, j + 1 < lk.len ? st_char(pq_old, (i64)lk.t0 + j) : (lk.chars >> 2) & 3u);
+    }
+}
+
 // Substitution-safe bits.  Path index u carries the char ch[u] of the step from position u to u+1.  Bit u says:
 // the 2k steps around u lie on one path, and replacing ch[u] by any other base gives, in each of the k windows
 // of k chars that contain it, a k-mer that is NOT in the index (3k exact lookups in the depth-k sparse table).
@@ -448,7 +615,7 @@ __device__ __forceinline__ bool sp_present(const SbwtIndexView &ix, u64 key) {
 __global__ void __launch_bounds__(256) k_path_safe(SbwtIndexView ix, unsigned *pq_words) {
     const i64 u = (i64)blockIdx.x * 256 + threadIdx.x;
     const int k = ix.k;
-    if (u < k || u + k > ix.n_nodes) return;
+    if (u < k || u + k > ix.n_pos) return;
     const i64 lo = u - k;                               // steps lo .. lo+2k-1 must all be kept
     const uint4 *q = ix.pq + (lo >> 5);
     const uint4 a = q[0], b = q[1], c = q[2];
@@ -479,7 +646,7 @@ __global__ void __launch_bounds__(256) k_path_safe(SbwtIndexView ix, unsigned *p
 // of its lanes costs as much as one that does it for 64 -- 69 -> 6 ms at 142 M columns)
 __global__ void __launch_bounds__(256) k_path_list_heads(SbwtIndexView ix, unsigned *__restrict__ list, u64 *count) {
     const i64 t = (i64)blockIdx.x * 256 + threadIdx.x;
-    const bool head = t < ix.n_nodes && (t == 0 || !((ix.pq[(t - 1) >> 5].z >> (int)((t - 1) & 31)) & 1u));   // step t-1 does not go on
+    const bool head = t < ix.n_pos && (t == 0 || !((ix.pq[(t - 1) >> 5].z >> (int)((t - 1) & 31)) & 1u));   // step t-1 does not go on
     const u64 slot = block_append_slot(count, head);
     if (slot != ~0ull) list[slot] = (unsigned)t;
 }
@@ -509,7 +676,7 @@ __global__ void __launch_bounds__(256) k_path_safe_labels(SbwtIndexView ix, unsi
                                                           unsigned char *__restrict__ alt_safe) {
     const i64 u = (i64)blockIdx.x * 256 + threadIdx.x;
     const int k = ix.k;
-    if (u >= ix.n_nodes) return;
+    if (u >= ix.n_pos) return;
     // steps 32(q-1) .. 32(q+2)-1 in three quads; step u is number o = 32 + s of them
     const i64 q = u >> 5;
     const int s = (int)(u & 31), o = 32 + s;
@@ -562,7 +729,7 @@ __global__ void __launch_bounds__(256) k_path_oth(SbwtIndexView ix, unsigned *__
                                                   unsigned long long *__restrict__ counters) {
     const i64 t = (i64)blockIdx.x * 256 + threadIdx.x;
     int n_ent = 0, branch = 0;
-    if (t < ix.n_nodes) {
+    if (t < ix.n_pos) {
         const PathGroup pg = path_group(ix, (i64)ix.col[t]);
         const bool go = (ix.pq[t >> 5].z >> (int)(t & 31)) & 1u;        // (build-time layout: z = GO, w = SAFE)
         if (!go) n_ent = pg.deg;
@@ -581,7 +748,7 @@ __global__ void __launch_bounds__(256) k_path_oth(SbwtIndexView ix, unsigned *__
 __global__ void __launch_bounds__(256) k_trans_insert(SbwtIndexView ix, unsigned *__restrict__ table, unsigned n_slots,
                                                       const unsigned char *__restrict__ alt_safe) {
     const i64 t = (i64)blockIdx.x * 256 + threadIdx.x;
-    if (t >= ix.n_nodes) return;
+    if (t >= ix.n_pos) return;
     const uint4 Q = ix.pq[t >> 5];
     const int s = (int)(t & 31);
     const bool go = ((~Q.z | Q.w) >> s) & 1u, only = ((~Q.z & Q.w) >> s) & 1u;
@@ -755,39 +922,164 @@ long long sbwt_count_paths(const SbwtIndexView &ix, hipStream_t stream) {
     unsigned long long *d = nullptr, h = 0;
     if (hipMalloc((void **)&d, 8) != hipSuccess) return -1;
     (void)hipMemsetAsync(d, 0, 8, stream);
-    hipLaunchKernelGGL(k_path_count_ends, dim3(grid_for(ix.n_nodes / 32 + 1)), dim3(256), 0, stream, ix.pq, (i64)ix.n_nodes, d);
+    hipLaunchKernelGGL(k_path_count_ends, dim3(grid_for(ix.n_pos / 32 + 1)), dim3(256), 0, stream, ix.pq, (i64)ix.n_pos, d);
     hipError_t e = hipMemcpyAsync(&h, d, 8, hipMemcpyDeviceToHost, stream);
     if (e == hipSuccess) e = hipStreamSynchronize(stream);
     (void)hipFree(d);
     return e == hipSuccess ? (long long)h : -1;
 }
 // rule 1: 2k steps around u on one path; rule 2 (needs d_hlab: sbwt_path_safe_scratch_bytes of scratch): k steps from u on
-long long sbwt_path_safe_scratch_bytes(long long n_nodes) { return (((long long)n_nodes * 12 + 15) & ~15ll) + 256; }
+long long sbwt_path_safe_scratch_bytes(long long n_pos) { return (((long long)n_pos * 12 + 15) & ~15ll) + 256; }
 void sbwt_launch_path_safe(const SbwtIndexView &ix, uint4 *d_pq, int rule, void *d_hlab, unsigned char *d_alt_safe,
                            hipStream_t stream) {
-    if (d_alt_safe) (void)hipMemsetAsync(d_alt_safe, 0, (size_t)ix.n_nodes, stream);
+    if (d_alt_safe) (void)hipMemsetAsync(d_alt_safe, 0, (size_t)ix.n_pos, stream);
     if (rule < 2 || !d_hlab) {
-        hipLaunchKernelGGL(k_path_safe, dim3(grid_for(ix.n_nodes)), dim3(256), 0, stream, ix, reinterpret_cast<unsigned *>(d_pq));
+        hipLaunchKernelGGL(k_path_safe, dim3(grid_for(ix.n_pos)), dim3(256), 0, stream, ix, reinterpret_cast<unsigned *>(d_pq));
         return;
     }
     // d_hlab: [ hlab : n x 8 B ][ list of heads : n x 4 B ][ their number : 8 B ]
     u64 *hlab = reinterpret_cast<u64 *>(d_hlab);
-    unsigned *list = reinterpret_cast<unsigned *>(hlab + ix.n_nodes);
-    u64 *count = reinterpret_cast<u64 *>(reinterpret_cast<char *>(d_hlab) + (((size_t)ix.n_nodes * 12 + 15) & ~(size_t)15));
+    unsigned *list = reinterpret_cast<unsigned *>(hlab + ix.n_pos);
+    u64 *count = reinterpret_cast<u64 *>(reinterpret_cast<char *>(d_hlab) + (((size_t)ix.n_pos * 12 + 15) & ~(size_t)15));
     (void)hipMemsetAsync(count, 0, 8, stream);
-    hipLaunchKernelGGL(k_path_list_heads, dim3(grid_for(ix.n_nodes)), dim3(256), 0, stream, ix, list, count);
+    hipLaunchKernelGGL(k_path_list_heads, dim3(grid_for(ix.n_pos)), dim3(256), 0, stream, ix, list, count);
     // (the grid covers every position; blocks beyond the number of heads return at once)
     if (ix.n_mega > 1)
-        hipLaunchKernelGGL(k_path_head_labels<true>, dim3(grid_for(ix.n_nodes)), dim3(256), 0, stream, ix, list, count, hlab);
+        hipLaunchKernelGGL(k_path_head_labels<true>, dim3(grid_for(ix.n_pos)), dim3(256), 0, stream, ix, list, count, hlab);
     else
-        hipLaunchKernelGGL(k_path_head_labels<false>, dim3(grid_for(ix.n_nodes)), dim3(256), 0, stream, ix, list, count, hlab);
-    hipLaunchKernelGGL(k_path_safe_labels, dim3(grid_for(ix.n_nodes)), dim3(256), 0, stream, ix,
+        hipLaunchKernelGGL(k_path_head_labels<false>, dim3(grid_for(ix.n_pos)), dim3(256), 0, stream, ix, list, count, hlab);
+    hipLaunchKernelGGL(k_path_safe_labels, dim3(grid_for(ix.n_pos)), dim3(256), 0, stream, ix,
                        reinterpret_cast<unsigned *>(d_pq), hlab, d_alt_safe);
 }
 
-// d_col, d_pos: n_nodes (+4 padding) u32 each; d_pq: sbwt_path_quads() quads.  Synchronises the stream.
-int sbwt_launch_build_path(const SbwtIndexView &ix, unsigned *d_col, unsigned *d_pos, uint4 *d_pq, uint4 *d_trans,
-                           void *d_scratch, int lookahead, hipStream_t stream) {
+// Joins the disjoint paths (col_o / pos_o / pq_o, k_path_place) into chains with copied stretches (see "Stitched paths"):
+// d_col / d_pq have room for pos_cap positions.  Returns the number of positions (>= n), or -1.
+static long long stitch_paths(const SbwtIndexView &ix, const unsigned *col_o, const unsigned *pos_o, const uint4 *pq_o,
+                              unsigned *d_col, unsigned *d_pos, uint4 *d_pq, long long pos_cap, int min_copy, hipStream_t stream) {
+    const i64 n = ix.n_nodes;
+    const unsigned g = grid_for(n);
+    const i64 nbk = (n + 1023) / 1024;
+    i64 *flag = nullptr, *pex = nullptr, *bsum = nullptr, *chainlen = nullptr, *cbase = nullptr;
+    unsigned *pid_of = nullptr, *start = nullptr;
+    int *claim = nullptr, *ctl = nullptr;
+    StLink *link = nullptr;
+    unsigned char *spent = nullptr;
+    unsigned *prop = nullptr;
+    uint4 *cand = nullptr;
+    uint4 *R[2] = {nullptr, nullptr};
+    unsigned long long *budget = nullptr;
+    long long n_pos = -1;
+    i64 np = 0, total = 0;
+    int cur = 0;
+#define ST_TRY(x) do { if ((x) != hipSuccess) goto out; } while (0)
+    ST_TRY(hipMalloc((void **)&flag, (size_t)(n + 1) * 8));
+    ST_TRY(hipMalloc((void **)&pex, (size_t)(n + 2) * 8));
+    ST_TRY(hipMalloc((void **)&bsum, (size_t)(nbk + 2) * 8));
+    ST_TRY(hipMalloc((void **)&pid_of, (size_t)(n + 4) * 4));
+    ST_TRY(hipMalloc((void **)&ctl, 64));
+    ST_TRY(hipMalloc((void **)&budget, 16));
+    hipLaunchKernelGGL(k_st_flags, dim3(g), dim3(256), 0, stream, pq_o, n, flag);
+    hipLaunchKernelGGL(k_scan_block_sums, dim3((unsigned)nbk), dim3(256), 0, stream, flag, n, bsum);
+    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, stream, bsum, nbk);
+    hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nbk), dim3(256), 0, stream, flag, n, bsum, pex);
+    ST_TRY(hipMemcpyAsync(&np, pex + n, 8, hipMemcpyDeviceToHost, stream));
+    ST_TRY(hipStreamSynchronize(stream));
+    {
+        const unsigned gp = grid_for(np);
+        const i64 nbp = (np + 1023) / 1024;
+        ST_TRY(hipMalloc((void **)&start, (size_t)(np + 2) * 4));
+        ST_TRY(hipMalloc((void **)&claim, (size_t)(np + 1) * 4));
+        ST_TRY(hipMalloc((void **)&link, (size_t)(np + 1) * sizeof(StLink)));
+        ST_TRY(hipMalloc((void **)&R[0], (size_t)(np + 1) * 16));
+        ST_TRY(hipMalloc((void **)&R[1], (size_t)(np + 1) * 16));
+        ST_TRY(hipMalloc((void **)&chainlen, (size_t)(np + 2) * 8));
+        ST_TRY(hipMalloc((void **)&cbase, (size_t)(np + 2) * 8));
+        hipLaunchKernelGGL(k_st_paths, dim3(g), dim3(256), 0, stream, flag, pex, n, start, pid_of);
+        ST_TRY(hipMemsetAsync(claim, 0xFF, (size_t)(np + 1) * 4, stream));
+        ST_TRY(hipMemsetAsync(budget, 0, 16, stream));
+        ST_TRY(hipMalloc((void **)&spent, (size_t)np + 16));
+        ST_TRY(hipMalloc((void **)&prop, (size_t)(np + 1) * 4));
+        ST_TRY(hipMalloc((void **)&cand, (size_t)(np + 1) * 16));
+        ST_TRY(hipMemsetAsync(spent, 0, (size_t)np + 16, stream));
+        hipLaunchKernelGGL(k_st_link_init, dim3(gp), dim3(256), 0, stream, np, link);
+        for (int round = 0; round < 64; round++) {
+            ST_TRY(hipMemsetAsync(prop, 0xFF, (size_t)(np + 1) * 4, stream));
+            ST_TRY(hipMemsetAsync(ctl, 0, 4, stream));
+            hipLaunchKernelGGL(k_st_propose, dim3(gp), dim3(256), 0, stream, ix, col_o, pos_o, pq_o, pid_of, start, np, n, claim, link,
+                               spent, prop, cand, min_copy, ctl);
+            hipLaunchKernelGGL(k_st_accept, dim3(gp), dim3(256), 0, stream, np, prop, cand, claim, link, budget);
+            int h_any = 0;
+            ST_TRY(hipMemcpyAsync(&h_any, ctl, 4, hipMemcpyDeviceToHost, stream));
+            ST_TRY(hipStreamSynchronize(stream));
+            if (!h_any) break;
+        }
+        {
+            // A graph whose tails need more copied positions than there is room for, or whose copies would repeat many
+            // BRANCHING columns (three transition entries each), is too branchy for this -- a pan-genome of many strains:
+            // every merge is followed by somebody else's bubble within a few columns; the copies bought 0.7 % of the time
+            // for 27 % of the image on config 3.  It keeps its vertex-disjoint paths.
+            unsigned long long h_b[2] = {0, 0};
+            ST_TRY(hipMemcpyAsync(h_b, budget, 16, hipMemcpyDeviceToHost, stream));
+            ST_TRY(hipStreamSynchronize(stream));
+            const unsigned long long cap = pos_cap > n ? (unsigned long long)(pos_cap - n) : 0ull;
+            if (h_b[0] > cap || h_b[1] > (unsigned long long)(n / 32)) goto out;
+        }
+        // rank the paths within their chains; chains of paths that close on themselves are opened at their smallest path
+        int rounds = 1;
+        while (((i64)1 << rounds) < np) rounds++;
+        rounds++;
+        for (int attempt = 0; attempt < 4; attempt++) {
+            cur = 0;
+            hipLaunchKernelGGL(k_st_rank_init, dim3(gp), dim3(256), 0, stream, claim, link, start, np, R[0]);
+            for (int r = 0; r < rounds; r++) {
+                ST_TRY(hipMemsetAsync(ctl, 0, 4, stream));
+                hipLaunchKernelGGL(k_st_rank_jump, dim3(gp), dim3(256), 0, stream, np, R[cur], R[cur ^ 1], ctl);
+                cur ^= 1;
+                if (r >= 5) {
+                    int h_moved = 1;
+                    ST_TRY(hipMemcpyAsync(&h_moved, ctl, 4, hipMemcpyDeviceToHost, stream));
+                    ST_TRY(hipStreamSynchronize(stream));
+                    if (!h_moved) break;
+                }
+            }
+            ST_TRY(hipMemsetAsync(ctl + 1, 0, 4, stream));
+            hipLaunchKernelGGL(k_st_rank_cut, dim3(gp), dim3(256), 0, stream, np, R[cur], claim, link, ctl + 1);
+            int h_flag = 0;
+            ST_TRY(hipMemcpyAsync(&h_flag, ctl + 1, 4, hipMemcpyDeviceToHost, stream));
+            ST_TRY(hipStreamSynchronize(stream));
+            if (!h_flag) break;
+            if (attempt == 3) goto out;                 // cannot happen: one cut per cycle opens every cycle
+        }
+        ST_TRY(hipMemsetAsync(chainlen, 0, (size_t)(np + 2) * 8, stream));
+        hipLaunchKernelGGL(k_st_chainlen, dim3(gp), dim3(256), 0, stream, np, R[cur], link, start, chainlen);
+        // (chainlen is zero for paths that are not the first of a chain: its exclusive scan is the chains' first positions)
+        hipLaunchKernelGGL(k_scan_block_sums, dim3((unsigned)nbp), dim3(256), 0, stream, chainlen, np, bsum);
+        hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, stream, bsum, nbp);
+        hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nbp), dim3(256), 0, stream, chainlen, np, bsum, cbase);
+        ST_TRY(hipMemcpyAsync(&total, cbase + np, 8, hipMemcpyDeviceToHost, stream));
+        ST_TRY(hipStreamSynchronize(stream));
+        if (total < n || total > pos_cap) goto out;
+        ST_TRY(hipMemsetAsync(d_pq, 0, (size_t)sbwt_path_quads(pos_cap) * 16, stream));
+        hipLaunchKernelGGL(k_st_place, dim3(g), dim3(256), 0, stream, n, col_o, pq_o, pid_of, start, R[cur], cbase, link, d_col, d_pos,
+                           reinterpret_cast<unsigned *>(d_pq));
+        hipLaunchKernelGGL(k_st_copy, dim3(gp), dim3(256), 0, stream, np, col_o, pq_o, start, R[cur], cbase, link, d_col,
+                           reinterpret_cast<unsigned *>(d_pq));
+        ST_TRY(hipStreamSynchronize(stream));
+        n_pos = total;
+    }
+out:
+#undef ST_TRY
+    (void)hipFree(flag); (void)hipFree(pex); (void)hipFree(bsum); (void)hipFree(pid_of); (void)hipFree(start); (void)hipFree(claim);
+    (void)hipFree(link); (void)hipFree(R[0]); (void)hipFree(R[1]); (void)hipFree(chainlen); (void)hipFree(cbase); (void)hipFree(ctl);
+    (void)hipFree(budget); (void)hipFree(spent); (void)hipFree(prop); (void)hipFree(cand);
+    if (n_pos < 0) (void)hipGetLastError();
+    return n_pos;
+}
+
+// d_col: pos_cap (+4 padding) u32, d_pos: n_nodes (+4) u32; d_pq: sbwt_path_quads(pos_cap) quads.  *n_pos: the positions of
+// the path order (n_nodes, or more when paths were stitched: stitch != 0 and pos_cap > n_nodes).  Synchronises the stream.
+int sbwt_launch_build_path(const SbwtIndexView &ix, unsigned *d_col, unsigned *d_pos, uint4 *d_pq, long long pos_cap,
+                           long long *n_pos, int stitch, int min_copy, void *d_scratch, int lookahead, hipStream_t stream) {
     const i64 n = ix.n_nodes;
     const long long np = path_pad(n);
     const i64 nb = (n + 1023) / 1024;
@@ -851,11 +1143,28 @@ int sbwt_launch_build_path(const SbwtIndexView &ix, unsigned *d_col, unsigned *d
     hipLaunchKernelGGL(k_scan_block_sums, dim3((unsigned)nb), dim3(256), 0, stream, reinterpret_cast<const i64 *>(len), n, bsum);
     hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, stream, bsum, nb);
     hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nb), dim3(256), 0, stream, reinterpret_cast<const i64 *>(len), n, bsum, pbase);
-    (void)hipMemsetAsync(d_pq, 0, (size_t)sbwt_path_quads(n) * 16, stream);
+    *n_pos = n;
+    if (stitch && pos_cap > n) {
+        unsigned *col_o = nullptr, *pos_o = nullptr;
+        uint4 *pq_o = nullptr;
+        long long got = -1;
+        if (hipMalloc((void **)&col_o, (size_t)(n + 4) * 4) == hipSuccess && hipMalloc((void **)&pos_o, (size_t)(n + 4) * 4) == hipSuccess &&
+            hipMalloc((void **)&pq_o, (size_t)sbwt_path_quads(n) * 16) == hipSuccess) {
+            (void)hipMemsetAsync(pq_o, 0, (size_t)sbwt_path_quads(n) * 16, stream);
+            hipLaunchKernelGGL(k_path_place, dim3(g), dim3(256), 0, stream, n, jb[cur], pbase, succ, sch, pos_o, col_o,
+                               reinterpret_cast<unsigned *>(pq_o));
+            got = stitch_paths(ix, col_o, pos_o, pq_o, d_col, d_pos, d_pq, pos_cap, min_copy, stream);
+        } else {
+            (void)hipGetLastError();
+        }
+        (void)hipFree(col_o); (void)hipFree(pos_o); (void)hipFree(pq_o);
+        if (got >= n) { *n_pos = got; return 0; }
+        // (no room or a failure: the disjoint paths as they are)
+    }
+    (void)hipMemsetAsync(d_pq, 0, (size_t)sbwt_path_quads(pos_cap > n ? pos_cap : n) * 16, stream);
     hipLaunchKernelGGL(k_path_place, dim3(g), dim3(256), 0, stream, n, jb[cur], pbase, succ, sch, d_pos,
                        d_col, reinterpret_cast<unsigned *>(d_pq));
     if (hipStreamSynchronize(stream) != hipSuccess) return -1;
-    (void)d_trans;                                      // filled by sbwt_launch_path_trans once the safe bits are final
     return 0;
 }
 // The ONLY bits, then the path groups' final encoding (k_path_reencode); returns the number of transition entries
@@ -863,12 +1172,12 @@ int sbwt_launch_build_path(const SbwtIndexView &ix, unsigned *d_col, unsigned *d
 long long sbwt_launch_path_oth(const SbwtIndexView &ix, uint4 *d_pq, long long *n_branch, hipStream_t stream) {
     unsigned long long *d = nullptr, h[2] = {0, 0};
     unsigned *only = nullptr;
-    const i64 n_quads = sbwt_path_quads(ix.n_nodes);
+    const i64 n_quads = sbwt_path_quads(ix.n_pos);
     if (hipMalloc((void **)&d, 16) != hipSuccess) return -1;
     if (hipMalloc((void **)&only, (size_t)n_quads * 4) != hipSuccess) { (void)hipFree(d); return -1; }
     (void)hipMemsetAsync(d, 0, 16, stream);
     (void)hipMemsetAsync(only, 0, (size_t)n_quads * 4, stream);
-    hipLaunchKernelGGL(k_path_oth, dim3(grid_for(ix.n_nodes)), dim3(256), 0, stream, ix, only, d);
+    hipLaunchKernelGGL(k_path_oth, dim3(grid_for(ix.n_pos)), dim3(256), 0, stream, ix, only, d);
     hipLaunchKernelGGL(k_path_reencode, dim3(grid_for(n_quads)), dim3(256), 0, stream, d_pq, n_quads, only);
     hipError_t e = hipMemcpyAsync(h, d, 16, hipMemcpyDeviceToHost, stream);
     if (e == hipSuccess) e = hipStreamSynchronize(stream);
@@ -883,6 +1192,6 @@ long long sbwt_launch_path_oth(const SbwtIndexView &ix, uint4 *d_pq, long long *
 void sbwt_launch_trans_insert(const SbwtIndexView &ix, uint4 *d_trans, long long n_slots, const unsigned char *d_alt_safe,
                               hipStream_t stream) {
     (void)hipMemsetAsync(d_trans, 0, (size_t)32 * (size_t)n_slots, stream);
-    hipLaunchKernelGGL(k_trans_insert, dim3(grid_for(ix.n_nodes)), dim3(256), 0, stream, ix, reinterpret_cast<unsigned *>(d_trans), (unsigned)n_slots,
+    hipLaunchKernelGGL(k_trans_insert, dim3(grid_for(ix.n_pos)), dim3(256), 0, stream, ix, reinterpret_cast<unsigned *>(d_trans), (unsigned)n_slots,
                        d_alt_safe);
 }

@@ -42,6 +42,7 @@ struct SbwtIndexView {
     const longlong2 *ptab;          // device prefix table, depth p_dev (nullptr if p_dev == 0)
     const unsigned long long *mega; // [4][n_mega]
     long long n_nodes;
+    long long n_pos;                // positions of the path order: n_nodes, or more when paths were stitched (sbwt_derived.hip)
     long long C[4];
     int k;
     int p_dev;
@@ -90,6 +91,7 @@ struct SbwtBlobHeader {
     int32_t force_mega;             // block counts are relative to mega[c][0] although n_mega == 1 (see SbwtIndexView)
     int64_t n_tslots;               // transition table: its number of 32-byte slots
     int64_t n_sb;                   // sparse prefix table: its number of 32-byte buckets
+    int64_t n_pos;                  // positions of the path order (>= n_nodes: stitched chains repeat the columns of shared stretches)
     int64_t n_trans;                // ... and how many of them are in use
     int64_t n_paths;                // paths of the path order
     int64_t n_branch;               // columns with two or more successors (n_nodes / n_branch = columns between choices)
@@ -198,8 +200,8 @@ long long sbwt_path_safe_scratch_bytes(long long n_nodes);
 long long sbwt_launch_path_oth(const SbwtIndexView &ix, uint4 *d_pq, long long *n_branch, hipStream_t stream);
 void sbwt_launch_trans_insert(const SbwtIndexView &ix, uint4 *d_trans, long long n_slots, const unsigned char *d_alt_safe,
                               hipStream_t stream);
-int sbwt_launch_build_path(const SbwtIndexView &ix, unsigned *d_col, unsigned *d_pos, uint4 *d_pq, uint4 *d_trans,
-                           void *d_scratch, int lookahead, hipStream_t stream);
+int sbwt_launch_build_path(const SbwtIndexView &ix, unsigned *d_col, unsigned *d_pos, uint4 *d_pq, long long pos_cap,
+                           long long *n_pos, int stitch, int min_copy, void *d_scratch, int lookahead, hipStream_t stream);
 int sbwt_launch_build_sparse(const SbwtIndexView &ix, int p_dense, int p_sparse, long long n_buckets, uint4 *d_table,
                              void *d_scratch, const unsigned *d_pos, int p_filter, int log2f, uint4 *d_filter,
                              long long n_entries2, uint4 *d_table2, hipStream_t stream);

@@ -105,6 +105,9 @@ static int g_force_mega = 0;    // tests: store every image's block counts relat
 static int g_path_safe = [] { const char *e = getenv("SBWTGPU_PATH_SAFE"); return e ? atoi(e) : 2; }();   // 0 off, 1 narrow rule, 2 wide
 static int g_path_lookahead = [] { const char *e = getenv("SBWTGPU_PATH_LOOKAHEAD"); return e ? atoi(e) : 8; }();   // 0: the blind rule
 static int g_path_order = [] { const char *e = getenv("SBWTGPU_PATH_ORDER"); return e ? atoi(e) : 1; }();
+// stitched chains (sbwt_derived.hip): 0 = vertex-disjoint paths only; the shortest stretch worth copying
+static int g_path_stitch = [] { const char *e = getenv("SBWTGPU_PATH_STITCH"); return e ? atoi(e) : 1; }();
+static int g_path_stitch_min = [] { const char *e = getenv("SBWTGPU_PATH_STITCH_MIN"); return e ? atoi(e) : 1; }();
 static int g_sparse_depth = [] { const char *e = getenv("SBWTGPU_SPARSE_PRECALC"); return e ? atoi(e) : 31; }();
 
 struct sbwtgpu_index {
@@ -130,6 +133,7 @@ struct sbwtgpu_index {
         v.ptab = h.p_dev > 0 ? reinterpret_cast<const longlong2 *>(blob + h.off_ptab) : nullptr;
         v.mega = reinterpret_cast<const unsigned long long *>(blob + h.off_mega);
         v.n_nodes = h.n_nodes;
+        v.n_pos = h.n_pos > 0 ? h.n_pos : h.n_nodes;
         for (int i = 0; i < 4; i++) v.C[i] = h.C[i];
         v.k = (int)h.k;
         v.p_dev = (int)h.p_dev;
@@ -184,6 +188,8 @@ int sbwtgpu_set_tuning(const char *key, int64_t value) {
     if (!strcmp(key, "path_safe")) { g_path_safe = (int)value; return SBWTGPU_OK; }   // indexes created afterwards
     if (!strcmp(key, "path_lookahead")) { g_path_lookahead = value < 0 ? 0 : value > 64 ? 64 : (int)value; return SBWTGPU_OK; }
     if (!strcmp(key, "path_order")) { g_path_order = (int)value; return SBWTGPU_OK; }   // indexes created afterwards
+    if (!strcmp(key, "path_stitch")) { g_path_stitch = (int)value; return SBWTGPU_OK; }   // indexes created afterwards
+    if (!strcmp(key, "path_stitch_min")) { g_path_stitch_min = (int)value < 1 ? 1 : (int)value; return SBWTGPU_OK; }
     if (!strcmp(key, "sparse_depth")) {      // takes effect for indexes created afterwards
         if (value < 0 || value > 31) return fail(SBWTGPU_ERR_INVALID_ARG, "sparse_depth must be in [0,31]");
         g_sparse_depth = (int)value;
@@ -316,12 +322,17 @@ int sbwtgpu_index_create(const sbwtgpu_index_desc *d, int device, sbwtgpu_index 
     }
     // path order: needs suffix-group marks (given or derived) and 32-bit columns
     const bool marks = d->suffix_group_starts || (g_derive_ssup && d->k >= 2);
+    int64_t pos_cap = n;
     if (g_path_order && level == 0 && marks && n < ((int64_t)1 << 31) - 64 && n_mega == 1) {
+        // room for the path order with stitched chains (copies of shared stretches: at most a fifth of the columns, and
+        // positions stay below 2^31); the finished image keeps what was used
+        pos_cap = g_path_stitch ? std::min<int64_t>(n + n / 5 + 64, ((int64_t)1 << 31) - 64) : n;
+        if (pos_cap < n) pos_cap = n;
         h.has_path = 1;
         h.off_col = h.blob_bytes;
-        h.off_pos = align256(h.off_col + (n + 4) * 4);
+        h.off_pos = align256(h.off_col + (pos_cap + 4) * 4);
         h.off_pq = align256(h.off_pos + (n + 4) * 4);
-        h.off_trans = align256(h.off_pq + sbwt_path_quads(n) * 16);
+        h.off_trans = align256(h.off_pq + sbwt_path_quads(pos_cap) * 16);
         h.blob_bytes = h.off_trans;        // the transition table follows once the path order has said how many entries it needs
     }
     idx->device = device;
@@ -463,12 +474,14 @@ int sbwtgpu_index_create(const sbwtgpu_index_desc *d, int device, sbwtgpu_index 
         if (h.has_path) {
             void *scr = nullptr;
             if ((e = hipMalloc(&scr, (size_t)sbwt_path_scratch_bytes(n))) != hipSuccess) break;
+            long long n_pos = n;
             int prc = sbwt_launch_build_path(v, reinterpret_cast<unsigned *>(idx->blob + h.off_col),
                                              reinterpret_cast<unsigned *>(idx->blob + h.off_pos),
-                                             reinterpret_cast<uint4 *>(idx->blob + h.off_pq),
-                                             reinterpret_cast<uint4 *>(idx->blob + h.off_trans), scr, g_path_lookahead, 0);
+                                             reinterpret_cast<uint4 *>(idx->blob + h.off_pq), pos_cap, &n_pos, g_path_stitch,
+                                             g_path_stitch_min, scr, g_path_lookahead, 0);
             (void)hipFree(scr);
             if (prc != 0) { e = hipErrorUnknown; break; }
+            h.n_pos = n_pos;
         }
         if (h.p_sparse > 0) {
             void *scr = nullptr;
@@ -491,13 +504,13 @@ int sbwtgpu_index_create(const sbwtgpu_index_desc *d, int device, sbwtgpu_index 
                 SbwtIndexView v2 = idx->view();
                 // (rule 2 keeps the path heads' labels and their list in scratch)
                 void *hscr = nullptr;
-                if (g_path_safe >= 2 && hipMalloc(&hscr, (size_t)sbwt_path_safe_scratch_bytes(n)) != hipSuccess) {
+                if (g_path_safe >= 2 && hipMalloc(&hscr, (size_t)sbwt_path_safe_scratch_bytes(h.n_pos)) != hipSuccess) {
                     (void)hipGetLastError();
                     hscr = nullptr;                     // no room for rule 2: the narrow rule needs none
                 }
                 // ... and hands the per-substitute verdicts to the transition table's negative entries through alt_safe (a byte
                 // per position; without it only the steps that are safe for all three substitutes bridge)
-                if (hscr && hipMalloc((void **)&alt_safe, (size_t)n) != hipSuccess) {
+                if (hscr && hipMalloc((void **)&alt_safe, (size_t)h.n_pos) != hipSuccess) {
                     (void)hipGetLastError();
                     alt_safe = nullptr;
                 }
@@ -521,13 +534,25 @@ int sbwtgpu_index_create(const sbwtgpu_index_desc *d, int device, sbwtgpu_index 
             const int64_t n_slots = 3 * n_ent + 64;                         // load factor 1/3: ~1.25 probes per lookup
             if (n_slots >= ((int64_t)1 << 32)) { e = hipErrorOutOfMemory; break; }
             h.n_tslots = n_slots;
-            const int64_t full = align256(h.off_trans + 32 * n_slots);
+            // the finished image keeps the path arrays at the size the path order turned out to have
+            const int64_t col_bytes = align256((h.n_pos + 4) * 4), pos_bytes = align256((n + 4) * 4);
+            const int64_t pq_bytes = align256(sbwt_path_quads(h.n_pos) * 16);
+            const int64_t new_pos = h.off_col + col_bytes, new_pq = new_pos + pos_bytes, new_trans = new_pq + pq_bytes;
+            const int64_t full = align256(new_trans + 32 * n_slots);
             if (g_max_image_bytes > 0 && full > g_max_image_bytes && level < 2) { e = hipErrorOutOfMemory; break; }
             char *nblob = nullptr;
             if ((e = hipMalloc((void **)&nblob, (size_t)full)) != hipSuccess) break;
-            if ((e = hipMemcpy(nblob, idx->blob, (size_t)h.blob_bytes, hipMemcpyDeviceToDevice)) != hipSuccess) { (void)hipFree(nblob); break; }
+            if ((e = hipMemcpy(nblob, idx->blob, (size_t)(h.off_col + col_bytes), hipMemcpyDeviceToDevice)) != hipSuccess ||
+                (e = hipMemcpy(nblob + new_pos, idx->blob + h.off_pos, (size_t)pos_bytes, hipMemcpyDeviceToDevice)) != hipSuccess ||
+                (e = hipMemcpy(nblob + new_pq, idx->blob + h.off_pq, (size_t)pq_bytes, hipMemcpyDeviceToDevice)) != hipSuccess) {
+                (void)hipFree(nblob);
+                break;
+            }
             (void)hipFree(idx->blob);
             idx->blob = nblob;
+            h.off_pos = new_pos;
+            h.off_pq = new_pq;
+            h.off_trans = new_trans;
             h.blob_bytes = full;
             sbwt_launch_trans_insert(idx->view(), reinterpret_cast<uint4 *>(idx->blob + h.off_trans), n_slots, alt_safe, 0);
             if ((e = hipDeviceSynchronize()) != hipSuccess) break;

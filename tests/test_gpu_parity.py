@@ -630,3 +630,44 @@ def test_reads_that_hop_between_strains(gpu, genome_case, variant):
         assert np.array_equal(got, oracle_batch(orc, bases2, off, True)), variant
     finally:
         capi.set_tuning("search_variant", -1)
+
+
+@pytest.mark.parametrize("variant", [4, 5])
+def test_stitched_chains_are_derived_data(gpu, variant):
+    # strains that share long stretches: the path order joins tails to heads through COPIES of the shared stretch
+    # ("path_stitch", on by default; "path_stitch_min" = shortest copy).  With copies, without, with few: the same bits,
+    # for reads that follow one strain and for reads that hop between strains inside the shared stretches.
+    k = 30
+    genomes = synth.coli3_like(150_000)
+    orc = OracleIndex.build([g.tobytes() for g in genomes], k, True, False, 8)
+    rng = np.random.default_rng(12)
+    bases, off = synth.sample_reads(genomes, 3000, 150, 0.01, 5)
+    n, L = 1500, 150
+    start = rng.integers(0, min(len(g) for g in genomes) - L, size=n)
+    which = rng.integers(0, 3, size=(n, 3))
+    hop = np.empty(n * L, dtype=np.uint8)
+    for r in range(n):
+        for seg in range(3):
+            hop[r * L + seg * 50:r * L + seg * 50 + 50] = genomes[which[r, seg]][start[r] + seg * 50:start[r] + seg * 50 + 50]
+    bases = np.concatenate([bases, hop])
+    off = np.concatenate([off, off[-1] + np.arange(1, n + 1, dtype=np.int64) * L])
+    bases = synth.inject(bases, 60, ord("N"), 3)
+    want_s = oracle_batch(orc, bases, off, True)
+    want_f = oracle_batch(orc, bases, off, False)
+    chains = {}
+    capi.set_tuning("search_variant", variant)
+    try:
+        for stitch, mn in ((1, 1), (0, 1), (1, 12)):
+            capi.set_tuning("path_stitch", stitch)
+            capi.set_tuning("path_stitch_min", mn)
+            idx = gpu_index_from_oracle(orc)
+            chains[(stitch, mn)] = idx.n_paths
+            got, _ = idx.streaming_search(bases, off)
+            assert np.array_equal(got, want_s), (stitch, mn)
+            got, _ = idx.search(bases, off)
+            assert np.array_equal(got, want_f), (stitch, mn)
+    finally:
+        capi.set_tuning("search_variant", -1)
+        capi.set_tuning("path_stitch", 1)
+        capi.set_tuning("path_stitch_min", 1)
+    assert chains[(1, 1)] < chains[(0, 1)], chains          # the copies did join paths

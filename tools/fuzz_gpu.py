@@ -38,6 +38,8 @@ while time.time() < t_end:
     capi.set_tuning("path_lookahead", int(rng.choice([0, 1, 8])))
     capi.set_tuning("path_safe", int(rng.choice([0, 1, 2, 2])))
     capi.set_tuning("image_level", int(rng.choice([0, 0, 0, 1, 2])))
+    capi.set_tuning("path_stitch", int(rng.choice([1, 1, 1, 0])))
+    capi.set_tuning("path_stitch_min", int(rng.choice([1, 1, 4, 16])))
     idx = capi.Index.create(bits.cols[0], bits.cols[1], bits.cols[2], bits.cols[3], bits.ssup if ssup else None,
                             bits.n_nodes, k, bits.n_kmers, int(rng.choice([0, 0, 2, min(k, 8)])))
     # reads
@@ -100,4 +102,5 @@ while time.time() < t_end:
 capi.set_tuning("search_variant", -1)
 capi.set_tuning("sort_reads", -1)
 capi.set_tuning("path_lookahead", 8); capi.set_tuning("path_safe", 2); capi.set_tuning("image_level", 0)
+capi.set_tuning("path_stitch", 1); capi.set_tuning("path_stitch_min", 1)
 print("fuzz ok:", case, "cases")
