@@ -142,7 +142,23 @@ struct SbwtWorkHeader {
     // (a base that is not upper-case ACGT), and that kernel's own ticket counter
     unsigned long long n_deferred;
     unsigned long long ticket2;
-    unsigned long long pad[17];
+    unsigned long long n_pieces;    // pieces of long reads planned for this launch (SbwtPieceTab)
+    unsigned long long pad[16];
+};
+
+// Long reads on the device.  One lane walks one read, so a read of more than 2 * piece k-mers is cut into pieces of
+// about `piece` k-mers (128 for small batches, so that a few genomes fill the chip, .. SBWT_PIECE for large ones, so that
+// the table stays small) that lanes take like reads of their own: ticket n_reads + z is piece z.  The check kernel that
+// runs ahead of every search lists the pieces' zones (k_check_uniform*), k_piece_bounds turns each zone into
+// pairs[z] = { first base, one past the last base } (global base offsets, like read_off[r], read_off[r + 1]) and
+// outs[z] = { first result slot, - }.  A piece starts at a k-mer whose window holds no lower-case acgt: for such a k-mer
+// the reference's result does not depend on what came before it (SBWT.hh:565-566 vs :427), so the results tile the read's.
+#define SBWT_PIECE 1024
+struct SbwtPieceTab {
+    uint4 *pairs = nullptr;         // nullptr: no splitting
+    uint4 *outs = nullptr;          // (the check kernel parks { read, zone, zones of the read } here first)
+    long long cap = 0;              // entries: total_bases / piece + 2 always suffice
+    int piece = SBWT_PIECE;         // k-mers per zone
 };
 static_assert(sizeof(SbwtWorkHeader) == 256, "workspace header is 256 bytes");
 
@@ -152,18 +168,21 @@ void sbwt_launch_encode(const char *d_bases, long long total_bases, uint4 *d_pac
 void sbwt_launch_search(const SbwtIndexView &ix, const uint4 *d_packed, const long long *d_read_off,
                         const long long *d_out_off, long long *d_out, long long n_reads, SbwtWorkHeader *ws,
                         int streaming, hipStream_t stream, int variant, long long total_groups, void *d_sort_scratch,
-                        long long sort_scratch_bytes, int sort_key_bits);
+                        long long sort_scratch_bytes, int sort_key_bits, SbwtPieceTab pt);
 // the fused route for batches of equal-length reads (sbwt_search_fused.hip): check + fused kernel + (for what it hands on)
 // selective encode + the general path kernel.  d_defer: room for one 32-bit entry per read.
 void sbwt_launch_search_fused(const SbwtIndexView &ix, const char *d_bases, long long total_bases, uint4 *d_packed,
                               const long long *d_read_off, const long long *d_out_off, long long *d_out, long long n_reads,
                               SbwtWorkHeader *ws, int streaming, hipStream_t stream, unsigned *d_defer,
-                              hipEvent_t ev_begin, hipEvent_t ev_end);
+                              hipEvent_t ev_begin, hipEvent_t ev_end, SbwtPieceTab pt);
 void sbwt_launch_encode_chained(const char *d_bases, long long total_bases, uint4 *d_packed, SbwtWorkHeader *ws,
                                 const unsigned *d_defer, int k, hipStream_t stream);
 void sbwt_launch_search_chained(const SbwtIndexView &ix, const uint4 *d_packed, const long long *d_read_off,
                                 const long long *d_out_off, long long *d_out, long long n_reads, SbwtWorkHeader *ws,
-                                int streaming, hipStream_t stream, const unsigned *d_defer);
+                                int streaming, hipStream_t stream, const unsigned *d_defer, SbwtPieceTab pt);
+// turns the zones the check kernel listed into pieces (after the bases are packed, before the search kernel)
+void sbwt_launch_piece_bounds(const uint4 *d_packed, const long long *d_read_off, const long long *d_out_off, int k,
+                              SbwtWorkHeader *ws, SbwtPieceTab pt, int behind_fused, hipStream_t stream);
 long long sbwt_sort_scratch_bytes(long long n_reads, int key_bits);
 const unsigned *sbwt_launch_sort_reads(const SbwtIndexView &ix, const uint4 *d_packed, const long long *d_read_off,
                                        long long n_reads, const SbwtWorkHeader *ws, void *d_scratch, long long scratch_bytes,

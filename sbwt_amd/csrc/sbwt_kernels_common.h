@@ -138,4 +138,26 @@ __device__ __forceinline__ bool sbwt_fused_ok(const SbwtWorkHeader *ws, int k) {
     return ws->u_bad == 0 && len >= 32 && len <= 32 * SBWT_FUSED_MAXG && len >= k;
 }
 
+// ---- long reads (SbwtPieceTab, sbwt_device.h) ----
+// the check kernels call this with every lane of a wave (valid: the lane has a read): a long read reserves its zones, and
+// the wave together notes { read, zone, zones of the read } for each of them (a genome as one read has 40 000)
+__device__ __forceinline__ void piece_zones_of_wave(i64 r, i64 len, bool valid, int k, SbwtWorkHeader *ws, const SbwtPieceTab &pt) {
+    const i64 m = len - k + 1;
+    const bool isl = valid && pt.pairs != nullptr && m > 2 * (i64)pt.piece;
+    u64 mask = __ballot(isl);
+    if (!mask) return;
+    const i64 nz = isl ? m / pt.piece : 0;
+    const i64 base = isl ? (i64)atomicAdd(&ws->n_pieces, (unsigned long long)nz) : 0;
+    const int lane = threadIdx.x & 63;
+    while (mask) {
+        const int src = __ffsll((i64)mask) - 1;
+        mask &= mask - 1;
+        const i64 rr = __shfl(r, src), bb = __shfl(base, src), nn = __shfl(nz, src);
+        for (i64 j = lane; j < nn && bb + j < pt.cap; j += 64)
+            pt.outs[bb + j] = make_uint4((unsigned)rr, (unsigned)((u64)rr >> 32), (unsigned)j, (unsigned)nn);
+    }
+}
+// is read r one that its pieces answer?  (the search kernels skip it then)
+__device__ __forceinline__ bool piece_read_is_cut(i64 m, int piece) { return m > 2 * (i64)piece; }
+
 static inline unsigned grid_for(i64 n) { return (unsigned)((n + 255) / 256); }

@@ -381,7 +381,7 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
                                                         const i64 *__restrict__ out_off, i64 *__restrict__ out,
                                                         i64 n_reads, SbwtWorkHeader *ws, int streaming,
                                                         const unsigned *__restrict__ perm,
-                                                        const unsigned *__restrict__ defer_list) {
+                                                        const unsigned *__restrict__ defer_list, SbwtPieceTab pt) {
     // perm != nullptr: ticket t is read perm[t] (the reads sorted by where they start in the path order, sbwt_sort.hip:
     // the lanes of a wave then walk the same paths and share their lines of col / pq / trans)
     // defer_list != nullptr: this launch runs behind k_search_fused (sbwt_search_fused.hip).  If that kernel took the batch,
@@ -391,6 +391,13 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
         n_reads = (i64)ws->n_deferred;
         perm = defer_list;
         if (n_reads == 0) return;                      // the usual case: nothing was handed on
+    }
+    // long reads: tickets n_reads .. n_tickets-1 are their pieces (SbwtPieceTab), the reads themselves are skipped
+    const bool cut = pt.pairs != nullptr && perm == nullptr;
+    i64 n_tickets = n_reads;
+    if (cut) {
+        const i64 np = (i64)ws->n_pieces;
+        n_tickets += np < pt.cap ? np : pt.cap;
     }
     typedef typename SearchTypes<WIDE>::pos_t pos_t;
     typedef typename SearchTypes<WIDE>::stage_t stage_t;
@@ -451,9 +458,9 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
             const unsigned rank = (unsigned)__popcll(need & low_mask(lane));
             if (mode == M_IDLE && rank < avail) {
                 rd = (i64)(pool_next + rank);
-                mode = (rd < n_reads) ? M_FETCH : M_DEAD;
+                mode = (rd < n_tickets) ? M_FETCH : M_DEAD;
                 rdok = (perm == nullptr);
-                if (uni && mode == M_FETCH && rdok) {
+                if (uni && mode == M_FETCH && rdok && rd < n_reads) {
                     // reads of one length: offsets by arithmetic, the walk for the first k-mer starts right away
                     const i64 P0 = u_read0 + rd * u_len;
                     obase = u_out0 + rd * u_stride;
@@ -467,7 +474,7 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
                     wstart = 0;
                     j = 0;
                     wk = (ps > 0) ? 1 : 0;
-                    if (m <= 0) mode = M_IDLE;
+                    if (m <= 0 || (cut && piece_read_is_cut(m, pt.piece))) mode = M_IDLE;
                     else if (p > 0) mode = M_INIT;
                     else { mode = M_STEP; l = 0; r = last_node; }
                 }
@@ -494,7 +501,10 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
         unsigned seg_src = 0;
         if (mode == M_FETCH) {
             kind = K_FETCH;                            // {read_off[rd], read_off[rd+1]}, {out_off[rd], ..}
-            if (rdok) {
+            if (rdok && rd >= n_reads) {               // a piece of a long read
+                a1 = pt.pairs + (rd - n_reads);
+                a2 = pt.outs + (rd - n_reads);
+            } else if (rdok) {
                 a1 = reinterpret_cast<const uint4 *>(read_off + rd);
                 a2 = reinterpret_cast<const uint4 *>(out_off + rd);
             } else {                                   // the aligned 16 bytes holding perm[ticket]
@@ -656,7 +666,7 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
                 if (SEG) { nseg = 0; i0 = 0; }
                 b = -1;
                 blo = -1;
-                if (m > 0) { do_plan = true; force = true; }
+                if (m > 0 && !(cut && rd < n_reads && piece_read_is_cut(m, pt.piece))) { do_plan = true; force = true; }
                 else mode = M_IDLE;
             }
         } else if (kind == K_RELOAD) {
@@ -1209,15 +1219,50 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
 // Do all reads have one length and all result ranges one stride?  (Sequencing reads usually do.)  Then the search
 // kernel computes a read's offsets instead of fetching them: one iteration and two gathers less per read.
 __global__ void __launch_bounds__(256) k_check_uniform(const i64 *__restrict__ read_off, const i64 *__restrict__ out_off,
-                                                       i64 n_reads, SbwtWorkHeader *ws) {
+                                                       i64 n_reads, SbwtWorkHeader *ws, int k, SbwtPieceTab pt) {
     const i64 t = (i64)blockIdx.x * 256 + threadIdx.x;
     const i64 len = read_off[1] - read_off[0], stride = (n_reads > 1) ? out_off[1] - out_off[0] : 0;
     if (t == 0) { ws->u_read0 = read_off[0]; ws->u_len = len; ws->u_out0 = out_off[0]; ws->u_stride = stride; }
-    if (t >= n_reads) return;
-    const bool bad = (read_off[t + 1] - read_off[t] != len) || (t + 1 < n_reads && out_off[t + 1] - out_off[t] != stride);
+    const bool valid = t < n_reads;
+    const i64 mylen = valid ? read_off[t + 1] - read_off[t] : 0;
+    piece_zones_of_wave(t, mylen, valid, k, ws, pt);
+    if (!valid) return;
+    const bool bad = (mylen != len) || (t + 1 < n_reads && out_off[t + 1] - out_off[t] != stride);
     // (a plain store: every writer stores the same value.  An atomicAdd per wave serialises on one address -- 0.75 ms for
     // 4 M ragged reads, a quarter of the search itself)
     if (__ballot(bad) != 0 && (threadIdx.x & 63) == 0) ws->u_bad = 1ull;
+}
+
+// ---- long reads: zones -> pieces (SbwtPieceTab, sbwt_device.h) ----
+// the first k-mer x' >= x of the read at base P0 whose window holds no lower-case acgt (packed groups: .z = ACGT after
+// toupper, .w = ACGT as written), or m
+__device__ static i64 piece_adjust(const uint4 *__restrict__ packed, i64 P0, i64 x, i64 m, int k) {
+    i64 cand = x, gi = -1;
+    unsigned low = 0;
+    for (i64 t = x; cand < m; t++) {
+        if (t - cand >= k) return cand;                // bases cand .. cand + k - 1 are clean
+        const i64 g = (P0 + t) >> 5;
+        if (g != gi) { const uint4 q = packed[g]; low = q.z & ~q.w; gi = g; }
+        if ((low >> ((P0 + t) & 31)) & 1u) cand = t + 1;
+    }
+    return m;
+}
+__global__ void __launch_bounds__(256) k_piece_bounds(const uint4 *__restrict__ packed, const i64 *__restrict__ read_off,
+                                                      const i64 *__restrict__ out_off, int k, const SbwtWorkHeader *ws,
+                                                      SbwtPieceTab pt, int behind_fused) {
+    if (behind_fused && sbwt_fused_ok(ws, k)) return;          // the fused kernel took the batch: no long reads in it
+    const i64 z = (i64)blockIdx.x * 256 + threadIdx.x;
+    const i64 np = (i64)ws->n_pieces < pt.cap ? (i64)ws->n_pieces : pt.cap;
+    if (z >= np) return;
+    const uint4 d = pt.outs[z];
+    const i64 r = (i64)(((u64)d.y << 32) | (u64)d.x), j = (i64)d.z, nz = (i64)d.w;
+    const i64 P0 = read_off[r], m = read_off[r + 1] - P0 - k + 1, ob = out_off[r];
+    const i64 s = j ? piece_adjust(packed, P0, j * pt.piece, m, k) : 0;
+    const i64 e = (j + 1 == nz) ? m : piece_adjust(packed, P0, (j + 1) * pt.piece, m, k);
+    const i64 b0 = P0 + (e > s ? s : 0), b1 = e > s ? P0 + e + k - 1 : P0;     // (an empty zone: a read of no bases)
+    const i64 o0 = ob + (e > s ? s : 0);
+    pt.pairs[z] = make_uint4((unsigned)b0, (unsigned)((u64)b0 >> 32), (unsigned)b1, (unsigned)((u64)b1 >> 32));
+    pt.outs[z] = make_uint4((unsigned)o0, (unsigned)((u64)o0 >> 32), 0u, 0u);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1244,22 +1289,36 @@ void sbwt_launch_encode_chained(const char *d_bases, long long total_bases, uint
 // the general path kernel behind k_search_fused: all reads when that kernel declined the batch, else the reads it handed on
 void sbwt_launch_search_chained(const SbwtIndexView &ix, const uint4 *d_packed, const long long *d_read_off,
                                 const long long *d_out_off, long long *d_out, long long n_reads, SbwtWorkHeader *ws,
-                                int streaming, hipStream_t stream, const unsigned *d_defer) {
-    const i64 want1 = (n_reads + 255) / 256;
+                                int streaming, hipStream_t stream, const unsigned *d_defer, SbwtPieceTab pt) {
+    const i64 want1 = (n_reads + pt.cap + 255) / 256;
     const unsigned cap = (ix.debug >> 8) ? (unsigned)(ix.debug >> 8) : 1280u;
     const unsigned g = (unsigned)(want1 < (i64)cap ? want1 : (i64)cap);
     hipLaunchKernelGGL((k_search_cert<false, 4, true>), dim3(g), dim3(256), 0, stream, ix, d_packed, d_read_off,
-                       d_out_off, d_out, (i64)n_reads, ws, streaming, (const unsigned *)nullptr, d_defer);
+                       d_out_off, d_out, (i64)n_reads, ws, streaming, (const unsigned *)nullptr, d_defer, pt);
+}
+
+void sbwt_launch_piece_bounds(const uint4 *d_packed, const long long *d_read_off, const long long *d_out_off, int k,
+                              SbwtWorkHeader *ws, SbwtPieceTab pt, int behind_fused, hipStream_t stream) {
+    if (!pt.pairs || pt.cap <= 0) return;
+    hipLaunchKernelGGL(k_piece_bounds, dim3(grid_for(pt.cap)), dim3(256), 0, stream, d_packed, d_read_off, d_out_off, k, ws, pt,
+                       behind_fused);
 }
 
 void sbwt_launch_search(const SbwtIndexView &ix, const uint4 *d_packed, const long long *d_read_off,
                         const long long *d_out_off, long long *d_out, long long n_reads, SbwtWorkHeader *ws,
                         int streaming, hipStream_t stream, int variant, long long total_groups, void *d_sort_scratch,
-                        long long sort_scratch_bytes, int sort_key_bits) {
+                        long long sort_scratch_bytes, int sort_key_bits, SbwtPieceTab pt) {
     if (n_reads <= 0) return;
     const unsigned *d_perm = nullptr;
     if (variant >= 1) {
-        i64 want1 = (n_reads + 255) / 256;
+        if (d_sort_scratch) pt = SbwtPieceTab();       // (sorted tickets: whole reads)
+        i64 want1 = (n_reads + pt.cap + 255) / 256;
+        // the check kernel notes what the path kernel wants to know about the offsets and lists the zones of long reads
+        if (!(ix.debug & 8) || pt.pairs)
+            hipLaunchKernelGGL(k_check_uniform, dim3(grid_for(n_reads)), dim3(256), 0, stream, d_read_off, d_out_off,
+                               (i64)n_reads, ws, ix.k, pt);
+        if (ix.debug & 8) (void)hipMemsetAsync(&ws->u_bad, 0xFF, 8, stream);       // experiment: the general offset path
+        sbwt_launch_piece_bounds(d_packed, d_read_off, d_out_off, ix.k, ws, pt, 0, stream);
         unsigned grid1 = (unsigned)(want1 < 2048 ? want1 : 2048);
         // 32-bit positions need every column index (and n_nodes + 64) below 2^31 and < 2^31 packed groups
         const bool wide = ix.n_nodes >= ((1ll << 31) - 128) || total_groups >= (1ll << 31) - 4 || (ix.debug & 16);
@@ -1268,21 +1327,16 @@ void sbwt_launch_search(const SbwtIndexView &ix, const uint4 *d_packed, const lo
         unsigned g = grid1 < cap ? grid1 : cap;
         if (wide)
             hipLaunchKernelGGL((k_search_cert<true, 4, false>), dim3(g), dim3(256), 0, stream, ix, d_packed, d_read_off,
-                               d_out_off, d_out, (i64)n_reads, ws, streaming, d_perm, (const unsigned *)nullptr);
+                               d_out_off, d_out, (i64)n_reads, ws, streaming, d_perm, (const unsigned *)nullptr, pt);
         else if (variant >= 2 && ix.col && streaming) {    // path order (the default when the index has one)
-            if (!(ix.debug & 8))
-                hipLaunchKernelGGL(k_check_uniform, dim3(grid_for(n_reads)), dim3(256), 0, stream, d_read_off, d_out_off,
-                                   (i64)n_reads, ws);
-            else
-                (void)hipMemsetAsync(&ws->u_bad, 0xFF, 8, stream);       // experiment: the general offset path
             if (d_sort_scratch)
                 d_perm = sbwt_launch_sort_reads(ix, d_packed, d_read_off, n_reads, ws, d_sort_scratch, sort_scratch_bytes,
                                                 sort_key_bits, stream);
             hipLaunchKernelGGL((k_search_cert<false, 4, true>), dim3(g), dim3(256), 0, stream, ix, d_packed, d_read_off,
-                               d_out_off, d_out, (i64)n_reads, ws, streaming, d_perm, (const unsigned *)nullptr);
+                               d_out_off, d_out, (i64)n_reads, ws, streaming, d_perm, (const unsigned *)nullptr, pt);
         } else
             hipLaunchKernelGGL((k_search_cert<false, 4, false>), dim3(g), dim3(256), 0, stream, ix, d_packed, d_read_off,
-                               d_out_off, d_out, (i64)n_reads, ws, streaming, d_perm, (const unsigned *)nullptr);
+                               d_out_off, d_out, (i64)n_reads, ws, streaming, d_perm, (const unsigned *)nullptr, pt);
         return;
     }
     // persistent-style grid: enough 256-thread workgroups to fill 256 CUs x 8 workgroups, never

@@ -743,21 +743,25 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
 
 // Do all reads have one length and all result ranges one stride?  Thread 0 also notes the first offsets.
 __global__ void __launch_bounds__(256) k_check_uniform2(const i64 *__restrict__ read_off, const i64 *__restrict__ out_off,
-                                                        i64 n_reads, SbwtWorkHeader *ws) {
+                                                        i64 n_reads, SbwtWorkHeader *ws, int k, SbwtPieceTab pt) {
     const i64 t = (i64)blockIdx.x * 256 + threadIdx.x;
     const i64 len = read_off[1] - read_off[0], stride = (n_reads > 1) ? out_off[1] - out_off[0] : 0;
     if (t == 0) { ws->u_read0 = read_off[0]; ws->u_len = len; ws->u_out0 = out_off[0]; ws->u_stride = stride; }
-    if (t >= n_reads) return;
-    const bool bad = (read_off[t + 1] - read_off[t] != len) || (t + 1 < n_reads && out_off[t + 1] - out_off[t] != stride);
+    const bool valid = t < n_reads;
+    const i64 mylen = valid ? read_off[t + 1] - read_off[t] : 0;
+    piece_zones_of_wave(t, mylen, valid, k, ws, pt);                       // long reads: for the general kernel behind
+    if (!valid) return;
+    const bool bad = (mylen != len) || (t + 1 < n_reads && out_off[t + 1] - out_off[t] != stride);
     if (__ballot(bad) != 0 && (threadIdx.x & 63) == 0) ws->u_bad = 1ull;
 }
 
 void sbwt_launch_search_fused(const SbwtIndexView &ix, const char *d_bases, long long total_bases, uint4 *d_packed,
                               const long long *d_read_off, const long long *d_out_off, long long *d_out, long long n_reads,
                               SbwtWorkHeader *ws, int streaming, hipStream_t stream, unsigned *d_defer,
-                              hipEvent_t ev_begin, hipEvent_t ev_end) {
+                              hipEvent_t ev_begin, hipEvent_t ev_end, SbwtPieceTab pt) {
     if (n_reads <= 0) return;
-    hipLaunchKernelGGL(k_check_uniform2, dim3(grid_for(n_reads)), dim3(256), 0, stream, d_read_off, d_out_off, (i64)n_reads, ws);
+    hipLaunchKernelGGL(k_check_uniform2, dim3(grid_for(n_reads)), dim3(256), 0, stream, d_read_off, d_out_off, (i64)n_reads, ws,
+                       ix.k, pt);
     const i64 want = (n_reads + 255) / 256;
     const unsigned cap = (ix.debug >> 8) ? (unsigned)(ix.debug >> 8) : 1280u;
     const unsigned g = (unsigned)(want < (i64)cap ? want : (i64)cap);
@@ -767,5 +771,6 @@ void sbwt_launch_search_fused(const SbwtIndexView &ix, const char *d_bases, long
     if (ev_end) (void)hipEventRecord(ev_end, stream);
     // what the fused kernel did not take: everything when the reads are not of one length, else the reads it handed on
     sbwt_launch_encode_chained(d_bases, total_bases, d_packed, ws, d_defer, ix.k, stream);
-    sbwt_launch_search_chained(ix, d_packed, d_read_off, d_out_off, d_out, n_reads, ws, streaming, stream, d_defer);
+    sbwt_launch_piece_bounds(d_packed, d_read_off, d_out_off, ix.k, ws, pt, 1, stream);
+    sbwt_launch_search_chained(ix, d_packed, d_read_off, d_out_off, d_out, n_reads, ws, streaming, stream, d_defer, pt);
 }

@@ -106,6 +106,8 @@ static int g_path_safe = [] { const char *e = getenv("SBWTGPU_PATH_SAFE"); retur
 static int g_path_lookahead = [] { const char *e = getenv("SBWTGPU_PATH_LOOKAHEAD"); return e ? atoi(e) : 8; }();   // 0: the blind rule
 static int g_path_order = [] { const char *e = getenv("SBWTGPU_PATH_ORDER"); return e ? atoi(e) : 1; }();
 // stitched chains (sbwt_derived.hip): 0 = vertex-disjoint paths only; the shortest stretch worth copying
+// long reads are cut into pieces on the device (SbwtPieceTab); 0: one lane per read whatever its length (tests)
+static int g_split_long = [] { const char *e = getenv("SBWTGPU_SPLIT_LONG"); return e ? atoi(e) : 1; }();
 static int g_path_stitch = [] { const char *e = getenv("SBWTGPU_PATH_STITCH"); return e ? atoi(e) : 1; }();
 static int g_path_stitch_min = [] { const char *e = getenv("SBWTGPU_PATH_STITCH_MIN"); return e ? atoi(e) : 1; }();
 static int g_sparse_depth = [] { const char *e = getenv("SBWTGPU_SPARSE_PRECALC"); return e ? atoi(e) : 31; }();
@@ -188,6 +190,7 @@ int sbwtgpu_set_tuning(const char *key, int64_t value) {
     if (!strcmp(key, "path_safe")) { g_path_safe = (int)value; return SBWTGPU_OK; }   // indexes created afterwards
     if (!strcmp(key, "path_lookahead")) { g_path_lookahead = value < 0 ? 0 : value > 64 ? 64 : (int)value; return SBWTGPU_OK; }
     if (!strcmp(key, "path_order")) { g_path_order = (int)value; return SBWTGPU_OK; }   // indexes created afterwards
+    if (!strcmp(key, "split_long")) { g_split_long = (int)value; return SBWTGPU_OK; }
     if (!strcmp(key, "path_stitch")) { g_path_stitch = (int)value; return SBWTGPU_OK; }   // indexes created afterwards
     if (!strcmp(key, "path_stitch_min")) { g_path_stitch_min = (int)value < 1 ? 1 : (int)value; return SBWTGPU_OK; }
     if (!strcmp(key, "sparse_depth")) {      // takes effect for indexes created afterwards
@@ -775,10 +778,35 @@ static inline int64_t ws_sort_capacity(int64_t total_bases) {      // only when 
 }
 // the fused route's list of reads handed on to the general kernel: one 32-bit entry per read, reads of >= 32 bases
 static inline int64_t ws_defer_bytes(int64_t total_bases) { return align256(total_bases / 8 + 256); }
+// the pieces of long reads (SbwtPieceTab, sbwt_device.h): two 16-byte entries per zone.  Zones of 128 k-mers while that
+// makes at most 2^18 of them (a few genomes as single reads then fill the chip), doubling up to SBWT_PIECE beyond.
+static inline int ws_piece_len(int64_t total_bases) {
+    int piece = 128;
+    while (piece < SBWT_PIECE && total_bases / piece > ((int64_t)1 << 18)) piece *= 2;
+    return piece;
+}
+// (entries: non-decreasing in total_bases -- a workspace sized for a large batch serves every smaller one)
+static inline int64_t ws_piece_cap(int64_t total_bases) {
+    return std::max<int64_t>(total_bases / SBWT_PIECE, std::min<int64_t>(total_bases / 128, (int64_t)1 << 18)) + 2;
+}
+static inline int64_t ws_piece_bytes(int64_t total_bases) { return align256(ws_piece_cap(total_bases) * 32); }
+static inline int64_t ws_fixed_bytes(int64_t total_bases) {
+    return align256(ws_packed_bytes(total_bases)) + ws_defer_bytes(total_bases) + ws_piece_bytes(total_bases);
+}
 int64_t sbwtgpu_search_workspace_bytes(int64_t total_bases) {
     if (total_bases < 0) total_bases = 0;
     const int64_t n_cap = ws_sort_capacity(total_bases);
-    return align256(ws_packed_bytes(total_bases)) + ws_defer_bytes(total_bases) + (n_cap ? 32 * n_cap + ((int64_t)16 << 20) : 0);
+    return ws_fixed_bytes(total_bases) + (n_cap ? 32 * n_cap + ((int64_t)16 << 20) : 0);
+}
+static SbwtPieceTab ws_piece_tab(void *d_ws, int64_t total_bases) {
+    SbwtPieceTab pt;
+    if (!g_split_long) return pt;
+    char *base = static_cast<char *>(d_ws) + align256(ws_packed_bytes(total_bases)) + ws_defer_bytes(total_bases);
+    pt.cap = ws_piece_cap(total_bases);
+    pt.piece = ws_piece_len(total_bases);
+    pt.pairs = reinterpret_cast<uint4 *>(base);
+    pt.outs = pt.pairs + pt.cap;
+    return pt;
 }
 
 static const char *RANK_ONLY_MSG =
@@ -857,13 +885,14 @@ int sbwtgpu_search_encoded_dev(const sbwtgpu_index *idx, int64_t total_bases, co
     const bool want_sort = path_kernel && g_sort_reads > 0;
     if (want_sort) {
         // the scratch lives in the caller's workspace, behind the packed bases (no allocation, nothing shared between calls)
-        const int64_t off = align256(ws_packed_bytes(total_bases)) + ws_defer_bytes(total_bases);
+        const int64_t off = ws_fixed_bytes(total_bases);
         sort_bytes = sbwt_sort_scratch_bytes(n_reads, key_bits);
         if (n_reads <= ws_sort_capacity(total_bases) && off + sort_bytes <= ws_bytes) sort_scratch = static_cast<char *>(d_ws) + off;
     }
     sbwt_launch_search(idx->view(), packed, reinterpret_cast<const long long *>(d_read_off),
                        reinterpret_cast<const long long *>(d_out_off), reinterpret_cast<long long *>(d_out), n_reads,
-                       ws, eff_streaming, st, variant, total_bases / SBWT_GROUP_BASES + 2, sort_scratch, sort_bytes, key_bits);
+                       ws, eff_streaming, st, variant, total_bases / SBWT_GROUP_BASES + 2, sort_scratch, sort_bytes, key_bits,
+                       ws_piece_tab(d_ws, total_bases));
     e = hipGetLastError();
     if (e != hipSuccess) return fail(SBWTGPU_ERR_HIP, "kernel launch: %s", hipGetErrorString(e));
     return SBWTGPU_OK;
@@ -936,7 +965,7 @@ static int search_dev_common(const sbwtgpu_index *idx, const char *d_bases, int6
             }
             sbwt_launch_search_fused(idx->view(), d_bases, total_bases, packed, reinterpret_cast<const long long *>(d_read_off),
                                      reinterpret_cast<const long long *>(d_out_off), reinterpret_cast<long long *>(d_out), n_reads,
-                                     ws, eff_streaming, st, defer, e0, e1);
+                                     ws, eff_streaming, st, defer, e0, e1, ws_piece_tab(d_ws, total_bases));
             hipError_t e = hipGetLastError();
             if (e != hipSuccess) return fail(SBWTGPU_ERR_HIP, "kernel launch: %s", hipGetErrorString(e));
             return SBWTGPU_OK;

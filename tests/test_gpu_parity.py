@@ -671,3 +671,61 @@ def test_stitched_chains_are_derived_data(gpu, variant):
         capi.set_tuning("path_stitch", 1)
         capi.set_tuning("path_stitch_min", 1)
     assert chains[(1, 1)] < chains[(0, 1)], chains          # the copies did join paths
+
+
+def _search_dev(idx, bases, off, k, streaming):
+    import torch
+    dev = torch.device("cuda:0")
+    lens = np.diff(off)
+    oo = np.concatenate([[0], np.cumsum(np.maximum(lens - k + 1, 0))]).astype(np.int64)
+    d_b = torch.from_numpy(np.ascontiguousarray(bases)).to(dev)
+    d_ro = torch.from_numpy(off.astype(np.int64)).to(dev)
+    d_oo = torch.from_numpy(oo).to(dev)
+    d_out = torch.full((int(oo[-1]),), -7, dtype=torch.int64, device=dev)
+    wsb = capi.search_workspace_bytes(d_b.numel())
+    d_ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    idx.streaming_search_dev(d_b.data_ptr(), d_b.numel(), d_ro.data_ptr(), len(off) - 1, d_out.data_ptr(), d_oo.data_ptr(),
+                             d_ws.data_ptr(), wsb, torch.cuda.current_stream().cuda_stream, streaming)
+    torch.cuda.synchronize()
+    return d_out.cpu().numpy()
+
+
+@pytest.mark.parametrize("variant", [5, 4, 1])
+def test_long_reads_are_cut_on_the_device_too(gpu, genome_case, variant):
+    # the device-pointer entry points cannot cut reads on the host: the check kernel lists the zones of reads longer than
+    # 2 * SBWT_PIECE (1024) k-mers, k_piece_bounds moves each cut to a k-mer without lower-case bases, lanes take the pieces
+    # as tickets of their own.  Lower case around the cut points, a read that is all lower case, lengths around the
+    # threshold, short reads in between; then a batch of equally long reads (the path kernel's offset arithmetic).
+    genomes, orc = genome_case
+    idx = gpu_index_from_oracle(orc)
+    k = orc.k
+    g0 = genomes[0].tobytes()
+    long1 = bytearray(g0[1000:151000])
+    rnd = random.Random(6)
+    for _ in range(300):
+        long1[rnd.randrange(len(long1))] = ord(rnd.choice("ACGTNacgtn"))
+    lower_run = bytearray(g0[20000:60000])
+    lower_run[1000:1100] = bytes(lower_run[1000:1100]).lower()          # lower case exactly around cut points
+    lower_run[2040:2060] = bytes(lower_run[2040:2060]).lower()
+    lower_run[3070:3075] = b"acgta"
+    lower_run[5000:9000] = bytes(lower_run[5000:9000]).lower()          # ... and across several zones
+    all_lower = g0[500:20500].lower()
+    reads = [bytes(long1), g0[:100], bytes(lower_run), all_lower, g0[300:300 + 2048 + k - 1], g0[300:300 + 2048 + k],
+             g0[7:7 + 3 * 1024 + k + 4], b"", b"ACGT", genomes[1].tobytes()[:90000], g0[40:190]]
+    bases, off = capi.concat_reads(reads)
+    capi.set_tuning("search_variant", variant)
+    try:
+        for streaming in (True, False):
+            want = oracle_batch(orc, bases, off, streaming)
+            assert np.array_equal(_search_dev(idx, bases, off, k, streaming), want), streaming
+            capi.set_tuning("split_long", 0)               # one lane per read: the same bits
+            try:
+                assert np.array_equal(_search_dev(idx, bases, off, k, streaming), want), streaming
+            finally:
+                capi.set_tuning("split_long", 1)
+        uni = [genomes[2].tobytes()[s:s + 5000] for s in range(0, 100000, 4000)]
+        uni[3] = uni[3][:2000] + uni[3][2000:2100].lower() + uni[3][2100:]
+        bases, off = capi.concat_reads(uni)
+        assert np.array_equal(_search_dev(idx, bases, off, k, True), oracle_batch(orc, bases, off, True))
+    finally:
+        capi.set_tuning("search_variant", -1)

@@ -60,6 +60,24 @@ while time.time() < t_end:
             bases[off[r]:off[r + 1]] = cat[st[r]:st[r] + lens[r]]
         flip = rng.random(len(bases)) < 0.01
         bases[flip] = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=int(flip.sum()))]
+    if rng.integers(0, 4) == 0:      # a few long reads (cut into pieces on the device), some with lower-case stretches
+        cat = np.concatenate(genomes)
+        extra = []
+        for _ in range(int(rng.integers(1, 12))):
+            ln = int(min(rng.integers(260, 6000), len(cat)))
+            s0 = int(rng.integers(0, len(cat) - ln + 1))
+            rd = cat[s0:s0 + ln].copy()
+            for _ in range(int(rng.integers(0, 4))):
+                a0 = int(rng.integers(0, ln)); a1 = min(ln, a0 + int(rng.integers(1, 400)))
+                rd[a0:a1] = np.frombuffer(rd[a0:a1].tobytes().lower(), dtype=np.uint8)
+            extra.append(rd)
+        pos = int(rng.integers(0, len(off)))                      # ... somewhere among the others
+        lens = np.diff(off)
+        parts = [bases[off[r]:off[r + 1]] for r in range(len(lens))]
+        parts[pos:pos] = extra
+        bases = np.concatenate(parts) if parts else np.zeros(0, dtype=np.uint8)
+        off = np.concatenate([[0], np.cumsum([len(x) for x in parts])]).astype(np.int64)
+        nr = len(parts)
     if len(bases) > 100:
         bases = synth.inject(bases, int(rng.integers(0, 30)), ord("N"), int(rng.integers(1, 1 << 30)))
         bases = synth.inject(bases, int(rng.integers(0, 30)), int(rng.choice(list(b"acgtn"))), int(rng.integers(1, 1 << 30)))
