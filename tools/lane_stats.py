@@ -10,6 +10,6 @@ import tools.ab_bench as ab   # runs the bench
 raw = torch.zeros(32, dtype=torch.int64)
 hdr = ab.d_ws[:256].cpu().numpy().view("uint64")
 names = ["fetch", "reload", "init", "step", "trans", "pos/bridge", "ext", "idle"]
-tot = sum(int(hdr[13 + 8 + q]) for q in range(8))
-print({n: int(hdr[13 + 8 + q]) for q, n in enumerate(names)}, "lane-iterations", tot, "wave-iterations", int(hdr[13 + 16]), "lanes busy/iter", (tot - int(hdr[13 + 8 + 7])) / max(1, int(hdr[13 + 16])),
-      "path-run iterations cut short by the window", int(hdr[13 + 17]))
+tot = sum(int(hdr[14 + 8 + q]) for q in range(8))
+print({n: int(hdr[14 + 8 + q]) for q, n in enumerate(names)}, "lane-iterations", tot, "wave-iterations", int(hdr[14 + 16]), "lanes busy/iter", (tot - int(hdr[14 + 8 + 7])) / max(1, int(hdr[14 + 16])),
+      "path-run iterations cut short by the window", int(hdr[14 + 17]))

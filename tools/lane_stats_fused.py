@@ -7,7 +7,7 @@ import tools.ab_step as ab
 hdr = ab.d_ws[:256].cpu().numpy().view("uint64")
 names = ["sparse lookup", "filter probe", "dense table", "second level", "interval update", "path run", "transition", "bridge", "pos",
          "idle"]
-base = 15        # pad[0] is the 16th 8-byte word of the header
+base = 16        # pad[0] is the 17th 8-byte word of the header
 vals = [int(hdr[base + q]) for q in range(10)]
 tot = sum(vals)
 nr = ab.n_reads
