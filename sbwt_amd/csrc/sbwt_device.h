@@ -126,7 +126,7 @@ static __host__ __device__ inline unsigned sbwt_pf_bits(unsigned long long h) { 
 struct SbwtWorkHeader {
     unsigned long long ticket;      // next read to hand out
     int status;                     // 0 or SBWTGPU_ERR_NOT_SINGLETON
-    int pad0;
+    int rg_sample;                  // reads the check kernel sampled for rg_long (0: ragged batches go the two-pass route)
     // work done by the last search launch (for the roofline's algorithmic-byte accounting)
     unsigned long long n_stream;    // streaming one-step extensions (SBWT.hh:562-575)
     unsigned long long n_search;    // full searches started (SBWT.hh:389-415)
@@ -143,7 +143,8 @@ struct SbwtWorkHeader {
     unsigned long long n_deferred;
     unsigned long long ticket2;
     unsigned long long n_pieces;    // pieces of long reads planned for this launch (SbwtPieceTab)
-    unsigned long long pad[16];
+    unsigned long long pad[15];
+    unsigned long long rg_long;     // of the sampled reads, those too long for the fused kernel
 };
 
 // Long reads on the device.  One lane walks one read, so a read of more than 2 * piece k-mers is cut into pieces of
@@ -174,9 +175,9 @@ void sbwt_launch_search(const SbwtIndexView &ix, const uint4 *d_packed, const lo
 void sbwt_launch_search_fused(const SbwtIndexView &ix, const char *d_bases, long long total_bases, uint4 *d_packed,
                               const long long *d_read_off, const long long *d_out_off, long long *d_out, long long n_reads,
                               SbwtWorkHeader *ws, int streaming, hipStream_t stream, unsigned *d_defer,
-                              hipEvent_t ev_begin, hipEvent_t ev_end, SbwtPieceTab pt);
+                              hipEvent_t ev_begin, hipEvent_t ev_end, SbwtPieceTab pt, int ragged_ok);
 void sbwt_launch_encode_chained(const char *d_bases, long long total_bases, uint4 *d_packed, SbwtWorkHeader *ws,
-                                const unsigned *d_defer, int k, hipStream_t stream);
+                                const unsigned *d_defer, const long long *d_read_off, int k, hipStream_t stream);
 void sbwt_launch_search_chained(const SbwtIndexView &ix, const uint4 *d_packed, const long long *d_read_off,
                                 const long long *d_out_off, long long *d_out, long long n_reads, SbwtWorkHeader *ws,
                                 int streaming, hipStream_t stream, const unsigned *d_defer, SbwtPieceTab pt);

@@ -133,9 +133,22 @@ __device__ __forceinline__ unsigned sbwt_trans_slot(unsigned t, unsigned c, unsi
 // (k_check_uniform2 has filled in the header) that holds at least one k-mer; the kernels chained behind it ask the same
 // question to know what is left for them.
 #define SBWT_FUSED_MAXG 5
-__device__ __forceinline__ bool sbwt_fused_ok(const SbwtWorkHeader *ws, int k) {
+// 0: the batch is the general kernel's; 1: reads of one length (offsets by arithmetic); 2: reads of any lengths, the
+// fused kernel fetches their offsets and hands on what is longer than 32 * SBWT_FUSED_MAXG bases (at most one in eight
+// of the reads the check kernel sampled: more, and its refills would mostly encode reads it cannot take)
+#define SBWT_FUSED_MAXLEN (32 * SBWT_FUSED_MAXG)
+__device__ __forceinline__ int sbwt_fused_mode(const SbwtWorkHeader *ws, int k) {
     const long long len = ws->u_len;
-    return ws->u_bad == 0 && len >= 32 && len <= 32 * SBWT_FUSED_MAXG && len >= k;
+    if (ws->u_bad == 0) return (len >= 32 && len <= SBWT_FUSED_MAXLEN && len >= k) ? 1 : 0;
+    return (ws->rg_sample > 0 && ws->rg_long * 8ull <= (unsigned long long)ws->rg_sample) ? 2 : 0;
+}
+// the check kernels: thread t of the first blocks counts into the sample
+#define SBWT_RG_SAMPLE 4096
+__device__ __forceinline__ void fused_sample_of_wave(i64 t, i64 len, bool valid, i64 n_reads, int rg_enable, SbwtWorkHeader *ws) {
+    if (t == 0) ws->rg_sample = rg_enable ? (int)(n_reads < SBWT_RG_SAMPLE ? n_reads : SBWT_RG_SAMPLE) : 0;
+    if (t - (threadIdx.x & 63) >= SBWT_RG_SAMPLE) return;          // (wave-uniform)
+    const u64 lm = __ballot(valid && t < SBWT_RG_SAMPLE && len > SBWT_FUSED_MAXLEN);
+    if (lm && (threadIdx.x & 63) == 0) atomicAdd(&ws->rg_long, (unsigned long long)__popcll(lm));
 }
 
 // ---- long reads (SbwtPieceTab, sbwt_device.h) ----

@@ -82,10 +82,24 @@ __global__ void __launch_bounds__(256) k_encode(const unsigned char *__restrict_
 // workspace header alone: the fused kernel's counters are in it.
 __global__ void __launch_bounds__(256) k_encode_chained(const unsigned char *__restrict__ bases, i64 total,
                                                         uint4 *__restrict__ packed, i64 n_groups, const SbwtWorkHeader *ws,
-                                                        const unsigned *__restrict__ defer_list, int k, int aligned16) {
+                                                        const unsigned *__restrict__ defer_list,
+                                                        const i64 *__restrict__ read_off, int k, int aligned16) {
     const i64 t0 = (i64)blockIdx.x * 256 + threadIdx.x, stride = (i64)gridDim.x * 256;
-    if (!sbwt_fused_ok(ws, k)) {
+    const int fmode = sbwt_fused_mode(ws, k);
+    if (fmode == 0) {
         for (i64 g = t0; g < n_groups; g += stride) packed[g] = encode_group(bases, total, g, aligned16);
+        return;
+    }
+    if (fmode == 2) {
+        // reads of any lengths: a wave per read that was handed on, its lanes over the read's groups (it may be a genome)
+        const i64 nd = (i64)ws->n_deferred, nw = stride >> 6;
+        const int lane = threadIdx.x & 63;
+        for (i64 d = t0 >> 6; d < nd; d += nw) {
+            const i64 r = (i64)defer_list[d], P0 = read_off[r], P1 = read_off[r + 1];
+            if (P1 <= P0) continue;
+            for (i64 g = (P0 >> 5) + lane; g <= ((P1 - 1) >> 5) && g < n_groups; g += 64)
+                packed[g] = encode_group(bases, total, g, aligned16);
+        }
         return;
     }
     const i64 nd = (i64)ws->n_deferred, len = ws->u_len, r0 = ws->u_read0;
@@ -387,13 +401,14 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
     // defer_list != nullptr: this launch runs behind k_search_fused (sbwt_search_fused.hip).  If that kernel took the batch,
     // what is left are the reads it handed on: n_deferred tickets, ticket t is read defer_list[t].
     unsigned long long *const ticket = defer_list ? &ws->ticket2 : &ws->ticket;
-    if (defer_list && sbwt_fused_ok(ws, ix.k)) {
+    if (defer_list && sbwt_fused_mode(ws, ix.k)) {
         n_reads = (i64)ws->n_deferred;
         perm = defer_list;
         if (n_reads == 0) return;                      // the usual case: nothing was handed on
     }
-    // long reads: tickets n_reads .. n_tickets-1 are their pieces (SbwtPieceTab), the reads themselves are skipped
-    const bool cut = pt.pairs != nullptr && perm == nullptr;
+    // long reads: tickets n_reads .. n_tickets-1 are their pieces (SbwtPieceTab), the reads themselves are skipped.
+    // (a lane holds piece z as rd = -(z + 1): with perm, read numbers and ticket numbers are different things)
+    const bool cut = pt.pairs != nullptr;
     i64 n_tickets = n_reads;
     if (cut) {
         const i64 np = (i64)ws->n_pieces;
@@ -460,7 +475,8 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
                 rd = (i64)(pool_next + rank);
                 mode = (rd < n_tickets) ? M_FETCH : M_DEAD;
                 rdok = (perm == nullptr);
-                if (uni && mode == M_FETCH && rdok && rd < n_reads) {
+                if (rd >= n_reads) { rd = -(rd - n_reads) - 1; rdok = true; }
+                if (uni && mode == M_FETCH && rdok && rd >= 0) {
                     // reads of one length: offsets by arithmetic, the walk for the first k-mer starts right away
                     const i64 P0 = u_read0 + rd * u_len;
                     obase = u_out0 + rd * u_stride;
@@ -501,9 +517,9 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
         unsigned seg_src = 0;
         if (mode == M_FETCH) {
             kind = K_FETCH;                            // {read_off[rd], read_off[rd+1]}, {out_off[rd], ..}
-            if (rdok && rd >= n_reads) {               // a piece of a long read
-                a1 = pt.pairs + (rd - n_reads);
-                a2 = pt.outs + (rd - n_reads);
+            if (rdok && rd < 0) {                      // a piece of a long read
+                a1 = pt.pairs + (-rd - 1);
+                a2 = pt.outs + (-rd - 1);
             } else if (rdok) {
                 a1 = reinterpret_cast<const uint4 *>(read_off + rd);
                 a2 = reinterpret_cast<const uint4 *>(out_off + rd);
@@ -666,7 +682,7 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
                 if (SEG) { nseg = 0; i0 = 0; }
                 b = -1;
                 blo = -1;
-                if (m > 0 && !(cut && rd < n_reads && piece_read_is_cut(m, pt.piece))) { do_plan = true; force = true; }
+                if (m > 0 && !(cut && rd >= 0 && piece_read_is_cut(m, pt.piece))) { do_plan = true; force = true; }
                 else mode = M_IDLE;
             }
         } else if (kind == K_RELOAD) {
@@ -1220,6 +1236,7 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
 // kernel computes a read's offsets instead of fetching them: one iteration and two gathers less per read.
 __global__ void __launch_bounds__(256) k_check_uniform(const i64 *__restrict__ read_off, const i64 *__restrict__ out_off,
                                                        i64 n_reads, SbwtWorkHeader *ws, int k, SbwtPieceTab pt) {
+    // (rg_sample stays 0: a launch without the fused kernel in front)
     const i64 t = (i64)blockIdx.x * 256 + threadIdx.x;
     const i64 len = read_off[1] - read_off[0], stride = (n_reads > 1) ? out_off[1] - out_off[0] : 0;
     if (t == 0) { ws->u_read0 = read_off[0]; ws->u_len = len; ws->u_out0 = out_off[0]; ws->u_stride = stride; }
@@ -1250,7 +1267,7 @@ __device__ static i64 piece_adjust(const uint4 *__restrict__ packed, i64 P0, i64
 __global__ void __launch_bounds__(256) k_piece_bounds(const uint4 *__restrict__ packed, const i64 *__restrict__ read_off,
                                                       const i64 *__restrict__ out_off, int k, const SbwtWorkHeader *ws,
                                                       SbwtPieceTab pt, int behind_fused) {
-    if (behind_fused && sbwt_fused_ok(ws, k)) return;          // the fused kernel took the batch: no long reads in it
+    if (behind_fused && sbwt_fused_mode(ws, k) == 1) return;   // the fused kernel took a batch of short reads
     const i64 z = (i64)blockIdx.x * 256 + threadIdx.x;
     const i64 np = (i64)ws->n_pieces < pt.cap ? (i64)ws->n_pieces : pt.cap;
     if (z >= np) return;
@@ -1278,12 +1295,13 @@ void sbwt_launch_encode(const char *d_bases, long long total_bases, uint4 *d_pac
 }
 
 void sbwt_launch_encode_chained(const char *d_bases, long long total_bases, uint4 *d_packed, SbwtWorkHeader *ws,
-                                const unsigned *d_defer, int k, hipStream_t stream) {
+                                const unsigned *d_defer, const long long *d_read_off, int k, hipStream_t stream) {
     i64 n_groups = (total_bases + SBWT_GROUP_BASES - 1) / SBWT_GROUP_BASES + 2;
     int aligned = ((uintptr_t)d_bases & 15) == 0;
     const i64 want = (n_groups + 255) / 256;
     hipLaunchKernelGGL(k_encode_chained, dim3((unsigned)(want < 4096 ? want : 4096)), dim3(256), 0, stream,
-                       reinterpret_cast<const unsigned char *>(d_bases), (i64)total_bases, d_packed, n_groups, ws, d_defer, k, aligned);
+                       reinterpret_cast<const unsigned char *>(d_bases), (i64)total_bases, d_packed, n_groups, ws, d_defer, d_read_off, k,
+                       aligned);
 }
 
 // the general path kernel behind k_search_fused: all reads when that kernel declined the batch, else the reads it handed on

@@ -57,15 +57,19 @@ __device__ __forceinline__ u64 fz_encode32(const unsigned w[8], const unsigned t
 
 __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const unsigned char *__restrict__ bases,
                                                           i64 total_bases, i64 *__restrict__ out, i64 n_reads,
-                                                          SbwtWorkHeader *ws, unsigned *__restrict__ defer_list) {
+                                                          SbwtWorkHeader *ws, unsigned *__restrict__ defer_list,
+                                                          const i64 *__restrict__ read_off, const i64 *__restrict__ out_off) {
     __shared__ u64 pool_codes[SBWT_FUSED_MAXG][256];        // the wave's pool of 64 tickets, encoded ([group][wave * 64 + ticket])
     __shared__ u64 cur_codes[SBWT_FUSED_MAXG][256];         // the read this lane is working on
     __shared__ unsigned seg_src[FZ_NSEG][256];              // segment lists: source ...
     __shared__ unsigned char seg_at[FZ_NSEG][256];          // ... and first k-mer
-    if (!sbwt_fused_ok(ws, ix.k)) return;                   // not one length (or too long / short): the general route does it all
+    __shared__ unsigned char pool_len[256];                 // ragged batches: the lengths of the pool's reads (161: too long)
+    const int fmode = sbwt_fused_mode(ws, ix.k);
+    if (fmode == 0) return;                                 // the general route does it all
+    const bool ragged = fmode == 2;                         // reads of any lengths: offsets fetched with every refill
     const int tid = threadIdx.x, lane = tid & 63, wbase = tid & ~63;
     const int k = ix.k, p = ix.p_dev, L0 = ix.probe_len, ps = ix.p_sparse;
-    const int ulen = (int)ws->u_len, m = ulen - k + 1, G = (ulen + 31) >> 5;
+    const int ulen = ragged ? SBWT_FUSED_MAXLEN : (int)ws->u_len, m = ulen - k + 1, G = (ulen + 31) >> 5;
     const i64 u_read0 = ws->u_read0, u_out0 = ws->u_out0, u_stride = ws->u_stride;
     const bool pfon = ix.pfil && ix.p_filter == L0 && L0 > p;
     const u64 m2 = (k - ps >= 32) ? ~0ull : low_mask(2 * ((k - ps) & 31));   // key mask of the second-level window
@@ -100,7 +104,21 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
                 pool_end = pool_next + 64;
                 pool_bad = 0;
                 if ((i64)pool_next < n_reads) {
-                    const i64 woff = u_read0 + (i64)pool_next * ulen;                 // first byte of the pool's 64 reads
+                    i64 woff = u_read0 + (i64)pool_next * ulen;                       // first byte of the pool's 64 reads
+                    unsigned vrel = (unsigned)lane * (unsigned)ulen;                  // this lane's read in there
+                    int len_l = ulen;
+                    if (ragged) {
+                        i64 ta = (i64)pool_next + lane, tb = ta + 1;
+                        if (ta > n_reads) ta = n_reads;
+                        if (tb > n_reads) tb = n_reads;
+                        const i64 ro0 = read_off[ta], ro1 = read_off[tb];
+                        woff = (i64)uniform64((u64)ro0);
+                        const i64 rel = ro0 - woff, ln = ro1 - ro0;
+                        vrel = rel > 0xFFFF0000ll ? 0xFFFF0000u : (unsigned)rel;     // (beyond the descriptor: reads as zeros, handed on)
+                        len_l = ln > SBWT_FUSED_MAXLEN ? SBWT_FUSED_MAXLEN + 1 : (int)ln;
+                        pool_len[wbase + lane] = (unsigned char)len_l;
+                    }
+                    const int len_e = len_l > SBWT_FUSED_MAXLEN ? SBWT_FUSED_MAXLEN : len_l;
                     i64 remain = total_bases - woff;
                     if (remain < 0) remain = 0;
                     if (remain > 0xFFFFFFF0ll) remain = 0xFFFFFFF0ll;
@@ -111,7 +129,7 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
                     const unsigned delta = (unsigned)((uintptr_t)p0 & 3u);
                     __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
                         const_cast<unsigned char *>(p0 - delta), (short)0, (int)(((unsigned)remain + delta + 3u) & ~3u), 0x00020000);
-                    const unsigned vo = delta + (unsigned)lane * (unsigned)ulen;
+                    const unsigned vo = delta + vrel;
                     unsigned bad = 0;
 #pragma unroll
                     for (int g = 0; g < SBWT_FUSED_MAXG; g++) {
@@ -125,13 +143,13 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
 #pragma unroll
                             for (int d = 0; d < 8; d++) {
                                 w[d] = __builtin_amdgcn_alignbyte(raw[d + 1], raw[d], sh);
-                                const int nb = ulen - 32 * g - 4 * d;                  // bytes of this dword inside the read
+                                const int nb = len_e - 32 * g - 4 * d;                 // bytes of this dword inside the read
                                 tm[d] = nb >= 4 ? 0x80808080u : nb <= 0 ? 0u : (0x80808080u & ((1u << (8 * nb)) - 1u));
                             }
                             pool_codes[g][wbase + lane] = fz_encode32(w, tm, bad);
                         }
                     }
-                    const bool isbad = bad != 0 && (i64)(pool_next + (u64)lane) < n_reads;
+                    const bool isbad = (bad != 0 || len_l > SBWT_FUSED_MAXLEN) && (i64)(pool_next + (u64)lane) < n_reads;
                     pool_bad = __ballot(isbad);
                     if (pool_bad) {                                                    // hand them on (rare)
                         unsigned long long at = 0;
@@ -151,13 +169,14 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
             if (mode == F_IDLE && rank < avail) {
                 const u64 tk = pool_next + rank;
                 const int q = (int)(tk & 63ull);
-                if ((i64)tk < n_reads && !((pool_bad >> q) & 1ull)) {
+                const int mq = ragged ? (int)pool_len[wbase + q] - k + 1 : m;     // (a read shorter than k: nothing to answer)
+                if ((i64)tk < n_reads && !((pool_bad >> q) & 1ull) && mq > 0) {
                     rd = (unsigned)tk;
 #pragma unroll
                     for (int g = 0; g < SBWT_FUSED_MAXG; g++)
                         if (g < G) cur_codes[g][tid] = pool_codes[g][wbase + q];
                     i = 0;
-                    mend = m;
+                    mend = mq;
                     nseg = 0;
                     i0 = 0;
                     b = -1;
@@ -609,7 +628,10 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
                 const int ns = __shfl(nseg, L), a = __shfl(i0, L), e = __shfl(i, L);
                 fL[u] = L;
                 fe[u] = e;
-                fob[u] = u_out0 + (i64)uniform32((unsigned)__shfl((int)rd, L)) * u_stride;
+                {
+                    const i64 rdu = (i64)uniform32((unsigned)__shfl((int)rd, L));
+                    fob[u] = ragged ? out_off[rdu] : u_out0 + rdu * u_stride;
+                }
                 long_read = long_read || (e - a > 128);
                 const int tl = wbase + L;
                 const int j0 = a + 2 * lane, j1 = j0 + 1;
@@ -743,12 +765,14 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
 
 // Do all reads have one length and all result ranges one stride?  Thread 0 also notes the first offsets.
 __global__ void __launch_bounds__(256) k_check_uniform2(const i64 *__restrict__ read_off, const i64 *__restrict__ out_off,
-                                                        i64 n_reads, SbwtWorkHeader *ws, int k, SbwtPieceTab pt) {
+                                                        i64 n_reads, SbwtWorkHeader *ws, int k, SbwtPieceTab pt,
+                                                        int rg_enable) {
     const i64 t = (i64)blockIdx.x * 256 + threadIdx.x;
     const i64 len = read_off[1] - read_off[0], stride = (n_reads > 1) ? out_off[1] - out_off[0] : 0;
     if (t == 0) { ws->u_read0 = read_off[0]; ws->u_len = len; ws->u_out0 = out_off[0]; ws->u_stride = stride; }
     const bool valid = t < n_reads;
     const i64 mylen = valid ? read_off[t + 1] - read_off[t] : 0;
+    fused_sample_of_wave(t, mylen, valid, n_reads, rg_enable, ws);
     piece_zones_of_wave(t, mylen, valid, k, ws, pt);                       // long reads: for the general kernel behind
     if (!valid) return;
     const bool bad = (mylen != len) || (t + 1 < n_reads && out_off[t + 1] - out_off[t] != stride);
@@ -758,19 +782,19 @@ __global__ void __launch_bounds__(256) k_check_uniform2(const i64 *__restrict__ 
 void sbwt_launch_search_fused(const SbwtIndexView &ix, const char *d_bases, long long total_bases, uint4 *d_packed,
                               const long long *d_read_off, const long long *d_out_off, long long *d_out, long long n_reads,
                               SbwtWorkHeader *ws, int streaming, hipStream_t stream, unsigned *d_defer,
-                              hipEvent_t ev_begin, hipEvent_t ev_end, SbwtPieceTab pt) {
+                              hipEvent_t ev_begin, hipEvent_t ev_end, SbwtPieceTab pt, int ragged_ok) {
     if (n_reads <= 0) return;
     hipLaunchKernelGGL(k_check_uniform2, dim3(grid_for(n_reads)), dim3(256), 0, stream, d_read_off, d_out_off, (i64)n_reads, ws,
-                       ix.k, pt);
+                       ix.k, pt, ragged_ok);
     const i64 want = (n_reads + 255) / 256;
     const unsigned cap = (ix.debug >> 8) ? (unsigned)(ix.debug >> 8) : 1280u;
     const unsigned g = (unsigned)(want < (i64)cap ? want : (i64)cap);
     if (ev_begin) (void)hipEventRecord(ev_begin, stream);
     hipLaunchKernelGGL(k_search_fused, dim3(g), dim3(256), 0, stream, ix, reinterpret_cast<const unsigned char *>(d_bases),
-                       (i64)total_bases, d_out, (i64)n_reads, ws, d_defer);
+                       (i64)total_bases, d_out, (i64)n_reads, ws, d_defer, d_read_off, d_out_off);
     if (ev_end) (void)hipEventRecord(ev_end, stream);
     // what the fused kernel did not take: everything when the reads are not of one length, else the reads it handed on
-    sbwt_launch_encode_chained(d_bases, total_bases, d_packed, ws, d_defer, ix.k, stream);
+    sbwt_launch_encode_chained(d_bases, total_bases, d_packed, ws, d_defer, d_read_off, ix.k, stream);
     sbwt_launch_piece_bounds(d_packed, d_read_off, d_out_off, ix.k, ws, pt, 1, stream);
     sbwt_launch_search_chained(ix, d_packed, d_read_off, d_out_off, d_out, n_reads, ws, streaming, stream, d_defer, pt);
 }

@@ -729,3 +729,43 @@ def test_long_reads_are_cut_on_the_device_too(gpu, genome_case, variant):
         assert np.array_equal(_search_dev(idx, bases, off, k, True), oracle_batch(orc, bases, off, True))
     finally:
         capi.set_tuning("search_variant", -1)
+
+
+def test_fused_kernel_takes_batches_of_mixed_lengths(gpu, genome_case):
+    # "fused_ragged" (on by default): a batch whose reads differ in length still goes through the fused kernel -- it fetches
+    # the offsets of its 64 tickets with every refill --, which hands on what it cannot take: reads of more than 160 bases
+    # (one of them a 120 kbp read that the general kernel behind it answers in pieces), reads with N or lower case.  Reads
+    # shorter than k and empty reads answer nothing.  Same bits as the two-pass route and as the oracle.
+    genomes, orc = genome_case
+    idx = gpu_index_from_oracle(orc)
+    k = orc.k
+    rng = np.random.default_rng(21)
+    cat = np.concatenate(genomes)
+    n = 6000
+    lens = rng.integers(0, 161, size=n)
+    lens[rng.integers(0, n, size=60)] = rng.integers(161, 400, size=60)       # too long for the fused kernel
+    lens[17] = 120_000
+    lens[n - 1] = 150
+    st = (rng.random(n) * (len(cat) - lens)).astype(np.int64)
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    bases = np.empty(int(off[-1]), dtype=np.uint8)
+    for r in range(n):
+        bases[off[r]:off[r + 1]] = cat[st[r]:st[r] + lens[r]]
+    bases = synth.mutate(bases, 0.01, 3)
+    bases = synth.inject(bases, 100, ord("N"), 4)
+    bases = synth.inject(bases, 100, ord("c"), 5)
+    for streaming in (True, False):
+        want = oracle_batch(orc, bases, off, streaming)
+        for ragged in (1, 0):
+            capi.set_tuning("fused_ragged", ragged)
+            try:
+                got = _search_dev(idx, bases, off, k, streaming)
+            finally:
+                capi.set_tuning("fused_ragged", 1)
+            assert np.array_equal(got, want), (streaming, ragged)
+    # mostly long reads: the check kernel's sample sends the batch to the general route (same bits)
+    lens2 = rng.integers(150, 400, size=3000)
+    st2 = (rng.random(3000) * (len(cat) - lens2)).astype(np.int64)
+    off2 = np.concatenate([[0], np.cumsum(lens2)]).astype(np.int64)
+    bases2 = np.concatenate([cat[a:a + l] for a, l in zip(st2, lens2)])
+    assert np.array_equal(_search_dev(idx, bases2, off2, k, True), oracle_batch(orc, bases2, off2, True))

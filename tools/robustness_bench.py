@@ -52,6 +52,19 @@ b, o = synth.sample_reads(base, n_reads, 150, 0.01, 42)
 run("config 2: 3 strains 5% apart, 150 bp reads, 1% substitutions", idx0, b, o)
 b, o = synth.ragged_reads(base, n_reads, 80, 250, 0.01, 43)
 run("ragged read lengths 80-250", idx0, b, o)
+# reads of different lengths that the fused kernel can take (<= 160 bases): trimmed reads; with "fused_ragged" = 0 the
+# two-pass route as before
+b, o = synth.ragged_reads(base, n_reads, 80, 150, 0.01, 49)
+run("trimmed reads: lengths 80-150", idx0, b, o)
+capi.set_tuning("fused_ragged", 0)
+run("trimmed reads: lengths 80-150, two-pass route", idx0, b, o)
+capi.set_tuning("fused_ragged", 1)
+b, o = synth.sample_reads(base, n_reads, 150, 0.01, 42)
+b = np.concatenate([b, b[:151]]); o = np.concatenate([o, [o[-1] + 151]])
+run("150 bp reads and one of 151", idx0, b, o)
+capi.set_tuning("fused_ragged", 0)
+run("150 bp reads and one of 151, two-pass route", idx0, b, o)
+capi.set_tuning("fused_ragged", 1)
 b, o = synth.sample_reads(base, n_reads, 250, 0.01, 48)
 run("250 bp reads, 1% substitutions", idx0, b, o)
 b, o = synth.indel_reads(base, n_reads, 150, 0.01, 0.002, 44)
