@@ -37,7 +37,13 @@ d_bases = B.gpu_reads(genomes, n_reads, 42, dev)
 m = L - K + 1
 d_roff = torch.arange(n_reads + 1, dtype=torch.int64, device=dev) * L
 d_ooff = torch.arange(n_reads + 1, dtype=torch.int64, device=dev) * m
-d_out = torch.empty(n_reads * m, dtype=torch.int64, device=dev)
+if os.environ.get("RAGGED"):       # RAGGED=lo: reads of lo .. READLEN bases (host generator), checksum over a flat view
+    hb, ho = synth.ragged_reads(genomes, n_reads, int(os.environ["RAGGED"]), L, 0.01, 43)
+    d_bases = torch.from_numpy(hb).to(dev)
+    d_roff = torch.from_numpy(ho).to(dev)
+    d_ooff = torch.from_numpy(capi.out_offsets(ho, K)).to(dev)
+n_kmers = int(d_ooff[-1].item())
+d_out = torch.empty(n_kmers, dtype=torch.int64, device=dev)
 wsb = capi.search_workspace_bytes(d_bases.numel())
 d_ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
 st = torch.cuda.current_stream().cuda_stream
@@ -57,7 +63,10 @@ for rnd in range(rounds + 1):
                                  d_ws.data_ptr(), wsb, st, bool(streaming))
         e1.record(); torch.cuda.synchronize()
         if rnd == 0:
-            chk = int(((d_out.view(n_reads, m) * w).sum(dim=1) * torch.arange(1, n_reads + 1, device=dev)).sum().item())
+            if os.environ.get("RAGGED"):
+                chk = int((d_out * (torch.arange(n_kmers, device=dev) % 1009 + 1)).sum().item())
+            else:
+                chk = int(((d_out.view(n_reads, m) * w).sum(dim=1) * torch.arange(1, n_reads + 1, device=dev)).sum().item())
             if ref is None: ref = chk
             print("config", c, "checksum", chk, "same" if chk == ref else "DIFFERENT", "stats", idx.workspace_stats(d_ws.data_ptr(), st),
                   "bridges", idx.workspace_bridges(d_ws.data_ptr(), st), flush=True)
@@ -68,4 +77,4 @@ for rnd in range(rounds + 1):
 for c, v in times.items():
     kt = ktimes[c]
     print(f"variant={c[0]} debug={c[1] if len(c) > 1 else 0}: step median {np.median(v):.3f} ms min {min(v):.3f} ms -> "
-          f"{n_reads * m / np.median(v) / 1e6:.2f} G kmers/s" + (f"; fused kernel median {np.median(kt):.3f} ms" if kt else ""))
+          f"{n_kmers / np.median(v) / 1e6:.2f} G kmers/s" + (f"; fused kernel median {np.median(kt):.3f} ms" if kt else ""))
