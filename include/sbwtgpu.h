@@ -80,11 +80,17 @@ const char *sbwtgpu_version(void);
 const char *sbwtgpu_last_error(void);
 int         sbwtgpu_device_count(int *count);
 /* Process-wide tuning knobs for experiments (results never depend on them):
- *   "search_variant"  -1 (default) = by the index: 4 on an index with a path order (2 only when its paths were chosen
- *                     blindly, "path_lookahead" = 0, and more than one column in 64 has a choice of successors); 0 = k_search (the reference's order of searches), 1 = k_search_cert on
- *                     the blocks, 2 = k_search_cert along the path order, results staged per lane and written by
- *                     descriptors, 3 = k_search_pool (reads pooled in LDS, re-assigned to lanes by state), 4 = the path
- *                     order with per-read segment lists, a read's results written by the whole wave when it ends
+ *   "search_variant"  -1 (default) = by the index: 5 on an index with a path order, else the blocks kernel.  5 = the fused route
+ *                     (k_search_fused re-encodes the bases itself and takes batches of reads of up to 160 bases; the
+ *                     general kernel runs behind it for what it hands on or declines); 4 = always two passes (encode +
+ *                     k_search_cert along the path order, per-read segment lists written by the whole wave); 1 =
+ *                     k_search_cert on the blocks only; 0 = k_search (the reference's order of searches; cross-checks)
+ *   "fused_ragged"    1 (default): the fused route also takes batches of reads of different lengths (it fetches their
+ *                     offsets); 0: only batches of reads of one length (SBWTGPU_FUSED_RAGGED)
+ *   "split_long"      1 (default): the device entry points cut reads of more than two pieces' worth of k-mers (a piece:
+ *                     128 .. 1024 k-mers by batch size) into pieces that lanes take separately, at k-mers whose result
+ *                     does not depend on history; 0: one lane per read whatever its length (SBWTGPU_SPLIT_LONG)
+ *   "kernel_events"   1: HIP events around the dominant kernel of every search call (sbwtgpu_kernel_times)
  *   "sort_reads"      1: the path-order kernels take the reads sorted by where they start in the path order (a lookup of one
  *                     k-mer per read + a radix sort of (position, read) pairs before the search; lanes of a wave then
  *                     share lines of the index); default 0: the pre-pass costs more than it saves while the path order
@@ -95,15 +101,14 @@ int         sbwtgpu_device_count(int *count);
  *                     the device so that the per-k-mer search loop can use streaming steps internally
  *   "debug"           kernel experiment bits (0 = product behaviour)
  *   "poison_results"  1: every search first fills its result range with 0xA5 (parity tests)
- *   "trans_ext"       -1 (default): the kernel decides per wave whether a transition step runs on along the 8 path
- *                     steps quoted in its table entry (pays on pan-genomes); 0 never, 1 always
+ *   "trans_ext", "trans_wide"   accepted and ignored (round-2 table formats)
  * Read when an index is CREATED (derived acceleration structures inside the device image; environment
  * variables of the same meaning: SBWTGPU_SPARSE_PRECALC, SBWTGPU_PROBE_FILTER, SBWTGPU_PATH_ORDER):
  *   "sparse_depth"    depth of the sparse (hashed) prefix table, 0 = none, default 31 (capped at k)
  *   "probe_filter"    1 (default): Bloom filter over the probe_len-mers of the index for the certificate probes
  *   "path_order"      1 (default): path order + transition table (32-bit indexes with suffix-group marks)
  *   "image_level"     0 (default): the image carries every derived structure (path order + transition table, sparse
- *                     prefix table, probe filter: 139-168 bytes per column); 1: no path order (about 66 bytes per
+ *                     prefix table, probe filter: 79-94 bytes per column for k <= 31); 1: no path order (about 60 bytes per
  *                     column); 2: blocks + dense prefix table only (1 byte per column + the table).  Results are the
  *                     same at every level; throughput is not.  SBWTGPU_IMAGE_LEVEL.
  *   "max_image_bytes" > 0: index_create moves to the next level while the image would be larger than this (and fails
@@ -111,9 +116,6 @@ int         sbwtgpu_device_count(int *count);
  *                     memory runs out.  SBWTGPU_MAX_IMAGE_BYTES.
  *   "force_mega"      1: rank-only images (arbitrary bit vectors) store their block counts relative to a 64-bit base as
  *                     images whose counts pass 2^32 do (tests of that layout at small sizes); default 0
- *   "trans_wide"      -1 (default): 32-byte transition entries (the second half = the columns of the successor's next four
- *                     path steps, for the staged-writer kernel) only on a branchy index with blind paths; 0 never; 1 always
- *                     (+64 bytes per column; SBWTGPU_TRANS_WIDE)
  *   "sort_reads"      1: the path-order kernels take the reads in the order of their first k-mer's path position (a lookup
  *                     and a radix sort per batch inside the caller's workspace; pays only when nothing upstream orders the
  *                     reads and the index is large); default off (SBWTGPU_SORT_READS)
@@ -121,7 +123,11 @@ int         sbwtgpu_device_count(int *count);
  *                     which successor a column's path takes (paths follow the core of a pan-genome); 0: blind choice
  *                     (SBWTGPU_PATH_LOOKAHEAD)
  *   "path_safe"       substitution-safe bits along the paths (k <= 31; SBWTGPU_PATH_SAFE): 2 (default) wherever the next k
- *                     steps lie on the path, 1 only where the k steps before do too (the first rule), 0 none */
+ *                     steps lie on the path, 1 only where the k steps before do too (the first rule), 0 none
+ *   "path_stitch"     1 (default): the vertex-disjoint paths are joined into chains through copies of the stretches that
+ *                     strains share (at most n/5 copied positions; a graph whose copies would repeat more than n/32
+ *                     branching columns keeps its disjoint paths); 0: disjoint paths (SBWTGPU_PATH_STITCH)
+ *   "path_stitch_min" shortest stretch worth a copy, default 1 (SBWTGPU_PATH_STITCH_MIN) */
 int         sbwtgpu_set_tuning(const char *key, int64_t value);
 
 /* ---- index life cycle ---- */
@@ -209,8 +215,10 @@ int  sbwtgpu_select_batch(const sbwtgpu_index *idx, const int64_t *j, const char
  * non-decreasing, that out_off matches max(0, len-k+1) per read, that no read has 2^31 or more bases
  * and that one call carries fewer than 2^36 bases. */
 /* Scratch the search kernels need: a work-queue header, the 2-bit re-encoding of the bases (total_bases/2 + 64
- * bytes) and, while "sort_reads" is on, room to sort the reads (about one more byte per base).  The caller
- * allocates it once and may reuse it across calls on the same stream. */
+ * bytes), the list of reads the fused kernel hands on (total_bases/8), the pieces of long reads (total_bases/32, at
+ * least 8 MB for batches of more than 32 Mbases) and, while "sort_reads" is on, room to sort the reads (about one more
+ * byte per base).  Non-decreasing in total_bases: the caller allocates it once for its largest batch and may reuse it
+ * across calls on the same stream. */
 int64_t sbwtgpu_search_workspace_bytes(int64_t total_bases);
 int  sbwtgpu_streaming_search_dev(const sbwtgpu_index *idx, const char *d_bases, int64_t total_bases,
                                   const int64_t *d_read_off, int64_t n_reads, int64_t *d_out,

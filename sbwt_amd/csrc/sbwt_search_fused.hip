@@ -63,7 +63,6 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
     __shared__ u64 cur_codes[SBWT_FUSED_MAXG][256];         // the read this lane is working on
     __shared__ unsigned seg_src[FZ_NSEG][256];              // segment lists: source ...
     __shared__ unsigned char seg_at[FZ_NSEG][256];          // ... and first k-mer
-    __shared__ unsigned char pool_len[256];                 // ragged batches: the lengths of the pool's reads (161: too long)
     const int fmode = sbwt_fused_mode(ws, ix.k);
     if (fmode == 0) return;                                 // the general route does it all
     const bool ragged = fmode == 2;                         // reads of any lengths: offsets fetched with every refill
@@ -91,6 +90,7 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
     int l = 0, r = 0;               // walk interval; F_EXT ..: r = path position
     unsigned c_ext = 0, c_brg = 0;  // per lane: k-mers answered along paths, substitutions bridged
     u64 pool_next = 0, pool_end = 0, pool_bad = 0;  // wave-uniform pool of read tickets; tickets of it that are handed on
+    int pool_len = 0;               // ragged batches: the length of the read this lane encoded at the last refill (161: too long)
     unsigned c_stream = 0, c_search = 0, c_lf = 0, c_tab = 0;     // wave-uniform work counters
 
     for (;;) {
@@ -116,7 +116,7 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
                         const i64 rel = ro0 - woff, ln = ro1 - ro0;
                         vrel = rel > 0xFFFF0000ll ? 0xFFFF0000u : (unsigned)rel;     // (beyond the descriptor: reads as zeros, handed on)
                         len_l = ln > SBWT_FUSED_MAXLEN ? SBWT_FUSED_MAXLEN + 1 : (int)ln;
-                        pool_len[wbase + lane] = (unsigned char)len_l;
+                        pool_len = len_l;
                     }
                     const int len_e = len_l > SBWT_FUSED_MAXLEN ? SBWT_FUSED_MAXLEN : len_l;
                     i64 remain = total_bases - woff;
@@ -166,10 +166,12 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
             const unsigned avail = (unsigned)(pool_end - pool_next);
             const unsigned n = (unsigned)__popcll(need);
             const unsigned rank = (unsigned)__popcll(need & low_mask(lane));
+            // (ragged batches: the length of ticket q's read sits in lane q -- fetched with every lane of the wave active)
+            const int mq_r = ragged ? __shfl(pool_len, (int)((pool_next + rank) & 63ull)) - k + 1 : m;
             if (mode == F_IDLE && rank < avail) {
                 const u64 tk = pool_next + rank;
                 const int q = (int)(tk & 63ull);
-                const int mq = ragged ? (int)pool_len[wbase + q] - k + 1 : m;     // (a read shorter than k: nothing to answer)
+                const int mq = mq_r;                   // (a read shorter than k: nothing to answer)
                 if ((i64)tk < n_reads && !((pool_bad >> q) & 1ull) && mq > 0) {
                     rd = (unsigned)tk;
 #pragma unroll
