@@ -57,3 +57,19 @@ def test_product_does_not_reference_the_oracle():
                 if re.search(r"sbwt_oracle|liboracle|from oracle|import oracle|orc_", t):
                     bad.append(os.path.join(d, f))
     assert not bad, bad
+
+
+def test_search_workspace_is_monotone_in_the_batch_size():
+    # pure arithmetic, no GPU: a workspace sized for the largest batch must serve every smaller one -- the packed bases,
+    # the list of handed-on reads and the piece table of long reads (whose zone length changes with the batch size) all
+    # grow with total_bases
+    from sbwt_amd import capi
+    sizes = sorted(set([0, 1, 31, 32, 1000, 1 << 20, (1 << 25) - 1, 1 << 25, (1 << 25) + 1, 1 << 26, 1 << 27, (1 << 28) + 5,
+                        1 << 30, 3 << 30, (1 << 36) - 1] + [int(1.37 ** e) for e in range(5, 78)]))
+    prev = -1
+    for b in sizes:
+        w = capi.search_workspace_bytes(b)
+        assert w >= prev, (b, w, prev)
+        assert w % 256 == 0 and w >= b // 2
+        prev = w
+    assert capi.search_workspace_bytes(1_500_000_000) < 1_500_000_000      # 0.66 bytes per base + a constant
