@@ -17,6 +17,8 @@
 #include <thread>
 #include <utility>
 #include <vector>
+#include <chrono>
+#include <iostream>
 
 #include "../../../include/sbwtgpu.h"
 #include "bitvector.hh"
@@ -424,7 +426,11 @@ public:
     }
     void load(std::istream &is) {
         IndexFileData f;
+        const auto t_file0 = std::chrono::steady_clock::now();
         f.load(is);
+        if (getenv("SBWT_CLI_TIMING"))
+            std::cerr << "timing: index file read "
+                      << std::chrono::duration<double>(std::chrono::steady_clock::now() - t_file0).count() << " s" << std::endl;
         subset_rank = SubsetMatrixRank(f.A_bits, f.C_bits, f.G_bits, f.T_bits);
         suffix_group_starts = f.suffix_group_starts;
         precalc_k = f.precalc_k; n_nodes = f.n_nodes; n_kmers = f.n_kmers; k = f.k;

@@ -175,6 +175,11 @@ struct TextBatch {
 // pipelined: a reader thread parses the next batch and a writer thread writes the previous one while
 // the GPU searches the current one.  The output is written strictly in input order.
 // (get_index: the index, waited for at the first use -- while it loads, the reader thread already parses the input)
+static int64_t g_t0 = 0;             // process time at the start of search_main (stage marks under SBWT_CLI_TIMING)
+static void timing_mark(const char *what) {
+    if (getenv("SBWT_CLI_TIMING")) std::cerr << "timing: t+" << (cur_time_micros() - g_t0) / 1e6 << " s " << what << std::endl;
+}
+
 QueryStats run_file(const string &infile, const string &outfile, const std::function<const plain_matrix_sbwt_t &()> &get_index,
                     bool gzip_output, int64_t batch_bases, bool host_format) {
     seq_io::Reader reader(infile);
@@ -222,6 +227,7 @@ QueryStats run_file(const string &infile, const string &outfile, const std::func
     std::exception_ptr search_err;
     try {
         const plain_matrix_sbwt_t &index = get_index();
+        timing_mark("index ready");
         const bool streaming = index.has_streaming_query_support();
         write_log(string("Running ") + (streaming ? "streaming" : "non-streaming") + " queries from input file " + infile +
                       " to output file " + outfile,
@@ -260,6 +266,7 @@ QueryStats run_file(const string &infile, const string &outfile, const std::func
                                                        });
                 st.micros += cur_time_micros() - t0 - t_sink;
                 t_write += t_sink;
+                timing_mark("a batch searched and written");
                 continue;
             } else {
                 // several devices (every device's text is a piece of its own), or compressed output (a writer thread)
@@ -274,14 +281,19 @@ QueryStats run_file(const string &infile, const string &outfile, const std::func
         ReadBatch drop;
         while (to_search.pop(drop)) {}
     }
+    timing_mark("search loop left");
     to_write.close();
     reader_thread.join();
+    timing_mark("reader joined");
     writer_thread.join();
+    timing_mark("writer joined");
     if (search_err) std::rethrow_exception(search_err);
     if (reader_err) std::rethrow_exception(reader_err);
     if (writer_err) std::rethrow_exception(writer_err);
     write_log("us/query: " + std::to_string((double)st.micros / (double)st.queries) + " (excluding I/O etc)",
               LogLevel::MAJOR);
+    writer.close();
+    timing_mark("output closed");
     if (timing)
         std::cerr << "timing: parse " << t_parse / 1e6 << " s, search (GPU + PCIe) " << st.micros / 1e6 << " s, write "
                   << t_write / 1e6 << " s" << std::endl;
@@ -290,6 +302,7 @@ QueryStats run_file(const string &infile, const string &outfile, const std::func
 
 int search_main(int argc, char **argv) {
     int64_t micros_start = cur_time_micros();
+    g_t0 = micros_start;
     set_log_level(LogLevel::MINOR);
     Options opts({
         {"out-file", 'o', true, "Output filename.", ""},
@@ -370,6 +383,7 @@ int search_main(int argc, char **argv) {
     std::thread loader([&] {
         try {
             const int64_t load0 = cur_time_micros();
+            timing_mark("loader thread started");
             index.load(in);
             if (getenv("SBWT_CLI_TIMING"))
                 std::cerr << "timing: index load + device image " << (cur_time_micros() - load0) / 1e6 << " s" << std::endl;
@@ -400,6 +414,7 @@ int search_main(int argc, char **argv) {
     }
     if (!joined) { loader.join(); joined = true; }
 
+    timing_mark("all files done");
     int64_t total_micros = cur_time_micros() - micros_start;
     write_log("us/query end-to-end: " + std::to_string((double)total_micros / (double)number_of_queries), LogLevel::MAJOR);
     return 0;
