@@ -1091,7 +1091,9 @@ SmallSlot *small_slot(int device, size_t need) {
 inline size_t up256(size_t x) { return (x + 255) & ~(size_t)255; }
 }  // namespace
 
-static int check_reads(const int64_t *read_off, const int64_t *out_off, int64_t n_reads, int64_t k) {
+// (*any_long: some read has more than 2 * PIECE k-mers -- the host entry points cut those into pieces, below)
+static int check_reads(const int64_t *read_off, const int64_t *out_off, int64_t n_reads, int64_t k, bool *any_long = nullptr) {
+    int64_t longest = 0;
     for (int64_t r = 0; r < n_reads; r++) {
         int64_t len = read_off[r + 1] - read_off[r];
         if (len < 0) return fail(SBWTGPU_ERR_INVALID_ARG, "read_off is not non-decreasing at read %lld", (long long)r);
@@ -1101,7 +1103,9 @@ static int check_reads(const int64_t *read_off, const int64_t *out_off, int64_t 
         if (out_off[r + 1] - out_off[r] != m)
             return fail(SBWTGPU_ERR_INVALID_ARG, "out_off[%lld+1]-out_off[%lld] must be max(0,len-k+1) = %lld",
                         (long long)r, (long long)r, (long long)m);
+        if (m > longest) longest = m;
     }
+    if (any_long) *any_long = longest > 4096;          // = 2 * PIECE
     return SBWTGPU_OK;
 }
 
@@ -1115,6 +1119,7 @@ static int check_reads(const int64_t *read_off, const int64_t *out_off, int64_t 
 // reference's result does not depend on what came before (streaming step and full search agree,
 // tests/test_large.hh:104-115; only lower-case input makes the two differ).
 static const int64_t PIECE = 2048;
+static_assert(2 * PIECE == 4096, "check_reads flags reads of more than 4096 k-mers");
 
 static inline bool window_has_lower(const char *s, int64_t k) {
     for (int64_t t = 0; t < k; t++) {
@@ -1199,12 +1204,13 @@ void parallel_memcpy(char *dst, const char *src, size_t n) {
 const int64_t PIPE_MIN = (int64_t)64 << 20;
 }  // namespace
 
-// ro / oo: offsets rebased to 0 (nv + 1 entries); src_bases: the bases of the batch; out: where result 0 goes
+// ro / oo: nv + 1 offsets into src_bases / out (rebased to 0 or not: only ro[0], oo[0] and differences are used)
 static int search_host_pipelined(const sbwtgpu_index *idx, const char *src_bases, const int64_t *ro, const int64_t *oo,
                                  int64_t nv, int64_t *out, int streaming) {
     const bool pin_in = is_pinned(src_bases), pin_out = is_pinned(out);
     // chunks: results <= 512 MiB when they land in the caller's pinned memory, <= 128 MiB when they are staged
-    const int64_t CH_OUT = (pin_out ? (int64_t)512 : (int64_t)128) << 20;
+    static const int64_t chunk_mb = [] { const char *e = getenv("SBWTGPU_PIPE_CHUNK_MB"); return e ? atoll(e) : 0ll; }();
+    const int64_t CH_OUT = (chunk_mb > 0 ? chunk_mb : (pin_out ? (int64_t)512 : (int64_t)128)) << 20;
     std::vector<int64_t> cuts{0};
     int64_t max_bases = 0, max_reads = 0, max_vals = 0;
     for (int64_t lo = 0; lo < nv;) {
@@ -1337,18 +1343,21 @@ static int search_host_common(const sbwtgpu_index *idx, const char *bases, const
     if (n_reads < 0) return fail(SBWTGPU_ERR_INVALID_ARG, "negative n_reads");
     if (n_reads == 0) return SBWTGPU_OK;
     if (!read_off || !out_off) return fail(SBWTGPU_ERR_INVALID_ARG, "NULL offsets");
-    int rc = check_reads(read_off, out_off, n_reads, idx->h.k);
+    bool any_long = false;
+    int rc = check_reads(read_off, out_off, n_reads, idx->h.k, &any_long);
     if (rc != SBWTGPU_OK) return rc;
     const int64_t base0 = read_off[0], total = read_off[n_reads] - base0;
     const int64_t out0 = out_off[0], n_out = out_off[n_reads] - out0;
     if (total > 0 && !bases) return fail(SBWTGPU_ERR_INVALID_ARG, "bases is NULL");
     if (n_out > 0 && !out) return fail(SBWTGPU_ERR_INVALID_ARG, "out is NULL");
     if (n_out == 0) return SBWTGPU_OK;
+    // a large batch of ordinary reads: the pipeline works on the caller's arrays as they are (it only ever uses
+    // differences of offsets; every chunk's offsets are rebased into its staging buffer anyway)
+    if (!any_long && n_out * 8 >= PIPE_MIN)
+        return search_host_pipelined(idx, bases, read_off, out_off, n_reads, out, streaming);
 
     // offsets are rebased so that device buffers start at 0; long reads are cut into pieces (see above)
     const int64_t kk = idx->h.k;
-    bool any_long = false;
-    for (int64_t r = 0; r < n_reads && !any_long; r++) any_long = (read_off[r + 1] - read_off[r] - kk + 1) > 2 * PIECE;
     std::vector<int64_t> ro, oo;
     std::vector<char> vbases;
     const char *src_bases = bases + base0;
