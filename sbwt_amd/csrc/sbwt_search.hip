@@ -886,8 +886,11 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
                         if (wk == 3) {
                             l = 0;                     // range probe: "perhaps present" only moves the guess
                         } else {
-                            again = true;              // perhaps present: the dense table walks the window exactly
-                            wk = 0;
+                            // perhaps present (in a pan-genome usually truly: the window is another strain's variant):
+                            // no certificate from this window -- the reference's own search of k-mer i decides
+                            again = true;
+                            do_plan = true;
+                            force = true;
                         }
                     } else {
                         l = -1;                        // read[wstart .. wstart+L0-1] is not in the index
@@ -985,8 +988,10 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
                 blo = wstart;                          // the bad base is somewhere in [wstart, tfail]
                 b = tfail;
             } else {
-                // a walk that started AT the known-bad position says nothing about where the next one is
-                b = (wstart == b) ? -1 : tfail;
+                // a walk that started AT the known-bad position says nothing about where the next one is; a window around
+                // it leaves it where it is
+                if (wstart == b) b = -1;
+                else if (!(b > wstart && b <= tfail)) b = tfail;
                 blo = b;
             }
             if (burst_hi == i) { ev = EV_EMIT1; burst_hi = -1; }   // a single -1 goes through the stage
@@ -1204,6 +1209,8 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
                     nwk = 3;
                 } else {
                     s0 = (b - i >= L0 - 1) ? (b - L0 + 1) : b;
+                    // a window that starts at b but runs past k-mer i: the last window inside k-mer i holds b as well
+                    if (pfon && s0 == b && b + L0 - 1 > i + k - 1 && k > L0) s0 = i + k - L0;
                     if (s0 + p - 1 > i + k - 1) s0 = i;
                     if (s0 != i) nwk = (pfon && s0 + L0 - 1 <= i + k - 1) ? 2 : 0;
                 }
