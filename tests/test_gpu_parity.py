@@ -670,7 +670,8 @@ def test_stitched_chains_are_derived_data(gpu, variant):
         capi.set_tuning("search_variant", -1)
         capi.set_tuning("path_stitch", 1)
         capi.set_tuning("path_stitch_min", 1)
-    assert chains[(1, 1)] < chains[(0, 1)], chains          # the copies did join paths
+    if chains[(0, 1)] > 0:                                  # (an image without a path order, SBWTGPU_IMAGE_LEVEL >= 1: nothing to join)
+        assert chains[(1, 1)] < chains[(0, 1)], chains      # the copies did join paths
 
 
 def _search_dev(idx, bases, off, k, streaming):

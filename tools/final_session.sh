@@ -24,3 +24,7 @@ for c in (2, 5, 3):
     except Exception as e:
         print("config", c, "ERR", e)
 PY
+# results must not depend on the builder / route knobs: the parity tests under non-default environments
+for e in SBWTGPU_PATH_LOOKAHEAD=0 SBWTGPU_IMAGE_LEVEL=1 SBWTGPU_IMAGE_LEVEL=2 SBWTGPU_PATH_SAFE=0 SBWTGPU_PATH_STITCH=0 SBWTGPU_FUSED_RAGGED=0 SBWTGPU_SPLIT_LONG=0; do
+  env $e timeout 600 python -m pytest tests/test_gpu_parity.py tests/test_gpu_workloads.py -x -q -m gpu 2>&1 | tail -1 | sed "s/^/$e: /"
+done | tee $O/knob_sweep.log
