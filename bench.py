@@ -362,7 +362,7 @@ def main() -> int:
             try:
                 bits = capi.build_bits_gpu([g.tobytes() for g in genomes], K, False, streaming, device=local_rank)
             except capi.SbwtGpuError as ex:
-                if ex.code not in (capi.ERR_OOM, capi.ERR_HIP):
+                if ex.code != capi.ERR_OOM:         # a kernel fault is an error, not a reason to fall back
                     raise
                 log(f"device builder: {ex.msg}; building the columns on the host instead")
                 columns_on = "host (device builder did not fit)"

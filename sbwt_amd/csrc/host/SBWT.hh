@@ -60,10 +60,15 @@ inline PlainMatrixBits build_plain_matrix_bits_any(const std::vector<std::string
     const int rc = sbwtgpu_build_plain_matrix(ptr.data(), len.data(), (int64_t)seqs.size(), k, add_revcomp ? 1 : 0,
                                               build_streaming_support ? 1 : 0, detail::default_device(), &b);
     // the device builder holds the text, its packed form, two key arrays and the sort's temporary at once; an input that
-    // does not fit (or a device that fails) is built by the host builder, as before the device builder existed.  (This is
-    // index CONSTRUCTION; queries have no host path.)
-    if (rc == SBWTGPU_ERR_OOM || rc == SBWTGPU_ERR_HIP)
+    // does not fit (SBWTGPU_ERR_OOM: its fit limit and its dummy-record limit both map to it) is built by the host
+    // builder, and the log says so.  Any other failure (a kernel fault, a launch error) is an error, not a reason to
+    // fall back silently.  (This is index CONSTRUCTION; queries have no host path.)
+    if (rc == SBWTGPU_ERR_OOM) {
+        const char *m = sbwtgpu_last_error();
+        write_log(std::string("Device builder: ") + (m && *m ? m : "out of device memory") + "; building the columns on the host",
+                  LogLevel::MAJOR);
         return build_plain_matrix_bits(seqs, k, add_revcomp, build_streaming_support, n_threads);
+    }
     detail::gpu_check(rc);
     PlainMatrixBits out;
     out.n_nodes = b.n_nodes; out.n_kmers = b.n_kmers; out.k = b.k;

@@ -5,9 +5,11 @@
 // the GPU path, not part of it.
 #pragma once
 #include <fcntl.h>
+#include <sys/stat.h>
 #include <unistd.h>
 #include <zlib.h>
 
+#include <cerrno>
 #include <cctype>
 #include <cstdint>
 #include <cstring>
@@ -60,30 +62,47 @@ public:
         const FileFormat ff = figure_out_file_format(filename);
         fmt_ = ff.format;
         if (!ff.gzipped) {
-            // (a file that is gzip data under a plain name is still read through zlib, like gzread would)
-            FILE *probe = fopen(filename.c_str(), "rb");
-            if (!probe) throw std::runtime_error("Error opening file: " + filename);
+            // (a file that is gzip data under a plain name is still read through zlib, like gzread would.)  The probe
+            // reads the first two bytes with read(2) and KEEPS them as the start of the parse buffer -- no rewind: the
+            // input may be a pipe or a FIFO (`-q <(zcat reads.fq.gz)`, /dev/stdin), where seeking back is impossible.
+            // A regular file that turns out to be gzip data is reopened through zlib; gzip data arriving on a pipe
+            // under a plain name is rejected loudly (the two bytes are gone) instead of being parsed as text.
+            const int fd = ::open(filename.c_str(), O_RDONLY);
+            if (fd < 0) throw std::runtime_error("Error opening file: " + filename);
             unsigned char magic[2] = {0, 0};
-            const size_t got = fread(magic, 1, 2, probe);
+            size_t got = 0;
+            while (got < 2) {
+                const ssize_t r = ::read(fd, magic + got, 2 - got);
+                if (r < 0 && errno == EINTR) continue;
+                if (r < 0) { ::close(fd); throw std::runtime_error("Error reading file: " + filename); }
+                if (r == 0) break;
+                got += (size_t)r;
+            }
             if (got == 2 && magic[0] == 0x1f && magic[1] == 0x8b) {
-                fclose(probe);
+                struct stat sb;
+                const bool regular = ::fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode);
+                ::close(fd);
+                if (!regular)
+                    throw std::runtime_error("Error: gzip data on a non-seekable input needs a .gz file name: " + filename);
             } else {
-                rewind(probe);
-                setvbuf(probe, nullptr, _IONBF, 0);
-                plain_ = probe;
+                plain_fd_ = fd;
+                buf_.resize((size_t)8 << 20);
+                memcpy(buf_.data(), magic, got);     // the probed bytes are the first bytes of the parse buffer
+                pos_ = 0;
+                end_ = got;
             }
         }
-        if (!plain_) {
+        if (plain_fd_ < 0) {
             f_ = gzopen(filename.c_str(), "rb");
             if (!f_) throw std::runtime_error("Error opening file: " + filename);
             gzbuffer(f_, 1 << 20);
+            buf_.resize((size_t)1 << 20);
         }
-        buf_.resize(plain_ ? (size_t)8 << 20 : (size_t)1 << 20);
         seq_.reserve(1 << 10);
     }
     ~Reader() {
         if (f_) gzclose(f_);
-        if (plain_) fclose(plain_);
+        if (plain_fd_ >= 0) ::close(plain_fd_);
     }
     Reader(const Reader &) = delete;
     Reader &operator=(const Reader &) = delete;
@@ -171,9 +190,10 @@ private:
     }
     bool fill() {
         int n;
-        if (plain_) {                // not compressed: straight read(2) into the parse buffer (gzread copies twice)
-            n = (int)::fread(buf_.data(), 1, buf_.size(), plain_);
-            if (n == 0 && ferror(plain_)) n = -1;
+        if (plain_fd_ >= 0) {        // not compressed: straight read(2) into the parse buffer (gzread copies twice)
+            do {
+                n = (int)::read(plain_fd_, buf_.data(), std::min(buf_.size(), (size_t)1 << 30));
+            } while (n < 0 && errno == EINTR);
         } else {
             n = gzread(f_, buf_.data(), (unsigned)buf_.size());
         }
@@ -227,7 +247,7 @@ private:
     std::string filename_;
     Format fmt_;
     gzFile f_ = nullptr;
-    FILE *plain_ = nullptr;         // uncompressed input: read directly
+    int plain_fd_ = -1;             // uncompressed input: read(2) directly (regular file, pipe or FIFO)
     std::vector<char> buf_;
     size_t pos_ = 0, end_ = 0;
     std::vector<char> seq_;
@@ -333,17 +353,17 @@ private:
         size_t used = std::min(pending_.size(), n_blocks * BLOCK);
         pending_.erase(pending_.begin(), pending_.begin() + (long)used);
     }
-    bool pwrite_all(const char *p, int64_t n, int64_t at) const {
+    // sequential append with write(2): works on pipes, FIFOs and /dev/stdout as well as on files (the reference writes
+    // through an ofstream); EINTR and short writes are retried
+    void put(const void *data, size_t n) {
+        const char *p = (const char *)data;
         while (n > 0) {
-            const ssize_t w = ::pwrite(fd_, p, (size_t)std::min<int64_t>(n, (int64_t)1 << 30), (off_t)at);
-            if (w <= 0) return false;
-            p += w; n -= w; at += w;
+            const ssize_t w = ::write(fd_, p, std::min(n, (size_t)1 << 30));
+            if (w < 0 && errno == EINTR) continue;
+            if (w <= 0) throw std::runtime_error("Error writing to file " + filename_);
+            p += w;
+            n -= (size_t)w;
         }
-        return true;
-    }
-    void put(const void *p, size_t n) {     // sequential append
-        if (!pwrite_all((const char *)p, (int64_t)n, off_)) throw std::runtime_error("Error writing to file " + filename_);
-        off_ += (int64_t)n;
     }
     void flush_small() {
         if (small_.empty()) return;
@@ -354,7 +374,6 @@ private:
     bool gzip_;
     int n_threads_ = 1;
     int fd_ = -1;
-    int64_t off_ = 0;
     std::vector<char> small_;
     std::vector<char> pending_;
     bool wrote_member_ = false;

@@ -143,3 +143,27 @@ def indel_reads(genomes: List[np.ndarray], n_reads: int, read_len: int, sub_rate
     out[pos[ins] - 1] = ACGT[rng.integers(0, 4, size=int(ins.sum()))]
     read_off = np.concatenate([[0], pos[off[1:] - 1]]).astype(np.int64)
     return out, read_off
+
+
+_COMP = np.zeros(256, dtype=np.uint8)
+_COMP[ACGT] = np.frombuffer(b"TGCA", dtype=np.uint8)
+
+
+def revcomp(seq: np.ndarray) -> np.ndarray:
+    """Reverse complement of an ACGT byte array (globals.hh:19-35)."""
+    return _COMP[seq[::-1]]
+
+
+def both_strand_reads(genomes: List[np.ndarray], n_reads: int, read_len: int, sub_rate: float, seed: int
+                      ) -> Tuple[np.ndarray, np.ndarray]:
+    """sample_reads, but every read comes from the forward or the reverse strand with probability 1/2 -- what a
+    sequencer delivers, and what an index built with --add-reverse-complements (tests/test_CLI.hh:43) is for."""
+    bases, off = sample_reads(genomes, n_reads, read_len, 0.0, seed)
+    rng = np.random.Generator(np.random.PCG64(seed + 29))
+    flip = rng.random(n_reads) < 0.5
+    rows = bases.reshape(n_reads, read_len)
+    rows[flip] = _COMP[rows[flip][:, ::-1]]
+    bases = rows.reshape(-1)
+    if sub_rate > 0:
+        bases = mutate(bases, sub_rate, seed + 1)
+    return bases, off

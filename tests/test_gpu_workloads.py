@@ -1,5 +1,6 @@
 """GPU parity on the harder synthetic workloads of DESIGN.md section 7 (one test per generator in sbwt_amd/synth.py):
-repeated content in the genome, reads with indels, ragged read lengths -- every kernel variant against the oracle."""
+repeated content in the genome, reads with indels, ragged read lengths, a reverse-complement index queried from both
+strands -- every kernel variant against the oracle."""
 import numpy as np
 import pytest
 
@@ -9,9 +10,9 @@ from sbwt_amd import capi, synth
 pytestmark = pytest.mark.gpu
 
 
-def check(genomes, k, bases, off):
+def check(genomes, k, bases, off, revcomp=False):
     seqs = [g.tobytes() for g in genomes]
-    bits = capi.build_bits_gpu(seqs, k, False, True)
+    bits = capi.build_bits_gpu(seqs, k, revcomp, True)
     orc = OracleIndex.from_bits(bits.cols[0], bits.cols[1], bits.cols[2], bits.cols[3], bits.ssup, bits.n_nodes, k,
                                 bits.n_kmers, 8)
     idx = capi.Index.create(bits.cols[0], bits.cols[1], bits.cols[2], bits.cols[3], bits.ssup, bits.n_nodes, k,
@@ -52,3 +53,25 @@ def test_ragged_read_lengths(gpu):
     bases, off = synth.ragged_reads(genomes, 3000, 20, 250, 0.01, 43)      # some reads shorter than k
     assert (np.diff(off) < 31).any()
     check(genomes, 31, bases, off)
+
+
+def test_revcomp_index_reads_from_both_strands(gpu):
+    """How the tool is normally used (and how the reference's own KAT is built, tests/test_CLI.hh:43): the index holds
+    every k-mer and its reverse complement, the reads come from either strand.  Palindromic k-mers merge the two strands'
+    paths; the hit rate must be the same as on a forward-only index queried with forward reads."""
+    genomes = [synth.random_genome(200_000, 11), None]
+    genomes[1] = synth.mutate(genomes[0], 0.05, 12)
+    bases, off = synth.both_strand_reads(genomes, 3000, 150, 0.01, 47)
+    for k in (30, 31):                       # even k: palindromic k-mers exist; odd k: none
+        want = check(genomes, k, bases, off, revcomp=True)
+        assert 0.65 < (want >= 0).mean() < 0.82
+    # a read and its reverse complement hit the same number of k-mers, mirrored
+    fwd, foff = synth.sample_reads(genomes, 500, 150, 0.01, 48)
+    rc = np.concatenate([synth.revcomp(fwd[foff[r]:foff[r + 1]]) for r in range(500)])
+    bits = capi.build_bits_gpu([g.tobytes() for g in genomes], 31, True, True)
+    idx = capi.Index.create(bits.cols[0], bits.cols[1], bits.cols[2], bits.cols[3], bits.ssup, bits.n_nodes, 31,
+                            bits.n_kmers, 8)
+    a, _ = idx.streaming_search(fwd, foff)
+    b, _ = idx.streaming_search(rc, foff)
+    m = 150 - 31 + 1
+    assert np.array_equal((a.reshape(500, m) >= 0), (b.reshape(500, m) >= 0)[:, ::-1])

@@ -1,6 +1,7 @@
 """GPU fuzz: random indexes (k, genome shapes with repeats / related strains / tiny alphabets) and random reads
-(substitutions, N, lower case, ragged lengths); the product kernel (variant 2, and 1) must equal the reference-order
-kernel (variant 0) bit for bit, and a sample must equal the oracle.  Usage: python tools/fuzz_gpu.py [seconds]"""
+(substitutions, N, lower case, ragged lengths, long reads); every route (5 fused, 4 two-pass path kernel, 1 blocks) must
+equal the reference-order kernel (variant 0) bit for bit, and a sample must equal the oracle.
+Usage: python tools/fuzz_gpu.py [seconds]   (SEED=n);   tests/test_gpu_fuzz.py runs fuzz() under the driver's -m gpu suite"""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -8,117 +9,145 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from sbwt_amd import capi, hostlib, synth
 from oracle import OracleIndex
 
-budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
-capi.set_tuning("poison_results", 1)
-t_end = time.time() + budget
-case = 0
-rng = np.random.default_rng(int(os.environ.get("SEED", 1)))
-while time.time() < t_end:
-    case += 1
-    k = int(rng.choice([4, 7, 12, 16, 21, 30, 31, 32, 33, 40, 63]))
-    shape = int(rng.integers(0, 5))
-    glen = int(rng.integers(2_000, 120_000))
-    g0 = synth.random_genome(glen, int(rng.integers(1, 1 << 30)))
-    if shape == 0:
-        genomes = [g0]
-    elif shape == 1:
-        genomes = [g0, synth.mutate(g0, float(rng.choice([0.001, 0.01, 0.05])), int(rng.integers(1, 1 << 30)))]
-    elif shape == 2:      # tandem repeats and a low-complexity stretch
-        unit = g0[: int(rng.integers(3, 40))]
-        genomes = [np.concatenate([g0[:500], np.tile(unit, 60), g0[500:1500], np.frombuffer(b"AC" * 200, dtype=np.uint8), g0[1500:]])]
-    elif shape == 3:      # several short sequences (many dummy nodes)
-        genomes = [g0[i:i + int(rng.integers(k, 4 * k + 10))].copy() for i in range(0, min(glen, 20_000), 997)]
-    else:                 # star of related genomes
-        genomes = [g0] + [synth.mutate(g0, 0.02, int(rng.integers(1, 1 << 30))) for _ in range(4)]
-    genomes = [g for g in genomes if len(g) >= k + 2]
-    ssup = bool(rng.integers(0, 2))
-    rc = bool(rng.integers(0, 2))
-    bits = hostlib.build_bits([g.tobytes() for g in genomes], k, rc, ssup, n_threads=4)
-    # knobs that must not change results: how the paths are chosen, which safe rule, the image level
-    capi.set_tuning("path_lookahead", int(rng.choice([0, 1, 8])))
-    capi.set_tuning("path_safe", int(rng.choice([0, 1, 2, 2])))
-    capi.set_tuning("image_level", int(rng.choice([0, 0, 0, 1, 2])))
-    capi.set_tuning("path_stitch", int(rng.choice([1, 1, 1, 0])))
-    capi.set_tuning("path_stitch_min", int(rng.choice([1, 1, 4, 16])))
-    idx = capi.Index.create(bits.cols[0], bits.cols[1], bits.cols[2], bits.cols[3], bits.ssup if ssup else None,
-                            bits.n_nodes, k, bits.n_kmers, int(rng.choice([0, 0, 2, min(k, 8)])))
-    # reads
-    nr = int(rng.integers(200, 4000))
-    if rng.integers(0, 2):
-        L = int(rng.integers(max(k - 2, 1), 4 * k + 60))
-        long_enough = [g for g in genomes if len(g) >= L]
-        if not long_enough:
-            continue
-        bases, off = synth.sample_reads(long_enough, nr, L, float(rng.choice([0, 0.005, 0.02, 0.1])), int(rng.integers(1, 1 << 30)))
-    else:                 # ragged lengths
-        cat = np.concatenate(genomes)
-        lens = np.minimum(rng.integers(0, 3 * k + 40, size=nr), len(cat))
-        st = (rng.random(nr) * (len(cat) - lens + 1)).astype(np.int64)
-        off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
-        bases = np.empty(int(off[-1]), dtype=np.uint8)
-        for r in range(nr):
-            bases[off[r]:off[r + 1]] = cat[st[r]:st[r] + lens[r]]
-        flip = rng.random(len(bases)) < 0.01
-        bases[flip] = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=int(flip.sum()))]
-    if rng.integers(0, 4) == 0:      # a few long reads (cut into pieces on the device), some with lower-case stretches
-        cat = np.concatenate(genomes)
-        extra = []
-        for _ in range(int(rng.integers(1, 12))):
-            ln = int(min(rng.integers(260, 6000), len(cat)))
-            s0 = int(rng.integers(0, len(cat) - ln + 1))
-            rd = cat[s0:s0 + ln].copy()
-            for _ in range(int(rng.integers(0, 4))):
-                a0 = int(rng.integers(0, ln)); a1 = min(ln, a0 + int(rng.integers(1, 400)))
-                rd[a0:a1] = np.frombuffer(rd[a0:a1].tobytes().lower(), dtype=np.uint8)
-            extra.append(rd)
-        pos = int(rng.integers(0, len(off)))                      # ... somewhere among the others
-        lens = np.diff(off)
-        parts = [bases[off[r]:off[r + 1]] for r in range(len(lens))]
-        parts[pos:pos] = extra
-        bases = np.concatenate(parts) if parts else np.zeros(0, dtype=np.uint8)
-        off = np.concatenate([[0], np.cumsum([len(x) for x in parts])]).astype(np.int64)
-        nr = len(parts)
-    if len(bases) > 100:
-        bases = synth.inject(bases, int(rng.integers(0, 30)), ord("N"), int(rng.integers(1, 1 << 30)))
-        bases = synth.inject(bases, int(rng.integers(0, 30)), int(rng.choice(list(b"acgtn"))), int(rng.integers(1, 1 << 30)))
-    res = {}
-    for v in (0, 1, 4, 5):
-        capi.set_tuning("search_variant", v)
-        capi.set_tuning("sort_reads", int(rng.integers(0, 2)) if v == 4 else -1)
-        a = idx.streaming_search(bases, off)[0] if ssup else None
-        b = idx.search(bases, off)[0]
-        res[(v, -1)] = (a, b)
-    ref = res[(0, -1)]
 
-    def explain(got, want):
-        """where two result vectors differ: the read, its text, both results around the first difference"""
-        d = int(np.flatnonzero(got != want)[0])
-        oo = np.concatenate([[0], np.cumsum(np.maximum(np.diff(off) - k + 1, 0))])
-        r = int(np.searchsorted(oo, d, side="right") - 1)
-        print(" first difference at result", d, "= k-mer", d - int(oo[r]), "of read", r, "length", int(off[r + 1] - off[r]),
-              "differences in all:", int((got != want).sum()))
-        print(" read:", bases[off[r]:off[r + 1]].tobytes().decode("latin1"))
-        print(" got :", got[oo[r]:oo[r + 1]].tolist())
-        print(" want:", want[oo[r]:oo[r + 1]].tolist())
-        print(" index: n_nodes", bits.n_nodes, "device precalc", idx.device_precalc_k, "paths", idx.n_paths, "branching", idx.n_branch)
 
-    for key, (a, b) in res.items():
-        if ssup and not np.array_equal(a, ref[0]):
-            print("MISMATCH streaming", key, "case", case, "k", k, "shape", shape, "ssup", ssup, "rc", rc); explain(a, ref[0]); sys.exit(1)
-        if not np.array_equal(b, ref[1]):
-            print("MISMATCH search", key, "case", case, "k", k, "shape", shape, "ssup", ssup, "rc", rc); explain(b, ref[1]); sys.exit(1)
-    if case % 10 == 1 and bits.n_nodes < 400_000:     # the oracle on a sample
-        orc = OracleIndex.from_bits(bits.cols[0], bits.cols[1], bits.cols[2], bits.cols[3], bits.ssup if ssup else None,
-                                    bits.n_nodes, k, bits.n_kmers, 0)
-        for r in range(min(nr, 40)):
-            s = bases[off[r]:off[r + 1]].tobytes()
-            want = orc.streaming_search(s) if ssup else orc.search_all(s)
+class FuzzMismatch(AssertionError):
+    pass
+
+
+def reset_tuning():
+    capi.set_tuning("search_variant", -1)
+    capi.set_tuning("sort_reads", -1)
+    capi.set_tuning("path_lookahead", 8); capi.set_tuning("path_safe", 2); capi.set_tuning("image_level", 0)
+    capi.set_tuning("path_stitch", 1); capi.set_tuning("path_stitch_min", 1)
+
+
+def fuzz(budget, seed, max_cases=None):
+    """Runs random cases for `budget` seconds (or max_cases); returns the number of cases.  Raises FuzzMismatch with a
+    description of the first difference."""
+    try:
+        return _fuzz(budget, seed, max_cases)
+    finally:
+        reset_tuning()
+
+
+def _fuzz(budget, seed, max_cases):
+    capi.set_tuning("poison_results", 1)
+    t_end = time.time() + budget
+    case = 0
+    rng = np.random.default_rng(seed)
+    while time.time() < t_end and (max_cases is None or case < max_cases):
+        case += 1
+        k = int(rng.choice([4, 7, 12, 16, 21, 30, 31, 32, 33, 40, 63]))
+        shape = int(rng.integers(0, 5))
+        glen = int(rng.integers(2_000, 120_000))
+        g0 = synth.random_genome(glen, int(rng.integers(1, 1 << 30)))
+        if shape == 0:
+            genomes = [g0]
+        elif shape == 1:
+            genomes = [g0, synth.mutate(g0, float(rng.choice([0.001, 0.01, 0.05])), int(rng.integers(1, 1 << 30)))]
+        elif shape == 2:      # tandem repeats and a low-complexity stretch
+            unit = g0[: int(rng.integers(3, 40))]
+            genomes = [np.concatenate([g0[:500], np.tile(unit, 60), g0[500:1500], np.frombuffer(b"AC" * 200, dtype=np.uint8), g0[1500:]])]
+        elif shape == 3:      # several short sequences (many dummy nodes)
+            genomes = [g0[i:i + int(rng.integers(k, 4 * k + 10))].copy() for i in range(0, min(glen, 20_000), 997)]
+        else:                 # star of related genomes
+            genomes = [g0] + [synth.mutate(g0, 0.02, int(rng.integers(1, 1 << 30))) for _ in range(4)]
+        genomes = [g for g in genomes if len(g) >= k + 2]
+        ssup = bool(rng.integers(0, 2))
+        rc = bool(rng.integers(0, 2))
+        bits = hostlib.build_bits([g.tobytes() for g in genomes], k, rc, ssup, n_threads=4)
+        # knobs that must not change results: how the paths are chosen, which safe rule, the image level
+        capi.set_tuning("path_lookahead", int(rng.choice([0, 1, 8])))
+        capi.set_tuning("path_safe", int(rng.choice([0, 1, 2, 2])))
+        capi.set_tuning("image_level", int(rng.choice([0, 0, 0, 1, 2])))
+        capi.set_tuning("path_stitch", int(rng.choice([1, 1, 1, 0])))
+        capi.set_tuning("path_stitch_min", int(rng.choice([1, 1, 4, 16])))
+        idx = capi.Index.create(bits.cols[0], bits.cols[1], bits.cols[2], bits.cols[3], bits.ssup if ssup else None,
+                                bits.n_nodes, k, bits.n_kmers, int(rng.choice([0, 0, 2, min(k, 8)])))
+        # reads
+        nr = int(rng.integers(200, 4000))
+        if rng.integers(0, 2):
+            L = int(rng.integers(max(k - 2, 1), 4 * k + 60))
+            long_enough = [g for g in genomes if len(g) >= L]
+            if not long_enough:
+                continue
+            bases, off = synth.sample_reads(long_enough, nr, L, float(rng.choice([0, 0.005, 0.02, 0.1])), int(rng.integers(1, 1 << 30)))
+        else:                 # ragged lengths
+            cat = np.concatenate(genomes)
+            lens = np.minimum(rng.integers(0, 3 * k + 40, size=nr), len(cat))
+            st = (rng.random(nr) * (len(cat) - lens + 1)).astype(np.int64)
+            off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+            bases = np.empty(int(off[-1]), dtype=np.uint8)
+            for r in range(nr):
+                bases[off[r]:off[r + 1]] = cat[st[r]:st[r] + lens[r]]
+            flip = rng.random(len(bases)) < 0.01
+            bases[flip] = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=int(flip.sum()))]
+        if rng.integers(0, 4) == 0:      # a few long reads (cut into pieces on the device), some with lower-case stretches
+            cat = np.concatenate(genomes)
+            extra = []
+            for _ in range(int(rng.integers(1, 12))):
+                ln = int(min(rng.integers(260, 6000), len(cat)))
+                s0 = int(rng.integers(0, len(cat) - ln + 1))
+                rd = cat[s0:s0 + ln].copy()
+                for _ in range(int(rng.integers(0, 4))):
+                    a0 = int(rng.integers(0, ln)); a1 = min(ln, a0 + int(rng.integers(1, 400)))
+                    rd[a0:a1] = np.frombuffer(rd[a0:a1].tobytes().lower(), dtype=np.uint8)
+                extra.append(rd)
+            pos = int(rng.integers(0, len(off)))                      # ... somewhere among the others
+            lens = np.diff(off)
+            parts = [bases[off[r]:off[r + 1]] for r in range(len(lens))]
+            parts[pos:pos] = extra
+            bases = np.concatenate(parts) if parts else np.zeros(0, dtype=np.uint8)
+            off = np.concatenate([[0], np.cumsum([len(x) for x in parts])]).astype(np.int64)
+            nr = len(parts)
+        if len(bases) > 100:
+            bases = synth.inject(bases, int(rng.integers(0, 30)), ord("N"), int(rng.integers(1, 1 << 30)))
+            bases = synth.inject(bases, int(rng.integers(0, 30)), int(rng.choice(list(b"acgtn"))), int(rng.integers(1, 1 << 30)))
+        res = {}
+        for v in (0, 1, 4, 5):
+            capi.set_tuning("search_variant", v)
+            capi.set_tuning("sort_reads", int(rng.integers(0, 2)) if v == 4 else -1)
+            a = idx.streaming_search(bases, off)[0] if ssup else None
+            b = idx.search(bases, off)[0]
+            res[(v, -1)] = (a, b)
+        ref = res[(0, -1)]
+
+        def explain(got, want):
+            """where two result vectors differ: the read, its text, both results around the first difference"""
+            d = int(np.flatnonzero(got != want)[0])
             oo = np.concatenate([[0], np.cumsum(np.maximum(np.diff(off) - k + 1, 0))])
-            got = (ref[0] if ssup else ref[1])[oo[r]:oo[r + 1]]
-            if not np.array_equal(got, want):
-                print("MISMATCH vs oracle case", case, "read", r); sys.exit(1)
-capi.set_tuning("search_variant", -1)
-capi.set_tuning("sort_reads", -1)
-capi.set_tuning("path_lookahead", 8); capi.set_tuning("path_safe", 2); capi.set_tuning("image_level", 0)
-capi.set_tuning("path_stitch", 1); capi.set_tuning("path_stitch_min", 1)
-print("fuzz ok:", case, "cases")
+            r = int(np.searchsorted(oo, d, side="right") - 1)
+            print(" first difference at result", d, "= k-mer", d - int(oo[r]), "of read", r, "length", int(off[r + 1] - off[r]),
+                  "differences in all:", int((got != want).sum()))
+            print(" read:", bases[off[r]:off[r + 1]].tobytes().decode("latin1"))
+            print(" got :", got[oo[r]:oo[r + 1]].tolist())
+            print(" want:", want[oo[r]:oo[r + 1]].tolist())
+            print(" index: n_nodes", bits.n_nodes, "device precalc", idx.device_precalc_k, "paths", idx.n_paths, "branching", idx.n_branch)
+
+        for key, (a, b) in res.items():
+            if ssup and not np.array_equal(a, ref[0]):
+                explain(a, ref[0]); raise FuzzMismatch("MISMATCH streaming %s seed %d case %d k %d shape %d ssup %s rc %s" % (key, seed, case, k, shape, ssup, rc))
+            if not np.array_equal(b, ref[1]):
+                explain(b, ref[1]); raise FuzzMismatch("MISMATCH search %s seed %d case %d k %d shape %d ssup %s rc %s" % (key, seed, case, k, shape, ssup, rc))
+        if case % 10 == 1 and bits.n_nodes < 400_000:     # the oracle on a sample
+            orc = OracleIndex.from_bits(bits.cols[0], bits.cols[1], bits.cols[2], bits.cols[3], bits.ssup if ssup else None,
+                                        bits.n_nodes, k, bits.n_kmers, 0)
+            for r in range(min(nr, 40)):
+                s = bases[off[r]:off[r + 1]].tobytes()
+                want = orc.streaming_search(s) if ssup else orc.search_all(s)
+                oo = np.concatenate([[0], np.cumsum(np.maximum(np.diff(off) - k + 1, 0))])
+                got = (ref[0] if ssup else ref[1])[oo[r]:oo[r + 1]]
+                if not np.array_equal(got, want):
+                    raise FuzzMismatch("MISMATCH vs oracle: seed %d case %d read %d" % (seed, case, r))
+    return case
+
+
+if __name__ == "__main__":
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+    try:
+        n = fuzz(budget, int(os.environ.get("SEED", 1)))
+    except FuzzMismatch as ex:
+        print(ex)
+        sys.exit(1)
+    print("fuzz ok:", n, "cases")

@@ -15,8 +15,8 @@ dev = torch.device("cuda", 0)
 st = torch.cuda.current_stream().cuda_stream
 
 
-def make_index(genomes):
-    bits = capi.build_bits_gpu([g.tobytes() for g in genomes], K, False, True)
+def make_index(genomes, rc=False):
+    bits = capi.build_bits_gpu([g.tobytes() for g in genomes], K, rc, True)
     return capi.Index.create(bits.cols[0], bits.cols[1], bits.cols[2], bits.cols[3], bits.ssup, bits.n_nodes, K, bits.n_kmers, PRE)
 
 
@@ -81,3 +81,10 @@ single = [synth.random_genome(3 * glen, 9)]
 idx2 = make_index(single)
 b, o = synth.sample_reads(single, n_reads, 150, 0.01, 47)
 run("one 15 Mbp strain (long unbranched paths)", idx2, b, o)
+
+# the normal use of the tool: an index with reverse complements (tests/test_CLI.hh:43), reads from both strands
+del idx1, idx2
+idx3 = make_index(base, rc=True)
+print(json.dumps({"revcomp_index": {"n_nodes": idx3.n_nodes, "image_MB": idx3.blob_bytes / 1e6, "paths": idx3.n_paths}}), flush=True)
+b, o = synth.both_strand_reads(base, n_reads, 150, 0.01, 50)
+run("reverse-complement index (2 x the k-mers), reads from both strands, 150 bp, 1% substitutions", idx3, b, o)
