@@ -70,6 +70,16 @@ def log(msg: str) -> None:
     print(f"[bench] {msg}", file=sys.stderr, flush=True)
 
 
+_T0 = time.time()
+
+
+def phase(rank: int, world: int, what: str) -> None:
+    """Multi-rank runs say where they are (rank 0 always; every rank with SBWT_BENCH_VERBOSE): a stalled 8-GPU run then
+    names the phase -- columns, image, broadcast, reads, warm-up, timed loop -- instead of just timing out."""
+    if world > 1 and (rank == 0 or os.environ.get("SBWT_BENCH_VERBOSE")):
+        log("rank %d/%d t+%.1fs: %s" % (rank, world, time.time() - _T0, what))
+
+
 def gpu_reads(genomes, n_reads: int, seed: int, dev: torch.device) -> torch.Tensor:
     """n_reads x READ_LEN substrings at uniform (genome, offset) with per-base substitutions,
     generated on the GPU (seeded) so that the inputs are resident in HBM."""
@@ -119,15 +129,33 @@ def kernel_source_sha16() -> str:
     return h.hexdigest()[:16]
 
 
-def load_traffic(config: int, n_reads: int):
-    """profiles/traffic.json entry for this workload, if it was measured on the current kernel sources."""
+def dominant_kernel(variant: int, image_level: int) -> str:
+    """The kernel that does a search step's work for (search variant, image level)."""
+    if variant == 0:
+        return "k_search"
+    if image_level != 0:
+        return "k_search_cert"
+    return {5: "k_search_fused", 4: "k_search_cert<PATH,SEG>", 2: "k_search_cert<PATH,SEG>", 3: "k_search_cert<PATH,SEG>"}.get(
+        variant, "k_search_cert")
+
+
+def traffic_key(config: int, image_level: int, variant: int) -> str:
+    return "config%d_level%d_variant%d" % (config, image_level, variant)
+
+
+def load_traffic(config: int, n_reads: int, image_level: int, variant: int, kernel: str):
+    """profiles/traffic.json entry for this workload, if it was measured on the current kernel sources, the same image
+    level, the same search route and the same dominant kernel -- a counter value never travels to another kernel's line."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
     try:
         tj = json.load(open(path))
     except Exception:
         return None
-    ent = tj.get("config%d" % config) if isinstance(tj.get("config%d" % config), dict) else None
-    if ent is None or ent.get("kernel_source_sha16") != kernel_source_sha16() or ent.get("reads_per_gpu") != n_reads:
+    ent = tj.get(traffic_key(config, image_level, variant))
+    if not isinstance(ent, dict):
+        return None
+    if (ent.get("kernel_source_sha16") != kernel_source_sha16() or ent.get("reads_per_gpu") != n_reads or
+            ent.get("kernel") != kernel or ent.get("image_level") != image_level or ent.get("search_variant") != variant):
         return None
     return ent
 
@@ -303,6 +331,13 @@ def main() -> int:
     # ---- launcher: `python bench.py --gpus N` without RANK in the environment starts the N ranks itself.
     # Decided here, before torch / HIP are even imported: a process that has touched the GPU is never re-executed.
     if args.gpus > 1 and "RANK" not in os.environ:
+        # (counting devices does not initialise the GPU on this image; SBWT_BENCH_FORCE_DEVICE = several ranks on one GPU)
+        if "SBWT_BENCH_FORCE_DEVICE" not in os.environ:
+            import torch as _t
+            have = _t.cuda.device_count()
+            if args.gpus > have:
+                log(f"error: --gpus {args.gpus} but only {have} HIP device(s) are visible on this node")
+                return 2
         return launch_ranks(args.gpus)
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
@@ -331,6 +366,9 @@ def main() -> int:
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the search path has no CPU fallback")
+    if "SBWT_BENCH_FORCE_DEVICE" not in os.environ and local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"bench.py: rank {rank} wants device {local_rank}, but only {torch.cuda.device_count()} HIP "
+                         f"device(s) are visible (--gpus {args.gpus})")
     # test hooks: run several ranks on one GPU (SBWT_BENCH_FORCE_DEVICE) over gloo (SBWT_BENCH_BACKEND) to
     # exercise the N>1 code path on a single-GPU box; the driver's multi-GPU run uses neither
     if "SBWT_BENCH_FORCE_DEVICE" in os.environ:
@@ -348,6 +386,7 @@ def main() -> int:
     if args.kernel == "rank":
         return rank_bench(args, rank, world, local_rank, dev)
 
+    phase(rank, world, "process group up (backend %s), device %d" % (backend if world > 1 else "-", local_rank))
     # ---- index: built once on rank 0 (host sort-based builder), replicated by one broadcast ----
     if args.config == 6:
         genomes = [synth.random_genome(args.hbm_genome_len, 7)]
@@ -370,6 +409,7 @@ def main() -> int:
         else:
             bits = hostlib.build_bits([g.tobytes() for g in genomes], K, False, streaming, n_threads=effective_cores())
         t_cols = time.time() - t0
+        phase(rank, world, "columns built (%.1f s)" % t_cols)
     capi.set_tuning("image_level", args.image_level)
     build_times = None
     t_bcast = None
@@ -408,6 +448,7 @@ def main() -> int:
                        "image_level": index.image_level, "image_bytes_per_column": index.blob_bytes / index.n_nodes,
                        "paths": index.n_paths, "branching_columns": index.n_branch,
                        "search_variant": index.default_search_variant}
+    phase(rank, world, "image ready on rank 0" if rank == 0 else "waiting for the image")
     if world > 1 and args.replicate == "image":
         hdr, blob = None, None
         if rank == 0:
@@ -421,6 +462,7 @@ def main() -> int:
         t_bcast = time.time() - tb
         if rank != 0:
             index = capi.Index.adopt(hdr, blob.data_ptr(), blob.numel(), local_rank, keepalive=blob)
+        phase(rank, world, "image broadcast done: %.2f GB in %.2f s" % (index.blob_bytes / 1e9, t_bcast))
 
     # ---- this rank's reads, resident in HBM ----
     m = READ_LEN - K + 1
@@ -471,11 +513,13 @@ def main() -> int:
         if ev is not None:
             ev[1].record()
 
+    phase(rank, world, "reads resident (%d reads), warm-up" % n_reads)
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
+    phase(rank, world, "timed loop: %d steps" % args.steps)
     events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     torch.cuda.synchronize()
     if one_call:
@@ -489,6 +533,7 @@ def main() -> int:
     elapsed = time.perf_counter() - t_start
     if world > 1:
         elapsed = sdist.max_over_ranks(elapsed, dev)
+    phase(rank, world, "timed loop done: %.2f ms per step (max over ranks)" % (elapsed / args.steps * 1e3))
 
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in events]))     # the whole call (two-call routes: the search call)
     if one_call:
@@ -557,8 +602,7 @@ def main() -> int:
         },
         "roofline": {
             "bound": "hbm",
-            "kernel": {5: "k_search_fused", 4: "k_search_cert<PATH,SEG>", 2: "k_search_cert<PATH>"}.get(
-                variant, "k_search_cert") if index.image_level == 0 else "k_search_cert",
+            "kernel": dominant_kernel(variant, index.image_level),
             "achieved": alg_bytes / (kernel_ms * 1e-3) / 1e9,
             "peak": HBM_PEAK_GBPS,
             "unit": "GB/s",
@@ -588,10 +632,16 @@ def main() -> int:
     # HBM-side bytes per launch from the PMC counters: measured by tools/profile.sh in separate rocprofv3 passes (a
     # bench run cannot collect counters on itself) and attached ONLY while the profile belongs to the kernels that
     # just ran (same source hash, same workload); otherwise null, never a stale number
-    tj = load_traffic(args.config, n_reads)
+    tj = load_traffic(args.config, n_reads, index.image_level, variant, result["roofline"]["kernel"])
+    result["roofline"]["traffic_over_algorithmic"] = None
+    result["roofline"]["read_lines_per_read"] = None
     if tj is not None:
         result["roofline"]["traffic"] = tj.get("hbm_bytes_per_launch")
         result["roofline"]["traffic_source"] = tj.get("source")
+        result["roofline"]["traffic_over_algorithmic"] = tj.get("hbm_bytes_per_launch") / alg_bytes
+        if tj.get("read_requests_128B"):
+            result["roofline"]["read_lines_per_read"] = tj["read_requests_128B"] / n_reads      # 128-byte fabric requests
+            result["roofline"]["write_requests_per_read"] = (tj.get("write_requests_64B") or 0) / n_reads
         # what the memory system actually moved per second during the kernel (every gather drags a 128-byte line):
         result["roofline"]["traffic_GBps"] = tj.get("hbm_bytes_per_launch") / (kernel_ms * 1e-3) / 1e9
         result["roofline"]["traffic_frac_of_peak"] = result["roofline"]["traffic_GBps"] / HBM_PEAK_GBPS
@@ -686,6 +736,10 @@ def main() -> int:
                       "(sbwt_search.cpp:54-56 style, best of 2 passes, output pre-faulted); wall clock of that "
                       "pass %.3f s" % (sample, sample * m, cores, best[1]),
             "value_1thread": m / per_read_1t,
+            "value_per_core": sample * m / wall / cores,
+            "cores_note": "cores = what this process may use (affinity mask capped by the cgroup CPU quota), not the host's "
+                          "%d logical CPUs; the GPU / CPU ratio below is against THESE cores -- scale value_per_core by a "
+                          "core count yourself, it is not measured beyond them" % (os.cpu_count() or 0),
             "host_logical_cpus": os.cpu_count(),
             "gpu_output_bit_identical_on_sample": parity,
         }

@@ -263,3 +263,52 @@ def test_parallel_gzip_writer_roundtrip(tmp_path):
     p = str(tmp_path / "plain.fna")
     hostlib.write_file(p, b">y\nACGT\n", gzip_output=False)
     assert open(p, "rb").read() == b">y\nACGT\n"
+
+
+def test_reader_and_writer_on_pipes(tmp_path):
+    """Non-seekable input and output: `-q <(zcat reads.fq.gz)`-style FIFOs feed the reader, and the writer
+    appends to a pipe (`-o /dev/stdout | ...`), like the reference's ifstream / ofstream do.  The reader's gzip probe
+    keeps the bytes it read instead of rewinding; the writer uses write(2), not pwrite."""
+    import threading
+    reads = [b"ACGTACGTAC", b"ttgaN", b"G" * 70000]
+    fq = b"".join(b"@r%d\n%s\n+\n%s\n" % (i, r, b"I" * len(r)) for i, r in enumerate(reads))
+    fifo = str(tmp_path / "in.fastq")
+    os.mkfifo(fifo)
+
+    def feed():
+        with open(fifo, "wb") as f:
+            f.write(fq)
+    t = threading.Thread(target=feed)
+    t.start()
+    bases, off = hostlib.read_sequences(fifo)
+    t.join()
+    assert len(off) == len(reads) + 1
+    assert bases.tobytes() == b"".join(r.upper() for r in reads)
+    # one-byte and empty inputs through a FIFO (the probe read less than it asked for)
+    for content, want in ((b">", 1), (b"", 0)):
+        fa = str(tmp_path / ("in%d.fna" % len(content)))
+        os.mkfifo(fa)
+        t = threading.Thread(target=lambda: open(fa, "wb").write(content))
+        t.start()
+        _, off = hostlib.read_sequences(fa)
+        t.join()
+        assert len(off) == 1                                 # no reads either way (a header without bases ends the stream)
+    # gzip data arriving on a pipe under a plain name: a loud error, not text parsing
+    fz = str(tmp_path / "z.fastq")
+    os.mkfifo(fz)
+    t = threading.Thread(target=lambda: open(fz, "wb").write(gzip.compress(fq)))
+    t.start()
+    with pytest.raises(RuntimeError):
+        hostlib.read_sequences(fz)
+    t.join()
+    # the writer on a FIFO, plain and gzip
+    for gz in (False, True):
+        out = str(tmp_path / ("out%d" % gz))
+        os.mkfifo(out)
+        got = []
+        t = threading.Thread(target=lambda: got.append(open(out, "rb").read()))
+        t.start()
+        data = os.urandom(3_000_000) + b"tail"
+        hostlib.write_file(out, data, gz, 2)
+        t.join()
+        assert (gzip.decompress(got[0]) if gz else got[0]) == data
