@@ -713,6 +713,132 @@ __global__ void __launch_bounds__(256) k_path_safe_labels(SbwtIndexView ix, unsi
     if (ok == 7u) atomicOr(&pq_words[(size_t)q * 4 + 3], 1u << s);
 }
 
+// ---- the same bits for 31 < k <= 63: whole k-mers live in the two-level table (stab at depth 31 + stab2), windows are up
+// to 126 bits wide (unsigned __int128), the k-1 steps left of u span up to three path groups.  Rule 2 only (head labels).
+typedef unsigned __int128 u128;
+__device__ __forceinline__ u128 mask128(int bits) { return bits >= 128 ? ~(u128)0 : ((((u128)1) << bits) - 1); }
+__device__ __forceinline__ bool sp_find(const SbwtIndexView &ix, u64 key, unsigned *first) {
+    size_t bkt = sbwt_sp_bucket(key, ix.n_sb, 0u);
+    for (;;) {
+        const uint4 e0 = ix.stab[2 * bkt], e1 = ix.stab[2 * bkt + 1];
+        const u64 w0 = quad_bits(e0), w1 = quad_bits(e1);
+        if ((w0 & ~SBWT_SP_OVERFLOW) == key) { *first = e0.z; return true; }
+        if (w1 == key) { *first = e1.z; return true; }
+        if (!(w0 & SBWT_SP_OVERFLOW)) return false;
+        bkt = bkt + 1 < ix.n_sb ? bkt + 1 : 0;
+    }
+}
+__device__ __forceinline__ bool sp2_present(const SbwtIndexView &ix, unsigned origin, u64 key2) {
+    unsigned e = sbwt_sp2_entry(origin, key2, ix.n_sb2, 0u);
+    for (;;) {
+        const uint4 a = ix.stab2[2 * (size_t)e];
+        if ((a.w & SBWT_SP2_USED) && quad_bits(a) == key2 && a.z == origin) return true;
+        if (!(a.w & SBWT_SP2_OVERFLOW)) return false;
+        e = e + 1 < ix.n_sb2 ? e + 1 : 0;
+    }
+}
+template <bool MEGA>
+__global__ void __launch_bounds__(256) k_path_head_labels_wide(SbwtIndexView ix, const unsigned *__restrict__ list,
+                                                               const u64 *__restrict__ count, u64 *__restrict__ hlab) {
+    const i64 e = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (i64)*count) return;
+    const i64 t = list[e];
+    const int k = ix.k;
+    i64 v = ix.col[t];
+    u128 lab = 0;                                       // char j of the label at bits 2j (first char lowest, as the table keys)
+    bool dummy = false;
+    for (int i = 0; i < k; i++) {
+        if (v == 0) { dummy = true; break; }            // a dummy column: its label starts with '$' -- never vouched for
+        int c = 0;
+        while (c + 1 < 4 && v >= ix.C[c + 1]) c++;
+        lab |= (u128)(unsigned)c << (2 * (k - 1 - i));
+        const i64 hi_c = (c < 3) ? ix.C[c + 1] : ix.n_nodes;
+        v = select_in_row<MEGA>(ix, c, v, hi_c - ix.C[c]);
+    }
+    hlab[2 * t] = dummy ? ~0ull : (u64)lab;
+    hlab[2 * t + 1] = dummy ? ~0ull : (u64)(lab >> 64);
+}
+__global__ void __launch_bounds__(256) k_path_safe_labels_wide(SbwtIndexView ix, unsigned *pq_words, const u64 *__restrict__ hlab,
+                                                               unsigned char *__restrict__ alt_safe) {
+    const i64 u = (i64)blockIdx.x * 256 + threadIdx.x;
+    const int k = ix.k;                                 // 32 .. 63
+    if (u >= ix.n_pos) return;
+    // steps 32(q-2) .. 32(q+3)-1 in five quads; step u is number o = 64 + s of them
+    const i64 q = u >> 5;
+    const int s = (int)(u & 31), o = 64 + s;
+    u64 Cw[7];
+    unsigned Gw[7];
+#pragma unroll
+    for (int j = 0; j < 5; j++) {
+        const i64 qq = q - 2 + j;
+        const uint4 v = qq >= 0 ? ix.pq[qq] : make_uint4(0u, 0u, 0u, 0u);
+        Cw[j] = quad_bits(v);
+        Gw[j] = v.z;                                    // (build-time layout: z = GO)
+    }
+    Cw[5] = Cw[6] = 0ull;
+    Gw[5] = Gw[6] = 0u;
+    const u128 glo = (u128)Gw[0] | ((u128)Gw[1] << 32) | ((u128)Gw[2] << 64) | ((u128)Gw[3] << 96);
+    const u64 ghi = (u64)Gw[4];
+    auto go_bits = [&](int f, int n) -> u64 {           // go bits of steps number f .. f+n-1 (n <= 63)
+        u128 v = glo >> f;
+        if (f) v |= (u128)ghi << (128 - f);
+        return (u64)v & low_mask(n);
+    };
+    auto chars = [&](int f, int n) -> u128 {            // chars of steps number f .. f+n-1 (n <= 63), 2 bits each
+        const int w = f >> 5, sh = 2 * (f & 31);
+        const u128 lo = (u128)Cw[w] | ((u128)Cw[w + 1] << 64);
+        u128 v = lo >> sh;
+        if (sh) v |= (u128)Cw[w + 2] << (128 - sh);
+        return v & mask128(2 * n);
+    };
+    // the k steps u .. u+k-1 and their chars
+    if (go_bits(o, k) != low_mask(k)) return;
+    const u128 right = chars(o, k);
+    // the k-1 steps before u: on this path, or as far back as its head and then the head's label
+    const int f = o - (k - 1);                          // first of them, in [2, 64]
+    const u64 gl = go_bits(f, k - 1);
+    const u128 val = chars(f, k - 1);
+    u128 left = val;
+    if (gl != low_mask(k - 1)) {
+        const int jz = 63 - __clzll((i64)(~gl & low_mask(k - 1)));      // the last step that does not go on
+        const int d = k - 2 - jz;                       // u is d steps after its path's head
+        const u64 H0 = hlab[2 * (u - d)], H1 = hlab[2 * (u - d) + 1];
+        if (H0 == ~0ull && H1 == ~0ull) return;
+        const u128 H = (u128)H0 | ((u128)H1 << 64);
+        const u128 lm = mask128(2 * (k - 1 - d));
+        left = ((H >> (2 * (d + 1))) & lm) | (val & ~lm);
+    }
+    // S = left (k-1 chars) . ch[u] . right's other k-1 chars; window number w starts at char w, ch[u] is its char k-1-w
+    const u128 Slo = left | (right << (2 * (k - 1)));
+    const u128 Shi = right >> (128 - 2 * (k - 1));      // (62 <= 2(k-1) <= 124)
+    const u128 km = mask128(2 * k);
+    const u64 m62 = low_mask(62);
+    const int rest = k - 31;                            // chars of the second-level key, 1 .. 32
+    const u64 mrest = rest >= 32 ? ~0ull : low_mask(2 * rest);
+    unsigned ok = 7u;                                   // substitutes not seen in any window yet
+    for (int w = 0; w < k && ok; w++) {
+        u128 key = Slo >> (2 * w);
+        if (w) key |= Shi << (128 - 2 * w);
+        key &= km;
+        const u64 P = (u64)key & m62, R = (u64)(key >> 62) & mrest;
+        const int a = k - 1 - w;                        // ch[u] is char a of the window
+        if (a < 31) {
+            for (u64 alt = 1; alt < 4; alt++) {
+                unsigned first = 0;
+                if (((ok >> (alt - 1)) & 1u) && sp_find(ix, P ^ (alt << (2 * a)), &first) && sp2_present(ix, first, R))
+                    ok &= ~(1u << (alt - 1));
+            }
+        } else {
+            unsigned first = 0;
+            if (sp_find(ix, P, &first))
+                for (u64 alt = 1; alt < 4; alt++)
+                    if (((ok >> (alt - 1)) & 1u) && sp2_present(ix, first, R ^ (alt << (2 * (a - 31))))) ok &= ~(1u << (alt - 1));
+        }
+    }
+    if (alt_safe) alt_safe[u] = (unsigned char)ok;
+    if (ok == 7u) atomicOr(&pq_words[(size_t)q * 4 + 3], 1u << s);
+}
+
 // Where a read can leave its path, and the transition table.  Position t (column v = col[t]) offers the successors of v's
 // suffix group; the path itself takes one of them (char y).  ONLY[t]: y is the only one -- a read that differs from the path
 // there gets -1 without any gather (SBWT.hh:572-575: no column of the group carries its char), or a bridge where the SAFE bit
@@ -928,22 +1054,37 @@ long long sbwt_count_paths(const SbwtIndexView &ix, hipStream_t stream) {
     (void)hipFree(d);
     return e == hipSuccess ? (long long)h : -1;
 }
-// rule 1: 2k steps around u on one path; rule 2 (needs d_hlab: sbwt_path_safe_scratch_bytes of scratch): k steps from u on
-long long sbwt_path_safe_scratch_bytes(long long n_pos) { return (((long long)n_pos * 12 + 15) & ~15ll) + 256; }
+// rule 1: 2k steps around u on one path; rule 2 (needs d_hlab: sbwt_path_safe_scratch_bytes of scratch): k steps from u on.
+// 31 < k <= 63 (whole k-mers in the two-level table): rule 2 only, head labels of 16 bytes.
+long long sbwt_path_safe_scratch_bytes(long long n_pos, int k) {
+    return (((long long)n_pos * (k > 31 ? 20 : 12) + 15) & ~15ll) + 256;
+}
 void sbwt_launch_path_safe(const SbwtIndexView &ix, uint4 *d_pq, int rule, void *d_hlab, unsigned char *d_alt_safe,
                            hipStream_t stream) {
     if (d_alt_safe) (void)hipMemsetAsync(d_alt_safe, 0, (size_t)ix.n_pos, stream);
-    if (rule < 2 || !d_hlab) {
+    const bool wide = ix.k > 31;
+    if (wide && !d_hlab) return;                        // (the caller does not set has_safe then)
+    if (!wide && (rule < 2 || !d_hlab)) {
         hipLaunchKernelGGL(k_path_safe, dim3(grid_for(ix.n_pos)), dim3(256), 0, stream, ix, reinterpret_cast<unsigned *>(d_pq));
         return;
     }
-    // d_hlab: [ hlab : n x 8 B ][ list of heads : n x 4 B ][ their number : 8 B ]
+    // d_hlab: [ hlab : n x 8 B (16 B for k > 31) ][ list of heads : n x 4 B ][ their number : 8 B ]
     u64 *hlab = reinterpret_cast<u64 *>(d_hlab);
-    unsigned *list = reinterpret_cast<unsigned *>(hlab + ix.n_pos);
-    u64 *count = reinterpret_cast<u64 *>(reinterpret_cast<char *>(d_hlab) + (((size_t)ix.n_pos * 12 + 15) & ~(size_t)15));
+    const size_t lab_words = wide ? 2 : 1;
+    unsigned *list = reinterpret_cast<unsigned *>(hlab + lab_words * (size_t)ix.n_pos);
+    u64 *count = reinterpret_cast<u64 *>(reinterpret_cast<char *>(d_hlab) + (((size_t)ix.n_pos * (wide ? 20 : 12) + 15) & ~(size_t)15));
     (void)hipMemsetAsync(count, 0, 8, stream);
     hipLaunchKernelGGL(k_path_list_heads, dim3(grid_for(ix.n_pos)), dim3(256), 0, stream, ix, list, count);
     // (the grid covers every position; blocks beyond the number of heads return at once)
+    if (wide) {
+        if (ix.n_mega > 1)
+            hipLaunchKernelGGL(k_path_head_labels_wide<true>, dim3(grid_for(ix.n_pos)), dim3(256), 0, stream, ix, list, count, hlab);
+        else
+            hipLaunchKernelGGL(k_path_head_labels_wide<false>, dim3(grid_for(ix.n_pos)), dim3(256), 0, stream, ix, list, count, hlab);
+        hipLaunchKernelGGL(k_path_safe_labels_wide, dim3(grid_for(ix.n_pos)), dim3(256), 0, stream, ix,
+                           reinterpret_cast<unsigned *>(d_pq), hlab, d_alt_safe);
+        return;
+    }
     if (ix.n_mega > 1)
         hipLaunchKernelGGL(k_path_head_labels<true>, dim3(grid_for(ix.n_pos)), dim3(256), 0, stream, ix, list, count, hlab);
     else

@@ -216,7 +216,7 @@ long long sbwt_path_quads(long long n_nodes);
 long long sbwt_count_paths(const SbwtIndexView &ix, hipStream_t stream);
 void sbwt_launch_path_safe(const SbwtIndexView &ix, uint4 *d_pq, int rule, void *d_hlab, unsigned char *d_alt_safe,
                            hipStream_t stream);
-long long sbwt_path_safe_scratch_bytes(long long n_nodes);
+long long sbwt_path_safe_scratch_bytes(long long n_pos, int k);
 long long sbwt_launch_path_oth(const SbwtIndexView &ix, uint4 *d_pq, long long *n_branch, hipStream_t stream);
 void sbwt_launch_trans_insert(const SbwtIndexView &ix, uint4 *d_trans, long long n_slots, const unsigned char *d_alt_safe,
                               hipStream_t stream);

@@ -1312,10 +1312,20 @@ void sbwt_launch_encode_chained(const char *d_bases, long long total_bases, uint
 }
 
 // the general path kernel behind k_search_fused: all reads when that kernel declined the batch, else the reads it handed on
-void sbwt_launch_search_chained(const SbwtIndexView &ix, const uint4 *d_packed, const long long *d_read_off,
+// The general kernel's bridge compares the k-1 bases after a substitution in ONE iteration (at most 32 of them): for
+// k > 32 it runs without the safe bits (a safe step is an only-successor step: -1 and the certificates, as before the
+// bits existed); the fused kernel's multi-iteration compare (F_CMP, sbwt_search_fused.hip) uses them for any k <= 64.
+static inline SbwtIndexView general_view(const SbwtIndexView &ix) {
+    SbwtIndexView v = ix;
+    if (v.k > 32) v.has_safe = 0;
+    return v;
+}
+
+void sbwt_launch_search_chained(const SbwtIndexView &ix_in, const uint4 *d_packed, const long long *d_read_off,
                                 const long long *d_out_off, long long *d_out, long long n_reads, SbwtWorkHeader *ws,
                                 int streaming, hipStream_t stream, const unsigned *d_defer, SbwtPieceTab pt) {
     const i64 want1 = (n_reads + pt.cap + 255) / 256;
+    const SbwtIndexView ix = general_view(ix_in);
     const unsigned cap = (ix.debug >> 8) ? (unsigned)(ix.debug >> 8) : 1280u;
     const unsigned g = (unsigned)(want1 < (i64)cap ? want1 : (i64)cap);
     hipLaunchKernelGGL((k_search_cert<false, 4, true>), dim3(g), dim3(256), 0, stream, ix, d_packed, d_read_off,
@@ -1329,11 +1339,12 @@ void sbwt_launch_piece_bounds(const uint4 *d_packed, const long long *d_read_off
                        behind_fused);
 }
 
-void sbwt_launch_search(const SbwtIndexView &ix, const uint4 *d_packed, const long long *d_read_off,
+void sbwt_launch_search(const SbwtIndexView &ix_in, const uint4 *d_packed, const long long *d_read_off,
                         const long long *d_out_off, long long *d_out, long long n_reads, SbwtWorkHeader *ws,
                         int streaming, hipStream_t stream, int variant, long long total_groups, void *d_sort_scratch,
                         long long sort_scratch_bytes, int sort_key_bits, SbwtPieceTab pt) {
     if (n_reads <= 0) return;
+    const SbwtIndexView ix = general_view(ix_in);
     const unsigned *d_perm = nullptr;
     if (variant >= 1) {
         if (d_sort_scratch) pt = SbwtPieceTab();       // (sorted tickets: whole reads)

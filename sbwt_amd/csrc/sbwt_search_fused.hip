@@ -14,7 +14,19 @@
 // runs behind this one over that list with the reference's validity rules (SBWT.hh:398-399,427-428,565-568).  With only
 // valid bases the streaming step's and the full search's validation agree, so `streaming` 1 and 2 are the same here.
 //
-// The state machine is the one of k_search_cert<PATH,SEG> (same certificates, same path-order steps, same segment-list
+// F_CMP (round 4): the read compared with the chars of the path it is ALIGNED to (read base j <-> path step co + j), up to
+// 64 bases per iteration, until the range is done or a second difference shows.  Two ways in:
+//   bridge  the read leaves its path at a substitution-safe step u: the next k-1 bases agree again -> the k k-mers that hold
+//           u are absent by the safe bit, on along the path (any k <= 64: as many iterations as the k-1 bases need)
+//   anchor  a k-mer's lookup failed and nothing says where in its window the bad base is: instead of bisecting with range
+//           probes, look the k-mer just past the suspect range up (the ANCHOR: one exact lookup); if it is there, its path
+//           position aligns the whole stretch, one or two compares find every difference exactly: k-mers without one are
+//           the path's own (a run out of col[]), k-mers with exactly one safe difference are absent by its safe bit, and
+//           what is left (two differences in one window, an unsafe step) goes to the certificates with the bad base KNOWN.
+// Every conclusion is exact -- a k-mer whose k bases equal k consecutive chars of one path IS that path's k-mer; a safe bit
+// is a precomputed certificate (k_path_safe_labels*) -- so a wrong guess only costs the lookup.
+//
+// The state machine is otherwise the one of k_search_cert<PATH,SEG> (same certificates, same path-order steps, same segment-list
 // writer; see the header comments there).  Reference semantics: SBWT::streaming_search include/sbwt/SBWT.hh:544-581,
 // SBWT::search :389-415, update_sbwt_interval :422-437.
 #include "sbwt_kernels_common.h"
@@ -26,12 +38,35 @@
 #define F_EXT 7
 #define F_TRANS 8
 #define F_POS 9
-#define F_BRIDGE 10
+#define F_BRIDGE 10             // entry of F_CMP from a substitution-safe step (set up at the top of the next iteration)
+#define F_CMP 11                // the read against its path's chars, 33 .. 64 bases per iteration: bridges and anchors (below)
 #define FE_NONE 0
 #define FE_EMIT1 1
 #define FE_FAIL 2
 #define FE_END 3
 #define FE_PRES 4
+#define FE_ANCH 5               // an anchor lookup found its k-mer: tpos = its path position
+#define FZ_ANCHORS 2            // anchor lookups per read at most (a read of unrelated sequence pays that many lines for nothing)
+#define FZ_ALIGNS 6             // seeds + resumed compares per read at most
+// F_CMP flags: the remembered differences' step states (S: substitution-safe, A / B: the path group's state bits), ...
+#define CF_S1 1u
+#define CF_A1 2u
+#define CF_B1 4u
+#define CF_S2 8u                // (the second difference's three bits: the first one's << 3)
+#define CF_A2 16u
+#define CF_B2 32u
+#define CF_ONP 64u              // ... k-mer i-1 is the path's own, at position co + i - 1 + k
+#define CF_ALIGNED 128u         // co is the read's last known alignment (a compare may be resumed on it)
+#define CF_ANCH 256u            // the lookup in flight is an anchor (wstart = its k-mer), not a walk inside k-mer i's window
+#define CF_SEED 512u            // the position lookup in flight is a seed's
+#define CA_GOON 0               // F_CMP goes on with the next bases
+#define CA_DONE 1               // the lane's last k-mer is answered
+#define CA_CERT 2               // to the certificates, b = m1
+#define CA_TRANS 3              // a transition lookup at position ctr
+#define CA_ABSENT 4             // one -1 (an only-successor step), then the certificates
+#define CA_LOST 5               // the alignment ran off its path: forget it
+#define CF_M1 (CF_S1 | CF_A1 | CF_B1)
+#define CF_M2 (CF_S2 | CF_A2 | CF_B2)
 
 #define FZ_SPLIT_MIN 16         // the tail: a lane gives away half of its remaining k-mers when it has at least this many left
 #define FZ_NSEG 9               // segments per lane: 256 x (9 x 4 + 9 x 1) B + 2 x 256 x 40 B of codes = 32 000 B = 5 workgroups per CU
@@ -55,6 +90,10 @@ __device__ __forceinline__ u64 fz_encode32(const unsigned w[8], const unsigned t
     return codes;
 }
 
+// WIDE = false: k <= 31 -- a read follows its path in F_EXT, a substitution-safe step is bridged in one compare (F_BRIDGE):
+// round 3's walk, the leanest code for k-mers that cost one lookup.  WIDE = true: 31 < k <= 63 (and "debug" bit 64) -- both
+// are the one state F_CMP, with anchors, seeds and resumed compares around it.
+template <bool WIDE>
 __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const unsigned char *__restrict__ bases,
                                                           i64 total_bases, i64 *__restrict__ out, i64 n_reads,
                                                           SbwtWorkHeader *ws, unsigned *__restrict__ defer_list,
@@ -71,7 +110,7 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
     const int ulen = ragged ? SBWT_FUSED_MAXLEN : (int)ws->u_len, m = ulen - k + 1, G = (ulen + 31) >> 5;
     const i64 u_read0 = ws->u_read0, u_out0 = ws->u_out0, u_stride = ws->u_stride;
     const bool pfon = ix.pfil && ix.p_filter == L0 && L0 > p;
-    const u64 m2 = (k - ps >= 32) ? ~0ull : low_mask(2 * ((k - ps) & 31));   // key mask of the second-level window
+    const u64 mk2 = (k - ps >= 32) ? ~0ull : low_mask(2 * ((k - ps) & 31));   // key mask of the second-level window
     const int pw = pfon ? L0 : p;                   // window of a range probe: the filter's when there is one
     const int last_node = (int)(ix.n_nodes - 1);
 
@@ -81,6 +120,19 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
                                     // 3 range probe, 5 second-level sparse lookup
     u64 hk = 0;                     // F_INIT: the window's key (filter: the bit positions), kept across the gather
     int blo = -1;                   // the last failure is known to lie in [blo, b]
+    // F_CMP: read base j <-> path step co + j; bases [cP, cE) still to compare; the first two differences seen (read
+    // positions, -1: none) and whether the first one's step is substitution-safe
+    int co = 0, cP = 0, m1 = -1, m2 = -1;
+    unsigned fl = 0;                // CF_* flags
+    int anc_tried = -1, anc_left = 0;       // the last anchor k-mer that was not there; anchor lookups this read may still make
+    int cmp_left = 0;               // alignments (seeds, resumed compares) this read may still start
+    int seed_col = -1;              // k > 31: the column of a unique 31-mer whose k-mer was not there -- a SEED for an alignment
+    // Anchors, seeds and resumed compares pay where a whole k-mer costs two lookups (31 < k <= 63: second-level table) and the
+    // certificates' probes are short against k; for k <= 31 the certificates alone measured faster (config 2: -1.3 %).
+    // "debug" bits: 32 = no anchors / seeds / resumes, 64 = all of them for k <= 31 as well.
+    const bool wide_k = WIDE && ((ix.stab2 != nullptr && ps < k) || (ix.stab_pos && ps == k)) && !(ix.debug & 32);
+    const bool anch_ok = wide_k;
+    const bool seed_ok = wide_k && ps < k;
     int bnext = -1;                 // a hint: the read's next difference from its path after b (a failed bridge's compare saw it)
     int mode = F_IDLE;
     unsigned rd = 0;                // the read this lane works on
@@ -184,6 +236,11 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
                     b = -1;
                     blo = -1;
                     bnext = -1;
+                    fl = 0;
+                    anc_tried = -1;
+                    anc_left = FZ_ANCHORS;
+                    cmp_left = FZ_ALIGNS;
+                    seed_col = -1;
                     wstart = 0;
                     j = 0;
                     wk = (ps > 0) ? 1 : 0;
@@ -233,6 +290,11 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
                     b = -1;
                     blo = -1;
                     bnext = -1;
+                    fl = 0;
+                    anc_tried = -1;
+                    anc_left = FZ_ANCHORS;
+                    cmp_left = FZ_ALIGNS;
+                    seed_col = -1;
                     wstart = mid;
                     j = 0;
                     wk = (ps > 0) ? 1 : 0;
@@ -244,11 +306,32 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
         }
 
 
+        // F_EXT and F_BRIDGE are the two ways into F_CMP from a k-mer that sits on its path:
+        if (!WIDE) {
+        } else if (mode == F_EXT) {                    // k-mer i-1 sits at path position r: on along the path
+            co = r - (i + k - 1);
+            cP = i + k - 1;
+            m1 = m2 = -1;
+            fl = (fl & ~(CF_M1 | CF_M2)) | CF_ONP;
+            mode = F_CMP;
+        } else if (mode == F_BRIDGE) {
+            // ... and the read's base u = i+k-1 differs from the path's char at step r, a substitution-safe step: the k
+            // k-mers that hold u are absent if nothing else in their windows differs
+            const int u = i + k - 1;
+            co = r - u;
+            cP = u + 1;
+            m1 = u;
+            m2 = -1;
+            fl = (fl & ~(CF_M1 | CF_M2 | CF_ONP)) | CF_M1;
+            mode = F_CMP;
+        }
+
         // ---- this iteration's gather: two 16-byte loads per lane, issued back to back, one wait ----
         int ev = FE_NONE, tfail = 0, c = 0;
         const uint4 *a1 = ix.blocks, *a2 = ix.blocks;
         int res = -1;
-        const bool ext = (mode == F_EXT), trn = (mode == F_TRANS), brg = (mode == F_BRIDGE);
+        const bool trn = (mode == F_TRANS), cmp = WIDE && (mode == F_CMP);
+        const bool ext = !WIDE && (mode == F_EXT), brg = !WIDE && (mode == F_BRIDGE);
         const bool busy = (mode != F_IDLE && mode != F_DEAD);
         bool rknown = false, ext_absent = false;
         int tnext = F_EXT;
@@ -257,7 +340,7 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
         unsigned seg_src_run = 0;
         // the read's bases from position P on: three words of codes out of the lane's LDS slot
         const int woff5 = (mode == F_INIT && wk == 5) ? ps : 0;       // the second-level window starts after the prefix
-        const int P = (ext || trn) ? (i + k - 1) : brg ? (i + k) : ((mode == F_INIT) ? (wstart + woff5) : (wstart + j));
+        const int P = (ext || trn) ? (i + k - 1) : brg ? (i + k) : cmp ? cP : ((mode == F_INIT) ? (wstart + woff5) : (wstart + j));
         const int s = P & 31, pg = busy ? (P >> 5) : 0;
         const u64 cw0 = cur_codes[pg < SBWT_FUSED_MAXG ? pg : SBWT_FUSED_MAXG - 1][tid];
         const u64 cw1 = cur_codes[pg + 1 < SBWT_FUSED_MAXG ? pg + 1 : SBWT_FUSED_MAXG - 1][tid];
@@ -269,7 +352,10 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
         } else if (busy) {
             const int wl = (wk == 1) ? ps : (wk == 2 || wk == 6) ? L0 : (wk == 3) ? pw : (wk == 5) ? k - ps : p;
             c = (int)((unsigned)rw & 3u);
-            if (ext || brg) {
+            if (cmp) {
+                a1 = ix.pq + ((unsigned)(co + cP) >> 5);               // the two quads holding path steps co + cP .. (33 to 64 of them)
+                a2 = a1 + 1;
+            } else if (ext || brg) {
                 a1 = ix.pq + (((unsigned)r + (brg ? 1u : 0u)) >> 5);   // the two quads holding path chars r (+1) .. +31
                 a2 = a1 + 1;
             } else if (trn) {
@@ -285,7 +371,7 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
                     a1 = ix.stab + 2 * bkt;
                     a2 = a1 + 1;
                 } else if (wk == 5) {          // second level: (prefix interval, rest of the k-mer) -> one entry
-                    hk = rw & m2;
+                    hk = rw & mk2;
                     const size_t bkt = sbwt_sp2_entry((unsigned)l, hk, ix.n_sb2, (unsigned)j);
                     a1 = ix.stab2 + 2 * bkt;
                     a2 = a1 + 1;
@@ -307,7 +393,7 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
         {   // lane-iterations by kind: pad[0..]: sparse lookup, filter probe, dense table, second level, interval update, path run,
             // transition, bridge, pos, idle/dead; pad[10] = wave-iterations
             const int cls = !busy ? 9 : mode == F_INIT ? (wk == 1 ? 0 : (wk == 2 || wk == 6 || (wk == 3 && pfon)) ? 1 : wk == 5 ? 3 : 2) :
-                            mode == F_STEP ? 4 : ext ? 5 : trn ? 6 : brg ? 7 : 8;
+                            mode == F_STEP ? 4 : (ext || (cmp && m1 < 0)) ? 5 : trn ? 6 : (cmp || brg) ? 7 : 8;
             for (int q = 0; q < 10; q++) {
                 const unsigned long long cq = __popcll(__ballot(cls == q));
                 if (lane == 0 && cq) atomicAdd(&ws->pad[q], cq);
@@ -330,12 +416,22 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
         // ---- consume ----
         bool tabhit = false, do_plan = false, force = false;
         bool imprecise = false;                        // this iteration's failure is a table-level miss
+        int pre_n = 0, abs_n = 0, post_n = 0;          // F_CMP's verdicts: a run along the path, k-mers absent by a safe bit, a run
+        int cact = 0, ctr = 0;                         // ... and what follows (CA_*)
         int burst_to = -1;                             // F_BRIDGE: k-mers i .. burst_to are certified absent
         bool bridged = false;                          // F_BRIDGE: ... and the read goes on along the path
         if (mode == F_POS) {
             const unsigned sel = (unsigned)l & 3u;
             r = (int)(sel == 0 ? v1.x : sel == 1 ? v1.y : sel == 2 ? v1.z : v1.w);
-            mode = F_EXT;
+            if (fl & CF_SEED) {
+                // a seed: the k-mer at position r ENDS with the 31 bases before read position -co; align the rest of the read
+                fl &= ~(CF_SEED | CF_M1 | CF_M2 | CF_ONP);
+                co += r;
+                if ((unsigned)(co + i) < (unsigned)ix.n_pos) { cP = i; m1 = m2 = -1; mode = F_CMP; }
+                else { mode = F_DEAD; do_plan = true; }
+            } else {
+                mode = F_EXT;
+            }
         } else if (trn) {
             // v1 = { r + 1, c | flags, successor column (SBWT.hh:562-575), its path position }, v2 = its path's next 32 steps
             if (v1.x == 0u) {
@@ -351,6 +447,8 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
                 } else {
                     ev = FE_EMIT1;
                     b = blo = i + k - 1;
+                    co = r - (i + k - 1);              // (the read was on this path up to here: an alignment to resume on)
+                    fl |= CF_ALIGNED;
                 }
             } else {
                 ev = FE_EMIT1;
@@ -451,6 +549,112 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
                 else { mode = (kind == PS_TRANS) ? F_TRANS : F_BRIDGE; j = 0; }
             }
             r += n;
+        } else if (cmp) {
+            // The read against the path it is aligned to: base j <-> step co + j.  Bases [.., cP) are compared; of the
+            // differences not behind k-mer i yet the first two are remembered (m1 < m2).  k-mer x is the path's own (position
+            // co + x + k) when the k steps of its window lie on one path and hold no difference, and absent when they hold
+            // exactly one, m1, at a substitution-safe step (k_path_safe_labels*).  Whatever else -- two differences in one
+            // window, an unsafe step, the path's end -- leaves this state: a transition where k-mer x-1 is the path's own and
+            // x ends at the difference (SBWT.hh:562-575 at a branching step), the certificates with b = m1 known exactly
+            // otherwise.
+            const int cE = mend + k - 1, last = mend - 1;
+            const unsigned pp = (unsigned)(co + cP);
+            const int sp = (int)(pp & 31u);
+            u64 pwd = quad_bits(v1) >> (2 * sp);
+            if (sp) pwd |= quad_bits(v2) << (64 - 2 * sp);
+            // the path groups' two state words (k_path_reencode): go = ~A | B, safe = A & B, only successor = ~A & B
+            const u64 fA = (((u64)v2.z << 32) | (u64)v1.z) >> sp, fB = (((u64)v2.w << 32) | (u64)v1.w) >> sp;
+            int n = cE - cP;
+            if (n > 64 - sp) n = 64 - sp;
+            if (n < 0) n = 0;
+            int pend = -1;                             // the path ends at the step of this base
+            {
+                const u64 ends = fA & ~fB;
+                if (ends) {
+                    const int nb = __ffsll((i64)ends) - 1;
+                    if (nb < n) { n = nb; pend = cP + nb; }
+                }
+            }
+            const u64 rw2 = s ? ((cw1 >> (2 * s)) | (cw2 << (64 - 2 * s))) : cw1;       // bases cP+32 ..
+            const u64 x1 = rw ^ pwd, x2 = rw2 ^ (quad_bits(v2) >> (2 * sp));
+            u64 d1 = (x1 | (x1 >> 1)) & 0x5555555555555555ull, d2 = (x2 | (x2 >> 1)) & 0x5555555555555555ull;
+            if (n < 32) { d1 &= low_mask(2 * n); d2 = 0; }
+            else if (n < 64) d2 &= low_mask(2 * (n - 32));
+            int c1 = -1, c2 = -1;                      // the first two differences of this window
+            if (d1) {
+                c1 = (__ffsll((i64)d1) - 1) >> 1;
+                d1 &= d1 - 1;
+                if (d1) c2 = (__ffsll((i64)d1) - 1) >> 1;
+            }
+            if (c2 < 0 && d2) {
+                const int t0 = 32 + ((__ffsll((i64)d2) - 1) >> 1);
+                d2 &= d2 - 1;
+                if (c1 < 0) { c1 = t0; if (d2) c2 = 32 + ((__ffsll((i64)d2) - 1) >> 1); }
+                else c2 = t0;
+            }
+            auto state_of = [&](int cc) -> unsigned {  // { S, A, B } of the step of this window's base cc, as CF_*1 bits
+                const unsigned A = (unsigned)(fA >> cc) & 1u, B = (unsigned)(fB >> cc) & 1u;
+                return ((A & B & (ix.has_safe ? 1u : 0u)) ? CF_S1 : 0u) | (A ? CF_A1 : 0u) | (B ? CF_B1 : 0u);
+            };
+            if (c1 >= 0) {
+                if (m1 < 0) {
+                    m1 = cP + c1;
+                    fl = (fl & ~CF_M1) | state_of(c1);
+                    if (c2 >= 0) { m2 = cP + c2; fl = (fl & ~CF_M2) | (state_of(c2) << 3); }
+                } else {
+                    m2 = cP + c1;
+                    fl = (fl & ~CF_M2) | (state_of(c1) << 3);
+                }
+            }
+            // (a second difference: what lies behind it in this window is compared again once m1's k-mers are answered)
+            if (m2 >= 0) { cP = m2 + 1; pend = -1; }
+            else cP += n;
+            // ---- verdicts: at most a run and a burst per iteration ----
+            int x = i;
+            bool onp = (fl & CF_ONP) != 0;
+            auto clean_run = [&](int bound, int &cnt) {    // k-mers x .. bound hold no difference
+                if (bound > last) bound = last;
+                if (bound >= x) { cnt = bound - x + 1; x = bound + 1; onp = true; }
+            };
+            if (m1 < 0) {
+                clean_run(cP - k, pre_n);
+                if (x > last) cact = CA_DONE;
+                else if (pend >= 0) { if (onp && x == pend - k + 1) { cact = CA_TRANS; ctr = co + pend; } else cact = CA_LOST; }
+            } else {
+                clean_run(m1 - k, pre_n);
+                if (x > last) {
+                    cact = CA_DONE;
+                } else if (fl & CF_S1) {
+                    const int lim = m2 >= 0 ? m2 : cP;
+                    int hi = m1 < lim - k ? m1 : lim - k;
+                    if (hi > last) hi = last;
+                    if (hi >= x) { abs_n = hi - x + 1; x = hi + 1; onp = false; }
+                    if (x > last) {
+                        cact = CA_DONE;
+                    } else if (x > m1) {               // every k-mer that holds m1 is answered: the next difference takes its place
+                        m1 = m2;
+                        m2 = -1;
+                        fl = (fl & ~(CF_M1 | CF_M2)) | ((fl & CF_M2) >> 3);
+                        if (pre_n == 0) {
+                            clean_run((m1 >= 0 ? m1 : cP) - k, post_n);
+                            if (x > last) cact = CA_DONE;
+                        }
+                    } else if (m2 >= 0) {
+                        cact = CA_CERT;                // k-mer x holds both differences
+                    } else if (pend >= 0) {
+                        cact = CA_CERT;                // the path ends inside the windows that hold m1
+                        fl &= ~CF_ALIGNED;
+                    }
+                } else if (onp && x == m1 - k + 1) {
+                    // k-mer x-1 is the path's own and the read's next base differs from the path's char: where F_EXT used to stop
+                    if (!(fl & CF_B1)) { cact = CA_TRANS; ctr = co + m1; }      // the step has other successors (or none)
+                    else cact = CA_ABSENT;             // only successor: the streaming step's answer is -1 (SBWT.hh:572-575)
+                } else {
+                    cact = CA_CERT;
+                }
+            }
+            fl = onp ? (fl | CF_ONP) : (fl & ~CF_ONP);
+            if (cact == CA_ABSENT) ext_absent = true;
         } else if (mode == F_INIT) {
             int wl = p;
             bool again = false;
@@ -483,20 +687,21 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
                     again = true;
                     j++;
                 } else {
+                    if (seed_ok && r == l) seed_col = l;   // the 31-mer is there, in ONE column: a seed for an alignment
                     l = -1;
                 }
             } else if (wk == 1) {
                 const u64 key = hk;
                 const u64 w0 = quad_bits(v1), w1 = quad_bits(v2);
-                const bool m0 = (w0 & ~SBWT_SP_OVERFLOW) == key, m1 = w1 == key;
+                const bool hit0 = (w0 & ~SBWT_SP_OVERFLOW) == key, hit1 = w1 == key;
                 wl = ps;
-                if (m0 | m1) {
-                    l = (int)(m0 ? v1.z : v2.z);
+                if (hit0 | hit1) {
+                    l = (int)(hit0 ? v1.z : v2.z);
                     if (ix.stab_pos) {                 // depth-k entries: one column, stored with its path position
                         r = l;
-                        tpos = (int)(m0 ? v1.w : v2.w);
+                        tpos = (int)(hit0 ? v1.w : v2.w);
                     } else {
-                        r = l + (int)(m0 ? v1.w : v2.w);
+                        r = l + (int)(hit0 ? v1.w : v2.w);
                     }
                 } else if (w0 & SBWT_SP_OVERFLOW) {
                     again = true;                      // a later bucket may hold the key
@@ -521,7 +726,8 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
                     j = 0;
                 } else {
                     j = wl;
-                    if (wstart + j == i + k) ev = FE_END;
+                    if (fl & CF_ANCH) ev = FE_ANCH;    // (only whole-k-mer lookups are anchors: wl == k)
+                    else if (wstart + j == i + k) ev = FE_END;
                     else mode = F_STEP;
                 }
             }
@@ -541,11 +747,29 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
 #ifdef SBWT_TRACE
         if (n_reads == 1 && lane == 0 && busy)
             printf("it: was ext%d trn%d brg%d init%d step%d | now mode %d i %d r %d l %d j %d ev %d res %d seg_n %d absent %d tnext %d wk %d wstart %d b %d | v1 %08x %08x %08x %08x v2 %08x %08x %08x %08x\n",
-                   (int)ext, (int)trn, (int)brg, 0, 0, mode, i, r, l, j, ev, res, seg_n, (int)ext_absent, tnext, wk, wstart, b,
+                   (int)ext, (int)trn, (int)(cmp || brg), 0, 0, mode, i, r, l, j, ev, res, seg_n, (int)ext_absent, tnext, wk, wstart, b,
                    v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w);
 #endif
         // ---- events: results, certificates, next state ----
         int burst_hi = -1;                             // >= i: k-mers i..burst_hi are certified absent
+        if ((fl & CF_ANCH) && (ev == FE_FAIL || ev == FE_ANCH)) {
+            // an anchor lookup is over.  Its window is NOT inside k-mer i's, so a miss certifies nothing here: the
+            // certificates go on as if it had not been tried (or a seed it left is taken up).  A hit aligns the read.
+            const int o = tpos - (wstart + k);
+            if (ev == FE_ANCH && tpos >= 0 && (unsigned)(o + i) < (unsigned)ix.n_pos) {
+                co = o;
+                cP = i;
+                m1 = m2 = -1;
+                fl &= ~(CF_M1 | CF_M2 | CF_ONP);
+                mode = F_CMP;
+            } else {
+                anc_tried = wstart;
+                mode = F_DEAD;
+                do_plan = true;
+            }
+            fl &= ~CF_ANCH;
+            ev = FE_NONE;
+        }
         if (ev == FE_END) {
             if (wstart == i) {                         // k chars matched from i: the k-mer is there
                 res = l;
@@ -609,7 +833,35 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
                 append(i, (burst_hi >= 0) ? 0xFFFFFFFFu : seg_src_run);
                 i += nleft;
             }
+            if (cmp) {                                 // F_CMP's verdicts (at most two segments)
+                if (pre_n > 0) { append(i, (unsigned)(co + i + k)); i += pre_n; c_ext += (unsigned)pre_n; }
+                if (abs_n > 0) { append(i, 0xFFFFFFFFu); i += abs_n; c_brg++; }
+                if (post_n > 0) { append(i, (unsigned)(co + i + k)); i += post_n; c_ext += (unsigned)post_n; }
+                if (cact == CA_DONE) {
+                    mode = F_IDLE;
+                } else if (cact == CA_TRANS) {
+                    mode = F_TRANS;                    // k-mer i-1 sits at ctr, the read's base i+k-1 is not the path's char there
+                    r = ctr;
+                    j = 0;
+                    fl &= ~CF_ALIGNED;
+                } else if (cact == CA_CERT) {
+                    b = blo = m1;                      // the certificates, with the bad base known exactly
+                    bnext = m2;
+                    fl |= CF_ALIGNED;
+                    mode = F_DEAD;
+                    do_plan = true;
+                } else if (cact == CA_LOST) {
+                    fl &= ~CF_ALIGNED;
+                    anc_tried = wstart;                // (an anchor whose stretch is not one path: no second try at it)
+                    mode = F_DEAD;
+                    do_plan = true;
+                } else if (cact == CA_ABSENT) {
+                    fl |= CF_ALIGNED;                  // (ext_absent, below: -1, b = m1, the certificates)
+                    mode = F_DEAD;
+                }
+            }
             if (ext_absent) {                          // the k-mer that left the path: -1, then the certificates
+                if (trn) { co = r - (i + k - 1); fl |= CF_ALIGNED; }     // (after a transition's quoted steps: the alignment to resume on)
                 append(i, 0xFFFFFFFFu);
                 b = blo = i + k - 1;
                 i++;
@@ -722,6 +974,27 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
                 do_plan = true;                        // SBWT.hh:557-559 (with certificates)
             }
         }
+        if (do_plan && !force && cmp_left > 0 &&
+            (seed_col >= 0 || ((fl & CF_ALIGNED) && wide_k && !(b >= i && b <= i + k - 1) && (unsigned)(co + i) < (unsigned)ix.n_pos))) {
+            // k > 31: an alignment instead of a walk.  A seed (the 31-mer [wstart, wstart + 31) is in the index in one column, the
+            // k-mer it began is not): that column's path position aligns the read.  Or the alignment the read had when it
+            // left its path, once every k-mer that holds the known bad base is answered.  F_CMP's conclusions are exact
+            // whatever the alignment is worth.
+            cmp_left--;
+            if (seed_col >= 0) {
+                l = seed_col;
+                co = -(wstart + ps);
+                fl |= CF_SEED;
+                mode = F_POS;
+            } else {
+                cP = i;
+                m1 = m2 = -1;
+                fl &= ~(CF_M1 | CF_M2 | CF_ONP);
+                mode = F_CMP;
+            }
+            do_plan = false;
+        }
+        seed_col = -1;
         if (do_plan) {
             // where the next walk starts (see k_search_cert): at k-mer i itself, or close to the last failure position b
             // when b lies inside k-mer i's window
@@ -733,7 +1006,14 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
             if (!force && pfon && !(b >= i && b <= i + k - 1) && bnext >= i && bnext <= i + k - 1) { b = blo = bnext; bnext = -1; hinted = true; }
             if (!force && L0 > 0 && b >= i && b <= i + k - 1) {
                 const int lo = blo > i ? blo : i;
-                if (lo < b && p > 0 && k - pw >= 1) {
+                if (lo < b && anch_ok && anc_left > 0 && b + 1 != anc_tried && b + 1 <= mend - 1) {
+                    // the bad base is somewhere in [lo, b]: the k-mer just past the range as an anchor (F_CMP) instead of
+                    // halving the range probe by probe
+                    s0 = b + 1;
+                    nwk = 1;
+                    fl |= CF_ANCH;
+                    anc_left--;
+                } else if (lo < b && p > 0 && k - pw >= 1) {
                     // the bad base is somewhere in [lo, b]: halve the range with a window that starts inside it
                     int x = lo + ((b - lo + 1) >> 1);
                     if (x > i + k - pw) x = i + k - pw;
@@ -800,8 +1080,13 @@ void sbwt_launch_search_fused(const SbwtIndexView &ix, const char *d_bases, long
     const unsigned cap = (ix.debug >> 8) ? (unsigned)(ix.debug >> 8) : 1280u;
     const unsigned g = (unsigned)(want < (i64)cap ? want : (i64)cap);
     if (ev_begin) (void)hipEventRecord(ev_begin, stream);
-    hipLaunchKernelGGL(k_search_fused, dim3(g), dim3(256), 0, stream, ix, reinterpret_cast<const unsigned char *>(d_bases),
-                       (i64)total_bases, d_out, (i64)n_reads, ws, d_defer, d_read_off, d_out_off);
+    // (k > 31: whole k-mers in the two-level table; "debug" bit 64: the wide walk for every k -- experiments and the fuzzer)
+    if ((ix.stab2 != nullptr && ix.p_sparse < ix.k) || (ix.debug & 64))
+        hipLaunchKernelGGL(k_search_fused<true>, dim3(g), dim3(256), 0, stream, ix, reinterpret_cast<const unsigned char *>(d_bases),
+                           (i64)total_bases, d_out, (i64)n_reads, ws, d_defer, d_read_off, d_out_off);
+    else
+        hipLaunchKernelGGL(k_search_fused<false>, dim3(g), dim3(256), 0, stream, ix, reinterpret_cast<const unsigned char *>(d_bases),
+                           (i64)total_bases, d_out, (i64)n_reads, ws, d_defer, d_read_off, d_out_off);
     if (ev_end) (void)hipEventRecord(ev_end, stream);
     // what the fused kernel did not take: everything when the reads are not of one length, else the reads it handed on
     sbwt_launch_encode_chained(d_bases, total_bases, d_packed, ws, d_defer, d_read_off, ix.k, stream);

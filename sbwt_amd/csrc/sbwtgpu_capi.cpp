@@ -506,11 +506,14 @@ int sbwtgpu_index_create(const sbwtgpu_index_desc *d, int device, sbwtgpu_index 
             if (e != hipSuccess) break;
             h.stab_pos = src > 0 ? 1 : 0;
             // substitution-safe bits of the path: need the whole k-mers in the sparse table
-            if (h.has_path && h.p_sparse == d->k && g_path_safe) {
+            // (31 < k <= 63: whole k-mers live in the two-level table -- the wide kernels, rule 2 only)
+            const bool whole_kmers = h.p_sparse == d->k || (h.n_sb2 > 0 && d->k > h.p_sparse);
+            if (h.has_path && whole_kmers && g_path_safe) {
                 SbwtIndexView v2 = idx->view();
                 // (rule 2 keeps the path heads' labels and their list in scratch)
                 void *hscr = nullptr;
-                if (g_path_safe >= 2 && hipMalloc(&hscr, (size_t)sbwt_path_safe_scratch_bytes(h.n_pos)) != hipSuccess) {
+                const bool wide_safe = d->k > h.p_sparse;
+                if ((g_path_safe >= 2 || wide_safe) && hipMalloc(&hscr, (size_t)sbwt_path_safe_scratch_bytes(h.n_pos, (int)d->k)) != hipSuccess) {
                     (void)hipGetLastError();
                     hscr = nullptr;                     // no room for rule 2: the narrow rule needs none
                 }
@@ -520,11 +523,12 @@ int sbwtgpu_index_create(const sbwtgpu_index_desc *d, int device, sbwtgpu_index 
                     (void)hipGetLastError();
                     alt_safe = nullptr;
                 }
-                sbwt_launch_path_safe(v2, reinterpret_cast<uint4 *>(idx->blob + h.off_pq), hscr ? g_path_safe : 1, hscr, alt_safe, 0);
+                sbwt_launch_path_safe(v2, reinterpret_cast<uint4 *>(idx->blob + h.off_pq), hscr ? (wide_safe ? 2 : g_path_safe) : 1, hscr, alt_safe, 0);
                 e = hipDeviceSynchronize();
+                const bool had_scratch = hscr != nullptr;
                 if (hscr) (void)hipFree(hscr);
                 if (e != hipSuccess) break;
-                h.has_safe = 1;
+                h.has_safe = (wide_safe && !had_scratch) ? 0 : 1;    // (no room for the head labels of long k-mers: no safe bits)
             }
         }
         if (h.has_path) {
