@@ -65,6 +65,9 @@
 #define CA_TRANS 3              // a transition lookup at position ctr
 #define CA_ABSENT 4             // one -1 (an only-successor step), then the certificates
 #define CA_LOST 5               // the alignment ran off its path: forget it
+#define CF_MISS 1024u            // two bits: own lookups of consecutive k-mers that failed without a certificate reaching further
+#define CF_MISS_MASK 3072u
+#define CF_NOCERT 4096u          // since the last own lookup: windows were probed, and every one of them is (perhaps) in the index
 #define CF_M1 (CF_S1 | CF_A1 | CF_B1)
 #define CF_M2 (CF_S2 | CF_A2 | CF_B2)
 
@@ -72,6 +75,36 @@
 #define FZ_NSEG 9               // segments per lane: 256 x (9 x 4 + 9 x 1) B + 2 x 256 x 40 B of codes = 32 000 B = 5 workgroups per CU
 
 typedef unsigned fz_u32x4 __attribute__((ext_vector_type(4)));
+
+#ifdef SBWT_STATS
+#ifndef SBWT_SLOW_LO
+#define SBWT_SLOW_LO 100
+#define SBWT_SLOW_HI 100000
+#endif
+// stats builds (tools/build_stats_lib.sh): lane-iterations per read (ticket or tail piece), bucket = iterations / 2
+__device__ unsigned long long g_iter_hist[64];
+__device__ unsigned long long g_iter_max[8];          // (iterations << 32 | read) of the slowest reads seen, by iterations mod 8
+extern "C" int sbwtgpu_debug_iter_hist(unsigned long long *out, int reset) {
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_iter_hist), sizeof(g_iter_hist)) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[64] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_iter_hist), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+extern "C" int sbwtgpu_debug_iter_max(unsigned long long *out, int reset) {
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_iter_max), sizeof(g_iter_max)) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[8] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_iter_max), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#define FZ_HIST_FLUSH() do { if (it_cnt) { atomicAdd(&g_iter_hist[(it_cnt >> 1) < 63 ? (it_cnt >> 1) : 63], 1ull); \
+    if (it_cnt >= SBWT_SLOW_LO && it_cnt < SBWT_SLOW_HI) atomicMax(&g_iter_max[it_cnt & 7u], ((unsigned long long)it_cnt << 32) | rd); it_cnt = 0; } } while (0)
+#else
+#define FZ_HIST_FLUSH() do { } while (0)
+#endif
 
 // 32 ASCII bases (8 dwords) -> 64 bits of 2-bit codes; `bad` collects bit 7 of every byte that is not one of "ACGT"
 // (exact per-byte zero detection, four bases per operation); tm[d] masks the bytes of dword d that belong to the read
@@ -144,6 +177,9 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
     u64 pool_next = 0, pool_end = 0, pool_bad = 0;  // wave-uniform pool of read tickets; tickets of it that are handed on
     int pool_len = 0;               // ragged batches: the length of the read this lane encoded at the last refill (161: too long)
     unsigned c_stream = 0, c_search = 0, c_lf = 0, c_tab = 0;     // wave-uniform work counters
+#ifdef SBWT_STATS
+    unsigned it_cnt = 0;
+#endif
 
     for (;;) {
         // ---- hand out reads to idle lanes from the wave's ticket pool; an empty pool is refilled with 64 encoded reads ----
@@ -225,6 +261,7 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
                 const int q = (int)(tk & 63ull);
                 const int mq = mq_r;                   // (a read shorter than k: nothing to answer)
                 if ((i64)tk < n_reads && !((pool_bad >> q) & 1ull) && mq > 0) {
+                    FZ_HIST_FLUSH();
                     rd = (unsigned)tk;
 #pragma unroll
                     for (int g = 0; g < SBWT_FUSED_MAXG; g++)
@@ -279,6 +316,7 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
                 if (lane == 0) atomicAdd(&ws->pad[13], (unsigned long long)n_pairs);
 #endif
                 if (taking) {
+                    FZ_HIST_FLUSH();
 #pragma unroll
                     for (int g = 0; g < SBWT_FUSED_MAXG; g++)
                         if (g < G) cur_codes[g][tid] = cur_codes[g][wbase + src];
@@ -399,6 +437,7 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
                 if (lane == 0 && cq) atomicAdd(&ws->pad[q], cq);
             }
             if (lane == 0) atomicAdd(&ws->pad[10], 1ull);
+            it_cnt += busy ? 1u : 0u;
             // the tail: wave-iterations and idle lane-iterations after the tickets ran out; k-mers still open then
             if (drained) {
                 const unsigned long long idl = __popcll(__ballot(!busy));
@@ -665,6 +704,7 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
                 const unsigned w2 = (b2 < 64) ? (b2 < 32 ? v1.x : v1.y) : (b2 < 96 ? v1.z : v1.w);
                 wl = L0;
                 if (((w1 >> (b1 & 31u)) & (w2 >> (b2 & 31u)) & 1u) != 0) {
+                    fl |= CF_NOCERT;
                     if (wk == 3 || wk == 6) {
                         l = 0;                         // range probe / hinted probe: "perhaps present" only moves the guess
                     } else {
@@ -721,6 +761,9 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
                     imprecise = (wk != 2 && wk != 6);  // ... but where inside the window it fails is not known
                 } else if (wk == 3 || wk == 6) {
                     ev = FE_PRES;
+                } else if (wk == 1 && ps < k && ix.stab2 && (fl & CF_ANCH) && seed_ok && r == l && cmp_left > 0) {
+                    seed_col = l;                      // an anchor's 31-mer in ONE column: that is a seed already -- its position
+                    ev = FE_FAIL;                      // aligns the read without the k-mer's other 32 bases having to be clean
                 } else if (wk == 1 && ps < k && ix.stab2) {
                     wk = 5;                            // the prefix is there (l = its first column): the rest in one more gather
                     j = 0;
@@ -777,6 +820,7 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
                 if (tpos >= 0) { r = tpos; rknown = true; emit_pos = (unsigned)tpos; }
                 ev = FE_EMIT1;
                 b = -1;
+                fl &= ~CF_MISS_MASK;
             } else {
                 do_plan = true;                        // probe inconclusive: the reference's own walk
                 force = true;
@@ -799,6 +843,18 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
                 if (wstart == b) b = -1;
                 else if (!(b > wstart && b <= tfail)) b = tfail;
                 blo = b;
+            }
+            // Certificates that keep failing: a substitution that happens to be ANOTHER strain's base makes every short window
+            // around it present, and only each k-mer's own search says it is absent (the reference's loop, SBWT.hh:557-559).
+            // Two own searches in a row that certified nothing but their own k-mer, each after probes that found every window (perhaps) present: stop probing (the planner goes blind: own
+            // searches only) until something is found again.  Without this such a read cost five to seven iterations per k-mer.
+            if (burst_hi > i || wk == 2 || wk == 3 || wk == 6) {
+                fl &= ~(CF_MISS_MASK | CF_NOCERT);     // a window that IS absent: probes work here
+            } else if (wstart == i) {                  // k-mer i's own search, and only k-mer i is answered by it
+                if ((fl & CF_MISS_MASK) >= 2u * CF_MISS) { }                 // blind already: until something is found
+                else if (!(fl & CF_NOCERT)) fl &= ~CF_MISS_MASK;
+                else fl += CF_MISS;
+                fl &= ~CF_NOCERT;
             }
             if (burst_hi == i) { ev = FE_EMIT1; burst_hi = -1; }
         }
@@ -834,7 +890,7 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
                 i += nleft;
             }
             if (cmp) {                                 // F_CMP's verdicts (at most two segments)
-                if (pre_n > 0) { append(i, (unsigned)(co + i + k)); i += pre_n; c_ext += (unsigned)pre_n; }
+                if (pre_n > 0) { append(i, (unsigned)(co + i + k)); i += pre_n; c_ext += (unsigned)pre_n; fl &= ~CF_MISS_MASK; }
                 if (abs_n > 0) { append(i, 0xFFFFFFFFu); i += abs_n; c_brg++; }
                 if (post_n > 0) { append(i, (unsigned)(co + i + k)); i += post_n; c_ext += (unsigned)post_n; }
                 if (cact == CA_DONE) {
@@ -974,7 +1030,7 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
                 do_plan = true;                        // SBWT.hh:557-559 (with certificates)
             }
         }
-        if (do_plan && !force && cmp_left > 0 &&
+        if (do_plan && !force && cmp_left > 0 && (fl & CF_MISS_MASK) < 2u * CF_MISS &&
             (seed_col >= 0 || ((fl & CF_ALIGNED) && wide_k && !(b >= i && b <= i + k - 1) && (unsigned)(co + i) < (unsigned)ix.n_pos))) {
             // k > 31: an alignment instead of a walk.  A seed (the 31-mer [wstart, wstart + 31) is in the index in one column, the
             // k-mer it began is not): that column's path position aligns the read.  Or the alignment the read had when it
@@ -999,6 +1055,7 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
             // where the next walk starts (see k_search_cert): at k-mer i itself, or close to the last failure position b
             // when b lies inside k-mer i's window
             int s0 = i, nwk = (ps > 0) ? 1 : 0;
+            if ((fl & CF_MISS_MASK) >= 2u * CF_MISS) force = true;      // blind: the k-mer's own search
             // nothing known about k-mer i's window, but a bridge compare has seen the read's next difference inside it: two
             // substitutions within k-1 bases -- start the certificates there instead of bisecting for it (a hint like b
             // itself: the probes prove what they prove wherever they start)
@@ -1039,6 +1096,7 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
         }
     }
 
+    FZ_HIST_FLUSH();
     {
         u64 e = c_ext, eb = c_brg;
 #pragma unroll

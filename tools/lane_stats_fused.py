@@ -17,3 +17,19 @@ print("lane-iterations per read", round(tot / nr, 2), "wave-iterations", int(hdr
 print("after the tickets ran out: wave-iterations", int(hdr[base + 11]), "(per wave %.1f)" % (int(hdr[base + 11]) / 5120), "idle lane-iterations",
       int(hdr[base + 12]), "= %.2f per read" % (int(hdr[base + 12]) / nr))
 print("splits", int(hdr[base + 13]), "donor-capable lane-iterations in the tail", int(hdr[base + 14]))
+
+try:
+    import ctypes
+    from sbwt_amd import capi
+    h = (ctypes.c_ulonglong * 64)()
+    if capi.lib().sbwtgpu_debug_iter_hist(h, 1) == 0:
+        tot = sum(h)
+        acc = 0
+        rows = []
+        for q in range(64):
+            acc += h[q]
+            if h[q]:
+                rows.append("%d-%d: %.4f (cum %.4f)" % (2 * q, 2 * q + 1, h[q] / tot, acc / tot))
+        print("lane-iterations per read or piece (%d of them):" % tot, "; ".join(rows))
+except Exception as ex:
+    print("no iteration histogram:", ex)
