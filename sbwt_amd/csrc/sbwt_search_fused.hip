@@ -67,6 +67,7 @@
 #define CA_LOST 5               // the alignment ran off its path: forget it
 #define CF_MISS 1024u            // two bits: own lookups of consecutive k-mers that failed without a certificate reaching further
 #define CF_MISS_MASK 3072u
+#define CF_WIN31 8192u           // k > 31: the sparse lookup in flight is a 31-base WINDOW probe (a certificate), not a k-mer's prefix
 #define CF_NOCERT 4096u          // since the last own lookup: windows were probed, and every one of them is (perhaps) in the index
 #define CF_M1 (CF_S1 | CF_A1 | CF_B1)
 #define CF_M2 (CF_S2 | CF_A2 | CF_B2)
@@ -454,6 +455,7 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
 
         // ---- consume ----
         bool tabhit = false, do_plan = false, force = false;
+        bool w31 = false;                              // k > 31: a filter window was (perhaps) present: try the 31-base window around b
         bool imprecise = false;                        // this iteration's failure is a table-level miss
         int pre_n = 0, abs_n = 0, post_n = 0;          // F_CMP's verdicts: a run along the path, k-mers absent by a safe bit, a run
         int cact = 0, ctr = 0;                         // ... and what follows (CA_*)
@@ -713,6 +715,7 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
                         again = true;
                         do_plan = true;
                         force = true;
+                        w31 = seed_ok;
                     }
                 } else {
                     l = -1;                            // read[wstart .. wstart+L0-1] is not in the index
@@ -735,7 +738,12 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
                 const u64 w0 = quad_bits(v1), w1 = quad_bits(v2);
                 const bool hit0 = (w0 & ~SBWT_SP_OVERFLOW) == key, hit1 = w1 == key;
                 wl = ps;
-                if (hit0 | hit1) {
+                if ((hit0 | hit1) && (fl & CF_WIN31)) {
+                    again = true;                      // the 31-base window is in the index: no certificate, k-mer i's own search
+                    do_plan = true;
+                    force = true;
+                    fl = (fl & ~CF_WIN31) | CF_NOCERT;
+                } else if (hit0 | hit1) {
                     l = (int)(hit0 ? v1.z : v2.z);
                     if (ix.stab_pos) {                 // depth-k entries: one column, stored with its path position
                         r = l;
@@ -758,7 +766,7 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
                 if (l == -1) {
                     ev = FE_FAIL;                      // read[wstart .. wstart+wl-1] is not in the index
                     tfail = wstart + wl - 1;
-                    imprecise = (wk != 2 && wk != 6);  // ... but where inside the window it fails is not known
+                    imprecise = (wk != 2 && wk != 6 && !(fl & CF_WIN31));  // ... but where inside the window it fails is not known
                 } else if (wk == 3 || wk == 6) {
                     ev = FE_PRES;
                 } else if (wk == 1 && ps < k && ix.stab2 && (fl & CF_ANCH) && seed_ok && r == l && cmp_left > 0) {
@@ -848,7 +856,7 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
             // around it present, and only each k-mer's own search says it is absent (the reference's loop, SBWT.hh:557-559).
             // Two own searches in a row that certified nothing but their own k-mer, each after probes that found every window (perhaps) present: stop probing (the planner goes blind: own
             // searches only) until something is found again.  Without this such a read cost five to seven iterations per k-mer.
-            if (burst_hi > i || wk == 2 || wk == 3 || wk == 6) {
+            if (burst_hi > i || wk == 2 || wk == 3 || wk == 6 || (fl & CF_WIN31)) {
                 fl &= ~(CF_MISS_MASK | CF_NOCERT);     // a window that IS absent: probes work here
             } else if (wstart == i) {                  // k-mer i's own search, and only k-mer i is answered by it
                 if ((fl & CF_MISS_MASK) >= 2u * CF_MISS) { }                 // blind already: until something is found
@@ -856,6 +864,7 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
                 else fl += CF_MISS;
                 fl &= ~CF_NOCERT;
             }
+            fl &= ~CF_WIN31;
             if (burst_hi == i) { ev = FE_EMIT1; burst_hi = -1; }
         }
         if (ev == FE_PRES) {                           // no bad base in [wstart, wstart+pw-1]: shrink the range
@@ -1055,13 +1064,24 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
             // where the next walk starts (see k_search_cert): at k-mer i itself, or close to the last failure position b
             // when b lies inside k-mer i's window
             int s0 = i, nwk = (ps > 0) ? 1 : 0;
+            // k > 31: the 16-base window at b is (perhaps) in the index -- as another strain's variant, usually.  The 31-base
+            // window that holds b and starts as late as k-mer i allows is an exact lookup in the sparse table, and absent far
+            // more often; it answers up to k - 30 k-mers.
+            bool win31 = false;
+            if (w31 && (fl & CF_MISS_MASK) < 2u * CF_MISS && b >= i && b <= i + k - 1) {
+                const int ws = b < i + k - ps ? b : i + k - ps;
+                if (ws > i) { win31 = true; force = false; s0 = ws; }
+            }
             if ((fl & CF_MISS_MASK) >= 2u * CF_MISS) force = true;      // blind: the k-mer's own search
             // nothing known about k-mer i's window, but a bridge compare has seen the read's next difference inside it: two
             // substitutions within k-1 bases -- start the certificates there instead of bisecting for it (a hint like b
             // itself: the probes prove what they prove wherever they start)
             bool hinted = false;
             if (!force && pfon && !(b >= i && b <= i + k - 1) && bnext >= i && bnext <= i + k - 1) { b = blo = bnext; bnext = -1; hinted = true; }
-            if (!force && L0 > 0 && b >= i && b <= i + k - 1) {
+            if (win31) {
+                nwk = 1;
+                fl |= CF_WIN31;
+            } else if (!force && L0 > 0 && b >= i && b <= i + k - 1) {
                 const int lo = blo > i ? blo : i;
                 if (lo < b && anch_ok && anc_left > 0 && b + 1 != anc_tried && b + 1 <= mend - 1) {
                     // the bad base is somewhere in [lo, b]: the k-mer just past the range as an anchor (F_CMP) instead of
