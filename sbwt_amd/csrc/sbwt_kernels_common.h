@@ -134,29 +134,68 @@ __device__ __forceinline__ unsigned sbwt_trans_slot(unsigned t, unsigned c, unsi
 // question to know what is left for them.
 #define SBWT_FUSED_MAXG 5
 // 0: the batch is the general kernel's; 1: reads of one length (offsets by arithmetic); 2: reads of any lengths, the
-// fused kernel fetches their offsets and hands on what is longer than 32 * SBWT_FUSED_MAXG bases (at most one in eight
-// of the reads the check kernel sampled: more, and its refills would mostly encode reads it cannot take)
+// fused kernel fetches their offsets and hands on what is too long for it (at most one in eight of the reads the check
+// kernel sampled: more, and its refills would mostly encode reads it cannot take).
+// Round 4: a read of more than 32 * SBWT_FUSED_MAXG bases is taken as up to SBWT_FUSED_MAXP PIECES of that many bases that
+// overlap by k-1 (piece pc holds the read's k-mers pc * kpp .. with kpp = SBWT_FUSED_MAXLEN - k + 1): a ticket is (read,
+// piece), P tickets per read for the whole batch (sbwt_fused_pieces).  Exact: the fused kernel only walks pieces of
+// upper-case ACGT, where a k-mer's result does not depend on what came before it (SBWT.hh:557-575; tests/test_large.hh:104-115).
 #define SBWT_FUSED_MAXLEN (32 * SBWT_FUSED_MAXG)
+#define SBWT_FUSED_MAXP 3
+__device__ __forceinline__ long long sbwt_fused_limit(int P, int k) {       // the longest read P pieces hold
+    const int kpp = SBWT_FUSED_MAXLEN - k + 1;
+    return (P <= 1 || kpp < 16) ? (long long)SBWT_FUSED_MAXLEN : (long long)P * kpp + k - 1;
+}
+// rg_long packs three counters of 20 bits: sampled reads that need more than 1, 2, 3 pieces
+// (rg_sample: the sample's size in bits 0-15, the most pieces a read may be taken as in bits 16-: "fused_pieces", 1 .. 3)
+__device__ __forceinline__ int sbwt_fused_pieces(const SbwtWorkHeader *ws, int k) {
+    const int sample = ws->rg_sample & 0xFFFF;
+    int maxp = ws->rg_sample >> 16;
+    if (maxp < 1) maxp = 1;
+    if (maxp > SBWT_FUSED_MAXP) maxp = SBWT_FUSED_MAXP;
+    if (ws->u_bad == 0) {
+        for (int P = 1; P <= maxp; P++)
+            if (ws->u_len <= sbwt_fused_limit(P, k)) return P;
+        return 0;
+    }
+    if (sample <= 0) return 0;
+    for (int P = 1; P <= maxp; P++) {
+        const unsigned long long longer = (ws->rg_long >> (20 * (P - 1))) & 0xFFFFFull;
+        if (longer * 8ull <= (unsigned long long)sample && (P == 1 || sbwt_fused_limit(P, k) > SBWT_FUSED_MAXLEN)) return P;
+    }
+    return 0;
+}
 __device__ __forceinline__ int sbwt_fused_mode(const SbwtWorkHeader *ws, int k) {
     const long long len = ws->u_len;
-    if (ws->u_bad == 0) return (len >= 32 && len <= SBWT_FUSED_MAXLEN && len >= k) ? 1 : 0;
-    return (ws->rg_sample > 0 && ws->rg_long * 8ull <= (unsigned long long)ws->rg_sample) ? 2 : 0;
+    if (ws->u_bad == 0) return (len >= 32 && len >= k && sbwt_fused_pieces(ws, k) > 0) ? 1 : 0;
+    return sbwt_fused_pieces(ws, k) > 0 ? 2 : 0;
 }
 // the check kernels: thread t of the first blocks counts into the sample
 #define SBWT_RG_SAMPLE 4096
-__device__ __forceinline__ void fused_sample_of_wave(i64 t, i64 len, bool valid, i64 n_reads, int rg_enable, SbwtWorkHeader *ws) {
-    if (t == 0) ws->rg_sample = rg_enable ? (int)(n_reads < SBWT_RG_SAMPLE ? n_reads : SBWT_RG_SAMPLE) : 0;
+__device__ __forceinline__ void fused_sample_of_wave(i64 t, i64 len, bool valid, i64 n_reads, int rg_enable, int k, SbwtWorkHeader *ws) {
+    // rg_enable: bit 0 = batches of mixed read lengths ("fused_ragged"), bits 8- = the most pieces per read ("fused_pieces")
+    if (t == 0) ws->rg_sample = ((rg_enable & 1) ? (int)(n_reads < SBWT_RG_SAMPLE ? n_reads : SBWT_RG_SAMPLE) : 0) | ((rg_enable >> 8) << 16);
     if (t - (threadIdx.x & 63) >= SBWT_RG_SAMPLE) return;          // (wave-uniform)
-    const u64 lm = __ballot(valid && t < SBWT_RG_SAMPLE && len > SBWT_FUSED_MAXLEN);
-    if (lm && (threadIdx.x & 63) == 0) atomicAdd(&ws->rg_long, (unsigned long long)__popcll(lm));
+    const bool in = valid && t < SBWT_RG_SAMPLE;
+    const u64 l1 = __ballot(in && len > sbwt_fused_limit(1, k)), l2 = __ballot(in && len > sbwt_fused_limit(2, k)),
+              l3 = __ballot(in && len > sbwt_fused_limit(3, k));
+    if (l1 && (threadIdx.x & 63) == 0)
+        atomicAdd(&ws->rg_long, (unsigned long long)__popcll(l1) | ((unsigned long long)__popcll(l2) << 20) |
+                                    ((unsigned long long)__popcll(l3) << 40));
 }
 
 // ---- long reads (SbwtPieceTab, sbwt_device.h) ----
+// is read r one that its pieces answer?  (the search kernels skip it then.)  More than two zones' worth of k-mers -- and more
+// than the fused kernel takes as its own pieces (at most 3 x 160 bases): a read that kernel may answer is never cut into
+// zones as well, whose tickets the kernel behind it would walk over bases that nobody encoded.
+__device__ __forceinline__ bool piece_read_is_cut(i64 m, int piece) {
+    return m > 2 * (i64)piece && m > (i64)SBWT_FUSED_MAXP * SBWT_FUSED_MAXLEN;
+}
 // the check kernels call this with every lane of a wave (valid: the lane has a read): a long read reserves its zones, and
 // the wave together notes { read, zone, zones of the read } for each of them (a genome as one read has 40 000)
 __device__ __forceinline__ void piece_zones_of_wave(i64 r, i64 len, bool valid, int k, SbwtWorkHeader *ws, const SbwtPieceTab &pt) {
     const i64 m = len - k + 1;
-    const bool isl = valid && pt.pairs != nullptr && m > 2 * (i64)pt.piece;
+    const bool isl = valid && pt.pairs != nullptr && piece_read_is_cut(m, pt.piece);
     u64 mask = __ballot(isl);
     if (!mask) return;
     const i64 nz = isl ? m / pt.piece : 0;
@@ -170,7 +209,5 @@ __device__ __forceinline__ void piece_zones_of_wave(i64 r, i64 len, bool valid, 
             pt.outs[bb + j] = make_uint4((unsigned)rr, (unsigned)((u64)rr >> 32), (unsigned)j, (unsigned)nn);
     }
 }
-// is read r one that its pieces answer?  (the search kernels skip it then)
-__device__ __forceinline__ bool piece_read_is_cut(i64 m, int piece) { return m > 2 * (i64)piece; }
 
 static inline unsigned grid_for(i64 n) { return (unsigned)((n + 255) / 256); }

@@ -103,7 +103,7 @@ __global__ void __launch_bounds__(256) k_encode_chained(const unsigned char *__r
         return;
     }
     const i64 nd = (i64)ws->n_deferred, len = ws->u_len, r0 = ws->u_read0;
-    constexpr int GP = SBWT_FUSED_MAXG + 1;                  // groups a read of <= 32 * MAXG bases can touch
+    const i64 GP = (len + 31) / 32 + 1;                      // groups a read of len bases can touch
     for (i64 t = t0; t < nd * GP; t += stride) {
         const i64 P0 = r0 + (i64)defer_list[t / GP] * len;
         const i64 g = (P0 >> 5) + (t % GP);
@@ -1274,7 +1274,8 @@ __device__ static i64 piece_adjust(const uint4 *__restrict__ packed, i64 P0, i64
 __global__ void __launch_bounds__(256) k_piece_bounds(const uint4 *__restrict__ packed, const i64 *__restrict__ read_off,
                                                       const i64 *__restrict__ out_off, int k, const SbwtWorkHeader *ws,
                                                       SbwtPieceTab pt, int behind_fused) {
-    if (behind_fused && sbwt_fused_mode(ws, k) == 1) return;   // the fused kernel took a batch of short reads
+    // (the fused kernel took a batch of reads of one length, none of them long enough to be cut into zones)
+    if (behind_fused && sbwt_fused_mode(ws, k) == 1 && !piece_read_is_cut(ws->u_len - k + 1, pt.piece)) return;
     const i64 z = (i64)blockIdx.x * 256 + threadIdx.x;
     const i64 np = (i64)ws->n_pieces < pt.cap ? (i64)ws->n_pieces : pt.cap;
     if (z >= np) return;

@@ -69,6 +69,11 @@
 #define CF_MISS_MASK 3072u
 #define CF_WIN31 8192u           // k > 31: the sparse lookup in flight is a 31-base WINDOW probe (a certificate), not a k-mer's prefix
 #define CF_NOCERT 4096u          // since the last own lookup: windows were probed, and every one of them is (perhaps) in the index
+#define CF_ANC_LEFT(f) (((f) >> 16) & 3u)
+#define CF_CMP_LEFT(f) (((f) >> 18) & 7u)
+#define CF_ANC_TRIED(f) ((int)(((f) >> 21) & 511u) - 1)
+#define CF_SET_TRIED(f, a) ((f) = ((f) & ~(511u << 21)) | ((((unsigned)((a) + 1)) & 511u) << 21))
+#define CF_BUDGETS (((unsigned)FZ_ANCHORS << 16) | ((unsigned)FZ_ALIGNS << 18))
 #define CF_M1 (CF_S1 | CF_A1 | CF_B1)
 #define CF_M2 (CF_S2 | CF_A2 | CF_B2)
 
@@ -141,7 +146,11 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
     const bool ragged = fmode == 2;                         // reads of any lengths: offsets fetched with every refill
     const int tid = threadIdx.x, lane = tid & 63, wbase = tid & ~63;
     const int k = ix.k, p = ix.p_dev, L0 = ix.probe_len, ps = ix.p_sparse;
-    const int ulen = ragged ? SBWT_FUSED_MAXLEN : (int)ws->u_len, m = ulen - k + 1, G = (ulen + 31) >> 5;
+    // tickets: P per read (reads of more than 160 bases as pieces that overlap by k-1; sbwt_kernels_common.h)
+    const int P = sbwt_fused_pieces(ws, k), kpp = SBWT_FUSED_MAXLEN - k + 1;
+    const bool varlen = ragged || P > 1;                    // the tickets' lengths differ: each refill notes them
+    const i64 n_tickets = n_reads * P;
+    const int ulen = ragged ? SBWT_FUSED_MAXLEN : (int)ws->u_len, m = ulen - k + 1, G = varlen ? SBWT_FUSED_MAXG : ((ulen + 31) >> 5);
     const i64 u_read0 = ws->u_read0, u_out0 = ws->u_out0, u_stride = ws->u_stride;
     const bool pfon = ix.pfil && ix.p_filter == L0 && L0 > p;
     const u64 mk2 = (k - ps >= 32) ? ~0ull : low_mask(2 * ((k - ps) & 31));   // key mask of the second-level window
@@ -156,11 +165,10 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
     int blo = -1;                   // the last failure is known to lie in [blo, b]
     // F_CMP: read base j <-> path step co + j; bases [cP, cE) still to compare; the first two differences seen (read
     // positions, -1: none) and whether the first one's step is substitution-safe
-    int co = 0, cP = 0, m1 = -1, m2 = -1;
+    int co = 0, cP = 0, m1 = -1;    // (m2 lives inside one iteration: a second difference is dealt with at once)
     unsigned fl = 0;                // CF_* flags
-    int anc_tried = -1, anc_left = 0;       // the last anchor k-mer that was not there; anchor lookups this read may still make
-    int cmp_left = 0;               // alignments (seeds, resumed compares) this read may still start
-    int seed_col = -1;              // k > 31: the column of a unique 31-mer whose k-mer was not there -- a SEED for an alignment
+    // (in fl's upper bits, to save registers: anchor lookups this read may still make, bits 16-17; alignments -- seeds, resumed
+    // compares -- it may still start, bits 18-20; the last anchor k-mer that was not there + 1, bits 21-29)
     // Anchors, seeds and resumed compares pay where a whole k-mer costs two lookups (31 < k <= 63: second-level table) and the
     // certificates' probes are short against k; for k <= 31 the certificates alone measured faster (config 2: -1.3 %).
     // "debug" bits: 32 = no anchors / seeds / resumes, 64 = all of them for k <= 31 as well.
@@ -176,7 +184,8 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
     int l = 0, r = 0;               // walk interval; F_EXT ..: r = path position
     unsigned c_ext = 0, c_brg = 0;  // per lane: k-mers answered along paths, substitutions bridged
     u64 pool_next = 0, pool_end = 0, pool_bad = 0;  // wave-uniform pool of read tickets; tickets of it that are handed on
-    int pool_len = 0;               // ragged batches: the length of the read this lane encoded at the last refill (161: too long)
+    int pool_len = 0;               // varlen: the length of the piece this lane encoded at the last refill (161: too long) | piece << 16
+    // (the piece number of the lane's ticket rides in i0's bits 16..: its first k-mer within its read is piece * kpp)
     unsigned c_stream = 0, c_search = 0, c_lf = 0, c_tab = 0;     // wave-uniform work counters
 #ifdef SBWT_STATS
     unsigned it_cnt = 0;
@@ -192,20 +201,34 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
                 pool_next = uniform64(t);
                 pool_end = pool_next + 64;
                 pool_bad = 0;
-                if ((i64)pool_next < n_reads) {
+                if ((i64)pool_next < n_tickets) {
                     i64 woff = u_read0 + (i64)pool_next * ulen;                       // first byte of the pool's 64 reads
                     unsigned vrel = (unsigned)lane * (unsigned)ulen;                  // this lane's read in there
                     int len_l = ulen;
-                    if (ragged) {
-                        i64 ta = (i64)pool_next + lane, tb = ta + 1;
-                        if (ta > n_reads) ta = n_reads;
-                        if (tb > n_reads) tb = n_reads;
-                        const i64 ro0 = read_off[ta], ro1 = read_off[tb];
-                        woff = (i64)uniform64((u64)ro0);
-                        const i64 rel = ro0 - woff, ln = ro1 - ro0;
-                        vrel = rel > 0xFFFF0000ll ? 0xFFFF0000u : (unsigned)rel;     // (beyond the descriptor: reads as zeros, handed on)
-                        len_l = ln > SBWT_FUSED_MAXLEN ? SBWT_FUSED_MAXLEN + 1 : (int)ln;
-                        pool_len = len_l;
+                    bool toolong = false;
+                    int pc = 0;
+                    if (varlen) {
+                        // this lane's ticket: piece pc of read tr
+                        i64 tk = (i64)pool_next + lane;
+                        if (tk > n_tickets) tk = n_tickets;
+                        const i64 tr = P == 1 ? tk : P == 2 ? (tk >> 1) : tk / 3;
+                        pc = (int)(tk - tr * P);
+                        i64 rstart, rlen;
+                        if (ragged) {
+                            const i64 ta = tr < n_reads ? tr : n_reads, tb = tr + 1 < n_reads ? tr + 1 : n_reads;
+                            rstart = read_off[ta];
+                            rlen = read_off[tb] - rstart;
+                        } else {
+                            rstart = u_read0 + tr * ulen;
+                            rlen = tr < n_reads ? ulen : 0;
+                        }
+                        toolong = rlen > sbwt_fused_limit(P, k);
+                        const i64 pstart = rstart + (i64)pc * kpp, plen = rlen - (i64)pc * kpp;
+                        woff = (i64)uniform64((u64)rstart);      // (lane 0's read: no later ticket starts before it)
+                        const i64 rel = pstart - woff;
+                        vrel = (rel < 0 || rel > 0xFFFF0000ll) ? 0xFFFF0000u : (unsigned)rel;     // (beyond the descriptor: reads as zeros, handed on)
+                        len_l = toolong ? SBWT_FUSED_MAXLEN + 1 : plen <= 0 ? 0 : plen > SBWT_FUSED_MAXLEN ? SBWT_FUSED_MAXLEN : (int)plen;
+                        pool_len = len_l | (pc << 16);
                     }
                     const int len_e = len_l > SBWT_FUSED_MAXLEN ? SBWT_FUSED_MAXLEN : len_l;
                     i64 remain = total_bases - woff;
@@ -238,13 +261,19 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
                             pool_codes[g][wbase + lane] = fz_encode32(w, tm, bad);
                         }
                     }
-                    const bool isbad = (bad != 0 || len_l > SBWT_FUSED_MAXLEN) && (i64)(pool_next + (u64)lane) < n_reads;
+                    const bool isbad = (bad != 0 || toolong) && (i64)(pool_next + (u64)lane) < n_tickets;
                     pool_bad = __ballot(isbad);
-                    if (pool_bad) {                                                    // hand them on (rare)
+                    // hand them on (rare): a read that is too long once (by its first piece's ticket); a read with other bytes
+                    // by every piece that holds some -- the general kernel may then answer it more than once, with the same
+                    // results, and its clean pieces are answered here as well (they do not depend on the rest)
+                    const u64 defer_m = __ballot(isbad && (!toolong || pc == 0));
+                    if (defer_m) {
                         unsigned long long at = 0;
-                        if (lane == 0) at = atomicAdd(&ws->n_deferred, (unsigned long long)__popcll(pool_bad));
+                        if (lane == 0) at = atomicAdd(&ws->n_deferred, (unsigned long long)__popcll(defer_m));
                         at = uniform64(at);
-                        if (isbad) defer_list[at + (u64)__popcll(pool_bad & low_mask(lane))] = (unsigned)(pool_next + (u64)lane);
+                        if ((defer_m >> lane) & 1ull)
+                            defer_list[at + (u64)__popcll(defer_m & low_mask(lane))] =
+                                (unsigned)(P == 1 ? (pool_next + (u64)lane) : P == 2 ? ((pool_next + (u64)lane) >> 1) : (pool_next + (u64)lane) / 3ull);
                     }
                 } else {
                     drained = true;                    // no read left anywhere: from now on idle lanes help busy ones (below)
@@ -256,29 +285,27 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
             const unsigned n = (unsigned)__popcll(need);
             const unsigned rank = (unsigned)__popcll(need & low_mask(lane));
             // (ragged batches: the length of ticket q's read sits in lane q -- fetched with every lane of the wave active)
-            const int mq_r = ragged ? __shfl(pool_len, (int)((pool_next + rank) & 63ull)) - k + 1 : m;
+            const int qsrc = (int)((pool_next + rank) & 63ull);
+            const int plq = varlen ? __shfl(pool_len, qsrc) : 0;
+            const int mq_r = varlen ? (plq & 0xFFFF) - k + 1 : m;
             if (mode == F_IDLE && rank < avail) {
                 const u64 tk = pool_next + rank;
                 const int q = (int)(tk & 63ull);
                 const int mq = mq_r;                   // (a read shorter than k: nothing to answer)
-                if ((i64)tk < n_reads && !((pool_bad >> q) & 1ull) && mq > 0) {
+                if ((i64)tk < n_tickets && !((pool_bad >> q) & 1ull) && mq > 0) {
                     FZ_HIST_FLUSH();
-                    rd = (unsigned)tk;
+                    rd = (unsigned)(P == 1 ? tk : P == 2 ? (tk >> 1) : tk / 3ull);
 #pragma unroll
                     for (int g = 0; g < SBWT_FUSED_MAXG; g++)
                         if (g < G) cur_codes[g][tid] = pool_codes[g][wbase + q];
                     i = 0;
                     mend = mq;
                     nseg = 0;
-                    i0 = 0;
+                    i0 = (plq >> 16) << 16;
                     b = -1;
                     blo = -1;
                     bnext = -1;
-                    fl = 0;
-                    anc_tried = -1;
-                    anc_left = FZ_ANCHORS;
-                    cmp_left = FZ_ALIGNS;
-                    seed_col = -1;
+                    fl = CF_BUDGETS;
                     wstart = 0;
                     j = 0;
                     wk = (ps > 0) ? 1 : 0;
@@ -311,6 +338,7 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
                 }
                 const int d_i = __shfl(i, src), d_end = __shfl(mend, src);
                 const unsigned d_rd = (unsigned)__shfl((int)rd, src);
+                const int d_pc = __shfl(i0, src) & ~0xFFFF;
                 const int mid = d_i + ((d_end - d_i + 1) >> 1);
                 if (giving) mend = i + ((mend - i + 1) >> 1);                        // (the same mid its taker computed)
 #ifdef SBWT_STATS
@@ -325,15 +353,11 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
                     i = mid;
                     mend = d_end;
                     nseg = 0;
-                    i0 = mid;
+                    i0 = mid | d_pc;
                     b = -1;
                     blo = -1;
                     bnext = -1;
-                    fl = 0;
-                    anc_tried = -1;
-                    anc_left = FZ_ANCHORS;
-                    cmp_left = FZ_ALIGNS;
-                    seed_col = -1;
+                    fl = CF_BUDGETS;
                     wstart = mid;
                     j = 0;
                     wk = (ps > 0) ? 1 : 0;
@@ -350,7 +374,7 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
         } else if (mode == F_EXT) {                    // k-mer i-1 sits at path position r: on along the path
             co = r - (i + k - 1);
             cP = i + k - 1;
-            m1 = m2 = -1;
+            m1 = -1;
             fl = (fl & ~(CF_M1 | CF_M2)) | CF_ONP;
             mode = F_CMP;
         } else if (mode == F_BRIDGE) {
@@ -360,7 +384,6 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
             co = r - u;
             cP = u + 1;
             m1 = u;
-            m2 = -1;
             fl = (fl & ~(CF_M1 | CF_M2 | CF_ONP)) | CF_M1;
             mode = F_CMP;
         }
@@ -456,6 +479,8 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
         // ---- consume ----
         bool tabhit = false, do_plan = false, force = false;
         bool w31 = false;                              // k > 31: a filter window was (perhaps) present: try the 31-base window around b
+        int m2 = -1;                                   // F_CMP: the second difference (this iteration's)
+        int seed_col = -1;                             // k > 31: the column of a unique 31-mer whose k-mer was not there: a SEED for an alignment
         bool imprecise = false;                        // this iteration's failure is a table-level miss
         int pre_n = 0, abs_n = 0, post_n = 0;          // F_CMP's verdicts: a run along the path, k-mers absent by a safe bit, a run
         int cact = 0, ctr = 0;                         // ... and what follows (CA_*)
@@ -468,7 +493,7 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
                 // a seed: the k-mer at position r ENDS with the 31 bases before read position -co; align the rest of the read
                 fl &= ~(CF_SEED | CF_M1 | CF_M2 | CF_ONP);
                 co += r;
-                if ((unsigned)(co + i) < (unsigned)ix.n_pos) { cP = i; m1 = m2 = -1; mode = F_CMP; }
+                if ((unsigned)(co + i) < (unsigned)ix.n_pos) { cP = i; m1 = -1; mode = F_CMP; }
                 else { mode = F_DEAD; do_plan = true; }
             } else {
                 mode = F_EXT;
@@ -769,7 +794,7 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
                     imprecise = (wk != 2 && wk != 6 && !(fl & CF_WIN31));  // ... but where inside the window it fails is not known
                 } else if (wk == 3 || wk == 6) {
                     ev = FE_PRES;
-                } else if (wk == 1 && ps < k && ix.stab2 && (fl & CF_ANCH) && seed_ok && r == l && cmp_left > 0) {
+                } else if (wk == 1 && ps < k && ix.stab2 && (fl & CF_ANCH) && seed_ok && r == l && CF_CMP_LEFT(fl) > 0) {
                     seed_col = l;                      // an anchor's 31-mer in ONE column: that is a seed already -- its position
                     ev = FE_FAIL;                      // aligns the read without the k-mer's other 32 bases having to be clean
                 } else if (wk == 1 && ps < k && ix.stab2) {
@@ -810,11 +835,11 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
             if (ev == FE_ANCH && tpos >= 0 && (unsigned)(o + i) < (unsigned)ix.n_pos) {
                 co = o;
                 cP = i;
-                m1 = m2 = -1;
+                m1 = -1;
                 fl &= ~(CF_M1 | CF_M2 | CF_ONP);
                 mode = F_CMP;
             } else {
-                anc_tried = wstart;
+                CF_SET_TRIED(fl, wstart);
                 mode = F_DEAD;
                 do_plan = true;
             }
@@ -917,7 +942,7 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
                     do_plan = true;
                 } else if (cact == CA_LOST) {
                     fl &= ~CF_ALIGNED;
-                    anc_tried = wstart;                // (an anchor whose stretch is not one path: no second try at it)
+                    CF_SET_TRIED(fl, wstart);          // (an anchor whose stretch is not one path: no second try at it)
                     mode = F_DEAD;
                     do_plan = true;
                 } else if (cact == CA_ABSENT) {
@@ -949,12 +974,13 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
                 if (fm == 0) continue;                 // wave-uniform: unused slots cost nothing
                 const int L = __ffsll((i64)fm) - 1;
                 fm &= fm - 1;
-                const int ns = __shfl(nseg, L), a = __shfl(i0, L), e = __shfl(i, L);
+                const int i0L = __shfl(i0, L);
+                const int ns = __shfl(nseg, L), a = i0L & 0xFFFF, e = __shfl(i, L);
                 fL[u] = L;
                 fe[u] = e;
                 {
                     const i64 rdu = (i64)uniform32((unsigned)__shfl((int)rd, L));
-                    fob[u] = ragged ? out_off[rdu] : u_out0 + rdu * u_stride;
+                    fob[u] = (ragged ? out_off[rdu] : u_out0 + rdu * u_stride) + (i64)((i0L >> 16) * kpp);
                 }
                 long_read = long_read || (e - a > 128);
                 const int tl = wbase + L;
@@ -997,7 +1023,7 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
 #pragma unroll
                 for (int u = 0; u < FP; u++) {
                     if (fL[u] < 0) continue;
-                    const int L = fL[u], ns = __shfl(nseg, L), a = __shfl(i0, L), e = fe[u];
+                    const int L = fL[u], ns = __shfl(nseg, L), a = __shfl(i0, L) & 0xFFFF, e = fe[u];
                     const int tl = wbase + L;
                     for (int base = a + 128; base < e; base += 128) {
                         const int j0 = base + 2 * lane, j1 = j0 + 1;
@@ -1023,7 +1049,7 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
             }
 #pragma unroll
             for (int u = 0; u < FP; u++)
-                if (lane == fL[u]) { nseg = 0; i0 = i; }
+                if (lane == fL[u]) { nseg = 0; i0 = i | (i0 & ~0xFFFF); }
         }
         if (ev == FE_EMIT1 || burst_hi >= 0) {
             if (i == mend) {
@@ -1039,13 +1065,13 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
                 do_plan = true;                        // SBWT.hh:557-559 (with certificates)
             }
         }
-        if (do_plan && !force && cmp_left > 0 && (fl & CF_MISS_MASK) < 2u * CF_MISS &&
+        if (do_plan && !force && CF_CMP_LEFT(fl) > 0 && (fl & CF_MISS_MASK) < 2u * CF_MISS &&
             (seed_col >= 0 || ((fl & CF_ALIGNED) && wide_k && !(b >= i && b <= i + k - 1) && (unsigned)(co + i) < (unsigned)ix.n_pos))) {
             // k > 31: an alignment instead of a walk.  A seed (the 31-mer [wstart, wstart + 31) is in the index in one column, the
             // k-mer it began is not): that column's path position aligns the read.  Or the alignment the read had when it
             // left its path, once every k-mer that holds the known bad base is answered.  F_CMP's conclusions are exact
             // whatever the alignment is worth.
-            cmp_left--;
+            fl -= 1u << 18;
             if (seed_col >= 0) {
                 l = seed_col;
                 co = -(wstart + ps);
@@ -1053,13 +1079,12 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
                 mode = F_POS;
             } else {
                 cP = i;
-                m1 = m2 = -1;
+                m1 = -1;
                 fl &= ~(CF_M1 | CF_M2 | CF_ONP);
                 mode = F_CMP;
             }
             do_plan = false;
         }
-        seed_col = -1;
         if (do_plan) {
             // where the next walk starts (see k_search_cert): at k-mer i itself, or close to the last failure position b
             // when b lies inside k-mer i's window
@@ -1083,13 +1108,13 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
                 fl |= CF_WIN31;
             } else if (!force && L0 > 0 && b >= i && b <= i + k - 1) {
                 const int lo = blo > i ? blo : i;
-                if (lo < b && anch_ok && anc_left > 0 && b + 1 != anc_tried && b + 1 <= mend - 1) {
+                if (lo < b && anch_ok && CF_ANC_LEFT(fl) > 0 && b + 1 != CF_ANC_TRIED(fl) && b + 1 <= mend - 1) {
                     // the bad base is somewhere in [lo, b]: the k-mer just past the range as an anchor (F_CMP) instead of
                     // halving the range probe by probe
                     s0 = b + 1;
                     nwk = 1;
                     fl |= CF_ANCH;
-                    anc_left--;
+                    fl -= 1u << 16;
                 } else if (lo < b && p > 0 && k - pw >= 1) {
                     // the bad base is somewhere in [lo, b]: halve the range with a window that starts inside it
                     int x = lo + ((b - lo + 1) >> 1);
@@ -1140,7 +1165,7 @@ __global__ void __launch_bounds__(256) k_check_uniform2(const i64 *__restrict__ 
     if (t == 0) { ws->u_read0 = read_off[0]; ws->u_len = len; ws->u_out0 = out_off[0]; ws->u_stride = stride; }
     const bool valid = t < n_reads;
     const i64 mylen = valid ? read_off[t + 1] - read_off[t] : 0;
-    fused_sample_of_wave(t, mylen, valid, n_reads, rg_enable, ws);
+    fused_sample_of_wave(t, mylen, valid, n_reads, rg_enable, k, ws);
     piece_zones_of_wave(t, mylen, valid, k, ws, pt);                       // long reads: for the general kernel behind
     if (!valid) return;
     const bool bad = (mylen != len) || (t + 1 < n_reads && out_off[t + 1] - out_off[t] != stride);

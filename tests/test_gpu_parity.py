@@ -770,3 +770,74 @@ def test_fused_kernel_takes_batches_of_mixed_lengths(gpu, genome_case):
     off2 = np.concatenate([[0], np.cumsum(lens2)]).astype(np.int64)
     bases2 = np.concatenate([cat[a:a + l] for a, l in zip(st2, lens2)])
     assert np.array_equal(_search_dev(idx, bases2, off2, k, True), oracle_batch(orc, bases2, off2, True))
+
+
+@pytest.mark.parametrize("k", [30, 63])
+def test_fused_kernel_takes_reads_of_161_to_400_bases_as_pieces(gpu, k):
+    # Round 4, "fused_pieces" = 2 or 3 (default 1: measured, no faster than the two-pass route -- DESIGN.md): a read of more than
+    # 160 bases is taken by the fused kernel as up to three pieces of 160 bases that overlap by k-1 (a ticket is (read, piece);
+    # SBWT.hh:556-579 has no length limit).  Reads of ONE length 161 .. 3 * (161 - k) + k - 1
+    # (offset arithmetic), reads of mixed lengths with two or three tickets each, N / lower case inside one piece (the read
+    # is handed on to the general kernel, its clean pieces are still answered here), reads beyond the limit (handed on
+    # whole), reads shorter than k.  Same bits as the oracle, and the fused kernel did the work (its run counter).
+    import torch
+    genomes = [synth.random_genome(120_000, 5)]
+    genomes.append(synth.mutate(genomes[0], 0.05, 6))
+    orc = OracleIndex.build([g.tobytes() for g in genomes], k, True, False, 8)
+    idx = gpu_index_from_oracle(orc)
+    st = torch.cuda.current_stream().cuda_stream
+    cat = np.concatenate(genomes)
+    rng = np.random.default_rng(77)
+    kpp = 161 - k
+    limit3 = 3 * kpp + k - 1
+
+    def run(bases, off):
+        for streaming in (True, False):
+            want = oracle_batch(orc, bases, off, streaming)
+            for variant, pieces in ((5, 3), (5, 2), (5, 1), (4, 1)):
+                capi.set_tuning("search_variant", variant)
+                capi.set_tuning("fused_pieces", pieces)
+                try:
+                    got = _search_dev(idx, bases, off, k, streaming)
+                finally:
+                    capi.set_tuning("search_variant", -1)
+                    capi.set_tuning("fused_pieces", 1)
+                assert np.array_equal(got, want), (streaming, variant, pieces)
+
+    # (1) reads of one length
+    for L in (161, 250, 2 * kpp + k - 1, 2 * kpp + k, min(320, limit3), limit3):
+        bases, off = synth.sample_reads(genomes, 700, L, 0.01, 100 + L)
+        bases = synth.inject(bases, 20, ord("N"), 9)
+        bases = synth.inject(bases, 20, ord("g"), 10)
+        run(bases, off)
+    # ... and the fused kernel really takes them: 4 000 clean reads of 250 bases, all k-mers answered along path runs
+    bases, off = synth.sample_reads(genomes, 4000, 250, 0.0, 5)
+    d_b = torch.from_numpy(bases).cuda()
+    oo = capi.out_offsets(off, k)
+    d_ro, d_oo = torch.from_numpy(off).cuda(), torch.from_numpy(oo).cuda()
+    d_out = torch.empty(int(oo[-1]), dtype=torch.int64, device="cuda")
+    wsb = capi.search_workspace_bytes(len(bases))
+    d_ws = torch.empty(wsb, dtype=torch.uint8, device="cuda")
+    capi.set_tuning("fused_pieces", 2)
+    try:
+        idx.streaming_search_dev(d_b.data_ptr(), len(bases), d_ro.data_ptr(), 4000, d_out.data_ptr(), d_oo.data_ptr(), d_ws.data_ptr(),
+                                 wsb, st, True)
+        torch.cuda.synchronize()
+    finally:
+        capi.set_tuning("fused_pieces", 1)
+    stats = idx.workspace_stats(d_ws.data_ptr(), st)
+    assert stats[4] > 0.9 * int(oo[-1]) and int((d_out >= 0).sum()) == int(oo[-1])
+    hdr = d_ws[:256].cpu().numpy().view(np.uint64)
+    assert int(hdr[13]) == 0, "reads of 250 bases were handed on to the general kernel"      # SbwtWorkHeader.n_deferred (byte 104)
+    # (2) mixed lengths: mostly 100 .. 320, some too long even for three pieces, some shorter than k, some empty
+    n = 5000
+    lens = rng.integers(100, 321, size=n)
+    lens[rng.integers(0, n, size=40)] = rng.integers(limit3 + 1, limit3 + 300, size=40)
+    lens[rng.integers(0, n, size=40)] = rng.integers(0, k, size=40)
+    sta = (rng.random(n) * (len(cat) - lens)).astype(np.int64)
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    bases = np.concatenate([cat[a:a + l] for a, l in zip(sta, lens)])
+    bases = synth.mutate(bases, 0.01, 3)
+    bases = synth.inject(bases, 120, ord("N"), 4)
+    bases = synth.inject(bases, 120, ord("t"), 5)
+    run(bases, off)

@@ -19,6 +19,7 @@ def reset_tuning():
     capi.set_tuning("search_variant", -1)
     capi.set_tuning("sort_reads", -1)
     capi.set_tuning("debug", 0)
+    capi.set_tuning("fused_pieces", 1)
     capi.set_tuning("path_lookahead", 8); capi.set_tuning("path_safe", 2); capi.set_tuning("image_level", 0)
     capi.set_tuning("path_stitch", 1); capi.set_tuning("path_stitch_min", 1)
 
@@ -69,14 +70,14 @@ def _fuzz(budget, seed, max_cases):
         # reads
         nr = int(rng.integers(200, 4000))
         if rng.integers(0, 2):
-            L = int(rng.integers(max(k - 2, 1), 4 * k + 60))
+            L = int(rng.integers(max(k - 2, 1), int(rng.choice([4 * k + 60, 480]))))      # (up to and past three fused pieces)
             long_enough = [g for g in genomes if len(g) >= L]
             if not long_enough:
                 continue
             bases, off = synth.sample_reads(long_enough, nr, L, float(rng.choice([0, 0.005, 0.02, 0.1])), int(rng.integers(1, 1 << 30)))
         else:                 # ragged lengths
             cat = np.concatenate(genomes)
-            lens = np.minimum(rng.integers(0, 3 * k + 40, size=nr), len(cat))
+            lens = np.minimum(rng.integers(0, int(rng.choice([3 * k + 40, 330, 460])), size=nr), len(cat))
             st = (rng.random(nr) * (len(cat) - lens + 1)).astype(np.int64)
             off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
             bases = np.empty(int(off[-1]), dtype=np.uint8)
@@ -111,6 +112,7 @@ def _fuzz(budget, seed, max_cases):
             capi.set_tuning("sort_reads", int(rng.integers(0, 2)) if v == 4 else -1)
             # the fused kernel's alignments (anchors, seeds, resumed compares): off / as shipped / for every k
             capi.set_tuning("debug", int(rng.choice([0, 0, 32, 64])) if v == 5 else 0)
+            capi.set_tuning("fused_pieces", int(rng.choice([1, 2, 3])) if v == 5 else 1)
             a = idx.streaming_search(bases, off)[0] if ssup else None
             b = idx.search(bases, off)[0]
             res[(v, -1)] = (a, b)
