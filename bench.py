@@ -300,6 +300,7 @@ def main() -> int:
     ap.add_argument("--no-end-to-end", action="store_true",
                     help="skip the end-to-end leg (host buffers over PCIe, and the `sbwt search` CLI on a FASTQ file)")
     ap.add_argument("--e2e-reads", type=int, default=2_000_000, help="reads of the end-to-end leg")
+    ap.add_argument("--no-cli-full", action="store_true", help="end-to-end leg: skip the `sbwt search` run on the whole batch")
     ap.add_argument("--config", type=int, default=2, choices=[2, 3, 5, 6],
                     help="BASELINE.json config: 2 = coli3-like k=30 (headline, default); 3 = pan-genome-like "
                          "k=31 (65 genomes, 100 M reads unless --reads); 5 = k=63 without streaming support")
@@ -786,6 +787,20 @@ def end_to_end_leg(args, index, genomes, d_bases, m, streaming, dev):
         capi._check(fn(index.handle, h_bases.data_ptr(), roff.ctypes.data, E, h_out.data_ptr(), ooff.ctypes.data))
         times.append(time.perf_counter() - t0)
     host_rate = n_k / float(np.median(times[1:]))
+    # the same with int32 results (sbwtgpu_*_batch_i32: the device narrows, 4 bytes of PCIe per k-mer)
+    host_rate_i32 = None
+    if index.n_nodes < (1 << 31):
+        h_out32 = torch.empty(n_k, dtype=torch.int32, pin_memory=True)
+        fn32 = capi.lib().sbwtgpu_streaming_search_batch_i32 if streaming else capi.lib().sbwtgpu_search_batch_i32
+        t32 = []
+        for _ in range(4):
+            t0 = time.perf_counter()
+            capi._check(fn32(index.handle, h_bases.data_ptr(), roff.ctypes.data, E, h_out32.data_ptr(), ooff.ctypes.data))
+            t32.append(time.perf_counter() - t0)
+        host_rate_i32 = n_k / float(np.median(t32[1:]))
+        if not torch.equal(h_out32.to(torch.int64), h_out):
+            raise RuntimeError("int32 results differ from the int64 results")
+        del h_out32
     # the copy rate PCIe gives this box, device -> pinned host, 1 GiB
     probe = torch.empty(1 << 30, dtype=torch.uint8, device=dev)
     hprobe = torch.empty(1 << 30, dtype=torch.uint8, pin_memory=True)
@@ -802,7 +817,10 @@ def end_to_end_leg(args, index, genomes, d_bases, m, streaming, dev):
     out = {"batch_reads": E, "host_buffers_kmers_per_s": host_rate, "host_buffers_s": float(np.median(times[1:])),
            "d2h_GBps": d2h / 1e9, "pcie_bound_kmers_per_s": d2h / 8.0,
            "host_buffers_frac_of_pcie_bound": host_rate / (d2h / 8.0),
-           "host_buffers": "pinned bases + pinned int64 results, offsets pageable; median of 3 after one warm-up call"}
+           "host_buffers": "pinned bases + pinned int64 results, offsets pageable; median of 3 after one warm-up call",
+           "host_buffers_i32_kmers_per_s": host_rate_i32,
+           "host_buffers_i32": "sbwtgpu_*_batch_i32: the same call with int32 results (narrowed on the device, 4 bytes of PCIe per "
+                               "k-mer; indexes of fewer than 2^31 columns)"}
     # the CLI: index file, FASTQ file, output text file
     sbwt = os.path.join(ROOT, "sbwt_amd", "bin", "sbwt")
     d = tempfile.mkdtemp(prefix="sbwt_e2e_", dir=os.environ.get("TMPDIR", "/tmp"))
@@ -814,28 +832,71 @@ def end_to_end_leg(args, index, genomes, d_bases, m, streaming, dev):
         if not streaming:
             cmd.append("--no-streaming-support")
         subprocess.run(cmd, check=True, capture_output=True)
-        rows = h_bases.numpy().reshape(E, READ_LEN)
-        rec = np.empty((E, 4 + READ_LEN + 3 + READ_LEN + 1), dtype=np.uint8)       # "@r\n" seq "\n+\n" qual "\n"
-        rec[:, 0:3] = np.frombuffer(b"@r\n", dtype=np.uint8)
-        rec[:, 3:3 + READ_LEN] = rows
-        rec[:, 3 + READ_LEN:6 + READ_LEN] = np.frombuffer(b"\n+\n", dtype=np.uint8)
-        rec[:, 6 + READ_LEN:6 + 2 * READ_LEN] = ord("I")
-        rec[:, 6 + 2 * READ_LEN:] = ord("\n")
-        rec = rec[:, :7 + 2 * READ_LEN]
-        rec.tofile(d + "/r.fastq")
-        best = None
-        for _ in range(2):
-            t0 = time.perf_counter()
-            p = subprocess.run([sbwt, "search", "-i", d + "/i.sbwt", "-q", d + "/r.fastq", "-o", d + "/out.txt"], capture_output=True)
-            dt = time.perf_counter() - t0
-            if p.returncode != 0:
-                raise RuntimeError("sbwt search failed: " + p.stderr.decode(errors="replace")[-300:])
-            best = dt if best is None else min(best, dt)
-        logs = [l.split("us/query")[1].strip() for l in p.stderr.decode().splitlines() if "us/query" in l]
+        def write_fastq(path, d_src, n):
+            """n reads as a 4-line FASTQ file, written in slices (10 M reads are 3 GB)"""
+            with open(path, "wb") as f:
+                for lo in range(0, n, 1_000_000):
+                    hi = min(n, lo + 1_000_000)
+                    rows = d_src[lo * READ_LEN:hi * READ_LEN].cpu().numpy().reshape(hi - lo, READ_LEN)
+                    rec = np.empty((hi - lo, 7 + 2 * READ_LEN), dtype=np.uint8)                # "@r\n" seq "\n+\n" qual "\n"
+                    rec[:, 0:3] = np.frombuffer(b"@r\n", dtype=np.uint8)
+                    rec[:, 3:3 + READ_LEN] = rows
+                    rec[:, 3 + READ_LEN:6 + READ_LEN] = np.frombuffer(b"\n+\n", dtype=np.uint8)
+                    rec[:, 6 + READ_LEN:6 + 2 * READ_LEN] = ord("I")
+                    rec[:, 6 + 2 * READ_LEN] = ord("\n")
+                    rec.tofile(f)
+
+        def run_cli(fastq, n, repeats):
+            best, stages = None, None
+            for _ in range(repeats):
+                t0 = time.perf_counter()
+                p = subprocess.run([sbwt, "search", "-i", d + "/i.sbwt", "-q", fastq, "-o", d + "/out.txt"], capture_output=True,
+                                   env=dict(os.environ, SBWT_CLI_TIMING="1"))
+                dt = time.perf_counter() - t0
+                if p.returncode != 0:
+                    raise RuntimeError("sbwt search failed: " + p.stderr.decode(errors="replace")[-300:])
+                if best is None or dt < best:
+                    best = dt
+                    stages = [l[len("timing: "):] for l in p.stderr.decode().splitlines() if l.startswith("timing: ")]
+            logs = [l.split("us/query")[1].strip() for l in p.stderr.decode().splitlines() if "us/query" in l]
+            return best, logs, stages
+
+        write_fastq(d + "/r.fastq", d_bases, E)
+        best, logs, stages = run_cli(d + "/r.fastq", E, 2)
         out.update({"cli_kmers_per_s": n_k / best, "cli_wall_s": best, "cli_us_per_query_lines": logs,
                     "cli_fastq_bytes": os.path.getsize(d + "/r.fastq"), "cli_output_bytes": os.path.getsize(d + "/out.txt"),
-                    "cli": "sbwt search -i index -q reads.fastq -o out.txt, process start to exit (index load, parse, search, "
-                           "format on the GPU, write), best of 2"})
+                    "cli_stage_marks": stages,
+                    "cli": "sbwt search -i index -q reads.fastq -o out.txt, process start to exit (index load, parse, search, format on the GPU, write), best of 2"})
+        # ... the same command on the whole batch (config 2: 10 M reads, 3 GB of FASTQ in, 8 GB of text out) when the scratch
+        # directory has the room: fixed costs (process and HIP start-up, index load) no longer dominate
+        big = args.reads
+        need = big * (7 + 2 * READ_LEN) + big * m * 8
+        if big > E and shutil.disk_usage(d).free > need + (4 << 30) and not args.no_cli_full:
+            os.remove(d + "/out.txt")
+            write_fastq(d + "/r.fastq", d_bases, big)
+            best_b, logs_b, stages_b = run_cli(d + "/r.fastq", big, 1)
+            out.update({"cli_full_reads": big, "cli_full_kmers_per_s": big * m / best_b, "cli_full_wall_s": best_b,
+                        "cli_full_fastq_bytes": os.path.getsize(d + "/r.fastq"), "cli_full_output_bytes": os.path.getsize(d + "/out.txt"),
+                        "cli_full_stage_marks": stages_b})
+            os.remove(d + "/out.txt")
+        # ... and what the reference's own CLI loop costs on the host: the oracle's restatement of run_file + print_vector
+        # (sbwt_search.cpp:21-105: ONE thread, read by read), on a bounded sample of the same file
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            from oracle import OracleIndex
+            f = hostlib.read_index_file(d + "/i.sbwt")
+            orc = OracleIndex.from_bits(f.cols[0], f.cols[1], f.cols[2], f.cols[3], f.ssup, f.n_nodes, f.k, f.n_kmers, f.precalc_k)
+            S = min(E, 200_000)
+            write_fastq(d + "/s.fastq", d_bases, S)
+            wall, qsecs, nr, nk = orc.search_file(d + "/s.fastq", d + "/s_out.txt")
+            out.update({"cpu_cli_port": {"reads": nr, "kmers": nk, "wall_s": wall, "query_s": qsecs, "kmers_per_s": nk / wall,
+                                         "threads": 1,
+                                         "what": "the oracle's restatement of the reference CLI loop (sbwt_search.cpp:21-105: parse, "
+                                                 "streaming_search / search per read, print_vector, write) on the first %d reads of "
+                                                 "the same FASTQ file, one thread like the reference; index load not included" % S}})
+            out["cli_vs_cpu_cli_port"] = out["cli_kmers_per_s"] / (nk / wall)
+        except Exception as ex:
+            out["cpu_cli_port"] = {"error": repr(ex)}
     finally:
         shutil.rmtree(d, ignore_errors=True)
     return out

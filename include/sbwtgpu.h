@@ -192,6 +192,14 @@ int  sbwtgpu_streaming_search_batch(const sbwtgpu_index *idx, const char *bases,
  * streaming support. */
 int  sbwtgpu_search_batch(const sbwtgpu_index *idx, const char *bases, const int64_t *read_off,
                           int64_t n_reads, int64_t *out, const int64_t *out_off);
+/* The same two calls with int32 results (result compaction; consumer: print_vector,
+ * src/CLI/sbwt_search.cpp:21-43, which only prints the values): the device narrows before the copy, so a result costs
+ * 4 bytes of PCIe instead of 8.  Only for indexes of fewer than 2^31 columns (SBWTGPU_ERR_INVALID_ARG otherwise); -1
+ * stays -1.  out[] is indexed like the int64 calls' (out_off in results, not bytes). */
+int  sbwtgpu_streaming_search_batch_i32(const sbwtgpu_index *idx, const char *bases, const int64_t *read_off,
+                                        int64_t n_reads, int32_t *out, const int64_t *out_off);
+int  sbwtgpu_search_batch_i32(const sbwtgpu_index *idx, const char *bases, const int64_t *read_off,
+                              int64_t n_reads, int32_t *out, const int64_t *out_off);
 /* SBWT::update_sbwt_interval(S, len, I) (SBWT.hh:422-437) for n independent queries:
  * query q extends interval (first[q], second[q]) by bases[off[q] .. off[q+1]) in place. */
 int  sbwtgpu_update_interval_batch(const sbwtgpu_index *idx, const char *bases, const int64_t *off,

@@ -619,3 +619,76 @@ void orc_count_work(const orc_index *idx, const char *bases, const int64_t *read
     }
     *n_stream_steps = ns; *n_searches = nf; *n_lf_steps = nl;
 }
+
+/* ------------------------------------------------------------------------- */
+/* The reference CLI's loop over one query file, for the end-to-end CPU figure */
+/* ------------------------------------------------------------------------- */
+/* run_file + run_queries_streaming / run_queries_not_streaming + print_vector, src/CLI/sbwt_search.cpp:21-105: one thread,
+ * read by read -- parse, query, format, write.  The reader is a minimal 4-line FASTQ / single- or multi-line FASTA parser
+ * (the reference uses its SeqIO submodule, absent here; sequences are upper-cased on read like SeqIO does [UPSTREAM-KNOWLEDGE]).
+ * Returns the wall time of the whole call in seconds (-1.0 on an I/O error); *query_secs gets the summed query time alone,
+ * the reference's "us/query (excluding I/O etc)" (sbwt_search.cpp:54-56). */
+double orc_search_file(const orc_index *idx, const char *query_path, const char *out_path, int64_t *n_reads_out,
+                       int64_t *n_kmers_out, double *query_secs) {
+    const double t0 = now_sec();
+    FILE *in = fopen(query_path, "rb");
+    if (!in) return -1.0;
+    FILE *out = fopen(out_path, "wb");
+    if (!out) { fclose(in); return -1.0; }
+    setvbuf(in, NULL, _IOFBF, 1 << 22);
+    setvbuf(out, NULL, _IOFBF, 1 << 22);
+    char *line = NULL;
+    size_t cap = 0;
+    ssize_t n;
+    int64_t n_reads = 0, n_kmers = 0, res_cap = 0, txt_cap = 0, seq_cap = 0, seq_len = 0;
+    int64_t *res = NULL;
+    char *txt = NULL, *seq = NULL;
+    double qsecs = 0.0;
+    int fastq = -1, ok = 1;
+    ssize_t pending = getline(&line, &cap, in);
+    while (ok && pending > 0) {
+        if (fastq < 0) fastq = line[0] == '@';
+        if (line[0] != (fastq ? '@' : '>')) { ok = 0; break; }
+        seq_len = 0;
+        if (fastq) {
+            n = getline(&line, &cap, in);
+            if (n <= 0) { ok = 0; break; }
+            while (n > 0 && (line[n - 1] == '\n' || line[n - 1] == '\r')) n--;
+            if (n + 1 > seq_cap) { seq_cap = 2 * (n + 1); seq = (char *)realloc(seq, (size_t)seq_cap); }
+            memcpy(seq, line, (size_t)n);
+            seq_len = n;
+            if (getline(&line, &cap, in) <= 0 || getline(&line, &cap, in) <= 0) { ok = 0; break; }   /* '+' and quality lines */
+            pending = getline(&line, &cap, in);
+        } else {
+            for (;;) {
+                pending = getline(&line, &cap, in);
+                if (pending <= 0 || line[0] == '>') break;
+                n = pending;
+                while (n > 0 && (line[n - 1] == '\n' || line[n - 1] == '\r')) n--;
+                if (seq_len + n + 1 > seq_cap) { seq_cap = 2 * (seq_len + n + 1); seq = (char *)realloc(seq, (size_t)seq_cap); }
+                memcpy(seq + seq_len, line, (size_t)n);
+                seq_len += n;
+            }
+        }
+        for (int64_t t = 0; t < seq_len; t++)
+            if (seq[t] >= 'a' && seq[t] <= 'z') seq[t] = (char)(seq[t] - 32);
+        int64_t m = seq_len - idx->k + 1;
+        if (m < 0) m = 0;
+        if (m + 1 > res_cap) { res_cap = 2 * (m + 1); res = (int64_t *)realloc(res, (size_t)res_cap * 8); }
+        if (21 * m + 2 > txt_cap) { txt_cap = 2 * (21 * m + 2); txt = (char *)realloc(txt, (size_t)txt_cap); }
+        const double q0 = now_sec();
+        const int64_t got = idx->ssup.n_bits > 0 ? orc_streaming_search(idx, seq, seq_len, res) : orc_search_all(idx, seq, seq_len, res);
+        qsecs += now_sec() - q0;
+        const int64_t bytes = orc_print_vector(res, got > 0 ? got : 0, txt);
+        if ((int64_t)fwrite(txt, 1, (size_t)bytes, out) != bytes) { ok = 0; break; }
+        n_reads++;
+        n_kmers += got > 0 ? got : 0;
+    }
+    free(line); free(res); free(txt); free(seq);
+    fclose(in);
+    if (fclose(out) != 0) ok = 0;
+    if (n_reads_out) *n_reads_out = n_reads;
+    if (n_kmers_out) *n_kmers_out = n_kmers;
+    if (query_secs) *query_secs = qsecs;
+    return ok ? now_sec() - t0 : -1.0;
+}

@@ -106,6 +106,12 @@ int64_t orc_print_vector(const int64_t *v, int64_t n, char *buf);
 double orc_batch_search(const orc_index *idx, const char *bases, const int64_t *read_off,
                         int64_t n_reads, int64_t *out, const int64_t *out_off, int n_threads);
 
+/* run_file + run_queries_* + print_vector, src/CLI/sbwt_search.cpp:21-105: the reference CLI's single-threaded loop over one
+ * FASTQ / FASTA file (parse, query, format, write).  Returns the wall seconds of the whole call (-1 on I/O error);
+ * *query_secs = the summed query time alone ("us/query (excluding I/O etc)", :54-56).  bench.py's end-to-end CPU figure. */
+double orc_search_file(const orc_index *idx, const char *query_path, const char *out_path, int64_t *n_reads_out,
+                       int64_t *n_kmers_out, double *query_secs);
+
 /* SBWT.hh:700-725: writes the k chars of column colex_rank's k-mer ('$' for dummy positions), no NUL. */
 void    orc_get_kmer(const orc_index *idx, int64_t colex_rank, char *buf);
 /* SubsetMatrixSelectSupport.hh:27-33: column of the j-th (1-based) set bit of row c; non-ACGT -> 0; -1 if j too large. */

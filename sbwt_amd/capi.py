@@ -32,6 +32,7 @@ EXPORTED_SYMBOLS = [
     "sbwtgpu_index_create", "sbwtgpu_index_destroy", "sbwtgpu_index_get_info", "sbwtgpu_index_get_precalc",
     "sbwtgpu_index_export_header", "sbwtgpu_index_blob", "sbwtgpu_index_copy_blob", "sbwtgpu_index_adopt", "sbwtgpu_index_bcast",
     "sbwtgpu_rank_batch", "sbwtgpu_streaming_search_batch", "sbwtgpu_search_batch",
+    "sbwtgpu_streaming_search_batch_i32", "sbwtgpu_search_batch_i32",
     "sbwtgpu_update_interval_batch", "sbwtgpu_forward_batch",
     "sbwtgpu_build_plain_matrix", "sbwtgpu_free_plain_matrix",
     "sbwtgpu_partial_search_batch", "sbwtgpu_get_kmer_batch", "sbwtgpu_select_batch",
@@ -106,6 +107,8 @@ def lib() -> C.CDLL:
     L.sbwtgpu_rank_batch.argtypes = [vp, vp, vp, i64, vp]
     L.sbwtgpu_streaming_search_batch.argtypes = [vp, vp, vp, i64, vp, vp]
     L.sbwtgpu_search_batch.argtypes = [vp, vp, vp, i64, vp, vp]
+    L.sbwtgpu_streaming_search_batch_i32.argtypes = [vp, vp, vp, i64, vp, vp]
+    L.sbwtgpu_search_batch_i32.argtypes = [vp, vp, vp, i64, vp, vp]
     L.sbwtgpu_update_interval_batch.argtypes = [vp, vp, vp, i64, vp, vp]
     L.sbwtgpu_forward_batch.argtypes = [vp, vp, vp, i64, vp]
     L.sbwtgpu_build_plain_matrix.argtypes = [C.POINTER(C.c_char_p), vp, i64, i64, ci, ci, ci, C.POINTER(PlainMatrixBitsC)]
@@ -312,6 +315,18 @@ class Index:
 
     def search(self, bases, read_off, out_off=None):
         return self._search(lib().sbwtgpu_search_batch, bases, read_off, out_off)
+
+    def search_i32(self, bases, read_off, streaming: bool = True, out_off=None):
+        """The same with int32 results (sbwtgpu_*_batch_i32: half the bytes over PCIe; indexes of fewer than 2^31 columns)."""
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        read_off = np.ascontiguousarray(read_off, dtype=np.int64)
+        if out_off is None:
+            out_off = out_offsets(read_off, self.k)
+        out_off = np.ascontiguousarray(out_off, dtype=np.int64)
+        out = np.full(int(out_off[-1]) if len(out_off) else 0, -12345, dtype=np.int32)
+        fn = lib().sbwtgpu_streaming_search_batch_i32 if streaming else lib().sbwtgpu_search_batch_i32
+        _check(fn(self._h, bases.ctypes.data, read_off.ctypes.data, len(read_off) - 1, out.ctypes.data, out_off.ctypes.data))
+        return out, out_off
 
     def streaming_search_reads(self, reads: Sequence[bytes]):
         bases, off = concat_reads(reads)

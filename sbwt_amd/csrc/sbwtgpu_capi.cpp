@@ -1214,9 +1214,11 @@ const int64_t PIPE_MIN = (int64_t)64 << 20;
 }  // namespace
 
 // ro / oo: nv + 1 offsets into src_bases / out (rebased to 0 or not: only ro[0], oo[0] and differences are used)
+// out32 != nullptr (and out == nullptr): the results leave the device as int32 (k_narrow_i32): half the bytes over PCIe
 static int search_host_pipelined(const sbwtgpu_index *idx, const char *src_bases, const int64_t *ro, const int64_t *oo,
-                                 int64_t nv, int64_t *out, int streaming) {
-    const bool pin_in = is_pinned(src_bases), pin_out = is_pinned(out);
+                                 int64_t nv, int64_t *out, int streaming, int32_t *out32 = nullptr) {
+    const int64_t vb = out32 ? 4 : 8;                   // bytes of a result on its way to the host
+    const bool pin_in = is_pinned(src_bases), pin_out = is_pinned(out32 ? (const void *)out32 : (const void *)out);
     // chunks: results <= 512 MiB when they land in the caller's pinned memory, <= 128 MiB when they are staged
     static const int64_t chunk_mb = [] { const char *e = getenv("SBWTGPU_PIPE_CHUNK_MB"); return e ? atoll(e) : 0ll; }();
     const int64_t CH_OUT = (chunk_mb > 0 ? chunk_mb : (pin_out ? (int64_t)512 : (int64_t)128)) << 20;
@@ -1228,7 +1230,7 @@ static int search_host_pipelined(const sbwtgpu_index *idx, const char *src_bases
         int64_t a = lo + 1, b = nv;
         while (a < b) {
             const int64_t mid = a + (b - a + 1) / 2;
-            if ((oo[mid] - oo[lo]) * 8 <= CH_OUT && ro[mid] - ro[lo] <= ((int64_t)1 << 30)) a = mid; else b = mid - 1;
+            if ((oo[mid] - oo[lo]) * vb <= CH_OUT && ro[mid] - ro[lo] <= ((int64_t)1 << 30)) a = mid; else b = mid - 1;
         }
         hi = a;
         cuts.push_back(hi);
@@ -1240,8 +1242,9 @@ static int search_host_pipelined(const sbwtgpu_index *idx, const char *src_bases
     const int64_t n_chunks = (int64_t)cuts.size() - 1;
     const int64_t ws_bytes = sbwtgpu_search_workspace_bytes(max_bases);
     const int64_t need_in = a256(max_bases + 16) + 2 * a256((max_reads + 1) * 8);
-    const int64_t need_out = pin_out ? 0 : a256(max_vals * 8 + 8);
-    const int64_t need_dev = a256(max_bases + 16) + 2 * a256((max_reads + 1) * 8) + a256(max_vals * 8 + 8) + a256(ws_bytes);
+    const int64_t need_out = pin_out ? 0 : a256(max_vals * vb + 8);
+    const int64_t need_dev = a256(max_bases + 16) + 2 * a256((max_reads + 1) * 8) + a256(max_vals * 8 + 8) + a256(ws_bytes) +
+                             (out32 ? a256(max_vals * 4 + 16) : 0);
     DeviceGuard guard(idx->device);
     PipeSlot S[2];
     {
@@ -1281,7 +1284,7 @@ static int search_host_pipelined(const sbwtgpu_index *idx, const char *src_bases
     }
     if (rc != SBWTGPU_OK) { (void)hipGetLastError(); cleanup(); return rc; }
     bool bug = false;
-    struct Carve { char *bases; int64_t *roff, *ooff, *out; char *ws; };
+    struct Carve { char *bases; int64_t *roff, *ooff, *out; char *ws; int32_t *out32; };
     auto carve = [&](PipeSlot &P) {
         Carve c;
         char *p = P.d_mem;
@@ -1289,7 +1292,8 @@ static int search_host_pipelined(const sbwtgpu_index *idx, const char *src_bases
         c.roff = (int64_t *)p; p += a256((max_reads + 1) * 8);
         c.ooff = (int64_t *)p; p += a256((max_reads + 1) * 8);
         c.out = (int64_t *)p; p += a256(max_vals * 8 + 8);
-        c.ws = p;
+        c.ws = p; p += a256(ws_bytes);
+        c.out32 = (int32_t *)p;
         return c;
     };
     auto submit = [&](int64_t c) -> int {
@@ -1307,8 +1311,13 @@ static int search_host_pipelined(const sbwtgpu_index *idx, const char *src_bases
             return fail(SBWTGPU_ERR_HIP, "H2D copy: %s", hipGetErrorString(e));
         int r2 = search_dev_common(idx, d.bases, nb, d.roff, nr, d.out, d.ooff, d.ws, ws_bytes, P.st, streaming);
         if (r2 != SBWTGPU_OK) return r2;
-        char *target = pin_out ? (char *)(out + oo[lo]) : P.h_out;
-        if ((e = hipMemcpyAsync(target, d.out, (size_t)nvals * 8, hipMemcpyDeviceToHost, P.st)) != hipSuccess ||
+        char *target = pin_out ? (out32 ? (char *)(out32 + oo[lo]) : (char *)(out + oo[lo])) : P.h_out;
+        const void *from = d.out;
+        if (out32) {
+            sbwt_launch_narrow_i32(reinterpret_cast<const long long *>(d.out), d.out32, nvals, P.st);
+            from = d.out32;
+        }
+        if ((e = hipMemcpyAsync(target, from, (size_t)(nvals * vb), hipMemcpyDeviceToHost, P.st)) != hipSuccess ||
             (e = hipMemcpyAsync(P.h_status, d.ws + offsetof(SbwtWorkHeader, status), 4, hipMemcpyDeviceToHost, P.st)) != hipSuccess)
             return fail(SBWTGPU_ERR_HIP, "D2H copy: %s", hipGetErrorString(e));
         return SBWTGPU_OK;
@@ -1319,7 +1328,7 @@ static int search_host_pipelined(const sbwtgpu_index *idx, const char *src_bases
         if (e != hipSuccess) return fail(SBWTGPU_ERR_HIP, "stream synchronize: %s", hipGetErrorString(e));
         if (P.h_status[0] != 0) bug = true;
         const int64_t lo = cuts[(size_t)c], hi = cuts[(size_t)c + 1];
-        if (!pin_out) parallel_memcpy((char *)(out + oo[lo]), P.h_out, (size_t)(oo[hi] - oo[lo]) * 8);
+        if (!pin_out) parallel_memcpy(out32 ? (char *)(out32 + oo[lo]) : (char *)(out + oo[lo]), P.h_out, (size_t)((oo[hi] - oo[lo]) * vb));
         return SBWTGPU_OK;
     };
     for (int64_t c = 0; c < n_chunks && rc == SBWTGPU_OK; c++) {
@@ -1452,6 +1461,46 @@ int sbwtgpu_streaming_search_batch(const sbwtgpu_index *idx, const char *bases, 
 int sbwtgpu_search_batch(const sbwtgpu_index *idx, const char *bases, const int64_t *read_off, int64_t n_reads,
                          int64_t *out, const int64_t *out_off) {
     return search_host_common(idx, bases, read_off, n_reads, out, out_off, 0);
+}
+
+// Results as int32 (result compaction): for indexes of fewer than 2^31 columns every rank fits, -1 stays -1.  The
+// device narrows (k_narrow_i32) before the copy, so a result costs 4 bytes of PCIe instead of 8.  Large batches go through
+// the same two-stream pipeline as the int64 calls; small ones through the int64 call and a host loop.
+static int search_host_i32(const sbwtgpu_index *idx, const char *bases, const int64_t *read_off, int64_t n_reads,
+                           int32_t *out, const int64_t *out_off, int streaming) {
+    if (!idx) return fail(SBWTGPU_ERR_INVALID_ARG, "idx is NULL");
+    if (idx->h.n_nodes >= ((int64_t)1 << 31))
+        return fail(SBWTGPU_ERR_INVALID_ARG, "int32 results need an index of fewer than 2^31 columns (this one has %lld)",
+                    (long long)idx->h.n_nodes);
+    if (streaming && !idx->h.has_ssup) return fail(SBWTGPU_ERR_NO_STREAMING, "Error: streaming search support not built");
+    if (n_reads < 0) return fail(SBWTGPU_ERR_INVALID_ARG, "negative n_reads");
+    if (n_reads == 0) return SBWTGPU_OK;
+    if (!read_off || !out_off) return fail(SBWTGPU_ERR_INVALID_ARG, "NULL offsets");
+    bool any_long = false;
+    int rc = check_reads(read_off, out_off, n_reads, idx->h.k, &any_long);
+    if (rc != SBWTGPU_OK) return rc;
+    const int64_t n_out = out_off[n_reads] - out_off[0];
+    if (n_out == 0) return SBWTGPU_OK;
+    if (!out) return fail(SBWTGPU_ERR_INVALID_ARG, "out is NULL");
+    if (!any_long && n_out * 4 >= PIPE_MIN)
+        return search_host_pipelined(idx, bases, read_off, out_off, n_reads, nullptr, streaming, out);
+    std::vector<int64_t> wide;
+    try { wide.resize((size_t)n_out); } catch (const std::bad_alloc &) { return fail(SBWTGPU_ERR_OOM, "out of host memory"); }
+    std::vector<int64_t> oo((size_t)n_reads + 1);
+    for (int64_t r = 0; r <= n_reads; r++) oo[(size_t)r] = out_off[r] - out_off[0];
+    rc = search_host_common(idx, bases, read_off, n_reads, wide.data(), oo.data(), streaming);
+    if (rc != SBWTGPU_OK) return rc;
+    int32_t *dst = out + out_off[0];
+    for (int64_t t = 0; t < n_out; t++) dst[t] = (int32_t)wide[(size_t)t];
+    return SBWTGPU_OK;
+}
+int sbwtgpu_streaming_search_batch_i32(const sbwtgpu_index *idx, const char *bases, const int64_t *read_off,
+                                       int64_t n_reads, int32_t *out, const int64_t *out_off) {
+    return search_host_i32(idx, bases, read_off, n_reads, out, out_off, 1);
+}
+int sbwtgpu_search_batch_i32(const sbwtgpu_index *idx, const char *bases, const int64_t *read_off, int64_t n_reads,
+                             int32_t *out, const int64_t *out_off) {
+    return search_host_i32(idx, bases, read_off, n_reads, out, out_off, 0);
 }
 
 int sbwtgpu_rank_batch(const sbwtgpu_index *idx, const int64_t *pos, const char *sym, int64_t n, int64_t *out) {

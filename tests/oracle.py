@@ -74,6 +74,8 @@ def lib() -> C.CDLL:
     L.orc_mark_suffix_groups.restype = None
     L.orc_print_vector.restype = i64
     L.orc_print_vector.argtypes = [vp, i64, C.c_char_p]
+    L.orc_search_file.restype = C.c_double
+    L.orc_search_file.argtypes = [P, C.c_char_p, C.c_char_p, C.POINTER(i64), C.POINTER(i64), C.POINTER(C.c_double)]
     L.orc_batch_search.restype = C.c_double
     L.orc_batch_search.argtypes = [P, vp, vp, i64, vp, vp, C.c_int]
     L.orc_get_kmer.restype = None
@@ -193,6 +195,15 @@ class OracleIndex:
         out = np.zeros((self.n_nodes + 63) // 64, dtype=np.uint64)
         lib().orc_mark_suffix_groups(self._p, out.ctypes.data)
         return out
+
+    def search_file(self, query_path: str, out_path: str):
+        """The reference CLI's single-threaded loop over one query file (sbwt_search.cpp:21-105): returns
+        (wall seconds, query seconds, reads, k-mers)."""
+        nr, nk, qs = C.c_int64(), C.c_int64(), C.c_double()
+        wall = lib().orc_search_file(self._p, query_path.encode(), out_path.encode(), C.byref(nr), C.byref(nk), C.byref(qs))
+        if wall < 0:
+            raise RuntimeError("orc_search_file: I/O error")
+        return wall, qs.value, nr.value, nk.value
 
     def batch_search(self, bases: np.ndarray, read_off: np.ndarray, out_off: np.ndarray, n_threads: int = 1,
                      out: Optional[np.ndarray] = None):

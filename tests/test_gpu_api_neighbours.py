@@ -236,3 +236,28 @@ def test_text_stream_pieces_and_kernel_events(gpu):
     assert len(kt) == 3 and all(0 < t < 1000 for t in kt)
     ref, _ = idx.streaming_search(bases[: n * 100], off[: n + 1])
     assert np.array_equal(d_out.cpu().numpy(), ref)
+
+
+def test_int32_results_small_and_pipelined(gpu):
+    """sbwtgpu_streaming_search_batch_i32 / sbwtgpu_search_batch_i32 (result compaction): the same values as
+    the int64 calls, narrowed on the device -- a small batch (host loop) and one large enough for the two-stream pipeline,
+    pageable and pinned destinations, N and short reads among them."""
+    import torch
+    genomes = [synth.random_genome(300_000, 3)]
+    genomes.append(synth.mutate(genomes[0], 0.05, 4))
+    bits = capi.build_bits_gpu([g.tobytes() for g in genomes], 30, False, True)
+    idx = capi.Index.create(bits.cols[0], bits.cols[1], bits.cols[2], bits.cols[3], bits.ssup, bits.n_nodes, 30, bits.n_kmers, 8)
+    for n_reads in (300, 200_000):                       # 200 000 x 121 x 4 B = 97 MB of int32 results: pipelined
+        bases, off = synth.sample_reads(genomes, n_reads, 150, 0.01, 9)
+        bases = synth.inject(bases, 50, ord("N"), 2)
+        want, oo = idx.streaming_search(bases, off)
+        for streaming in (True, False):
+            got, oo2 = idx.search_i32(bases, off, streaming)
+            assert got.dtype == np.int32 and np.array_equal(oo, oo2)
+            assert np.array_equal(got.astype(np.int64), want if streaming else idx.search(bases, off)[0])
+    # pinned destination: the DMA's target itself
+    hb = torch.from_numpy(bases).pin_memory()
+    ho = torch.empty(int(oo[-1]), dtype=torch.int32).pin_memory()
+    capi._check(capi.lib().sbwtgpu_streaming_search_batch_i32(idx.handle, hb.data_ptr(), off.ctypes.data, len(off) - 1, ho.data_ptr(),
+                                                              oo.ctypes.data))
+    assert np.array_equal(ho.numpy().astype(np.int64), want)

@@ -199,3 +199,22 @@ def test_reference_query_file_streaming_equals_search():
         assert np.array_equal(res, idx.search_all(r))
         hits += int((res >= 0).sum())
     assert hits > 10000
+
+
+def test_oracle_cli_loop_reproduces_the_reference_cli_output(tmp_path):
+    """orc_search_file (the CPU end-to-end figure of bench.py) = run_file + print_vector, src/CLI/sbwt_search.cpp:21-105:
+    on the reference's own CLI known-answer test (tests/test_CLI.hh:21-22,43,49,90) it writes the exact expected text,
+    from FASTQ and from multi-line FASTA, lower-case input upper-cased on read."""
+    import json
+    import os
+    kat = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_kats.json")))["cli_end_to_end"]
+    orc = OracleIndex.build([s.encode() for s in kat["seqs"]], kat["k"], True, True, kat["precalc"])
+    fq = tmp_path / "q.fastq"
+    fq.write_bytes(b"".join(b"@r\n%s\n+\n%s\n" % (q.encode(), b"I" * len(q)) for q in kat["queries"]))
+    wall, qsecs, nr, nk = orc.search_file(str(fq), str(tmp_path / "o1.txt"))
+    assert (tmp_path / "o1.txt").read_bytes() == kat["expected_output"].encode()
+    assert nr == len(kat["queries"]) and nk == sum(max(0, len(q) - kat["k"] + 1) for q in kat["queries"]) and 0 <= qsecs <= wall
+    fa = tmp_path / "q.fna"
+    fa.write_bytes(b"".join(b">r\n%s\n%s\n" % (q[:7].lower().encode(), q[7:].encode()) for q in kat["queries"]))
+    orc.search_file(str(fa), str(tmp_path / "o2.txt"))
+    assert (tmp_path / "o2.txt").read_bytes() == kat["expected_output"].encode()
