@@ -87,6 +87,9 @@ int         sbwtgpu_device_count(int *count);
  *                     k_search_cert on the blocks only; 0 = k_search (the reference's order of searches; cross-checks)
  *   "fused_ragged"    1 (default): the fused route also takes batches of reads of different lengths (it fetches their
  *                     offsets); 0: only batches of reads of one length (SBWTGPU_FUSED_RAGGED)
+ *   "fused_pieces"    1 (default) .. 3: the fused route takes a read of more than 160 bases as up to this many pieces of
+ *                     160 bases that overlap by k-1 (tickets are (read, piece)); 1: such reads go to the general kernel,
+ *                     which measured 3-5 % faster on them (NOTES.md).  SBWTGPU_FUSED_PIECES.
  *   "split_long"      1 (default): the device entry points cut reads of more than two pieces' worth of k-mers (a piece:
  *                     128 .. 1024 k-mers by batch size) into pieces that lanes take separately, at k-mers whose result
  *                     does not depend on history; 0: one lane per read whatever its length (SBWTGPU_SPLIT_LONG)
@@ -99,7 +102,8 @@ int         sbwtgpu_device_count(int *count);
  *   "probe_len"       length of the certificate probes (-1 = automatic, 0 = off)
  *   "derive_ssup"     1 (default): indexes created without suffix_group_starts get the marks derived on
  *                     the device so that the per-k-mer search loop can use streaming steps internally
- *   "debug"           kernel experiment bits (0 = product behaviour)
+ *   "debug"           kernel experiment bits (0 = product behaviour); fused kernel: 32 = no anchors / seeds / resumed compares,
+ *                     64 = the k > 31 walk (F_CMP) for every k
  *   "poison_results"  1: every search first fills its result range with 0xA5 (parity tests)
  *   "trans_ext", "trans_wide"   accepted and ignored (round-2 table formats)
  * Read when an index is CREATED (derived acceleration structures inside the device image; environment

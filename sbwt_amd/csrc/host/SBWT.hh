@@ -268,6 +268,16 @@ public:
                       const int64_t *out_off) const {
         run_sharded(false, bases, read_off, n_reads, out, out_off);
     }
+    // The same with int32 results (for consumers that only print or store the ranks, like print_vector,
+    // sbwt_search.cpp:21-43): narrowed on the device, half the bytes over PCIe.  One device; fewer than 2^31 columns.
+    void search_batch_i32(bool streaming, const char *bases, const int64_t *read_off, int64_t n_reads, int32_t *out,
+                          const int64_t *out_off) const {
+        if (streaming && suffix_group_starts.size() == 0) throw std::runtime_error("Error: streaming search support not built");
+        const int rc = streaming ? sbwtgpu_streaming_search_batch_i32(need_device(), bases, read_off, n_reads, out, out_off)
+                                 : sbwtgpu_search_batch_i32(need_device(), bases, read_off, n_reads, out, out_off);
+        bug_exit(rc);
+        detail::gpu_check(rc);
+    }
     // The whole inner loop of `sbwt search` for one batch: searches every read (streaming_search when
     // the index has streaming support, else the per-k-mer search loop) and returns the output text in
     // the reference's format (print_vector, sbwt_search.cpp:21-43), formatted on the GPU.  One text

@@ -167,3 +167,19 @@ def both_strand_reads(genomes: List[np.ndarray], n_reads: int, read_len: int, su
     if sub_rate > 0:
         bases = mutate(bases, sub_rate, seed + 1)
     return bases, off
+
+
+def variant_reads(genomes: List[np.ndarray], n_reads: int, read_len: int, seed: int) -> Tuple[np.ndarray, np.ndarray]:
+    """Reads of genomes[0] in which ONE base is replaced by the base genomes[1] has at that position, at places where
+    the two differ (genomes[1] = mutate(genomes[0], ...): same coordinates).  The substituted k-mers are usually absent --
+    the other strain's next difference is within k -- but every SHORT window around the base is in the index (as the
+    other strain's): the case where certificate probes prove nothing and only each k-mer's own search does."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    a, b = genomes[0], genomes[1]
+    diff = np.flatnonzero(a != b)
+    diff = diff[(diff >= read_len) & (diff < len(a) - read_len)]
+    at = rng.choice(diff, size=n_reads)
+    start = at - rng.integers(0, read_len, size=n_reads)
+    bases = a[(start[:, None] + np.arange(read_len)[None, :]).ravel()].copy()
+    bases[np.arange(n_reads) * read_len + (at - start)] = b[at]
+    return bases, np.arange(n_reads + 1, dtype=np.int64) * read_len

@@ -826,9 +826,11 @@ def test_fused_kernel_takes_reads_of_161_to_400_bases_as_pieces(gpu, k):
     finally:
         capi.set_tuning("fused_pieces", 1)
     stats = idx.workspace_stats(d_ws.data_ptr(), st)
-    assert stats[4] > 0.9 * int(oo[-1]) and int((d_out >= 0).sum()) == int(oo[-1])
-    hdr = d_ws[:256].cpu().numpy().view(np.uint64)
-    assert int(hdr[13]) == 0, "reads of 250 bases were handed on to the general kernel"      # SbwtWorkHeader.n_deferred (byte 104)
+    assert int((d_out >= 0).sum()) == int(oo[-1])
+    if idx.image_level == 0:                             # (SBWTGPU_IMAGE_LEVEL > 0 in the knob sweep: no path order, no fused kernel)
+        assert stats[4] > 0.9 * int(oo[-1])
+        hdr = d_ws[:256].cpu().numpy().view(np.uint64)
+        assert int(hdr[13]) == 0, "reads of 250 bases were handed on to the general kernel"  # SbwtWorkHeader.n_deferred (byte 104)
     # (2) mixed lengths: mostly 100 .. 320, some too long even for three pieces, some shorter than k, some empty
     n = 5000
     lens = rng.integers(100, 321, size=n)

@@ -75,3 +75,16 @@ def test_revcomp_index_reads_from_both_strands(gpu):
     b, _ = idx.streaming_search(rc, foff)
     m = 150 - 31 + 1
     assert np.array_equal((a.reshape(500, m) >= 0), (b.reshape(500, m) >= 0)[:, ::-1])
+
+
+@pytest.mark.parametrize("k", [30, 63])
+def test_substitutions_that_are_another_strains_base(gpu, k):
+    """A sequencing error that happens to be ANOTHER strain's base: every short window around it is in the index, so no
+    certificate probe proves anything, and only each k-mer's own search says it is absent -- the reference's loop after
+    a miss (SBWT.hh:557-559).  The planner's blind mode (and, for k > 31, the 31-base windows) must not change a bit."""
+    g0 = synth.random_genome(150_000, 21)
+    genomes = [g0, synth.mutate(g0, 0.05, 22)]
+    bases, off = synth.variant_reads(genomes, 2500, 150, 23)
+    bases = synth.mutate(bases, 0.005, 24)                   # and ordinary errors beside it
+    want = check(genomes, k, bases, off)
+    assert 0.3 < (want >= 0).mean() < 0.9

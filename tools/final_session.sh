@@ -1,30 +1,49 @@
 #!/bin/bash
-# The measurements a round's profiles/ are made of (GPU box, from the repo root): tests, fuzz, bench lines and rocprofv3
-# summaries of BASELINE configs 2, 5 and 3.  usage: tools/final_session.sh <tag, e.g. r03>
-TAG=${1:-r03}
+# The measurements a round's profiles/ are made of (GPU box, from the repo root): the driver's suite, fuzz, bench lines and
+# rocprofv3 summaries (kernel trace + PMC traffic, separate passes) of BASELINE configs 2, 5 and 3, the image levels with
+# their own counters, robustness and batch-size rows.  usage: tools/final_session.sh <tag, e.g. r04>
+TAG=${1:-r04}
 O=gpurun_out/final_$TAG
 mkdir -p $O
-timeout 900 python -m pytest tests/ -q -m gpu > $O/gputest.log 2>&1; tail -3 $O/gputest.log
+( time timeout 1500 python -m pytest tests/ -q -m gpu ) > $O/gputest.log 2>&1; tail -4 $O/gputest.log
 ( for seed in 1 2 3 4; do SEED=$seed timeout 150 python tools/fuzz_gpu.py 100 2>&1 | tail -1 | sed "s/^/seed $seed: /"; done ) > $O/fuzz.log 2>&1; cat $O/fuzz.log
-timeout 600 python bench.py --steps 25 --warmup 3 > $O/c2_bench.json 2> $O/c2_bench.err
-timeout 400 python bench.py --config 5 --steps 10 > $O/c5_bench.json 2> $O/c5_bench.err
+timeout 900 python bench.py --steps 25 --warmup 3 > $O/c2_bench.json 2> $O/c2_bench.err
+timeout 400 python bench.py --config 5 --steps 10 --no-cli-full > $O/c5_bench.json 2> $O/c5_bench.err
 timeout 900 python bench.py --config 3 --steps 5 > $O/c3_bench.json 2> $O/c3_bench.err
-bash tools/profile.sh ${TAG}_c2 --steps 5 --warmup 1 --no-cpu-baseline --no-end-to-end > /dev/null 2>&1
-bash tools/profile.sh ${TAG}_c5 --config 5 --steps 5 --warmup 1 --no-cpu-baseline --no-end-to-end > /dev/null 2>&1
-PMC_GROUPS="FETCH_SIZE|WRITE_SIZE|TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum TCC_EA0_RDREQ_128B_sum|TCC_HIT_sum TCC_MISS_sum|SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES" \
-  bash tools/profile.sh ${TAG}_c3 --config 3 --steps 3 --warmup 1 --no-cpu-baseline --no-end-to-end > /dev/null 2>&1
-for c in 2 5 3; do cp gpurun_out/prof_${TAG}_c$c/summary.txt $O/c${c}_rocprof_summary.txt; done
+PMC="FETCH_SIZE|WRITE_SIZE|TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum TCC_EA0_RDREQ_128B_sum|TCC_HIT_sum TCC_MISS_sum|SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES"
+prof() {   # prof <name> <config> <level> <variant> <reads> <bench args...>
+  local name=$1 cfg=$2 lvl=$3 var=$4 reads=$5; shift 5
+  PMC_GROUPS="$PMC" bash tools/profile.sh ${TAG}_$name "$@" --warmup 1 --no-cpu-baseline --no-end-to-end > /dev/null 2>&1
+  cp gpurun_out/prof_${TAG}_$name/summary.txt $O/${name}_rocprof_summary.txt
+  cp gpurun_out/prof_${TAG}_$name/trace_bench.json $O/${name}_bench_under_rocprof.json
+  python tools/make_traffic_json.py $O/${name}_rocprof_summary.txt $cfg $reads ${TAG}_${name}_rocprof_summary.txt $lvl $var > /dev/null 2>> $O/traffic.err
+}
+prof c2 2 0 5 10000000 --steps 5
+prof c5 5 0 5 10000000 --config 5 --steps 5
+prof c3 3 0 5 100000000 --config 3 --steps 3
+prof c2_level1 2 1 1 10000000 --steps 3 --image-level 1
+prof c2_level2 2 2 1 10000000 --steps 3 --image-level 2
+cp profiles/traffic.json $O/traffic.json
+# the committed lines: the same commands once more, now that traffic.json belongs to this code (roofline.traffic attached)
+timeout 900 python bench.py --steps 25 --warmup 3 --no-cpu-baseline --no-end-to-end > $O/c2_line.json 2>/dev/null
+timeout 400 python bench.py --config 5 --steps 10 --no-cpu-baseline --no-end-to-end > $O/c5_line.json 2>/dev/null
+timeout 900 python bench.py --config 3 --steps 5 --no-cpu-baseline --no-end-to-end > $O/c3_line.json 2>/dev/null
+timeout 600 python bench.py --steps 10 --image-level 1 --no-cpu-baseline --no-end-to-end > $O/c2_level1.json 2>/dev/null
+timeout 600 python bench.py --steps 10 --image-level 2 --no-cpu-baseline --no-end-to-end > $O/c2_level2.json 2>/dev/null
+NREADS=10000000 timeout 900 python tools/robustness_bench.py > $O/robustness.jsonl 2> $O/robustness.err
+for n in 1000000 4000000; do NREADS=$n ROUNDS=9 CONFIGS='[[5,0]]' python tools/ab_step.py 2>&1 | grep "^variant" | sed "s/^/config 2, $n reads: /"; done > $O/batch_size.txt 2>&1
 python - <<PY
 import json
-for c in (2, 5, 3):
+for c in ("c2", "c5", "c3", "c2_line", "c5_line", "c3_line", "c2_level1", "c2_level2"):
     try:
-        d = json.load(open("$O/c%d_bench.json" % c))
-        print("config", c, round(d["value"] / 1e9, 1), "G k-mers/s  step", round(d["ms_per_step"], 3), "kernel", round(d["roofline"]["kernel_ms"], 3),
-              "frac", round(d["roofline"]["frac"], 3), "B/col", round(d["index_build"]["image_bytes_per_column"], 1), "parity", d["cpu_baseline"]["gpu_output_bit_identical_on_sample"])
+        d = json.load(open("$O/%s_bench.json" % c if "_" not in c else "$O/%s.json" % c))
+        r = d["roofline"]
+        print(c, round(d["value"] / 1e9, 1), "G k-mers/s  step", round(d["ms_per_step"], 3), "kernel", r["kernel"], round(r["kernel_ms"], 3),
+              "frac", round(r["frac"], 3), "traffic/alg", r.get("traffic_over_algorithmic"), "lines/read", r.get("read_lines_per_read"))
     except Exception as e:
-        print("config", c, "ERR", e)
+        print(c, "ERR", e)
 PY
 # results must not depend on the builder / route knobs: the parity tests under non-default environments
-for e in SBWTGPU_PATH_LOOKAHEAD=0 SBWTGPU_IMAGE_LEVEL=1 SBWTGPU_IMAGE_LEVEL=2 SBWTGPU_PATH_SAFE=0 SBWTGPU_PATH_STITCH=0 SBWTGPU_FUSED_RAGGED=0 SBWTGPU_SPLIT_LONG=0; do
+for e in SBWTGPU_PATH_LOOKAHEAD=0 SBWTGPU_IMAGE_LEVEL=1 SBWTGPU_IMAGE_LEVEL=2 SBWTGPU_PATH_SAFE=0 SBWTGPU_PATH_STITCH=0 SBWTGPU_FUSED_RAGGED=0 SBWTGPU_SPLIT_LONG=0 SBWTGPU_FUSED_PIECES=3; do
   env $e timeout 600 python -m pytest tests/test_gpu_parity.py tests/test_gpu_workloads.py -x -q -m gpu 2>&1 | tail -1 | sed "s/^/$e: /"
 done | tee $O/knob_sweep.log

@@ -19,7 +19,7 @@ variant = int(sys.argv[6]) if len(sys.argv) > 6 else 5
 # the dominant kernel of the run: the fused kernel when it appears in the summary, else the general search kernel
 text = open(summary).read()
 fused = variant == 5 and level == 0 and "k_search_fused" in text
-KERNEL = r"k_search_fused" if fused else r"void k_search\S*"
+KERNEL = r"(?:void )?k_search_fused" if fused else r"void k_search(?!_fused)\S*"
 kernel_name = bench.dominant_kernel(variant, level)
 vals = {}
 for line in open(summary):
