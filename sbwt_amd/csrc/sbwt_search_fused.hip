@@ -46,8 +46,12 @@
 #define FE_END 3
 #define FE_PRES 4
 #define FE_ANCH 5               // an anchor lookup found its k-mer: tpos = its path position
-#define FZ_ANCHORS 2            // anchor lookups per read at most (a read of unrelated sequence pays that many lines for nothing)
-#define FZ_ALIGNS 6             // seeds + resumed compares per read at most
+#ifndef FZ_ANCHORS
+#define FZ_ANCHORS 3            // anchor lookups per read at most (a read of unrelated sequence pays that many lines for nothing)
+#endif
+#ifndef FZ_ALIGNS
+#define FZ_ALIGNS 7             // seeds + resumed compares per read at most
+#endif
 // F_CMP flags: the remembered differences' step states (S: substitution-safe, A / B: the path group's state bits), ...
 #define CF_S1 1u
 #define CF_A1 2u
