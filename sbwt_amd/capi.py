@@ -107,8 +107,12 @@ def lib() -> C.CDLL:
     L.sbwtgpu_rank_batch.argtypes = [vp, vp, vp, i64, vp]
     L.sbwtgpu_streaming_search_batch.argtypes = [vp, vp, vp, i64, vp, vp]
     L.sbwtgpu_search_batch.argtypes = [vp, vp, vp, i64, vp, vp]
-    L.sbwtgpu_streaming_search_batch_i32.argtypes = [vp, vp, vp, i64, vp, vp]
-    L.sbwtgpu_search_batch_i32.argtypes = [vp, vp, vp, i64, vp, vp]
+    try:                                    # (absent from older builds loaded through SBWTGPU_LIB for A/B runs)
+        L.sbwtgpu_streaming_search_batch_i32.argtypes = [vp, vp, vp, i64, vp, vp]
+        L.sbwtgpu_search_batch_i32.argtypes = [vp, vp, vp, i64, vp, vp]
+    except AttributeError:
+        if "SBWTGPU_LIB" not in os.environ:
+            raise
     L.sbwtgpu_update_interval_batch.argtypes = [vp, vp, vp, i64, vp, vp]
     L.sbwtgpu_forward_batch.argtypes = [vp, vp, vp, i64, vp]
     L.sbwtgpu_build_plain_matrix.argtypes = [C.POINTER(C.c_char_p), vp, i64, i64, ci, ci, ci, C.POINTER(PlainMatrixBitsC)]

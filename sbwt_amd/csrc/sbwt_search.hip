@@ -440,6 +440,11 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
                                     // 5 second-level sparse lookup (31 < k <= 63: l = the 31-prefix's first column)
     u64 hk = 0;                     // M_INIT: the window's key (filter: the bit positions), kept across the gather
     int blo = -1;                   // the last failure is known to lie in [blo, b] (blo >= b: exactly at b)
+    // Blind mode (as in k_search_fused): bits 0-1 = own searches of consecutive k-mers that answered nothing but their own
+    // k-mer, each behind probes that found every window (perhaps) present -- a substitution that is another strain's base;
+    // bit 2 = such probes since the last own search.  From two on the planner stops probing until a k-mer is found
+    // (the reference's own loop, SBWT.hh:557-559: 5 iterations per k-mer -> 1).
+    unsigned mz = 0;
     int mode = M_IDLE;              // M_DEAD once the ticket counter has run past the last read
     i64 obase = 0;                  // first result slot of the current read
     int pgrp = 0, poff = 0;         // the read starts at base poff of packed group pgrp
@@ -487,6 +492,7 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
                     if (SEG) { nseg = 0; i0 = 0; }
                     b = -1;
                     blo = -1;
+                    mz = 0;
                     wstart = 0;
                     j = 0;
                     wk = (ps > 0) ? 1 : 0;
@@ -682,6 +688,7 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
                 if (SEG) { nseg = 0; i0 = 0; }
                 b = -1;
                 blo = -1;
+                mz = 0;
                 if (m > 0 && !(cut && rd >= 0 && piece_read_is_cut(m, pt.piece))) { do_plan = true; force = true; }
                 else mode = M_IDLE;
             }
@@ -883,6 +890,7 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
                     const unsigned w2 = (b2 < 64) ? (b2 < 32 ? v1.x : v1.y) : (b2 < 96 ? v1.z : v1.w);
                     wl = L0;
                     if (((w1 >> (b1 & 31u)) & (w2 >> (b2 & 31u)) & 1u) != 0) {
+                        mz |= 4u;
                         if (wk == 3) {
                             l = 0;                     // range probe: "perhaps present" only moves the guess
                         } else {
@@ -971,6 +979,7 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
                 if (PATH && tpos >= 0) { r = tpos; rknown = true; emit_pos = (unsigned)tpos; }
                 ev = EV_EMIT1;
                 b = -1;
+                mz = 0;
             } else {
                 do_plan = true;                        // probe inconclusive: the reference's own walk
                 force = true;
@@ -994,6 +1003,9 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
                 else if (!(b > wstart && b <= tfail)) b = tfail;
                 blo = b;
             }
+            if (burst_hi > i || wk == 2 || wk == 3) mz = 0;                    // a window that IS absent: probes work here
+            else if (wstart == i && (mz & 3u) < 2u) mz = (mz & 4u) ? (mz & 3u) + 1u : 0u;   // k-mer i's own search answered only k-mer i
+            mz &= ~4u;
             if (burst_hi == i) { ev = EV_EMIT1; burst_hi = -1; }   // a single -1 goes through the stage
         }
         if (ev == EV_PRES) {                           // no bad base in [wstart, wstart+p-1]: shrink the range
@@ -1197,6 +1209,7 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
             // where the next walk starts (see the header comment): at k-mer i itself, or close to
             // the last failure position b when b lies inside k-mer i's window
             int s0 = i, nwk = (ps > 0) ? 1 : 0;
+            if ((mz & 3u) >= 2u) force = true;         // blind: the k-mer's own search
             if (!force && L0 > 0 && b >= i && b <= i + k - 1) {
                 const int lo = blo > i ? blo : i;
                 if (lo < b && p > 0 && k - pw >= 1) {
