@@ -2,6 +2,8 @@
 // search path touches: log lines (same text; timestamps are not parity relevant), timers, string
 // (de)serialisation of the index file framing, readable/writable checks, readlines.
 #pragma once
+#include <sys/stat.h>
+#include <unistd.h>
 #include <chrono>
 #include <cstdint>
 #include <ctime>
@@ -63,11 +65,25 @@ inline std::string load_string(std::istream &in) {
 }
 
 // throwing_streams.hh:32-35 message
+// (a FIFO, a pipe behind /dev/fd/N or /dev/stdout is not opened for the check: opening and closing a FIFO would cut its
+// writer off before the real reader arrives; the permission bits answer instead)
+inline bool is_regular_or_missing(const std::string &filename) {
+    struct stat sb;
+    return ::stat(filename.c_str(), &sb) != 0 || S_ISREG(sb.st_mode);
+}
 inline void check_readable(const std::string &filename) {       // globals.cpp:38-40
+    if (!is_regular_or_missing(filename)) {
+        if (::access(filename.c_str(), R_OK) != 0) throw std::runtime_error("Error opening file: " + filename);
+        return;
+    }
     std::ifstream f(filename);
     if (!f.good()) throw std::runtime_error("Error opening file: " + filename);
 }
 inline void check_writable(const std::string &filename) {       // globals.cpp:43-46 (out|app: does not truncate)
+    if (!is_regular_or_missing(filename)) {
+        if (::access(filename.c_str(), W_OK) != 0) throw std::runtime_error("Error opening file: " + filename);
+        return;
+    }
     std::ofstream f(filename, std::ofstream::out | std::ofstream::app);
     if (!f.good()) throw std::runtime_error("Error opening file: " + filename);
 }

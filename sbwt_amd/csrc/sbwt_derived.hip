@@ -122,18 +122,21 @@ __global__ void __launch_bounds__(256) k_sp2_insert(const SpItem2 *__restrict__ 
     if (t >= *n) return;
     const SpItem2 it = items[t];
     if (it.l != it.r) *wide_flag = 1;                  // a k-mer's interval is one column in an SBWT
+    // payload: the k-mer's path position when there is a path order (its column is col[position]), else its column
+    const unsigned payload = SBWT_SP2_USED | (pos ? pos[it.l] : it.l);
     size_t bkt = sbwt_sp2_entry(it.origin, it.key2, n_entries, 0u);
     for (;;) {
-        unsigned *e = reinterpret_cast<unsigned *>(&table[2 * bkt]);
-        if (atomicCAS(&e[3], 0u, SBWT_SP2_USED) == 0u) {     // keys are distinct: an empty entry is simply taken
-            e[0] = (unsigned)it.key2;
-            e[1] = (unsigned)(it.key2 >> 32);
-            e[2] = it.origin;
-            e[4] = it.l;
-            e[5] = pos ? pos[it.l] : 0u;
-            return;
+        unsigned *b0 = reinterpret_cast<unsigned *>(&table[2 * bkt]);
+        for (int e = 0; e < 2; e++) {
+            unsigned *w = b0 + 4 * e;
+            if (atomicCAS(&w[3], 0u, payload) == 0u) {       // keys are distinct: an empty entry is simply taken
+                w[0] = (unsigned)it.key2;
+                w[1] = (unsigned)(it.key2 >> 32);
+                atomicOr(&w[2], it.origin);                  // (entry 0's word also carries the overflow flag)
+                return;
+            }
         }
-        atomicOr(&e[3], SBWT_SP2_OVERFLOW);
+        atomicOr(&b0[2], SBWT_SP2_OVERFLOW);               // both entries taken: mark and move on
         bkt = bkt + 1 < n_entries ? bkt + 1 : 0;
     }
 }
@@ -731,9 +734,10 @@ __device__ __forceinline__ bool sp_find(const SbwtIndexView &ix, u64 key, unsign
 __device__ __forceinline__ bool sp2_present(const SbwtIndexView &ix, unsigned origin, u64 key2) {
     unsigned e = sbwt_sp2_entry(origin, key2, ix.n_sb2, 0u);
     for (;;) {
-        const uint4 a = ix.stab2[2 * (size_t)e];
-        if ((a.w & SBWT_SP2_USED) && quad_bits(a) == key2 && a.z == origin) return true;
-        if (!(a.w & SBWT_SP2_OVERFLOW)) return false;
+        const uint4 a = ix.stab2[2 * (size_t)e], b = ix.stab2[2 * (size_t)e + 1];
+        if ((a.w & SBWT_SP2_USED) && quad_bits(a) == key2 && (a.z & ~SBWT_SP2_OVERFLOW) == origin) return true;
+        if ((b.w & SBWT_SP2_USED) && quad_bits(b) == key2 && b.z == origin) return true;
+        if (!(a.z & SBWT_SP2_OVERFLOW)) return false;
         e = e + 1 < ix.n_sb2 ? e + 1 : 0;
     }
 }

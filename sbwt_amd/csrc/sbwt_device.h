@@ -12,8 +12,10 @@
 //                                    path position and the next 32 steps of its path; sized once the path order is known:
 //                                    3 entries per branching column + the successors of every path's last column
 //   [ pfil     : 2^log2f x 16 B  ]   probe filter (see k_pf_insert)
-//   [ stab2    : n_sb2 x 32 B    ]   second level for 31 < k <= 63: { rest key (8 B), first column of the 31-prefix's
-//                                    interval, flags } { column, path position, -, - }
+//   [ stab2    : n_sb2 x 32 B    ]   second level for 31 < k <= 63: buckets of two 16-byte entries { rest key (8 B), first
+//                                    column of the 31-prefix's interval | overflow flag (entry 0), payload | USED }; the
+//                                    payload is the k-mer's PATH POSITION when the image has a path order (its column is
+//                                    col[position]), else its column
 //   [ stab     : n_sb x 32 B     ]   sparse prefix table at depth p_sparse (only non-empty prefixes), hashed:
 //                                    bucket = two 16-byte entries { key | flags (u64), first (u32), second-first (u32) }
 //
@@ -57,7 +59,8 @@ struct SbwtIndexView {
                                     // only successor = ~A & B (k_path_reencode, sbwt_derived.hip)
     int has_safe;                   // the safe states are filled in (k_path_safe*)
     const uint4 *stab2;             // second-level sparse table for 31 < k <= 63 (nullptr = none): key = (first column of the
-    unsigned n_sb2;                 // 31-prefix's interval, the remaining k-31 bases) -> the k-mer's column and path position; its entries
+    unsigned n_sb2;                 // 31-prefix's interval, the remaining k-31 bases) -> the k-mer's path position (column
+                                    // without a path order); its number of 32-byte buckets of two entries
     const uint4 *pfil;              // probe filter: blocked Bloom filter over the p_filter-mers of the index (nullptr = none)
     int p_filter, log2f;            // its depth and log2 of its number of 16-byte blocks
     const uint4 *trans;             // transition table: hashed 32-byte entries (k_trans_insert, sbwt_derived.hip)
@@ -98,7 +101,7 @@ struct SbwtBlobHeader {
     int64_t image_level;            // 0 full, 1 no path order, 2 blocks + dense prefix table only
     int64_t row_ones[4];            // set bits of the rows A, C, G, T (select: valid j are 1 .. row_ones[c])
     int32_t log2b2_unused;
-    int64_t n_sb2;                  // second-level sparse table: its number of 32-byte entries (0 = none)
+    int64_t n_sb2;                  // second-level sparse table: its number of 32-byte buckets (0 = none)
     int64_t off_stab2;
     int64_t path_lookahead;         // steps the path order looked ahead / behind when it chose successors (0: blind rule)
 };
@@ -115,8 +118,8 @@ static __host__ __device__ inline unsigned long long sp2_hash(unsigned origin, u
     h ^= h >> 31;
     return (h + origin) * 0xD6E8FEB86659FD93ull;
 }
-#define SBWT_SP2_USED 1u                        // flags word of a second-level entry
-#define SBWT_SP2_OVERFLOW 2u
+#define SBWT_SP2_USED 0x80000000u               // in a second-level entry's payload word (.w)
+#define SBWT_SP2_OVERFLOW 0x80000000u           // in entry 0's origin word (.z): some key had to skip this bucket
 // probe filter hash (one multiply): block index in the top bits, two bit positions (7 bits each) from the
 // well-mixed middle of the product (returned in the low 14 bits of sbwt_pf_bits)
 static __host__ __device__ inline unsigned long long sbwt_pf_hash(unsigned long long key) { return key * SBWT_SP_HASH; }

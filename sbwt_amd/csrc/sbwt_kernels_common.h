@@ -113,8 +113,8 @@ __device__ __forceinline__ unsigned sbwt_sp_bucket(u64 key, unsigned n_buckets, 
     while (b >= n_buckets) b -= n_buckets;
     return b;
 }
-// entry of (first column of the 31-prefix's interval, rest of the k-mer) in the second-level table of n_entries 32-byte
-// entries, j entries past its home
+// bucket of (first column of the 31-prefix's interval, rest of the k-mer) in the second-level table of n_entries 32-byte
+// buckets, j buckets past its home
 __device__ __forceinline__ unsigned sbwt_sp2_entry(unsigned origin, u64 key2, unsigned n_entries, unsigned j) {
     unsigned e = (unsigned)__umul64hi(sp2_hash(origin, key2), (u64)n_entries) + j;
     while (e >= n_entries) e -= n_entries;

@@ -905,11 +905,16 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
                     }
                   } else if (wk == 5) {
                     wl = k;                            // a hit completes the k-mer; a miss says read[wstart .. wstart+k-1] is absent
-                    if ((v1.w & SBWT_SP2_USED) && quad_bits(v1) == hk && v1.z == (unsigned)l) {
-                        l = (pos_t)v2.x;
+                    const bool s0 = (v1.w & SBWT_SP2_USED) && quad_bits(v1) == hk && (v1.z & ~SBWT_SP2_OVERFLOW) == (unsigned)l;
+                    const bool s1 = (v2.w & SBWT_SP2_USED) && quad_bits(v2) == hk && v2.z == (unsigned)l;
+                    if (s0 | s1) {
+                        // the payload: the k-mer's path position on an image with a path order (column = col[position]), else
+                        // its column.  (The blocks-only kernel on a path-order image -- a cross-check route -- fetches it.)
+                        const unsigned pv = (s0 ? v1.w : v2.w) & ~SBWT_SP2_USED;
+                        if (PATH) { tpos = (pos_t)pv; l = (pos_t)pv; }
+                        else l = ix.col ? (pos_t)ix.col[pv] : (pos_t)pv;
                         r = l;
-                        if (PATH) tpos = (pos_t)v2.y;
-                    } else if (v1.w & SBWT_SP2_OVERFLOW) {
+                    } else if (v1.z & SBWT_SP2_OVERFLOW) {
                         again = true;
                         j++;
                     } else {

@@ -751,11 +751,13 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
                 }
             } else if (wk == 5) {
                 wl = k;                                // a hit completes the k-mer; a miss: read[wstart .. wstart+k-1] is absent
-                if ((v1.w & SBWT_SP2_USED) && quad_bits(v1) == hk && v1.z == (unsigned)l) {
-                    l = (int)v2.x;
+                const bool hit0 = (v1.w & SBWT_SP2_USED) && quad_bits(v1) == hk && (v1.z & ~SBWT_SP2_OVERFLOW) == (unsigned)l;
+                const bool hit1 = (v2.w & SBWT_SP2_USED) && quad_bits(v2) == hk && v2.z == (unsigned)l;
+                if (hit0 | hit1) {
+                    tpos = (int)((hit0 ? v1.w : v2.w) & ~SBWT_SP2_USED);     // the k-mer's path position: its column is col[tpos]
+                    l = tpos;                          // (stands in for the column: the result is emitted by position)
                     r = l;
-                    tpos = (int)v2.y;
-                } else if (v1.w & SBWT_SP2_OVERFLOW) {
+                } else if (v1.z & SBWT_SP2_OVERFLOW) {
                     again = true;
                     j++;
                 } else {

@@ -314,9 +314,10 @@ int sbwtgpu_index_create(const sbwtgpu_index_desc *d, int device, sbwtgpu_index 
         h.n_sb = n + n / 4 + 64;            // 1.25 two-entry buckets per column: 40 % of the entry slots in use, ~6 % of the keys overflow
         h.off_stab = h.blob_bytes;
         h.blob_bytes = align256(h.off_stab + 32 * h.n_sb);
-        // second level for 31 < k <= 63 (the remaining k-31 bases fit one 64-bit key): two entries' worth of space per column
+        // second level for 31 < k <= 63 (the remaining k-31 bases fit one 64-bit key): 1.25 two-entry buckets per column, like the
+        // first level (round 3: 2 n single 32-byte entries with linear probing -- a miss walked 2.5 of them)
         if (p_sparse == SBWT_SP_MAX_DEPTH && d->k > p_sparse && d->k - p_sparse <= 32) {
-            h.n_sb2 = 2 * n + 64;           // one entry per k-mer at load 0.5
+            h.n_sb2 = n + n / 4 + 64;
             h.off_stab2 = h.blob_bytes;
             h.blob_bytes = align256(h.off_stab2 + 32 * h.n_sb2);
         }

@@ -146,3 +146,30 @@ def test_cpp_api_mirror(gpu, tmp_path):
     assert p.returncode == 0, p.stderr.decode()[-2000:]
     assert p.stdout.splitlines()[-1].startswith(b"OK "), p.stdout[-500:]
     print(p.stdout.decode())                 # includes the measured cost of the scalar API (us per call)
+
+
+def test_cli_reads_from_a_fifo_and_writes_to_a_pipe(gpu, tmp_path):
+    """`sbwt search -q <(zcat reads.fq.gz) -o /dev/stdout | ...`: the query arrives on a FIFO, the output leaves through a
+    pipe (the reader must not rewind, the writer must not pwrite).  Same bytes as the reference's KAT, plain and
+    with -z."""
+    import threading
+    kat = KATS["cli_end_to_end"]
+    d = str(tmp_path)
+    write_fasta(d + "/g.fna", [s.encode() for s in kat["seqs"]])
+    index = d + "/index.sbwt"
+    run("build", "-i", d + "/g.fna", "-o", index, "-k", "6", "--add-reverse-complements", "--precalc-length", "4")
+    queries = [q.encode() for q in kat["queries"]]
+    fq = b"".join(b"@s%d\n%s\n+\n%s\n" % (i, s, b"I" * len(s)) for i, s in enumerate(queries))
+    for zflag in ([], ["-z"]):
+        fifo = d + "/in%d.fastq" % len(zflag)
+        os.mkfifo(fifo)
+        t = threading.Thread(target=lambda: open(fifo, "wb").write(fq))
+        t.start()
+        p = subprocess.Popen([SBWT, "search", "-i", index, "-q", fifo, "-o", "/dev/stdout"] + zflag, stdout=subprocess.PIPE,
+                             stderr=subprocess.PIPE)
+        out, err = p.communicate(timeout=300)
+        t.join()
+        assert p.returncode == 0, err.decode()
+        # (the log lines go to stderr; stdout carries the result text only)
+        text = gzip.decompress(out) if zflag else out
+        assert text == kat["expected_output"].encode()
