@@ -111,9 +111,10 @@ static int g_split_long = [] { const char *e = getenv("SBWTGPU_SPLIT_LONG"); ret
 // batches of reads of different lengths through the fused kernel (it fetches their offsets); 0: only reads of one length
 static int g_fused_ragged = [] { const char *e = getenv("SBWTGPU_FUSED_RAGGED"); return e ? atoi(e) : 1; }();
 // reads of more than 160 bases through the fused kernel as up to this many pieces of 160 bases (1: such reads go to the general
-// kernel -- the default: measured on 250-base reads and on lengths 80-250, pieces and the two-pass route come out the same,
-// DESIGN.md section 3)
-static int g_fused_pieces = [] { const char *e = getenv("SBWTGPU_FUSED_PIECES"); return e ? atoi(e) : 1; }();
+// kernel).  -1 (default) = by the index: 3 where the fused kernel walks with F_CMP (31 < k <= 63: 250-base reads 115 -> 211 G
+// k-mers/s, the general kernel has neither bridges nor anchors there), 1 for k <= 31 (pieces and the two-pass route come out
+// the same, NOTES.md)
+static int g_fused_pieces = [] { const char *e = getenv("SBWTGPU_FUSED_PIECES"); return e ? atoi(e) : -1; }();
 static int g_path_stitch = [] { const char *e = getenv("SBWTGPU_PATH_STITCH"); return e ? atoi(e) : 1; }();
 static int g_path_stitch_min = [] { const char *e = getenv("SBWTGPU_PATH_STITCH_MIN"); return e ? atoi(e) : 1; }();
 static int g_sparse_depth = [] { const char *e = getenv("SBWTGPU_SPARSE_PRECALC"); return e ? atoi(e) : 31; }();
@@ -197,7 +198,7 @@ int sbwtgpu_set_tuning(const char *key, int64_t value) {
     if (!strcmp(key, "path_lookahead")) { g_path_lookahead = value < 0 ? 0 : value > 64 ? 64 : (int)value; return SBWTGPU_OK; }
     if (!strcmp(key, "path_order")) { g_path_order = (int)value; return SBWTGPU_OK; }   // indexes created afterwards
     if (!strcmp(key, "fused_ragged")) { g_fused_ragged = (int)value; return SBWTGPU_OK; }
-    if (!strcmp(key, "fused_pieces")) { g_fused_pieces = value < 1 ? 1 : value > 3 ? 3 : (int)value; return SBWTGPU_OK; }
+    if (!strcmp(key, "fused_pieces")) { g_fused_pieces = value < 1 ? -1 : value > 3 ? 3 : (int)value; return SBWTGPU_OK; }
     if (!strcmp(key, "split_long")) { g_split_long = (int)value; return SBWTGPU_OK; }
     if (!strcmp(key, "path_stitch")) { g_path_stitch = (int)value; return SBWTGPU_OK; }   // indexes created afterwards
     if (!strcmp(key, "path_stitch_min")) { g_path_stitch_min = (int)value < 1 ? 1 : (int)value; return SBWTGPU_OK; }
@@ -980,7 +981,8 @@ static int search_dev_common(const sbwtgpu_index *idx, const char *d_bases, int6
                                      reinterpret_cast<const long long *>(d_out_off), reinterpret_cast<long long *>(d_out), n_reads,
                                      ws, eff_streaming, st, defer, e0, e1, ws_piece_tab(d_ws, total_bases),
                                      // (the list of reads handed on has one entry per 32 bases of the batch)
-                                     ((g_fused_ragged && n_reads <= total_bases / 32) ? 1 : 0) | (g_fused_pieces << 8));
+                                     ((g_fused_ragged && n_reads <= total_bases / 32) ? 1 : 0) |
+                                         ((g_fused_pieces > 0 ? g_fused_pieces : (idx->h.n_sb2 > 0 && idx->h.p_sparse < idx->h.k) ? 3 : 1) << 8));
             hipError_t e = hipGetLastError();
             if (e != hipSuccess) return fail(SBWTGPU_ERR_HIP, "kernel launch: %s", hipGetErrorString(e));
             return SBWTGPU_OK;

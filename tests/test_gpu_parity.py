@@ -774,7 +774,8 @@ def test_fused_kernel_takes_batches_of_mixed_lengths(gpu, genome_case):
 
 @pytest.mark.parametrize("k", [30, 63])
 def test_fused_kernel_takes_reads_of_161_to_400_bases_as_pieces(gpu, k):
-    # Round 4, "fused_pieces" = 2 or 3 (default 1: measured, no faster than the two-pass route -- DESIGN.md): a read of more than
+    # Round 4, "fused_pieces" = 2 or 3 (the default for k > 31, where it doubles the rate; for k <= 31 the default is 1: no faster
+    # than the two-pass route -- NOTES.md): a read of more than
     # 160 bases is taken by the fused kernel as up to three pieces of 160 bases that overlap by k-1 (a ticket is (read, piece);
     # SBWT.hh:556-579 has no length limit).  Reads of ONE length 161 .. 3 * (161 - k) + k - 1
     # (offset arithmetic), reads of mixed lengths with two or three tickets each, N / lower case inside one piece (the read
@@ -801,7 +802,7 @@ def test_fused_kernel_takes_reads_of_161_to_400_bases_as_pieces(gpu, k):
                     got = _search_dev(idx, bases, off, k, streaming)
                 finally:
                     capi.set_tuning("search_variant", -1)
-                    capi.set_tuning("fused_pieces", 1)
+                    capi.set_tuning("fused_pieces", -1)
                 assert np.array_equal(got, want), (streaming, variant, pieces)
 
     # (1) reads of one length
@@ -824,7 +825,7 @@ def test_fused_kernel_takes_reads_of_161_to_400_bases_as_pieces(gpu, k):
                                  wsb, st, True)
         torch.cuda.synchronize()
     finally:
-        capi.set_tuning("fused_pieces", 1)
+        capi.set_tuning("fused_pieces", -1)
     stats = idx.workspace_stats(d_ws.data_ptr(), st)
     assert int((d_out >= 0).sum()) == int(oo[-1])
     if idx.image_level == 0:                             # (SBWTGPU_IMAGE_LEVEL > 0 in the knob sweep: no path order, no fused kernel)

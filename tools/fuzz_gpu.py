@@ -19,7 +19,7 @@ def reset_tuning():
     capi.set_tuning("search_variant", -1)
     capi.set_tuning("sort_reads", -1)
     capi.set_tuning("debug", 0)
-    capi.set_tuning("fused_pieces", 1)
+    capi.set_tuning("fused_pieces", -1)
     capi.set_tuning("path_lookahead", 8); capi.set_tuning("path_safe", 2); capi.set_tuning("image_level", 0)
     capi.set_tuning("path_stitch", 1); capi.set_tuning("path_stitch_min", 1)
 
@@ -112,7 +112,7 @@ def _fuzz(budget, seed, max_cases):
             capi.set_tuning("sort_reads", int(rng.integers(0, 2)) if v == 4 else -1)
             # the fused kernel's alignments (anchors, seeds, resumed compares): off / as shipped / for every k
             capi.set_tuning("debug", int(rng.choice([0, 0, 32, 64])) if v == 5 else 0)
-            capi.set_tuning("fused_pieces", int(rng.choice([1, 2, 3])) if v == 5 else 1)
+            capi.set_tuning("fused_pieces", int(rng.choice([-1, 1, 2, 3])) if v == 5 else -1)
             a = idx.streaming_search(bases, off)[0] if ssup else None
             b = idx.search(bases, off)[0]
             res[(v, -1)] = (a, b)

@@ -71,7 +71,7 @@ capi.set_tuning("fused_pieces", 2)
 run("250 bp reads, fused kernel with two pieces per read", idx0, b, o)
 b2, o2 = synth.ragged_reads(base, n_reads, 80, 250, 0.01, 43)
 run("ragged read lengths 80-250, fused kernel with two pieces per read", idx0, b2, o2)
-capi.set_tuning("fused_pieces", 1)
+capi.set_tuning("fused_pieces", -1)
 b, o = synth.indel_reads(base, n_reads, 150, 0.01, 0.002, 44)
 run("0.2% indels + 1% substitutions", idx0, b, o)
 b, o = synth.random_reads(n_reads, 150, 45)
@@ -93,3 +93,14 @@ idx3 = make_index(base, rc=True)
 print(json.dumps({"revcomp_index": {"n_nodes": idx3.n_nodes, "image_MB": idx3.blob_bytes / 1e6, "paths": idx3.n_paths}}), flush=True)
 b, o = synth.both_strand_reads(base, n_reads, 150, 0.01, 50)
 run("reverse-complement index (2 x the k-mers), reads from both strands, 150 bp, 1% substitutions", idx3, b, o)
+
+# k > 31: reads of more than 160 bases go through the fused kernel as pieces by default (F_CMP; the general kernel has neither
+# bridges nor anchors there)
+del idx3
+K = 63
+idx5 = make_index(base)
+b, o = synth.sample_reads(base, n_reads, 250, 0.01, 51)
+run("k=63 index, 250 bp reads (fused kernel, pieces: the default for k > 31)", idx5, b, o)
+capi.set_tuning("fused_pieces", 1)
+run("k=63 index, 250 bp reads, two-pass route (general kernel)", idx5, b, o)
+capi.set_tuning("fused_pieces", -1)
