@@ -160,6 +160,24 @@ def load_traffic(config: int, n_reads: int, image_level: int, variant: int, kern
     return ent
 
 
+# What the memory system delivers per access shape on this chip (tools/micro/ceilings.hip, gather_modes.hip; measured,
+# profiles/r02_ceilings.txt, r03_gather_modes.txt): a random read leaves an XCD as ONE 128-byte fabric request whatever
+# the load width -- 56 G requests/s --, coalesced writes run at 5.1 TB/s = 80 G 64-byte requests/s.
+READ_REQ_CEILING = 56e9
+WRITE_REQ_CEILING = 5.1e12 / 64
+
+
+def request_model(read_requests: float, write_requests: float, kernel_ms: float) -> dict:
+    """The kernel's time against the request rates the memory system delivers: reads and writes share the fabric, so the
+    floor for a launch is read_requests / 56 G/s + write_requests / 80 G/s.  `frac_of_deliverable` near 1 says the kernel
+    runs at what the memory system gives this access pattern -- the only way on is fewer lines per read."""
+    floor_ms = (read_requests / READ_REQ_CEILING + write_requests / WRITE_REQ_CEILING) * 1e3
+    return {"read_requests_128B": read_requests, "write_requests_64B": write_requests,
+            "read_ceiling_Greq_s": READ_REQ_CEILING / 1e9, "write_ceiling_Greq_s": WRITE_REQ_CEILING / 1e9,
+            "floor_ms": floor_ms, "frac_of_deliverable": floor_ms / kernel_ms if kernel_ms > 0 else None,
+            "ceilings_source": "profiles/r02_ceilings.txt, profiles/r03_gather_modes.txt (tools/micro/)"}
+
+
 RANK_B_SURVEY = 72              # SURVEY 8d: one rank = 8 B count + 64 B block bits
 RANK_B_LAYOUT = 8 + 1 + 16 + 8  # this layout: pos + symbol + one 16-byte quad {bits, count} + result
 
@@ -300,6 +318,7 @@ def main() -> int:
     ap.add_argument("--no-end-to-end", action="store_true",
                     help="skip the end-to-end leg (host buffers over PCIe, and the `sbwt search` CLI on a FASTQ file)")
     ap.add_argument("--e2e-reads", type=int, default=2_000_000, help="reads of the end-to-end leg")
+    ap.add_argument("--no-two-in-flight", action="store_true", help="skip the extra leg that issues the same steps on two streams")
     ap.add_argument("--no-cli-full", action="store_true", help="end-to-end leg: skip the `sbwt search` run on the whole batch")
     ap.add_argument("--config", type=int, default=2, choices=[2, 3, 5, 6],
                     help="BASELINE.json config: 2 = coli3-like k=30 (headline, default); 3 = pan-genome-like "
@@ -546,6 +565,34 @@ def main() -> int:
     status = index.workspace_status(d_ws.data_ptr(), stream)
     if status != 0:
         raise SystemExit(f"search kernel reported status {status}")
+    # The same K steps once more with TWO batches in flight (two streams, workspaces and result buffers): a launch ends in
+    # ~0.5 ms in which its waves leave one by one (tools/timeline_fused.py); with a second launch queued behind, the chip
+    # stays full.  Reported beside the line, never as `value`: `value` is one launch at a time, like its kernel_ms.
+    two_in_flight = None
+    if one_call and world == 1 and not args.no_two_in_flight and n_kmers * 8 <= (24 << 30):
+        side = torch.cuda.Stream(device=dev)
+        outs, wss = [d_out, torch.empty_like(d_out)], [d_ws, torch.empty_like(d_ws)]
+        sts = [torch.cuda.current_stream(), side]
+
+        def steps2(n):
+            for s in range(n):
+                q = s & 1
+                with torch.cuda.stream(sts[q]):
+                    index.streaming_search_dev(d_bases.data_ptr(), total_bases, d_roff.data_ptr(), n_reads, outs[q].data_ptr(),
+                                               d_ooff.data_ptr(), wss[q].data_ptr(), ws_bytes, sts[q].cuda_stream, streaming)
+        steps2(2)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        steps2(args.steps)
+        torch.cuda.synchronize()
+        e2 = time.perf_counter() - t2
+        same = bool(torch.equal(outs[0], outs[1]))
+        two_in_flight = {"ms_per_step": e2 / args.steps * 1e3, "value": n_kmers * args.steps / e2, "unit": "k-mers/s",
+                         "results_identical": same,
+                         "note": "the same steps issued on two streams alternately (two workspaces, two result buffers): the next launch fills the chip while the waves of the last one leave"}
+        del outs, wss
+        if not same:
+            raise SystemExit("two batches in flight: the two result buffers differ")
     # Algorithmic bytes of the work the kernel EXECUTED, priced per operation at SURVEY 8d's figures:
     # streaming steps, walks (prefix-table entry + its window of bases), interval updates, and the
     # result of every k-mer that did not come from a streaming step.  (The reference's own order of
@@ -623,6 +670,8 @@ def main() -> int:
             "kernel_only_kmers_per_s": n_kmers / (kernel_ms * 1e-3),
         },
     }
+    if two_in_flight is not None:
+        result["two_batches_in_flight"] = two_in_flight
     if t_bcast is not None:
         result["index_broadcast_s"] = t_bcast
         result["index_replication"] = args.replicate
@@ -643,6 +692,7 @@ def main() -> int:
         if tj.get("read_requests_128B"):
             result["roofline"]["read_lines_per_read"] = tj["read_requests_128B"] / n_reads      # 128-byte fabric requests
             result["roofline"]["write_requests_per_read"] = (tj.get("write_requests_64B") or 0) / n_reads
+            result["roofline"]["request_model"] = request_model(tj["read_requests_128B"], tj.get("write_requests_64B") or 0, kernel_ms)
         # what the memory system actually moved per second during the kernel (every gather drags a 128-byte line):
         result["roofline"]["traffic_GBps"] = tj.get("hbm_bytes_per_launch") / (kernel_ms * 1e-3) / 1e9
         result["roofline"]["traffic_frac_of_peak"] = result["roofline"]["traffic_GBps"] / HBM_PEAK_GBPS

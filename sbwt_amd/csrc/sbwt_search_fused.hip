@@ -81,7 +81,9 @@
 #define CF_M1 (CF_S1 | CF_A1 | CF_B1)
 #define CF_M2 (CF_S2 | CF_A2 | CF_B2)
 
+#ifndef FZ_SPLIT_MIN
 #define FZ_SPLIT_MIN 16         // the tail: a lane gives away half of its remaining k-mers when it has at least this many left
+#endif
 #define FZ_NSEG 9               // segments per lane: 256 x (9 x 4 + 9 x 1) B + 2 x 256 x 40 B of codes = 32 000 B = 5 workgroups per CU
 
 typedef unsigned fz_u32x4 __attribute__((ext_vector_type(4)));
@@ -93,6 +95,15 @@ typedef unsigned fz_u32x4 __attribute__((ext_vector_type(4)));
 #endif
 // stats builds (tools/build_stats_lib.sh): lane-iterations per read (ticket or tail piece), bucket = iterations / 2
 __device__ unsigned long long g_iter_hist[64];
+__device__ unsigned long long g_tail_prof[192];       // [q], [64 + q], [128 + q]: waves / busy lanes / donor lanes at tail iteration q
+extern "C" int sbwtgpu_debug_tail_prof(unsigned long long *out, int reset) {
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tail_prof), sizeof(g_tail_prof)) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[192] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_tail_prof), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
 __device__ unsigned long long g_iter_max[8];          // (iterations << 32 | read) of the slowest reads seen, by iterations mod 8
 extern "C" int sbwtgpu_debug_iter_hist(unsigned long long *out, int reset) {
     if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_iter_hist), sizeof(g_iter_hist)) != hipSuccess) return -1;
@@ -114,6 +125,29 @@ extern "C" int sbwtgpu_debug_iter_max(unsigned long long *out, int reset) {
     if (it_cnt >= SBWT_SLOW_LO && it_cnt < SBWT_SLOW_HI) atomicMax(&g_iter_max[it_cnt & 7u], ((unsigned long long)it_cnt << 32) | rd); it_cnt = 0; } } while (0)
 #else
 #define FZ_HIST_FLUSH() do { } while (0)
+#endif
+
+// timeline builds (tools/build_stats_lib.sh timeline): when the waves of one launch start, see the ticket counter run out, and
+// leave (100 MHz clock).  g_fz_tl: [0] earliest start, [1] earliest / [2] latest "drained", [3] latest exit, [4] waves,
+// [5] sum of exit - drained, [6] sum of exit - start, [7] iterations before "drained"; g_fz_tl_hist[b]: waves that left in the
+// b-th 10 us after [0]; g_fz_tl_it[q], [64 + q]: clock ticks spent in / waves that ran iteration q after "drained"
+#ifdef SBWT_TIMELINE
+__device__ unsigned long long g_fz_tl[8];
+__device__ unsigned long long g_fz_tl_hist[1024];
+__device__ unsigned long long g_fz_tl_it[128];
+extern "C" int sbwtgpu_debug_timeline(unsigned long long *out, int reset) {
+    if (out && (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fz_tl), sizeof(g_fz_tl)) != hipSuccess ||
+                hipMemcpyFromSymbol(out + 8, HIP_SYMBOL(g_fz_tl_hist), sizeof(g_fz_tl_hist)) != hipSuccess ||
+                hipMemcpyFromSymbol(out + 8 + 1024, HIP_SYMBOL(g_fz_tl_it), sizeof(g_fz_tl_it)) != hipSuccess)) return -1;
+    if (reset) {
+        static unsigned long long z[1024];
+        unsigned long long t0[8] = {~0ull, ~0ull, 0, 0, 0, 0, 0, 0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_fz_tl), t0, sizeof(t0)) != hipSuccess ||
+            hipMemcpyToSymbol(HIP_SYMBOL(g_fz_tl_hist), z, sizeof(g_fz_tl_hist)) != hipSuccess ||
+            hipMemcpyToSymbol(HIP_SYMBOL(g_fz_tl_it), z, sizeof(g_fz_tl_it)) != hipSuccess) return -1;
+    }
+    return 0;
+}
 #endif
 
 // 32 ASCII bases (8 dwords) -> 64 bits of 2-bit codes; `bad` collects bit 7 of every byte that is not one of "ACGT"
@@ -192,7 +226,13 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
     // (the piece number of the lane's ticket rides in i0's bits 16..: its first k-mer within its read is piece * kpp)
     unsigned c_stream = 0, c_search = 0, c_lf = 0, c_tab = 0;     // wave-uniform work counters
 #ifdef SBWT_STATS
-    unsigned it_cnt = 0;
+    unsigned it_cnt = 0, tail_it = 0;
+#endif
+#ifdef SBWT_TIMELINE
+    const u64 tl_start = wall_clock64();
+    u64 tl_drain = 0, tl_last = 0;
+    unsigned tl_q = 0, tl_n = 0;
+    if (lane == 0) atomicMin(&g_fz_tl[0], tl_start);
 #endif
 
     for (;;) {
@@ -281,6 +321,9 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
                     }
                 } else {
                     drained = true;                    // no read left anywhere: from now on idle lanes help busy ones (below)
+#ifdef SBWT_TIMELINE
+                    tl_drain = tl_last = wall_clock64();
+#endif
                     pool_end = pool_next;
                 }
                 __builtin_amdgcn_wave_barrier();
@@ -319,6 +362,15 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
             }
             pool_next = uniform64(pool_next + ((n < avail) ? n : avail));
         }
+#ifdef SBWT_TIMELINE
+        if (!drained) tl_n++;
+        else if (lane == 0) {
+            const u64 now = wall_clock64();
+            if (tl_q > 0) { atomicAdd(&g_fz_tl_it[tl_q < 64u ? tl_q - 1u : 63u], now - tl_last); atomicAdd(&g_fz_tl_it[64u + (tl_q < 64u ? tl_q - 1u : 63u)], 1ull); }
+            tl_last = now;
+            tl_q++;
+        }
+#endif
         if (drained) {
             // ---- the tail of the batch: one lane per read means a wave waits for its slowest read.  An idle lane takes over
             //      the second half of what a busy lane still has to answer.  Exact: this kernel only walks reads of upper-case
@@ -468,6 +520,12 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
             it_cnt += busy ? 1u : 0u;
             // the tail: wave-iterations and idle lane-iterations after the tickets ran out; k-mers still open then
             if (drained) {
+                {       // the tail by iteration since the tickets ran out: waves still running, their busy lanes, donors
+                    const unsigned q = tail_it < 63u ? tail_it : 63u;
+                    const unsigned long long nb = __popcll(__ballot(busy)), nd = __popcll(__ballot(busy && mend - i >= FZ_SPLIT_MIN));
+                    if (lane == 0) { atomicAdd(&g_tail_prof[q], 1ull); atomicAdd(&g_tail_prof[64 + q], nb); atomicAdd(&g_tail_prof[128 + q], nd); }
+                }
+                tail_it++;
                 const unsigned long long idl = __popcll(__ballot(!busy));
                 const unsigned long long dn = __popcll(__ballot(busy && mend - i >= FZ_SPLIT_MIN));
                 if (lane == 0) { atomicAdd(&ws->pad[11], 1ull); atomicAdd(&ws->pad[12], idl); atomicAdd(&ws->pad[14], dn); }
@@ -1148,6 +1206,16 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
     }
 
     FZ_HIST_FLUSH();
+#ifdef SBWT_TIMELINE
+    if (lane == 0) {
+        const u64 tl_exit = wall_clock64(), t0 = g_fz_tl[0];
+        atomicMin(&g_fz_tl[1], tl_drain); atomicMax(&g_fz_tl[2], tl_drain); atomicMax(&g_fz_tl[3], tl_exit);
+        atomicAdd(&g_fz_tl[4], 1ull); atomicAdd(&g_fz_tl[5], tl_exit - tl_drain); atomicAdd(&g_fz_tl[6], tl_exit - tl_start);
+        atomicAdd(&g_fz_tl[7], (unsigned long long)tl_n);
+        const u64 bk = (tl_exit - t0) / 1000ull;
+        atomicAdd(&g_fz_tl_hist[bk < 1023 ? bk : 1023], 1ull);
+    }
+#endif
     {
         u64 e = c_ext, eb = c_brg;
 #pragma unroll

@@ -13,7 +13,7 @@ timeout 900 python bench.py --config 3 --steps 5 > $O/c3_bench.json 2> $O/c3_ben
 PMC="FETCH_SIZE|WRITE_SIZE|TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum TCC_EA0_RDREQ_128B_sum|TCC_HIT_sum TCC_MISS_sum|SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES"
 prof() {   # prof <name> <config> <level> <variant> <reads> <bench args...>
   local name=$1 cfg=$2 lvl=$3 var=$4 reads=$5; shift 5
-  PMC_GROUPS="$PMC" bash tools/profile.sh ${TAG}_$name "$@" --warmup 1 --no-cpu-baseline --no-end-to-end > /dev/null 2>&1
+  PMC_GROUPS="$PMC" bash tools/profile.sh ${TAG}_$name "$@" --warmup 1 --no-cpu-baseline --no-end-to-end --no-two-in-flight > /dev/null 2>&1
   cp gpurun_out/prof_${TAG}_$name/summary.txt $O/${name}_rocprof_summary.txt
   cp gpurun_out/prof_${TAG}_$name/trace_bench.json $O/${name}_bench_under_rocprof.json
   python tools/make_traffic_json.py $O/${name}_rocprof_summary.txt $cfg $reads ${TAG}_${name}_rocprof_summary.txt $lvl $var > /dev/null 2>> $O/traffic.err
@@ -47,3 +47,18 @@ PY
 for e in SBWTGPU_PATH_LOOKAHEAD=0 SBWTGPU_IMAGE_LEVEL=1 SBWTGPU_IMAGE_LEVEL=2 SBWTGPU_PATH_SAFE=0 SBWTGPU_PATH_STITCH=0 SBWTGPU_FUSED_RAGGED=0 SBWTGPU_SPLIT_LONG=0 SBWTGPU_FUSED_PIECES=3 SBWTGPU_FUSED_PIECES=1; do
   env $e timeout 600 python -m pytest tests/test_gpu_parity.py tests/test_gpu_workloads.py -x -q -m gpu 2>&1 | tail -1 | sed "s/^/$e: /"
 done | tee $O/knob_sweep.log
+# instrumented builds (tools/build_stats_lib.sh [timeline]; not the shipped library): lane-iterations by kind, the tail by
+# iteration, and when the waves of one launch start / see the tickets run out / leave; two batches in flight
+if [ -f sbwt_amd/lib/lib_stats.so ]; then
+  ( export SBWTGPU_LIB=$PWD/sbwt_amd/lib/lib_stats.so
+    echo "== config 2 (coli3-like, k=30, 10 M reads) =="; python tools/lane_stats_fused.py 2>&1 | grep -v "^config\|^index\|^variant\|amdgpu.ids"
+    echo "== config 5 (k=63, no streaming support, 10 M reads) =="; K=63 STREAMING=0 python tools/lane_stats_fused.py 2>&1 | grep -v "^config\|^index\|^variant\|amdgpu.ids"
+    echo "== config 3 index type (pan64, k=31), 20 M reads =="; GENOMES=pan64 K=31 NREADS=20000000 python tools/lane_stats_fused.py 2>&1 | grep -v "^config\|^index\|^variant\|amdgpu.ids" ) > $O/lane_stats.txt 2>&1
+fi
+if [ -f sbwt_amd/lib/lib_timeline.so ]; then
+  ( export SBWTGPU_LIB=$PWD/sbwt_amd/lib/lib_timeline.so
+    for n in 10000000 1000000; do NREADS=$n python tools/timeline_fused.py 2>&1 | grep -v "^config\|^index\|amdgpu.ids"; done ) > $O/timeline.txt 2>&1
+fi
+( NREADS=10000000 python tools/overlap_steps.py 2>&1 | grep "^reads"
+  NREADS=1000000 STEPS=50 python tools/overlap_steps.py 2>&1 | grep "^reads"
+  K=63 STREAMING=0 NREADS=10000000 python tools/overlap_steps.py 2>&1 | grep "^reads" ) > $O/two_in_flight.txt 2>&1

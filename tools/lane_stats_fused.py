@@ -33,3 +33,11 @@ try:
         print("lane-iterations per read or piece (%d of them):" % tot, "; ".join(rows))
 except Exception as ex:
     print("no iteration histogram:", ex)
+
+try:
+    t = (ctypes.c_ulonglong * 192)()
+    if capi.lib().sbwtgpu_debug_tail_prof(t, 1) == 0 and t[0]:
+        print("the tail by iteration since a wave saw the tickets run out -- waves still running (of %d), busy lanes per wave, lanes that could give work away:" % t[0])
+        print("; ".join("%d: %d %.1f %.1f" % (q, t[q], t[64 + q] / t[q], t[128 + q] / t[q]) for q in range(64) if t[q]))
+except Exception as ex:
+    print("no tail profile:", ex)
