@@ -121,30 +121,40 @@ extern "C" int sbwtgpu_debug_iter_max(unsigned long long *out, int reset) {
     }
     return 0;
 }
+// why substitutions are (not) bridged, k <= 31 (tools/lane_stats_fused.py prints the names)
+__device__ unsigned long long g_fz_why[16];
+extern "C" int sbwtgpu_debug_why(unsigned long long *out, int reset) {
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fz_why), sizeof(g_fz_why)) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[16] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_fz_why), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#define FZ_WHY(q, cond) do { const unsigned long long n_ = __popcll(__ballot(cond)); if (lane == 0 && n_) atomicAdd(&g_fz_why[q], n_); } while (0)
 #define FZ_HIST_FLUSH() do { if (it_cnt) { atomicAdd(&g_iter_hist[(it_cnt >> 1) < 63 ? (it_cnt >> 1) : 63], 1ull); \
     if (it_cnt >= SBWT_SLOW_LO && it_cnt < SBWT_SLOW_HI) atomicMax(&g_iter_max[it_cnt & 7u], ((unsigned long long)it_cnt << 32) | rd); it_cnt = 0; } } while (0)
 #else
 #define FZ_HIST_FLUSH() do { } while (0)
+#define FZ_WHY(q, cond) do { } while (0)
 #endif
 
 // timeline builds (tools/build_stats_lib.sh timeline): when the waves of one launch start, see the ticket counter run out, and
 // leave (100 MHz clock).  g_fz_tl: [0] earliest start, [1] earliest / [2] latest "drained", [3] latest exit, [4] waves,
 // [5] sum of exit - drained, [6] sum of exit - start, [7] iterations before "drained"; g_fz_tl_hist[b]: waves that left in the
-// b-th 10 us after [0]; g_fz_tl_it[q], [64 + q]: clock ticks spent in / waves that ran iteration q after "drained"
+// b-th 10 us after [0].  (Per-iteration clocks in the tail were tried and dropped: 5 120 waves adding to the same counters every
+// iteration slow the tail they measure.)
 #ifdef SBWT_TIMELINE
 __device__ unsigned long long g_fz_tl[8];
 __device__ unsigned long long g_fz_tl_hist[1024];
-__device__ unsigned long long g_fz_tl_it[128];
 extern "C" int sbwtgpu_debug_timeline(unsigned long long *out, int reset) {
     if (out && (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fz_tl), sizeof(g_fz_tl)) != hipSuccess ||
-                hipMemcpyFromSymbol(out + 8, HIP_SYMBOL(g_fz_tl_hist), sizeof(g_fz_tl_hist)) != hipSuccess ||
-                hipMemcpyFromSymbol(out + 8 + 1024, HIP_SYMBOL(g_fz_tl_it), sizeof(g_fz_tl_it)) != hipSuccess)) return -1;
+                hipMemcpyFromSymbol(out + 8, HIP_SYMBOL(g_fz_tl_hist), sizeof(g_fz_tl_hist)) != hipSuccess)) return -1;
     if (reset) {
         static unsigned long long z[1024];
         unsigned long long t0[8] = {~0ull, ~0ull, 0, 0, 0, 0, 0, 0};
         if (hipMemcpyToSymbol(HIP_SYMBOL(g_fz_tl), t0, sizeof(t0)) != hipSuccess ||
-            hipMemcpyToSymbol(HIP_SYMBOL(g_fz_tl_hist), z, sizeof(g_fz_tl_hist)) != hipSuccess ||
-            hipMemcpyToSymbol(HIP_SYMBOL(g_fz_tl_it), z, sizeof(g_fz_tl_it)) != hipSuccess) return -1;
+            hipMemcpyToSymbol(HIP_SYMBOL(g_fz_tl_hist), z, sizeof(g_fz_tl_hist)) != hipSuccess) return -1;
     }
     return 0;
 }
@@ -230,8 +240,8 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
 #endif
 #ifdef SBWT_TIMELINE
     const u64 tl_start = wall_clock64();
-    u64 tl_drain = 0, tl_last = 0;
-    unsigned tl_q = 0, tl_n = 0;
+    u64 tl_drain = 0;
+    unsigned tl_n = 0;
     if (lane == 0) atomicMin(&g_fz_tl[0], tl_start);
 #endif
 
@@ -322,7 +332,7 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
                 } else {
                     drained = true;                    // no read left anywhere: from now on idle lanes help busy ones (below)
 #ifdef SBWT_TIMELINE
-                    tl_drain = tl_last = wall_clock64();
+                    tl_drain = wall_clock64();
 #endif
                     pool_end = pool_next;
                 }
@@ -364,12 +374,6 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
         }
 #ifdef SBWT_TIMELINE
         if (!drained) tl_n++;
-        else if (lane == 0) {
-            const u64 now = wall_clock64();
-            if (tl_q > 0) { atomicAdd(&g_fz_tl_it[tl_q < 64u ? tl_q - 1u : 63u], now - tl_last); atomicAdd(&g_fz_tl_it[64u + (tl_q < 64u ? tl_q - 1u : 63u)], 1ull); }
-            tl_last = now;
-            tl_q++;
-        }
 #endif
         if (drained) {
             // ---- the tail of the batch: one lane per read means a wave waits for its slowest read.  An idle lane takes over
@@ -539,6 +543,12 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
         const uint4 v2 = *a2;
 
         // ---- consume ----
+#ifdef SBWT_STATS
+        unsigned why = 0;
+#define WHY(q) (why |= 1u << (q))
+#else
+#define WHY(q) ((void)0)
+#endif
         bool tabhit = false, do_plan = false, force = false;
         bool w31 = false;                              // k > 31: a filter window was (perhaps) present: try the 31-base window around b
         int m2 = -1;                                   // F_CMP: the second difference (this iteration's)
@@ -563,6 +573,7 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
         } else if (trn) {
             // v1 = { r + 1, c | flags, successor column (SBWT.hh:562-575), its path position }, v2 = its path's next 32 steps
             if (v1.x == 0u) {
+                WHY(5);
                 ev = FE_EMIT1;                         // a free slot: (r, c) has no entry -- a path's last column without a
                 b = blo = i + k - 1;                   // successor by c: -1
             } else if (v1.x != (unsigned)r + 1u || (v1.y & 3u) != (unsigned)c) {
@@ -571,14 +582,17 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
             } else if (v1.y & SBWT_TRANS_NEG) {
                 // no successor by this char at a step that has others; the entry says whether the step is safe for it
                 if (ix.has_safe && (v1.y & SBWT_TRANS_NEG_SAFE)) {
+                    WHY(6);
                     mode = F_BRIDGE;
                 } else {
+                    WHY(7);
                     ev = FE_EMIT1;
                     b = blo = i + k - 1;
                     co = r - (i + k - 1);              // (the read was on this path up to here: an alignment to resume on)
                     fl |= CF_ALIGNED;
                 }
             } else {
+                WHY(8);
                 ev = FE_EMIT1;
                 res = (int)v1.z;
                 r = (int)v1.w;
@@ -600,6 +614,7 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
                 c_ext += (unsigned)n2;
                 if (stop2) {
                     const int kind = path_stop_kind(nm < nv, (v2.z >> n2) & 1u, (v2.w >> n2) & 1u, ix.has_safe != 0);
+                    WHY(kind == PS_ABSENT ? 9 : kind == PS_TRANS ? 10 : 11);
                     if (kind == PS_ABSENT) ext_absent = true;
                     else tnext = (kind == PS_TRANS) ? F_TRANS : F_BRIDGE;
                 }
@@ -616,10 +631,12 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
             const int needb = (k - 1 < mend - 1 - i) ? (k - 1) : (mend - 1 - i);
             if (nm >= needb) {
                 ev = FE_FAIL;
+                WHY(needb == k - 1 ? 12 : 13);
                 burst_to = i + needb;
                 c_brg++;
                 bridged = needb == k - 1;              // back on the path: on with F_EXT from position r + k, no walk
             } else {
+                WHY(14);
                 ev = FE_EMIT1;                         // no bridge: a bridgeable step has no successor by the read's char
                 b = blo = i + k - 1;
                 bnext = i + k + nm;                    // ... and the compare has seen where the read differs next
@@ -662,6 +679,9 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
                 mode = F_IDLE;
             } else if (stopped) {
                 int kind = path_stop_kind(nm < nv, (unsigned)(fA >> n) & 1u, (unsigned)(fB >> n) & 1u, ix.has_safe != 0);
+                WHY(0);
+                WHY(kind == PS_TRANS ? 1 : kind == PS_BRIDGE ? 2 : 4);
+                if (kind == PS_TRANS && nm < nv) WHY(15);      // (a mismatch at a step with other successors, not the path's end)
                 if (kind == PS_BRIDGE && n < 32) {
                     // a bridge needs the next k-1 bases to agree with the path; a second difference already in this window:
                     // skip the attempt (the step has no successor by the read's char either way)
@@ -669,6 +689,7 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
                     const int chk = after < want ? after : want;
                     const u64 m2nd = chk > 0 ? ((mm >> (2 * (n + 1))) & low_mask(2 * chk)) : 0ull;
                     if (m2nd) {
+                        WHY(3);
                         kind = PS_ABSENT;
                         bnext = (i + k - 1) + n + 1 + ((__ffsll((i64)m2nd) - 1) >> 1);     // the second difference
                     }
@@ -881,6 +902,9 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
                 ev = FE_END;
             }
         }
+#ifdef SBWT_STATS
+        for (int q = 0; q < 16; q++) FZ_WHY(q, (why >> q) & 1u);
+#endif
         c_tab = uniform32(c_tab + (unsigned)__popcll(__ballot(tabhit)));
         c_stream = uniform32(c_stream + (unsigned)__popcll(__ballot(ev == FE_EMIT1 && trn)));
 

@@ -41,3 +41,19 @@ try:
         print("; ".join("%d: %d %.1f %.1f" % (q, t[q], t[64 + q] / t[q], t[128 + q] / t[q]) for q in range(64) if t[q]))
 except Exception as ex:
     print("no tail profile:", ex)
+
+try:
+    w = (ctypes.c_ulonglong * 16)()
+    if capi.lib().sbwtgpu_debug_why(w, 1) == 0 and w[0]:
+        names = ["path runs that stop (mismatch or end of path)", "... at a step with other successors or the path's end -> transition lookup",
+                 "... at a substitution-safe step -> bridge", "...... but a second difference within the window: certificates", "... at an only-successor step that is not safe: certificates",
+                 "transition lookups: free slot", "negative entry, safe for this char -> bridge", "negative entry, not safe: certificates", "successor found",
+                 "... whose quoted steps stop: absent", "... transition again", "... bridge",
+                 "bridges that hold (k-1 bases)", "bridges that hold to the read's end", "bridges that fail (another difference within k-1 bases)",
+                 "(of the stops at steps with other successors: mismatches, not path ends)"]
+        launches = 2
+        print("why substitutions are (not) bridged, per read:")
+        for q in range(16):
+            print("  %-90s %.3f" % (names[q], w[q] / launches / nr))
+except Exception as ex:
+    print("no why-counters:", ex)

@@ -8,7 +8,7 @@ import torch
 import tools.ab_step as ab
 from sbwt_amd import capi
 L = capi.lib()
-buf = (ctypes.c_ulonglong * (8 + 1024 + 128))()
+buf = (ctypes.c_ulonglong * (8 + 1024))()
 L.sbwtgpu_debug_timeline(None, 1)
 ab.idx.streaming_search_dev(ab.d_bases.data_ptr(), ab.d_bases.numel(), ab.d_roff.data_ptr(), ab.n_reads, ab.d_out.data_ptr(),
                             ab.d_ooff.data_ptr(), ab.d_ws.data_ptr(), ab.wsb, ab.st, bool(ab.streaming))
@@ -26,6 +26,4 @@ for q, v in enumerate(h):
     acc += v
     if v: rows.append("%d: %d (cum %.3f)" % (q * 10, v, acc / nw))
 print("waves leaving per 10 us after the first start:", "; ".join(rows))
-it = [int(buf[8 + 1024 + q]) for q in range(128)]
 print("before that: %.1f iterations per wave, %.2f us each" % (n_it / nw, us(s_life - s_tail) / max(1, n_it)))
-print("after that, iteration q takes (us, waves):", "; ".join("%d: %.1f %d" % (q, us(it[q]) / it[64 + q], it[64 + q]) for q in range(64) if it[64 + q]))
