@@ -231,7 +231,9 @@ int  sbwtgpu_select_batch(const sbwtgpu_index *idx, const int64_t *j, const char
  * bytes), the list of reads the fused kernel hands on (total_bases/8), the pieces of long reads (total_bases/32, at
  * least 8 MB for batches of more than 32 Mbases) and, while "sort_reads" is on, room to sort the reads (about one more
  * byte per base).  Non-decreasing in total_bases: the caller allocates it once for its largest batch and may reuse it
- * across calls on the same stream. */
+ * across calls on the same stream.  Calls on DIFFERENT streams may run concurrently on one handle when each has its own
+ * workspace (and result range): two batches in flight keep the chip full while the waves of the earlier launch leave one
+ * by one -- +6 % on 10 M-read batches, +20 % on 1 M-read batches. */
 int64_t sbwtgpu_search_workspace_bytes(int64_t total_bases);
 int  sbwtgpu_streaming_search_dev(const sbwtgpu_index *idx, const char *d_bases, int64_t total_bases,
                                   const int64_t *d_read_off, int64_t n_reads, int64_t *d_out,

@@ -7,7 +7,7 @@ for f in c2_bench.json c2_bench_under_rocprof.json c2_level1.json c2_level1_rocp
          lane_stats.txt timeline.txt two_in_flight.txt; do
   cp $S/$f profiles/${R}_$f
 done
-tail -4 $S/gputest.log > profiles/${R}_gputest_tail.txt
+( grep -E "passed|failed" $S/gputest.log | tail -2; tail -4 $S/gputest.log ) > profiles/${R}_gputest_tail.txt
 sed "s/${TAG}_/${R}_/g" $S/traffic.json > profiles/traffic.json
 python - <<PY
 import json, bench
