@@ -318,6 +318,7 @@ def main() -> int:
     ap.add_argument("--no-end-to-end", action="store_true",
                     help="skip the end-to-end leg (host buffers over PCIe, and the `sbwt search` CLI on a FASTQ file)")
     ap.add_argument("--e2e-reads", type=int, default=2_000_000, help="reads of the end-to-end leg")
+    ap.add_argument("--no-int32-leg", action="store_true", help="skip the extra leg with int32 results on the device")
     ap.add_argument("--no-two-in-flight", action="store_true", help="skip the extra leg that issues the same steps on two streams")
     ap.add_argument("--no-cli-full", action="store_true", help="end-to-end leg: skip the `sbwt search` run on the whole batch")
     ap.add_argument("--config", type=int, default=2, choices=[2, 3, 5, 6],
@@ -565,6 +566,37 @@ def main() -> int:
     status = index.workspace_status(d_ws.data_ptr(), stream)
     if status != 0:
         raise SystemExit(f"search kernel reported status {status}")
+    # The same K steps with int32 results on the device (sbwtgpu_*_dev_i32; n_nodes < 2^31): every kernel writes 4 bytes per
+    # k-mer, half the write requests of a launch.  Reported beside the line: `value` is the reference's int64 interface.
+    int32_leg = None
+    if one_call and world == 1 and not args.no_int32_leg and index.n_nodes < (1 << 31) and n_kmers * 8 <= (24 << 30):
+        d32 = torch.empty(n_kmers, dtype=torch.int32, device=dev)
+
+        def step32():
+            index.streaming_search_dev_i32(d_bases.data_ptr(), total_bases, d_roff.data_ptr(), n_reads, d32.data_ptr(),
+                                           d_ooff.data_ptr(), d_ws.data_ptr(), ws_bytes, stream, streaming)
+        step32()
+        torch.cuda.synchronize()
+        capi.set_tuning("kernel_events", 1)
+        t3 = time.perf_counter()
+        for _ in range(args.steps):
+            step32()
+        torch.cuda.synchronize()
+        e3 = time.perf_counter() - t3
+        kt3 = capi.kernel_times()
+        capi.set_tuning("kernel_events", 0)
+        same = True
+        CH = 1 << 28                                    # compared in pieces: no second 10 GB array
+        for lo in range(0, n_kmers, CH):
+            same = same and bool(torch.equal(d32[lo:lo + CH].to(torch.int64), d_out[lo:lo + CH]))
+        int32_leg = {"ms_per_step": e3 / args.steps * 1e3, "value": n_kmers * args.steps / e3, "unit": "k-mers/s",
+                     "kernel_ms": float(np.mean(kt3[-args.steps:])) if len(kt3) >= args.steps else None,
+                     "results_identical": same,
+                     "note": "sbwtgpu_streaming_search_dev_i32 / sbwtgpu_search_dev_i32: the same search writing int32 results (4 bytes per k-mer instead of 8)"}
+        del d32
+        if not same:
+            raise SystemExit("int32 results differ from the int64 results")
+        # (the workspace counters below are this leg's: the same work)
     # The same K steps once more with TWO batches in flight (two streams, workspaces and result buffers): a launch ends in
     # ~0.5 ms in which its waves leave one by one (tools/timeline_fused.py); with a second launch queued behind, the chip
     # stays full.  Reported beside the line, never as `value`: `value` is one launch at a time, like its kernel_ms.
@@ -670,6 +702,8 @@ def main() -> int:
             "kernel_only_kmers_per_s": n_kmers / (kernel_ms * 1e-3),
         },
     }
+    if int32_leg is not None:
+        result["int32_results_on_device"] = int32_leg
     if two_in_flight is not None:
         result["two_batches_in_flight"] = two_in_flight
     if t_bcast is not None:

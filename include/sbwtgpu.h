@@ -198,8 +198,8 @@ int  sbwtgpu_streaming_search_batch(const sbwtgpu_index *idx, const char *bases,
 int  sbwtgpu_search_batch(const sbwtgpu_index *idx, const char *bases, const int64_t *read_off,
                           int64_t n_reads, int64_t *out, const int64_t *out_off);
 /* The same two calls with int32 results (result compaction; consumer: print_vector,
- * src/CLI/sbwt_search.cpp:21-43, which only prints the values): the device narrows before the copy, so a result costs
- * 4 bytes of PCIe instead of 8.  Only for indexes of fewer than 2^31 columns (SBWTGPU_ERR_INVALID_ARG otherwise); -1
+ * src/CLI/sbwt_search.cpp:21-43, which only prints the values): the kernels write int32 themselves, so a result costs
+ * 4 bytes of HBM writes and of PCIe instead of 8.  Only for indexes of fewer than 2^31 columns (SBWTGPU_ERR_INVALID_ARG otherwise); -1
  * stays -1.  out[] is indexed like the int64 calls' (out_off in results, not bytes). */
 int  sbwtgpu_streaming_search_batch_i32(const sbwtgpu_index *idx, const char *bases, const int64_t *read_off,
                                         int64_t n_reads, int32_t *out, const int64_t *out_off);
@@ -243,6 +243,17 @@ int  sbwtgpu_search_dev(const sbwtgpu_index *idx, const char *d_bases, int64_t t
                         const int64_t *d_read_off, int64_t n_reads, int64_t *d_out,
                         const int64_t *d_out_off, void *d_workspace, int64_t workspace_bytes,
                         void *stream);
+/* The same two calls with int32 results on the device (d_out is an int32 array indexed by d_out_off, in results): every kernel
+ * of the route writes 4 bytes per k-mer, half the write requests of a launch (they are 40 % of its time: +20-25 % k-mers/s on
+ * BASELINE config 2).  Indexes of fewer than 2^31 columns only (SBWTGPU_ERR_INVALID_ARG otherwise); -1 stays -1. */
+int  sbwtgpu_streaming_search_dev_i32(const sbwtgpu_index *idx, const char *d_bases, int64_t total_bases,
+                                      const int64_t *d_read_off, int64_t n_reads, int32_t *d_out,
+                                      const int64_t *d_out_off, void *d_workspace, int64_t workspace_bytes,
+                                      void *stream);
+int  sbwtgpu_search_dev_i32(const sbwtgpu_index *idx, const char *d_bases, int64_t total_bases,
+                            const int64_t *d_read_off, int64_t n_reads, int32_t *d_out,
+                            const int64_t *d_out_off, void *d_workspace, int64_t workspace_bytes,
+                            void *stream);
 int  sbwtgpu_rank_dev(const sbwtgpu_index *idx, const int64_t *d_pos, const char *d_sym, int64_t n,
                       int64_t *d_out, void *stream);
 /* The two halves of the calls above, for callers that re-run a search on bases that are already

@@ -37,6 +37,7 @@ EXPORTED_SYMBOLS = [
     "sbwtgpu_build_plain_matrix", "sbwtgpu_free_plain_matrix",
     "sbwtgpu_partial_search_batch", "sbwtgpu_get_kmer_batch", "sbwtgpu_select_batch",
     "sbwtgpu_search_workspace_bytes", "sbwtgpu_streaming_search_dev", "sbwtgpu_search_dev",
+    "sbwtgpu_streaming_search_dev_i32", "sbwtgpu_search_dev_i32",
     "sbwtgpu_rank_dev", "sbwtgpu_encode_bases_dev", "sbwtgpu_search_encoded_dev",
     "sbwtgpu_workspace_status", "sbwtgpu_workspace_stats", "sbwtgpu_kernel_times",
     "sbwtgpu_format_text_bound", "sbwtgpu_format_scratch_bytes", "sbwtgpu_format_results_dev",
@@ -125,6 +126,12 @@ def lib() -> C.CDLL:
     L.sbwtgpu_search_workspace_bytes.restype = i64
     L.sbwtgpu_streaming_search_dev.argtypes = [vp, vp, i64, vp, i64, vp, vp, vp, i64, vp]
     L.sbwtgpu_search_dev.argtypes = [vp, vp, i64, vp, i64, vp, vp, vp, i64, vp]
+    try:
+        L.sbwtgpu_streaming_search_dev_i32.argtypes = [vp, vp, i64, vp, i64, vp, vp, vp, i64, vp]
+        L.sbwtgpu_search_dev_i32.argtypes = [vp, vp, i64, vp, i64, vp, vp, vp, i64, vp]
+    except AttributeError:                      # an older A/B build named by SBWTGPU_LIB
+        if not os.environ.get("SBWTGPU_LIB"):
+            raise
     L.sbwtgpu_rank_dev.argtypes = [vp, vp, vp, i64, vp, vp]
     L.sbwtgpu_workspace_status.argtypes = [vp, vp, C.POINTER(ci)]
     L.sbwtgpu_encode_bases_dev.argtypes = [vp, vp, i64, vp, i64, vp]
@@ -400,6 +407,12 @@ class Index:
                              d_out_off: int, d_ws: int, ws_bytes: int, stream: int = 0, streaming: bool = True):
         fn = lib().sbwtgpu_streaming_search_dev if streaming else lib().sbwtgpu_search_dev
         _check(fn(self._h, d_bases, total_bases, d_read_off, n_reads, d_out, d_out_off, d_ws, ws_bytes, stream))
+
+    def streaming_search_dev_i32(self, d_bases: int, total_bases: int, d_read_off: int, n_reads: int, d_out32: int,
+                                 d_out_off: int, d_ws: int, ws_bytes: int, stream: int = 0, streaming: bool = True):
+        """The same with an int32 result array on the device (sbwtgpu_*_dev_i32)."""
+        fn = lib().sbwtgpu_streaming_search_dev_i32 if streaming else lib().sbwtgpu_search_dev_i32
+        _check(fn(self._h, d_bases, total_bases, d_read_off, n_reads, d_out32, d_out_off, d_ws, ws_bytes, stream))
 
     def encode_bases_dev(self, d_bases: int, total_bases: int, d_ws: int, ws_bytes: int, stream: int = 0):
         _check(lib().sbwtgpu_encode_bases_dev(self._h, d_bases, total_bases, d_ws, ws_bytes, stream))

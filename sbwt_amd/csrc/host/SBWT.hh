@@ -555,6 +555,11 @@ private:
         detail::gpu_check(sbwtgpu_index_create(&d, detail::default_device(), &p->h));
         sbwtgpu_index_info info;
         detail::gpu_check(sbwtgpu_index_get_info(p->h, &info));
+        if (info.image_level > 0)       // the library steps down when device memory (or "max_image_bytes") does not hold the full image
+            write_log("Device image at level " + std::to_string(info.image_level) +
+                          (info.image_level == 1 ? " (no path order / transition table" : " (blocks and dense prefix table only") +
+                          "): searches run on the blocks-only kernel, three to four times slower than on the full image",
+                      LogLevel::MAJOR);
         C.assign(info.C, info.C + 4);
         kmer_prefix_precalc.assign(precalc_k ? ((size_t)1 << (2 * precalc_k)) : 0, {0, 0});
         static_assert(sizeof(std::pair<int64_t, int64_t>) == 16, "pair<int64,int64> must be 16 bytes");

@@ -67,6 +67,7 @@ struct SbwtIndexView {
     unsigned n_tslots;              // ... and their number (any: the hash is scaled to it)
     int stab_pos;                   // sparse entries are whole k-mers stored with their path position
     int debug;                      // experiments only: bit0 = skip result stores
+    int out32 = 0;                  // results are written as int32 (the *_i32 entry points; n_nodes < 2^31): the result pointer is an int32 array
     int force_mega;                 // one mega block whose counts do not fit 32 bits (dense rank-only images): cnt is relative
                                     // to mega[c][0] although n_mega == 1
 };
@@ -207,7 +208,6 @@ void sbwt_launch_select(const SbwtIndexView &ix, const long long *d_j, const cha
 long long sbwt_format_scratch_bytes(long long n_reads);
 void sbwt_launch_format(const long long *d_vals, const long long *d_out_off, long long n_reads, char *d_text,
                         long long *d_line_off, void *d_scratch, hipStream_t stream);
-void sbwt_launch_narrow_i32(const long long *d_in, int *d_out, long long n, hipStream_t stream);      // 16-byte aligned buffers
 long long sbwt_blocks_scratch_bytes(long long n_nodes);
 int sbwt_blocks_count(const unsigned long long *d_bits, long long n_nodes, void *d_scratch, long long totals[5], hipStream_t st);
 void sbwt_blocks_fill(const unsigned long long *d_bits, const unsigned long long *d_ssup, long long n_nodes, void *d_scratch,

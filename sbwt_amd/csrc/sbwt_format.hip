@@ -87,18 +87,3 @@ void sbwt_launch_format(const long long *d_vals, const long long *d_out_off, lon
 
 // scratch: last[n] + next[n] bytes + acc[n_blocks] words
 
-// ---- result compaction: int64 -> int32 on the device, for indexes of fewer than 2^31 columns.  Halves the
-// bytes the results take over PCIe (sbwtgpu_*_batch_i32); -1 stays -1.
-__global__ void __launch_bounds__(256) k_narrow_i32(const i64 *__restrict__ in, int *__restrict__ out, i64 n) {
-    const i64 t = ((i64)blockIdx.x * 256 + threadIdx.x) * 4;
-    if (t + 3 < n) {
-        const longlong2 a = *reinterpret_cast<const longlong2 *>(in + t), b = *reinterpret_cast<const longlong2 *>(in + t + 2);
-        *reinterpret_cast<int4 *>(out + t) = make_int4((int)a.x, (int)a.y, (int)b.x, (int)b.y);
-    } else {
-        for (i64 u = t; u < n; u++) out[u] = (int)in[u];
-    }
-}
-void sbwt_launch_narrow_i32(const long long *d_in, int *d_out, long long n, hipStream_t stream) {
-    if (n <= 0) return;
-    hipLaunchKernelGGL(k_narrow_i32, dim3(grid_for((n + 3) / 4)), dim3(256), 0, stream, d_in, d_out, (i64)n);
-}

@@ -35,6 +35,21 @@ __device__ __forceinline__ void st_stream2(i64 *p, i64 a, i64 b) {
     i64x2_a8 v = {a, b};
     __builtin_nontemporal_store(v, reinterpret_cast<i64x2_a8 *>(p));
 }
+// a result / two consecutive results at slot `at` of the caller's array: int64, or int32 when the call asked for that
+// (o32 is wave-uniform: one launch writes one kind)
+typedef int i32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));
+__device__ __forceinline__ void st_res(i64 *out, i64 at, i64 v, int o32) {
+    if (o32) __builtin_nontemporal_store((int)v, reinterpret_cast<int *>(out) + at);
+    else st_stream(out + at, v);
+}
+__device__ __forceinline__ void st_res2(i64 *out, i64 at, i64 a, i64 b, int o32) {
+    if (o32) {
+        i32x2_a4 v = {(int)a, (int)b};
+        __builtin_nontemporal_store(v, reinterpret_cast<i32x2_a4 *>(reinterpret_cast<int *>(out) + at));
+    } else {
+        st_stream2(out + at, a, b);
+    }
+}
 __device__ __forceinline__ uint4 ld_stream(const uint4 *p) {
     u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p));
     return make_uint4(v.x, v.y, v.z, v.w);

@@ -281,7 +281,8 @@ __global__ void __launch_bounds__(256) k_search(SbwtIndexView ix, const uint4 *_
 
         // ---- write one k-mer result and pick the next state ----
         if (emit) {
-            out[obase + i] = res;
+            if (ix.out32) reinterpret_cast<int *>(out)[obase + i] = (int)res;
+            else out[obase + i] = res;
             i++;
             if (i == m) {
                 mode = M_IDLE;
@@ -1109,8 +1110,8 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
                     const int v0 = (x0[u] >> 31) ? ((x0[u] == 0xFFFFFFFFu) ? -1 : (int)(x0[u] & 0x7FFFFFFFu)) : w0[u];
                     const int v1 = (x1[u] >> 31) ? ((x1[u] == 0xFFFFFFFFu) ? -1 : (int)(x1[u] & 0x7FFFFFFFu)) : w1[u];
                     if (!(ix.debug & 1)) {
-                        if (fj[u] + 1 < fe[u]) st_stream2(out + fob[u] + fj[u], (i64)v0, (i64)v1);
-                        else if (fj[u] < fe[u]) st_stream(out + fob[u] + fj[u], (i64)v0);
+                        if (fj[u] + 1 < fe[u]) st_res2(out, fob[u] + fj[u], (i64)v0, (i64)v1, ix.out32);
+                        else if (fj[u] < fe[u]) st_res(out, fob[u] + fj[u], (i64)v0, ix.out32);
                     }
                 }
                 if (long_read) {
@@ -1134,8 +1135,8 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
                             const int v0 = (c0.x >> 31) ? ((c0.x == 0xFFFFFFFFu) ? -1 : (int)(c0.x & 0x7FFFFFFFu)) : q0;
                             const int v1 = (c1.x >> 31) ? ((c1.x == 0xFFFFFFFFu) ? -1 : (int)(c1.x & 0x7FFFFFFFu)) : q1;
                             if (!(ix.debug & 1)) {
-                                if (j1 < e) st_stream2(out + fob[u] + j0, (i64)v0, (i64)v1);
-                                else if (j0 < e) st_stream(out + fob[u] + j0, (i64)v0);
+                                if (j1 < e) st_res2(out, fob[u] + j0, (i64)v0, (i64)v1, ix.out32);
+                                else if (j0 < e) st_res(out, fob[u] + j0, (i64)v0, ix.out32);
                             }
                         }
                     }
@@ -1165,8 +1166,8 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
                 const int nn = __shfl(nrun, srcl);
                 if (src >= 0 && sub < nn && !(ix.debug & 1)) {
                     const i64 val = (i64)(pos_t)stage[sub][(tid & ~63) + src];
-                    if (ix.debug & 2) out[d + sub] = val;
-                    else st_stream(out + d + sub, val);
+                    if ((ix.debug & 2) && !ix.out32) out[d + sub] = val;
+                    else st_res(out, d + sub, val, ix.out32);
                 }
             }
             if (fl) cnt = 0;
@@ -1188,8 +1189,8 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
                 const i64 d = __shfl(dst, srcl);
                 const int nn = __shfl(nrun, srcl);
                 if (src >= 0 && sub < nn && !(ix.debug & 1)) {
-                    if (ix.debug & 2) out[d + sub] = -1;
-                    else st_stream(out + d + sub, -1);
+                    if ((ix.debug & 2) && !ix.out32) out[d + sub] = -1;
+                    else st_res(out, d + sub, -1, ix.out32);
                 }
                 if ((served >> lane) & 1ull) { dst += DEPTH; nrun -= DEPTH; }
                 fm = __ballot(nrun > 0);

@@ -177,10 +177,10 @@ __device__ __forceinline__ u64 fz_encode32(const unsigned w[8], const unsigned t
     return codes;
 }
 
-// WIDE = false: k <= 31 -- a read follows its path in F_EXT, a substitution-safe step is bridged in one compare (F_BRIDGE):
+// O32: the results are written as int32 (sbwtgpu_*_dev_i32).  WIDE = false: k <= 31 -- a read follows its path in F_EXT, a substitution-safe step is bridged in one compare (F_BRIDGE):
 // round 3's walk, the leanest code for k-mers that cost one lookup.  WIDE = true: 31 < k <= 63 (and "debug" bit 64) -- both
 // are the one state F_CMP, with anchors, seeds and resumed compares around it.
-template <bool WIDE>
+template <bool WIDE, bool O32>
 __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const unsigned char *__restrict__ bases,
                                                           i64 total_bases, i64 *__restrict__ out, i64 n_reads,
                                                           SbwtWorkHeader *ws, unsigned *__restrict__ defer_list,
@@ -1102,8 +1102,8 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
                 const int q0 = (x0[u] >> 31) ? ((x0[u] == 0xFFFFFFFFu) ? -1 : (int)(x0[u] & 0x7FFFFFFFu)) : w0[u];
                 const int q1 = (x1[u] >> 31) ? ((x1[u] == 0xFFFFFFFFu) ? -1 : (int)(x1[u] & 0x7FFFFFFFu)) : w1[u];
                 if (!(ix.debug & 1)) {
-                    if (fj[u] + 1 < fe[u]) st_stream2(out + fob[u] + fj[u], (i64)q0, (i64)q1);
-                    else if (fj[u] < fe[u]) st_stream(out + fob[u] + fj[u], (i64)q0);
+                    if (fj[u] + 1 < fe[u]) st_res2(out, fob[u] + fj[u], (i64)q0, (i64)q1, O32);
+                    else if (fj[u] < fe[u]) st_res(out, fob[u] + fj[u], (i64)q0, O32);
                 }
             }
             if (long_read) {
@@ -1129,8 +1129,8 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
                         const int q0 = (c0s >> 31) ? ((c0s == 0xFFFFFFFFu) ? -1 : (int)(c0s & 0x7FFFFFFFu)) : y0;
                         const int q1 = (c1s >> 31) ? ((c1s == 0xFFFFFFFFu) ? -1 : (int)(c1s & 0x7FFFFFFFu)) : y1;
                         if (!(ix.debug & 1)) {
-                            if (j1 < e) st_stream2(out + fob[u] + j0, (i64)q0, (i64)q1);
-                            else if (j0 < e) st_stream(out + fob[u] + j0, (i64)q0);
+                            if (j1 < e) st_res2(out, fob[u] + j0, (i64)q0, (i64)q1, O32);
+                            else if (j0 < e) st_res(out, fob[u] + j0, (i64)q0, O32);
                         }
                     }
                 }
@@ -1282,12 +1282,13 @@ void sbwt_launch_search_fused(const SbwtIndexView &ix, const char *d_bases, long
     const unsigned g = (unsigned)(want < (i64)cap ? want : (i64)cap);
     if (ev_begin) (void)hipEventRecord(ev_begin, stream);
     // (k > 31: whole k-mers in the two-level table; "debug" bit 64: the wide walk for every k -- experiments and the fuzzer)
-    if ((ix.stab2 != nullptr && ix.p_sparse < ix.k) || (ix.debug & 64))
-        hipLaunchKernelGGL(k_search_fused<true>, dim3(g), dim3(256), 0, stream, ix, reinterpret_cast<const unsigned char *>(d_bases),
-                           (i64)total_bases, d_out, (i64)n_reads, ws, d_defer, d_read_off, d_out_off);
-    else
-        hipLaunchKernelGGL(k_search_fused<false>, dim3(g), dim3(256), 0, stream, ix, reinterpret_cast<const unsigned char *>(d_bases),
-                           (i64)total_bases, d_out, (i64)n_reads, ws, d_defer, d_read_off, d_out_off);
+    const bool wide = (ix.stab2 != nullptr && ix.p_sparse < ix.k) || (ix.debug & 64);
+#define FZ_LAUNCH(W, O) hipLaunchKernelGGL((k_search_fused<W, O>), dim3(g), dim3(256), 0, stream, ix, \
+                                           reinterpret_cast<const unsigned char *>(d_bases), (i64)total_bases, d_out, (i64)n_reads, ws, d_defer, \
+                                           d_read_off, d_out_off)
+    if (wide) { if (ix.out32) FZ_LAUNCH(true, true); else FZ_LAUNCH(true, false); }
+    else      { if (ix.out32) FZ_LAUNCH(false, true); else FZ_LAUNCH(false, false); }
+#undef FZ_LAUNCH
     if (ev_end) (void)hipEventRecord(ev_end, stream);
     // what the fused kernel did not take: everything when the reads are not of one length, else the reads it handed on
     sbwt_launch_encode_chained(d_bases, total_bases, d_packed, ws, d_defer, d_read_off, ix.k, stream);

@@ -92,6 +92,8 @@ static int tuning_variant() {
     return v;
 }
 static int g_variant_override = -1, g_probe_override = -1, g_debug = 0, g_derive_ssup = 1, g_kernel_events = 0;
+// set around a search call by the *_i32 entry points: the kernels of this call write int32 results (SbwtIndexView::out32)
+static thread_local int t_out32 = 0;
 static int64_t g_ev_count = 0;
 // depth of the sparse (hashed) prefix table built at index creation (capped at k and at 31 = one 62-bit key)
 // debug aid for the parity tests: fill the result range with a poison pattern before every search, so that a
@@ -150,6 +152,7 @@ struct sbwtgpu_index {
         v.has_ssup = h.has_ssup;
         v.probe_len = probe_len();
         v.debug = g_debug;
+        v.out32 = t_out32;
         v.force_mega = h.force_mega;
         v.p_sparse = (int)h.p_sparse;
         v.n_sb = (unsigned)h.n_sb;
@@ -876,7 +879,10 @@ int sbwtgpu_search_encoded_dev(const sbwtgpu_index *idx, int64_t total_bases, co
         HIP_TRY(hipMemcpyAsync(&ends[0], d_out_off, 8, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipMemcpyAsync(&ends[1], d_out_off + n_reads, 8, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
-        if (ends[1] > ends[0]) HIP_TRY(hipMemsetAsync(d_out + ends[0], 0xA5, (size_t)(ends[1] - ends[0]) * 8, st));
+        if (ends[1] > ends[0]) {
+                    const size_t vb = t_out32 ? 4 : 8;
+                    HIP_TRY(hipMemsetAsync(reinterpret_cast<char *>(d_out) + (size_t)ends[0] * vb, 0xA5, (size_t)(ends[1] - ends[0]) * vb, st));
+                }
     }
     // kernel: an explicit choice ("search_variant" / SBWTGPU_SEARCH_VARIANT), else by the index: the segment-list writer
     // where reads follow their paths for long (fewer than one column in 64 offers a choice of successors: config 2 has one
@@ -962,7 +968,10 @@ static int search_dev_common(const sbwtgpu_index *idx, const char *d_bases, int6
                 HIP_TRY(hipMemcpyAsync(&ends[0], d_out_off, 8, hipMemcpyDeviceToHost, st));
                 HIP_TRY(hipMemcpyAsync(&ends[1], d_out_off + n_reads, 8, hipMemcpyDeviceToHost, st));
                 HIP_TRY(hipStreamSynchronize(st));
-                if (ends[1] > ends[0]) HIP_TRY(hipMemsetAsync(d_out + ends[0], 0xA5, (size_t)(ends[1] - ends[0]) * 8, st));
+                if (ends[1] > ends[0]) {
+                    const size_t vb = t_out32 ? 4 : 8;
+                    HIP_TRY(hipMemsetAsync(reinterpret_cast<char *>(d_out) + (size_t)ends[0] * vb, 0xA5, (size_t)(ends[1] - ends[0]) * vb, st));
+                }
             }
             uint4 *packed = reinterpret_cast<uint4 *>(static_cast<char *>(d_ws) + sizeof(SbwtWorkHeader));
             unsigned *defer = reinterpret_cast<unsigned *>(static_cast<char *>(d_ws) + align256(ws_packed_bytes(total_bases)));
@@ -1006,6 +1015,32 @@ int sbwtgpu_search_dev(const sbwtgpu_index *idx, const char *d_bases, int64_t to
                        void *stream) {
     return search_dev_common(idx, d_bases, total_bases, d_read_off, n_reads, d_out, d_out_off, d_ws, ws_bytes, stream,
                              0);
+}
+
+// The same two calls with int32 results (result compaction): every kernel of the route writes 4 bytes per k-mer
+// instead of 8 -- half the write requests of a launch, which are 40 % of its time.
+static int search_dev_i32(const sbwtgpu_index *idx, const char *d_bases, int64_t total_bases, const int64_t *d_read_off,
+                          int64_t n_reads, int32_t *d_out, const int64_t *d_out_off, void *d_ws, int64_t ws_bytes, void *stream,
+                          int streaming) {
+    if (!idx) return fail(SBWTGPU_ERR_INVALID_ARG, "idx is NULL");
+    if (idx->h.n_nodes >= ((int64_t)1 << 31))
+        return fail(SBWTGPU_ERR_INVALID_ARG, "int32 results need an index of fewer than 2^31 columns (this one has %lld)",
+                    (long long)idx->h.n_nodes);
+    t_out32 = 1;
+    const int rc = search_dev_common(idx, d_bases, total_bases, d_read_off, n_reads, reinterpret_cast<int64_t *>(d_out), d_out_off,
+                                     d_ws, ws_bytes, stream, streaming);
+    t_out32 = 0;
+    return rc;
+}
+int sbwtgpu_streaming_search_dev_i32(const sbwtgpu_index *idx, const char *d_bases, int64_t total_bases,
+                                     const int64_t *d_read_off, int64_t n_reads, int32_t *d_out, const int64_t *d_out_off,
+                                     void *d_ws, int64_t ws_bytes, void *stream) {
+    return search_dev_i32(idx, d_bases, total_bases, d_read_off, n_reads, d_out, d_out_off, d_ws, ws_bytes, stream, 1);
+}
+int sbwtgpu_search_dev_i32(const sbwtgpu_index *idx, const char *d_bases, int64_t total_bases, const int64_t *d_read_off,
+                           int64_t n_reads, int32_t *d_out, const int64_t *d_out_off, void *d_ws, int64_t ws_bytes,
+                           void *stream) {
+    return search_dev_i32(idx, d_bases, total_bases, d_read_off, n_reads, d_out, d_out_off, d_ws, ws_bytes, stream, 0);
 }
 
 int sbwtgpu_rank_dev(const sbwtgpu_index *idx, const int64_t *d_pos, const char *d_sym, int64_t n, int64_t *d_out,
@@ -1217,7 +1252,7 @@ const int64_t PIPE_MIN = (int64_t)64 << 20;
 }  // namespace
 
 // ro / oo: nv + 1 offsets into src_bases / out (rebased to 0 or not: only ro[0], oo[0] and differences are used)
-// out32 != nullptr (and out == nullptr): the results leave the device as int32 (k_narrow_i32): half the bytes over PCIe
+// out32 != nullptr (and out == nullptr): the kernels write int32 results (SbwtIndexView::out32): half the bytes over PCIe
 static int search_host_pipelined(const sbwtgpu_index *idx, const char *src_bases, const int64_t *ro, const int64_t *oo,
                                  int64_t nv, int64_t *out, int streaming, int32_t *out32 = nullptr) {
     const int64_t vb = out32 ? 4 : 8;                   // bytes of a result on its way to the host
@@ -1246,8 +1281,7 @@ static int search_host_pipelined(const sbwtgpu_index *idx, const char *src_bases
     const int64_t ws_bytes = sbwtgpu_search_workspace_bytes(max_bases);
     const int64_t need_in = a256(max_bases + 16) + 2 * a256((max_reads + 1) * 8);
     const int64_t need_out = pin_out ? 0 : a256(max_vals * vb + 8);
-    const int64_t need_dev = a256(max_bases + 16) + 2 * a256((max_reads + 1) * 8) + a256(max_vals * 8 + 8) + a256(ws_bytes) +
-                             (out32 ? a256(max_vals * 4 + 16) : 0);
+    const int64_t need_dev = a256(max_bases + 16) + 2 * a256((max_reads + 1) * 8) + a256(max_vals * 8 + 8) + a256(ws_bytes);
     DeviceGuard guard(idx->device);
     PipeSlot S[2];
     {
@@ -1287,7 +1321,7 @@ static int search_host_pipelined(const sbwtgpu_index *idx, const char *src_bases
     }
     if (rc != SBWTGPU_OK) { (void)hipGetLastError(); cleanup(); return rc; }
     bool bug = false;
-    struct Carve { char *bases; int64_t *roff, *ooff, *out; char *ws; int32_t *out32; };
+    struct Carve { char *bases; int64_t *roff, *ooff, *out; char *ws; };
     auto carve = [&](PipeSlot &P) {
         Carve c;
         char *p = P.d_mem;
@@ -1295,8 +1329,7 @@ static int search_host_pipelined(const sbwtgpu_index *idx, const char *src_bases
         c.roff = (int64_t *)p; p += a256((max_reads + 1) * 8);
         c.ooff = (int64_t *)p; p += a256((max_reads + 1) * 8);
         c.out = (int64_t *)p; p += a256(max_vals * 8 + 8);
-        c.ws = p; p += a256(ws_bytes);
-        c.out32 = (int32_t *)p;
+        c.ws = p;
         return c;
     };
     auto submit = [&](int64_t c) -> int {
@@ -1312,14 +1345,12 @@ static int search_host_pipelined(const sbwtgpu_index *idx, const char *src_bases
             (e = hipMemcpyAsync(d.roff, hro, (size_t)(nr + 1) * 8, hipMemcpyHostToDevice, P.st)) != hipSuccess ||
             (e = hipMemcpyAsync(d.ooff, hoo, (size_t)(nr + 1) * 8, hipMemcpyHostToDevice, P.st)) != hipSuccess)
             return fail(SBWTGPU_ERR_HIP, "H2D copy: %s", hipGetErrorString(e));
+        t_out32 = out32 ? 1 : 0;                        // (int32 results: the kernels write them into the same device range)
         int r2 = search_dev_common(idx, d.bases, nb, d.roff, nr, d.out, d.ooff, d.ws, ws_bytes, P.st, streaming);
+        t_out32 = 0;
         if (r2 != SBWTGPU_OK) return r2;
         char *target = pin_out ? (out32 ? (char *)(out32 + oo[lo]) : (char *)(out + oo[lo])) : P.h_out;
         const void *from = d.out;
-        if (out32) {
-            sbwt_launch_narrow_i32(reinterpret_cast<const long long *>(d.out), d.out32, nvals, P.st);
-            from = d.out32;
-        }
         if ((e = hipMemcpyAsync(target, from, (size_t)(nvals * vb), hipMemcpyDeviceToHost, P.st)) != hipSuccess ||
             (e = hipMemcpyAsync(P.h_status, d.ws + offsetof(SbwtWorkHeader, status), 4, hipMemcpyDeviceToHost, P.st)) != hipSuccess)
             return fail(SBWTGPU_ERR_HIP, "D2H copy: %s", hipGetErrorString(e));
@@ -1467,7 +1498,7 @@ int sbwtgpu_search_batch(const sbwtgpu_index *idx, const char *bases, const int6
 }
 
 // Results as int32 (result compaction): for indexes of fewer than 2^31 columns every rank fits, -1 stays -1.  The
-// device narrows (k_narrow_i32) before the copy, so a result costs 4 bytes of PCIe instead of 8.  Large batches go through
+// kernels write int32 themselves, so a result costs 4 bytes of HBM writes and of PCIe instead of 8.  Large batches go through
 // the same two-stream pipeline as the int64 calls; small ones through the int64 call and a host loop.
 static int search_host_i32(const sbwtgpu_index *idx, const char *bases, const int64_t *read_off, int64_t n_reads,
                            int32_t *out, const int64_t *out_off, int streaming) {

@@ -240,7 +240,7 @@ def test_text_stream_pieces_and_kernel_events(gpu):
 
 def test_int32_results_small_and_pipelined(gpu):
     """sbwtgpu_streaming_search_batch_i32 / sbwtgpu_search_batch_i32 (result compaction): the same values as
-    the int64 calls, narrowed on the device -- a small batch (host loop) and one large enough for the two-stream pipeline,
+    the int64 calls, written as int32 by the kernels -- a small batch (host loop) and one large enough for the two-stream pipeline,
     pageable and pinned destinations, N and short reads among them."""
     import torch
     genomes = [synth.random_genome(300_000, 3)]
@@ -261,3 +261,47 @@ def test_int32_results_small_and_pipelined(gpu):
     capi._check(capi.lib().sbwtgpu_streaming_search_batch_i32(idx.handle, hb.data_ptr(), off.ctypes.data, len(off) - 1, ho.data_ptr(),
                                                               oo.ctypes.data))
     assert np.array_equal(ho.numpy().astype(np.int64), want)
+
+
+@pytest.mark.parametrize("k,streaming", [(30, True), (31, False), (63, False)])
+def test_int32_results_on_the_device_every_route(gpu, k, streaming):
+    """sbwtgpu_streaming_search_dev_i32 / sbwtgpu_search_dev_i32: every kernel of every route writes int32 results into the
+    caller's device array -- the same values as the int64 call, nothing outside the result range touched.  Reads of one
+    length, ragged ones (some shorter than k), reads of 250 and 5 000 bases (pieces / zones), N and lower case (handed on to
+    the general kernel), with the results poisoned first."""
+    import torch
+    dev = torch.device("cuda:0")
+    genomes = [synth.random_genome(200_000, 21)]
+    genomes.append(synth.mutate(genomes[0], 0.05, 22))
+    bits = capi.build_bits_gpu([g.tobytes() for g in genomes], k, False, streaming)
+    idx = capi.Index.create(bits.cols[0], bits.cols[1], bits.cols[2], bits.cols[3], bits.ssup, bits.n_nodes, k, bits.n_kmers, 8)
+    batches = [synth.sample_reads(genomes, 6000, 150, 0.01, 31), synth.ragged_reads(genomes, 5000, 20, 250, 0.01, 32),
+               synth.sample_reads(genomes, 3000, 250, 0.01, 33), synth.sample_reads(genomes, 40, 5000, 0.01, 34)]
+    b4, o4 = synth.sample_reads(genomes, 4000, 150, 0.01, 35)
+    b4 = synth.inject(synth.inject(b4, 300, ord("N"), 5), 300, ord("a"), 6)
+    batches.append((b4, o4))
+    st = torch.cuda.current_stream().cuda_stream
+    capi.set_tuning("poison_results", 1)
+    try:
+        for bases, off in batches:
+            ooff = capi.out_offsets(off, k)
+            n_out = int(ooff[-1])
+            d_b, d_ro, d_oo = torch.from_numpy(bases).to(dev), torch.from_numpy(off).to(dev), torch.from_numpy(ooff).to(dev)
+            wsb = capi.search_workspace_bytes(d_b.numel())
+            d_ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+            d64 = torch.empty(n_out, dtype=torch.int64, device=dev)
+            for variant in (5, 4, 1, 0):
+                capi.set_tuning("search_variant", variant)
+                try:
+                    idx.streaming_search_dev(d_b.data_ptr(), d_b.numel(), d_ro.data_ptr(), len(off) - 1, d64.data_ptr(), d_oo.data_ptr(),
+                                             d_ws.data_ptr(), wsb, st, streaming)
+                    d32 = torch.full((n_out + 64,), 77, dtype=torch.int32, device=dev)     # 64 guard values behind the results
+                    idx.streaming_search_dev_i32(d_b.data_ptr(), d_b.numel(), d_ro.data_ptr(), len(off) - 1, d32.data_ptr(),
+                                                 d_oo.data_ptr(), d_ws.data_ptr(), wsb, st, streaming)
+                finally:
+                    capi.set_tuning("search_variant", -1)
+                torch.cuda.synchronize()
+                assert torch.equal(d32[:n_out].to(torch.int64), d64), (variant, len(off))
+                assert bool((d32[n_out:] == 77).all()), variant
+    finally:
+        capi.set_tuning("poison_results", 0)

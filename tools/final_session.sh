@@ -13,7 +13,7 @@ timeout 900 python bench.py --config 3 --steps 5 > $O/c3_bench.json 2> $O/c3_ben
 PMC="FETCH_SIZE|WRITE_SIZE|TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum TCC_EA0_RDREQ_128B_sum|TCC_HIT_sum TCC_MISS_sum|SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES"
 prof() {   # prof <name> <config> <level> <variant> <reads> <bench args...>
   local name=$1 cfg=$2 lvl=$3 var=$4 reads=$5; shift 5
-  PMC_GROUPS="$PMC" bash tools/profile.sh ${TAG}_$name "$@" --warmup 1 --no-cpu-baseline --no-end-to-end --no-two-in-flight > /dev/null 2>&1
+  PMC_GROUPS="$PMC" bash tools/profile.sh ${TAG}_$name "$@" --warmup 1 --no-cpu-baseline --no-end-to-end --no-two-in-flight --no-int32-leg > /dev/null 2>&1
   cp gpurun_out/prof_${TAG}_$name/summary.txt $O/${name}_rocprof_summary.txt
   cp gpurun_out/prof_${TAG}_$name/trace_bench.json $O/${name}_bench_under_rocprof.json
   python tools/make_traffic_json.py $O/${name}_rocprof_summary.txt $cfg $reads ${TAG}_${name}_rocprof_summary.txt $lvl $var > /dev/null 2>> $O/traffic.err

@@ -15,6 +15,23 @@ class FuzzMismatch(AssertionError):
     pass
 
 
+def dev_i32(idx, bases, off, k, streaming):
+    """The device-pointer call with int32 results (sbwtgpu_*_dev_i32), back as int64."""
+    import torch
+    dev = torch.device("cuda:0")
+    ooff = capi.out_offsets(off, k)
+    if len(bases) == 0 or int(ooff[-1]) == 0:
+        return np.zeros(0, dtype=np.int64)
+    d_b, d_ro, d_oo = torch.from_numpy(np.ascontiguousarray(bases)).to(dev), torch.from_numpy(off).to(dev), torch.from_numpy(ooff).to(dev)
+    wsb = capi.search_workspace_bytes(d_b.numel())
+    d_ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    d32 = torch.full((int(ooff[-1]),), -99, dtype=torch.int32, device=dev)
+    idx.streaming_search_dev_i32(d_b.data_ptr(), d_b.numel(), d_ro.data_ptr(), len(off) - 1, d32.data_ptr(), d_oo.data_ptr(),
+                                 d_ws.data_ptr(), wsb, torch.cuda.current_stream().cuda_stream, streaming)
+    torch.cuda.synchronize()
+    return d32.cpu().numpy().astype(np.int64)
+
+
 def reset_tuning():
     capi.set_tuning("search_variant", -1)
     capi.set_tuning("sort_reads", -1)
@@ -116,6 +133,8 @@ def _fuzz(budget, seed, max_cases):
             a = idx.streaming_search(bases, off)[0] if ssup else None
             b = idx.search(bases, off)[0]
             res[(v, -1)] = (a, b)
+            if bits.n_nodes < (1 << 31) and int(rng.integers(0, 4)) == 0:      # the same route writing int32 results
+                res[(v, 32)] = (dev_i32(idx, bases, off, k, True) if ssup else None, dev_i32(idx, bases, off, k, False))
         ref = res[(0, -1)]
 
         def explain(got, want):
