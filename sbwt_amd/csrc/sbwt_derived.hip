@@ -182,7 +182,8 @@ __global__ void __launch_bounds__(256) k_pf_insert(const SpItem *__restrict__ it
 }
 // pos != nullptr: the items are whole k-mers (one column each); the second payload word is the column's path position
 __global__ void __launch_bounds__(256) k_sp_insert(const SpItem *__restrict__ items, const u64 *n, uint4 *table,
-                                                   unsigned n_buckets, const unsigned *__restrict__ pos) {
+                                                   unsigned n_buckets, const unsigned *__restrict__ pos,
+                                                   const unsigned *__restrict__ upos) {
     u64 t = (u64)blockIdx.x * 256 + threadIdx.x;
     if (t >= *n) return;
     const SpItem it = items[t];
@@ -194,7 +195,9 @@ __global__ void __launch_bounds__(256) k_sp_insert(const SpItem *__restrict__ it
             if (old == SBWT_SP_EMPTY) {
                 unsigned *pay = reinterpret_cast<unsigned *>(word) + 2;
                 pay[0] = (unsigned)it.l;
-                pay[1] = pos ? pos[it.l] : (unsigned)(it.r - it.l);
+                // depth k: the column's path position.  Depth < k: the interval's width -- or, for a prefix with ONE column when
+                // the image has a second level and a path order, that column's position (a seed for an alignment, no pos[] gather)
+                pay[1] = pos ? pos[it.l] : (upos && it.r == it.l) ? (SBWT_SP_UNIQ | upos[it.l]) : (unsigned)(it.r - it.l);
                 return;
             }
         }
@@ -1003,7 +1006,8 @@ int sbwt_launch_build_sparse(const SbwtIndexView &ix, int p_dense, int p_sparse,
         with_pos = h_flag ? 0 : 1;
     }
     hipLaunchKernelGGL(k_sp_insert, dim3(grid_for(ix.n_nodes + 64)), dim3(256), 0, stream, in, counters + ci, d_table,
-                       (unsigned)n_buckets, with_pos ? d_pos : (const unsigned *)nullptr);
+                       (unsigned)n_buckets, with_pos ? d_pos : (const unsigned *)nullptr,
+                       (!with_pos && d_pos && d_table2 && ix.k > p_sparse) ? d_pos : (const unsigned *)nullptr);
     if (d_table2 && ix.k > p_sparse) {
         // second level: carry every depth-p_sparse prefix on to depth k, remembering where it started
         (void)hipMemsetAsync(d_table2, 0, (size_t)32 * (size_t)n_entries2, stream);

@@ -111,6 +111,7 @@ struct SbwtBlobHeader {
 // Sparse prefix table entry words
 #define SBWT_SP_EMPTY (1ull << 63)              // the whole word of a free entry
 #define SBWT_SP_OVERFLOW (1ull << 62)           // set in entry 0 of a bucket some key had to skip
+#define SBWT_SP_UNIQ 0x80000000u                  // depth < k, payload word .w: the prefix has ONE column; the low 31 bits are its path position
 #define SBWT_SP_MAX_DEPTH 31                    // keys are 2 bits per base in the low 62 bits
 #define SBWT_SP_HASH 0x9E3779B97F4A7C15ull
 // second-level sparse table hash: (first column of the prefix's interval, remaining bases)

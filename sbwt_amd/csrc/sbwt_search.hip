@@ -932,7 +932,8 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
                             r = l;
                             if (PATH) tpos = (pos_t)(m0 ? v1.w : v2.w);
                         } else {
-                            r = l + (pos_t)(m0 ? v1.w : v2.w);
+                            const unsigned wv = m0 ? v1.w : v2.w;          // (SBWT_SP_UNIQ: one column, the rest is its position)
+                            r = (wv & SBWT_SP_UNIQ) ? l : l + (pos_t)wv;
                         }
                     } else if (w0 & SBWT_SP_OVERFLOW) {
                         again = true;                  // a later bucket may hold the key

@@ -553,6 +553,7 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
         bool w31 = false;                              // k > 31: a filter window was (perhaps) present: try the 31-base window around b
         int m2 = -1;                                   // F_CMP: the second difference (this iteration's)
         int seed_col = -1;                             // k > 31: the column of a unique 31-mer whose k-mer was not there: a SEED for an alignment
+        bool seed_is_pos = false;                      // ... seed_col is that column's path position already (the table entry carried it)
         bool imprecise = false;                        // this iteration's failure is a table-level miss
         int pre_n = 0, abs_n = 0, post_n = 0;          // F_CMP's verdicts: a run along the path, k-mers absent by a safe bit, a run
         int cact = 0, ctr = 0;                         // ... and what follows (CA_*)
@@ -840,7 +841,10 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
                     again = true;
                     j++;
                 } else {
-                    if (seed_ok && r == l) seed_col = l;   // the 31-mer is there, in ONE column: a seed for an alignment
+                    if (seed_ok && (r < 0 || r == l)) {    // the 31-mer is there, in ONE column: a seed for an alignment
+                        seed_is_pos = r < 0;               // ... whose path position came with the entry
+                        seed_col = r < 0 ? -1 - r : l;
+                    }
                     l = -1;
                 }
             } else if (wk == 1) {
@@ -859,7 +863,10 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
                         r = l;
                         tpos = (int)(hit0 ? v1.w : v2.w);
                     } else {
-                        r = l + (int)(hit0 ? v1.w : v2.w);
+                        // (a prefix with one column carries that column's path position: kept in r, negative, across the
+                        // second-level lookup -- the interval's end is not needed on that route)
+                        const unsigned wv = hit0 ? v1.w : v2.w;
+                        r = !(wv & SBWT_SP_UNIQ) ? l + (int)wv : (WIDE && ix.stab2 && ps < k) ? -1 - (int)(wv & ~SBWT_SP_UNIQ) : l;
                     }
                 } else if (w0 & SBWT_SP_OVERFLOW) {
                     again = true;                      // a later bucket may hold the key
@@ -879,8 +886,9 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
                     imprecise = (wk != 2 && wk != 6 && !(fl & CF_WIN31));  // ... but where inside the window it fails is not known
                 } else if (wk == 3 || wk == 6) {
                     ev = FE_PRES;
-                } else if (wk == 1 && ps < k && ix.stab2 && (fl & CF_ANCH) && seed_ok && r == l && CF_CMP_LEFT(fl) > 0) {
-                    seed_col = l;                      // an anchor's 31-mer in ONE column: that is a seed already -- its position
+                } else if (wk == 1 && ps < k && ix.stab2 && (fl & CF_ANCH) && seed_ok && (r < 0 || r == l) && CF_CMP_LEFT(fl) > 0) {
+                    seed_is_pos = r < 0;
+                    seed_col = r < 0 ? -1 - r : l;     // an anchor's 31-mer in ONE column: that is a seed already -- its position
                     ev = FE_FAIL;                      // aligns the read without the k-mer's other 32 bases having to be clean
                 } else if (wk == 1 && ps < k && ix.stab2) {
                     wk = 5;                            // the prefix is there (l = its first column): the rest in one more gather
@@ -1160,7 +1168,14 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
             // left its path, once every k-mer that holds the known bad base is answered.  F_CMP's conclusions are exact
             // whatever the alignment is worth.
             fl -= 1u << 18;
-            if (seed_col >= 0) {
+            bool keep_plan = false;
+            if (seed_col >= 0 && seed_is_pos) {
+                // (the position is known: what F_POS would do with it)
+                co = seed_col - (wstart + ps);
+                fl &= ~(CF_SEED | CF_M1 | CF_M2 | CF_ONP);
+                if ((unsigned)(co + i) < (unsigned)ix.n_pos) { cP = i; m1 = -1; mode = F_CMP; }
+                else keep_plan = true;                 // (no such alignment: the planner, one alignment poorer)
+            } else if (seed_col >= 0) {
                 l = seed_col;
                 co = -(wstart + ps);
                 fl |= CF_SEED;
@@ -1171,7 +1186,7 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
                 fl &= ~(CF_M1 | CF_M2 | CF_ONP);
                 mode = F_CMP;
             }
-            do_plan = false;
+            do_plan = keep_plan;
         }
         if (do_plan) {
             // where the next walk starts (see k_search_cert): at k-mer i itself, or close to the last failure position b
