@@ -72,6 +72,8 @@
 #define CF_MISS 1024u            // two bits: own lookups of consecutive k-mers that failed without a certificate reaching further
 #define CF_MISS_MASK 3072u
 #define CF_WIN31 8192u           // k > 31: the sparse lookup in flight is a 31-base WINDOW probe (a certificate), not a k-mer's prefix
+#define CF_SEED2 16384u          // k > 31: the seed's 31-prefix has TWO columns (l, l + 1): after the position lookup l holds the second
+                                 // one's path position -- tried when the compare on the first answers nothing
 #define CF_NOCERT 4096u          // since the last own lookup: windows were probed, and every one of them is (perhaps) in the index
 #define CF_ANC_LEFT(f) (((f) >> 16) & 3u)
 #define CF_CMP_LEFT(f) (((f) >> 18) & 7u)
@@ -122,11 +124,11 @@ extern "C" int sbwtgpu_debug_iter_max(unsigned long long *out, int reset) {
     return 0;
 }
 // why substitutions are (not) bridged, k <= 31 (tools/lane_stats_fused.py prints the names)
-__device__ unsigned long long g_fz_why[16];
+__device__ unsigned long long g_fz_why[24];
 extern "C" int sbwtgpu_debug_why(unsigned long long *out, int reset) {
     if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fz_why), sizeof(g_fz_why)) != hipSuccess) return -1;
     if (reset) {
-        unsigned long long z[16] = {0};
+        unsigned long long z[24] = {0};
         if (hipMemcpyToSymbol(HIP_SYMBOL(g_fz_why), z, sizeof(z)) != hipSuccess) return -1;
     }
     return 0;
@@ -470,7 +472,7 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
         const u64 rw = s ? ((cw0 >> (2 * s)) | (cw1 << (64 - 2 * s))) : cw0;      // bases P .. P+31
         if (mode == F_POS) {
             a1 = reinterpret_cast<const uint4 *>(ix.pos + ((unsigned)l & ~3u));  // the aligned 16 bytes holding pos[l]
-            a2 = a1;
+            a2 = a1 + ((((unsigned)l & 3u) == 3u && (fl & CF_SEED2)) ? 1 : 0);   // (a seed of two columns: pos[l + 1] as well)
         } else if (busy) {
             const int wl = (wk == 1) ? ps : (wk == 2 || wk == 6) ? L0 : (wk == 3) ? pw : (wk == 5) ? k - ps : p;
             c = (int)((unsigned)rw & 3u);
@@ -565,8 +567,16 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
             if (fl & CF_SEED) {
                 // a seed: the k-mer at position r ENDS with the 31 bases before read position -co; align the rest of the read
                 fl &= ~(CF_SEED | CF_M1 | CF_M2 | CF_ONP);
+                if (fl & CF_SEED2)                     // (the second column's position waits in l)
+                    l = (int)(sel == 0 ? v1.y : sel == 1 ? v1.z : sel == 2 ? v1.w : v2.x);
                 co += r;
                 if ((unsigned)(co + i) < (unsigned)ix.n_pos) { cP = i; m1 = -1; mode = F_CMP; }
+                else if (fl & CF_SEED2) {              // (the first column's alignment does not fit: the second at once)
+                    co += l - r;
+                    fl &= ~CF_SEED2;
+                    if ((unsigned)(co + i) < (unsigned)ix.n_pos) { cP = i; m1 = -1; mode = F_CMP; }
+                    else { mode = F_DEAD; do_plan = true; }
+                }
                 else { mode = F_DEAD; do_plan = true; }
             } else {
                 mode = F_EXT;
@@ -841,9 +851,14 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
                     again = true;
                     j++;
                 } else {
+#ifdef SBWT_STATS
+                    why |= (r < 0 || r == l) ? (1u << 16) : (r == l + 1) ? (1u << 17) : (r == l + 2) ? (1u << 18) : (1u << 19);
+#endif
                     if (seed_ok && (r < 0 || r == l)) {    // the 31-mer is there, in ONE column: a seed for an alignment
                         seed_is_pos = r < 0;               // ... whose path position came with the entry
                         seed_col = r < 0 ? -1 - r : l;
+                    } else if (seed_ok && r == l + 1) {    // ... or in two (the stretch two strains share): the read is one of them
+                        seed_col = -2 - l;                 // (two columns, l and l + 1: encoded below -1)
                     }
                     l = -1;
                 }
@@ -911,7 +926,7 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
             }
         }
 #ifdef SBWT_STATS
-        for (int q = 0; q < 16; q++) FZ_WHY(q, (why >> q) & 1u);
+        for (int q = 0; q < 20; q++) FZ_WHY(q, (why >> q) & 1u);
 #endif
         c_tab = uniform32(c_tab + (unsigned)__popcll(__ballot(tabhit)));
         c_stream = uniform32(c_stream + (unsigned)__popcll(__ballot(ev == FE_EMIT1 && trn)));
@@ -1018,6 +1033,20 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
             if (nleft > 0) {
                 append(i, (burst_hi >= 0) ? 0xFFFFFFFFu : seg_src_run);
                 i += nleft;
+            }
+            if (cmp && (fl & CF_SEED2)) {
+                // a seed of two columns whose first alignment answered nothing (two differences at once: the other strain's path,
+                // usually): the same compare on the second column's path, for one more of the read's alignments
+                fl &= ~CF_SEED2;
+                if (pre_n + abs_n + post_n == 0 && (cact == CA_CERT || cact == CA_LOST) && CF_CMP_LEFT(fl) > 0 &&
+                    (unsigned)(l - (wstart + ps) + i) < (unsigned)ix.n_pos) {
+                    fl -= 1u << 18;
+                    co = l - (wstart + ps);
+                    cP = i;
+                    m1 = -1;
+                    fl &= ~(CF_M1 | CF_M2 | CF_ONP);
+                    cact = CA_GOON;
+                }
             }
             if (cmp) {                                 // F_CMP's verdicts (at most two segments)
                 if (pre_n > 0) { append(i, (unsigned)(co + i + k)); i += pre_n; c_ext += (unsigned)pre_n; fl &= ~CF_MISS_MASK; }
@@ -1162,7 +1191,7 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
             }
         }
         if (do_plan && !force && CF_CMP_LEFT(fl) > 0 && (fl & CF_MISS_MASK) < 2u * CF_MISS &&
-            (seed_col >= 0 || ((fl & CF_ALIGNED) && wide_k && !(b >= i && b <= i + k - 1) && (unsigned)(co + i) < (unsigned)ix.n_pos))) {
+            (seed_col != -1 || ((fl & CF_ALIGNED) && wide_k && !(b >= i && b <= i + k - 1) && (unsigned)(co + i) < (unsigned)ix.n_pos))) {
             // k > 31: an alignment instead of a walk.  A seed (the 31-mer [wstart, wstart + 31) is in the index in one column, the
             // k-mer it began is not): that column's path position aligns the read.  Or the alignment the read had when it
             // left its path, once every k-mer that holds the known bad base is answered.  F_CMP's conclusions are exact
@@ -1175,10 +1204,10 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
                 fl &= ~(CF_SEED | CF_M1 | CF_M2 | CF_ONP);
                 if ((unsigned)(co + i) < (unsigned)ix.n_pos) { cP = i; m1 = -1; mode = F_CMP; }
                 else keep_plan = true;                 // (no such alignment: the planner, one alignment poorer)
-            } else if (seed_col >= 0) {
-                l = seed_col;
+            } else if (seed_col != -1) {
+                l = seed_col >= 0 ? seed_col : -2 - seed_col;
                 co = -(wstart + ps);
-                fl |= CF_SEED;
+                fl = (fl & ~CF_SEED2) | CF_SEED | (seed_col < 0 ? CF_SEED2 : 0u);
                 mode = F_POS;
             } else {
                 cP = i;

@@ -43,8 +43,8 @@ except Exception as ex:
     print("no tail profile:", ex)
 
 try:
-    w = (ctypes.c_ulonglong * 16)()
-    if capi.lib().sbwtgpu_debug_why(w, 1) == 0 and w[0]:
+    w = (ctypes.c_ulonglong * 24)()
+    if capi.lib().sbwtgpu_debug_why(w, 1) == 0 and any(w):
         names = ["path runs that stop (mismatch or end of path)", "... at a step with other successors or the path's end -> transition lookup",
                  "... at a substitution-safe step -> bridge", "...... but a second difference within the window: certificates", "... at an only-successor step that is not safe: certificates",
                  "transition lookups: free slot", "negative entry, safe for this char -> bridge", "negative entry, not safe: certificates", "successor found",
@@ -55,5 +55,8 @@ try:
         print("why substitutions are (not) bridged, per read:")
         for q in range(16):
             print("  %-90s %.3f" % (names[q], w[q] / launches / nr))
+        if any(w[16:20]):
+            print("k > 31, second-level misses (the k-mer is absent, its 31-prefix is there) by the prefix's columns, per read: one %.3f, two %.3f, three %.3f, more %.3f"
+                  % tuple(w[q] / launches / nr for q in range(16, 20)))
 except Exception as ex:
     print("no why-counters:", ex)
