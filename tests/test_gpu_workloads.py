@@ -88,3 +88,23 @@ def test_substitutions_that_are_another_strains_base(gpu, k):
     bases = synth.mutate(bases, 0.005, 24)                   # and ordinary errors beside it
     want = check(genomes, k, bases, off)
     assert 0.3 < (want >= 0).mean() < 0.9
+
+
+def test_reads_without_a_single_kmer_in_shared_stretches(gpu):
+    """k = 63, two substitutions 60 bases apart: every k-mer of the read is absent, so there is no k-mer to anchor on; in a
+    stretch two strains share every 31-base prefix sits in TWO columns.  The fused kernel aligns such a read through a seed
+    of two columns (sbwt_search_fused.hip, CF_SEED2) -- the slowest reads of BASELINE config 5 before it did."""
+    g0 = synth.random_genome(150_000, 5)
+    genomes = [g0, synth.mutate(g0, 0.02, 6)]                       # long shared stretches between the two strains
+    rng = np.random.Generator(np.random.PCG64(77))
+    n, L = 3000, 150
+    start = rng.integers(0, len(g0) - L, size=n)
+    src = rng.integers(0, 2, size=n)
+    bases = np.concatenate([genomes[s][a:a + L] for s, a in zip(src, start)]).copy()
+    for r in range(n):
+        for at in (int(rng.integers(40, 62)), int(rng.integers(100, 122))):
+            c = bases[r * L + at]
+            bases[r * L + at] = b"ACGT"[(b"ACGT".index(bytes([c])) + 1 + int(rng.integers(0, 3))) % 4]
+    off = np.arange(n + 1, dtype=np.int64) * L
+    want = check(genomes, 63, bases, off)
+    assert (want >= 0).mean() < 0.05
