@@ -309,6 +309,36 @@ def test_rank_beyond_2_pow_31_columns(gpu):
     idx.close()
 
 
+def test_search_beyond_2_pow_31_columns(gpu):
+    """The reference is int64 throughout (SBWT.hh:36-45); an index of 2^31 columns or more is served by the blocks-only kernel
+    (64-bit instantiation, block counts relative to a table of absolute counts every 2^31 columns) -- the 32-bit path order stops
+    there.  One random 2.25 Gbp sequence, k = 31: columns built on the GPU, streaming_search and search of reads from all over
+    the sequence (substitutions, N) against the oracle, int32 results refused."""
+    import torch
+    if torch.cuda.mem_get_info()[1] < (150 << 30):
+        pytest.skip("needs a GPU with > 150 GB for the builder's sort")
+    L = 2_250_000_000
+    genome = synth.random_genome(L, 7)
+    bits = capi.build_bits_gpu([genome.tobytes()], 31, False, True)
+    assert bits.n_nodes >= (1 << 31)
+    idx = capi.Index.create(bits.cols[0], bits.cols[1], bits.cols[2], bits.cols[3], bits.ssup, bits.n_nodes, 31, bits.n_kmers, 8)
+    assert idx.image_level >= 1                                      # no path order beyond 2^31 columns
+    bases, off = synth.sample_reads([genome], 3000, 150, 0.01, 5)
+    bases = synth.inject(bases, 40, ord("N"), 6)
+    got, _ = idx.streaming_search(bases, off)
+    got2, _ = idx.search(bases, off)
+    with pytest.raises(capi.SbwtGpuError, match="2\\^31"):
+        idx.search_i32(bases, off)
+    idx.close()
+    del genome
+    orc = OracleIndex.from_bits(bits.cols[0], bits.cols[1], bits.cols[2], bits.cols[3], bits.ssup, bits.n_nodes, 31, bits.n_kmers, 8)
+    sample = 600
+    want = oracle_batch(orc, bases[:off[sample]], off[:sample + 1], True)
+    assert np.array_equal(got[:len(want)], want) and np.array_equal(got2[:len(want)], oracle_batch(orc, bases[:off[sample]], off[:sample + 1], False))
+    assert np.array_equal(got, got2)                                 # upper-case and N: search == streaming_search
+    assert (got >= (1 << 31)).any() and 0.6 < (got >= 0).mean() < 0.85
+
+
 def test_device_side_print_vector(gpu, genome_case):
     # print_vector of src/CLI/sbwt_search.cpp:21-43 on the device (SURVEY 8f-2), incl. the pipelined
     # host path with more than one chunk, empty reads, and the 0 -> empty-token quirk
