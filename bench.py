@@ -160,11 +160,13 @@ def load_traffic(config: int, n_reads: int, image_level: int, variant: int, kern
     return ent
 
 
-# What the memory system delivers per access shape on this chip (tools/micro/ceilings.hip, gather_modes.hip; measured,
-# profiles/r02_ceilings.txt, r03_gather_modes.txt): a random read leaves an XCD as ONE 128-byte fabric request whatever
-# the load width -- 56 G requests/s --, coalesced writes run at 5.1 TB/s = 80 G 64-byte requests/s.
-READ_REQ_CEILING = 56e9
-WRITE_REQ_CEILING = 5.1e12 / 64
+# What the memory system delivers per access shape on this chip (tools/micro/ceilings.hip, gather_modes.hip, mixed_rw.hip;
+# measured, profiles/r02_ceilings.txt, r03_gather_modes.txt, r04_mixed_rw.txt): a random read leaves an XCD as ONE 128-byte
+# fabric request whatever the load width -- 56 G requests/s --; coalesced nontemporal 16-byte stores run at 6.46 TB/s = 101 G
+# 64-byte requests/s; a kernel that does both takes the SUM of the two times (mixes of gathers and stores run at 90-96 % of
+# that additive model), so reads and writes do not hide behind each other.
+READ_REQ_CEILING = 55.7e9
+WRITE_REQ_CEILING = 6.46e12 / 64
 
 
 def request_model(read_requests: float, write_requests: float, kernel_ms: float) -> dict:
@@ -175,7 +177,8 @@ def request_model(read_requests: float, write_requests: float, kernel_ms: float)
     return {"read_requests_128B": read_requests, "write_requests_64B": write_requests,
             "read_ceiling_Greq_s": READ_REQ_CEILING / 1e9, "write_ceiling_Greq_s": WRITE_REQ_CEILING / 1e9,
             "floor_ms": floor_ms, "frac_of_deliverable": floor_ms / kernel_ms if kernel_ms > 0 else None,
-            "ceilings_source": "profiles/r02_ceilings.txt, profiles/r03_gather_modes.txt (tools/micro/)"}
+            "ceilings_source": "profiles/r03_gather_modes.txt, profiles/r04_mixed_rw.txt (tools/micro/): measured ceilings; the "
+                               "micro benchmark's own gather + store mixes reach 90-96 % of this additive floor"}
 
 
 RANK_B_SURVEY = 72              # one rank = 8 B count + 64 B block bits

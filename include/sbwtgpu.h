@@ -244,8 +244,8 @@ int  sbwtgpu_search_dev(const sbwtgpu_index *idx, const char *d_bases, int64_t t
                         const int64_t *d_out_off, void *d_workspace, int64_t workspace_bytes,
                         void *stream);
 /* The same two calls with int32 results on the device (d_out is an int32 array indexed by d_out_off, in results): every kernel
- * of the route writes 4 bytes per k-mer, half the write requests of a launch (they are 40 % of its time: +20-25 % k-mers/s on
- * BASELINE config 2).  Indexes of fewer than 2^31 columns only (SBWTGPU_ERR_INVALID_ARG otherwise); -1 stays -1. */
+ * of the route writes 4 bytes per k-mer, half the write requests of a launch (a third of its time: +10-13 % k-mers/s on
+ * BASELINE config 2, 226 -> 256 G).  Indexes of fewer than 2^31 columns only (SBWTGPU_ERR_INVALID_ARG otherwise); -1 stays -1. */
 int  sbwtgpu_streaming_search_dev_i32(const sbwtgpu_index *idx, const char *d_bases, int64_t total_bases,
                                       const int64_t *d_read_off, int64_t n_reads, int32_t *d_out,
                                       const int64_t *d_out_off, void *d_workspace, int64_t workspace_bytes,
