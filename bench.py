@@ -80,9 +80,11 @@ def phase(rank: int, world: int, what: str) -> None:
         log("rank %d/%d t+%.1fs: %s" % (rank, world, time.time() - _T0, what))
 
 
-def gpu_reads(genomes, n_reads: int, seed: int, dev: torch.device) -> torch.Tensor:
+def gpu_reads(genomes, n_reads: int, seed: int, dev: torch.device, in_genome_order: bool = False) -> torch.Tensor:
     """n_reads x READ_LEN substrings at uniform (genome, offset) with per-base substitutions,
-    generated on the GPU (seeded) so that the inputs are resident in HBM."""
+    generated on the GPU (seeded) so that the inputs are resident in HBM.  in_genome_order (experiments only,
+    tools/ab_step.py SORTED=1): the same kind of reads, but each chunk of 2^20 laid out by (genome, offset) and the chunks
+    covering consecutive slices of the genomes -- what a batch sorted by locus looks like."""
     import torch
     gen = torch.Generator(device=dev)
     gen.manual_seed(seed)
@@ -100,6 +102,10 @@ def gpu_reads(genomes, n_reads: int, seed: int, dev: torch.device) -> torch.Tens
         which = torch.randint(0, len(genomes), (n,), device=dev, generator=gen)
         u = torch.rand(n, device=dev, generator=gen, dtype=torch.float64)
         off = (u * (lens[which] - READ_LEN + 1)).long() + starts[which]
+        if in_genome_order:
+            total = int(lens.sum().item()) - READ_LEN
+            a, b = total * lo // n_reads, total * (lo + n) // n_reads
+            off = torch.sort((u * (b - a)).long() + a).values
         r = cat[(off[:, None] + ar[None, :]).reshape(-1)]
         hit = torch.rand(n * READ_LEN, device=dev, generator=gen) < SUB_RATE
         shift = torch.randint(1, 4, (n * READ_LEN,), device=dev, generator=gen, dtype=torch.uint8)

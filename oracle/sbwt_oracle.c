@@ -670,6 +670,7 @@ double orc_search_file(const orc_index *idx, const char *query_path, const char 
                 seq_len += n;
             }
         }
+        if (seq_len == 0) break;   /* sbwt_search.cpp:49-50,72-73: `if(len == 0) break;` -- an empty record ends the file like EOF */
         for (int64_t t = 0; t < seq_len; t++)
             if (seq[t] >= 'a' && seq[t] <= 'z') seq[t] = (char)(seq[t] - 32);
         int64_t m = seq_len - idx->k + 1;

@@ -3,9 +3,14 @@
 //   sbwt::SBWT               (reference include/sbwt/SBWT.hh:31-332)
 //   sbwt::plain_matrix_sbwt_t (reference include/sbwt/variants.hh:19)
 // with the same method names, argument meaning and error behaviour, so that code written against
-// the reference's search API compiles against this header.  Every query is executed by the HIP
-// library through the C ABI of include/sbwtgpu.h -- scalar calls are batches of one; use the
-// *_batch members for throughput.  There is no CPU query path here.
+// the reference's search API compiles against this header.  Every BATCH is executed by the HIP
+// library through the C ABI of include/sbwtgpu.h and nothing else: use the *_batch members for
+// throughput; without a GPU no index can be made at all.  The SCALAR members that the reference's own
+// code calls once per step -- SubsetMatrixRank::rank / contains (SBWT.hh:347-349,430-431,572-573),
+// SBWT::search of ONE k-mer and update_sbwt_interval (api_examples/api_example.cpp:26-29) -- run on
+// the host from the rank directory this class keeps beside the bit vectors ("scalar rank()
+// runs on host, batched rank goes to the GPU"; round 5): a kernel launch per rank cost 30-60 us, the
+// directory answers in under 0.1 us.  tests/cpp/test_api.cpp holds the two paths against each other.
 #pragma once
 #include <cstdint>
 #include <algorithm>
@@ -82,15 +87,27 @@ inline PlainMatrixBits build_plain_matrix_bits_any(const std::vector<std::string
 
 class SubsetMatrixRank {
 public:
-    // public like the reference (SubsetMatrixRank.hh:19-23); the rank supports live on the GPU
+    // public like the reference (SubsetMatrixRank.hh:19-28): the four rows and their rank directories (the host's, for
+    // scalar calls and for serialize(); the GPU image has its own block counts)
     bit_vector A_bits, C_bits, G_bits, T_bits;
+    rank_support_v5_blob A_bits_rs, C_bits_rs, G_bits_rs, T_bits_rs;
 
     SubsetMatrixRank() {}
     SubsetMatrixRank(const bit_vector &A, const bit_vector &C, const bit_vector &G, const bit_vector &T)
-        : A_bits(A), C_bits(C), G_bits(G), T_bits(T) {}
+        : A_bits(A), C_bits(C), G_bits(G), T_bits(T) { init_supports(); }
 
-    // Count of character c in subsets up to pos, not including pos (SubsetMatrixRank.hh:31-37)
+    // Count of character c in subsets up to pos, not including pos (SubsetMatrixRank.hh:31-37): one position, on the host
     int64_t rank(int64_t pos, char c) const {
+        switch (c) {
+            case 'A': return A_bits_rs.rank(A_bits, pos);
+            case 'C': return C_bits_rs.rank(C_bits, pos);
+            case 'G': return G_bits_rs.rank(G_bits, pos);
+            case 'T': return T_bits_rs.rank(T_bits, pos);
+            default: return 0;
+        }
+    }
+    // the same through the GPU as a batch of one (what rank() was before round 5; tests compare the two)
+    int64_t rank_on_device(int64_t pos, char c) const {
         int64_t out = 0;
         detail::gpu_check(sbwtgpu_rank_batch(device().h, &pos, &c, 1, &out));
         return out;
@@ -113,11 +130,7 @@ public:
         written += C_bits.serialize(os);
         written += G_bits.serialize(os);
         written += T_bits.serialize(os);
-        for (const bit_vector *v : {&A_bits, &C_bits, &G_bits, &T_bits}) {
-            rank_support_v5_blob rs;
-            rs.build(*v);
-            written += rs.serialize(os);
-        }
+        for (const rank_support_v5_blob *rs : {&A_bits_rs, &C_bits_rs, &G_bits_rs, &T_bits_rs}) written += rs->serialize(os);
         write_log("MatrixRank bit vectors total " + std::to_string((double)written / (double)A_bits.size() * 8) +
                       " bits total per node",
                   LogLevel::MINOR);
@@ -128,7 +141,8 @@ public:
         C_bits.load(is);
         G_bits.load(is);
         T_bits.load(is);
-        for (int i = 0; i < 4; i++) rank_support_v5_blob::skip(is);
+        for (int i = 0; i < 4; i++) rank_support_v5_blob::skip(is);      // rebuilt from the bits: ranks depend on nothing else
+        init_supports();
         dev_.reset();
     }
     // used by SBWT to share its (full) device image instead of building a second one
@@ -137,6 +151,9 @@ public:
     std::shared_ptr<detail::DeviceIndex> device_image() const { device(); return dev_; }
 
 private:
+    void init_supports() {                         // SubsetMatrixRank.hh:52-58 (sdsl::util::init_support)
+        A_bits_rs.build(A_bits); C_bits_rs.build(C_bits); G_bits_rs.build(G_bits); T_bits_rs.build(T_bits);
+    }
     const detail::DeviceIndex &device() const {
         if (!dev_) {
             sbwtgpu_index_desc d;
@@ -235,7 +252,28 @@ public:
 
     // ---- queries ----
     int64_t search(const std::string &kmer) const { return search(kmer.c_str()); }   // SBWT.hh:383-387
-    int64_t search(const char *kmer) const {                                         // SBWT.hh:389-415
+    // One k-mer (reads exactly k bytes): on the host, the reference's own steps (SBWT.hh:389-415) over the host rank
+    // directory -- the file's prefix table, then k - p interval updates
+    int64_t search(const char *kmer) const {
+        need_device();
+        std::pair<int64_t, int64_t> I;
+        if (precalc_k > 0) {                               // SBWT.hh:394-405: raw chars, first char in the low bits
+            uint64_t precalc_idx = 0;
+            for (int64_t i = 0; i < precalc_k; i++) {
+                const int char_idx = DNA_to_char_idx(kmer[i]);
+                if (char_idx == -1) return -1;
+                precalc_idx |= (uint64_t)char_idx << (2 * i);
+            }
+            I = host_update_interval(kmer + precalc_k, k - precalc_k, kmer_prefix_precalc[(size_t)precalc_idx]);
+        } else {
+            I = host_update_interval(kmer, k, {0, n_nodes - 1});
+        }
+        if (I.first == -1) return -1;
+        if (I.first != I.second) bug_exit(SBWTGPU_ERR_NOT_SINGLETON);                 // SBWT.hh:410-413
+        return I.first;
+    }
+    // the same through the GPU as a batch of one (what search() was before round 5; tests compare the two)
+    int64_t search_on_device(const char *kmer) const {
         int64_t off[2] = {0, k}, ooff[2] = {0, 1}, out = -1;
         int rc = sbwtgpu_search_batch(need_device(), kmer, off, 1, &out, ooff);
         bug_exit(rc);
@@ -377,7 +415,13 @@ public:
         return update_sbwt_interval(S.c_str(), (int64_t)S.size(), I);
     }
     std::pair<int64_t, int64_t> update_sbwt_interval(const char *S, int64_t S_length,
-                                                     std::pair<int64_t, int64_t> I) const {   // SBWT.hh:422-437
+                                                     std::pair<int64_t, int64_t> I) const {   // SBWT.hh:422-437: on the host
+        need_device();
+        return host_update_interval(S, S_length, I);
+    }
+    // the same through the GPU as a batch of one
+    std::pair<int64_t, int64_t> update_sbwt_interval_on_device(const char *S, int64_t S_length,
+                                                               std::pair<int64_t, int64_t> I) const {
         int64_t off[2] = {0, S_length};
         detail::gpu_check(sbwtgpu_update_interval_batch(need_device(), S, off, 1, &I.first, &I.second));
         return I;
@@ -570,6 +614,19 @@ private:
     const sbwtgpu_index *need_device() const {
         if (!dev_) throw std::runtime_error("Error: the index is empty");
         return dev_->h;
+    }
+    // SBWT.hh:422-437 on the host rank directory: validates the RAW char, ranks with the upper-cased one
+    std::pair<int64_t, int64_t> host_update_interval(const char *S, int64_t S_length, std::pair<int64_t, int64_t> I) const {
+        if (I.first == -1) return I;
+        for (int64_t i = 0; i < S_length; i++) {
+            const char c = (char)toupper((unsigned char)S[i]);
+            const int char_idx = DNA_to_char_idx(S[i]);
+            if (char_idx == -1) return {-1, -1};
+            I.first = C[(size_t)char_idx] + subset_rank.rank(I.first, c);
+            I.second = C[(size_t)char_idx] + subset_rank.rank(I.second + 1, c) - 1;
+            if (I.first > I.second) return {-1, -1};
+        }
+        return I;
     }
     static void bug_exit(int rc) {                        // SBWT.hh:410-413
         if (rc == SBWTGPU_ERR_NOT_SINGLETON) {

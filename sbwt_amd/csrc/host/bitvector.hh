@@ -1,7 +1,9 @@
 // bitvector.hh -- minimal stand-ins for sdsl::bit_vector and sdsl::rank_support_v5<> as far as the
 // plain-matrix index FILE FORMAT needs them (the sdsl-lite submodule is absent from
 // the reference checkout, so the byte layout below is [UPSTREAM-KNOWLEDGE] and file-format parity
-// is unpinned).  No query is answered from these classes: rank queries run on the GPU.
+// is unpinned), and as far as the SCALAR members of the API need them ("scalar rank() runs
+// on host"): rank_support_v5_blob::rank answers SubsetMatrixRank::rank(pos, c) for ONE position from
+// the directory it would serialize -- a GPU launch per rank is 10^4 x the work.  Batches go to the GPU.
 #pragma once
 #include <cstdint>
 #include <istream>
@@ -97,6 +99,19 @@ public:
         } else {
             bb[j + 1] = second;
         }
+    }
+    // rank(idx) = number of ones in v[0, idx), idx in [0, v.size()] (sdsl::rank_support_v5<>::rank [UPSTREAM-KNOWLEDGE],
+    // SURVEY App. A): the superblock's absolute count, the 12-bit count of its 384-bit blocks before idx, the whole words
+    // between that block's start and idx's word, and the masked word.  v must be the vector build() was called with.
+    int64_t rank(const bit_vector &v, int64_t idx) const {
+        const uint64_t *p = &bb[(size_t)((idx >> 11) << 1)];
+        const int64_t in_sb = idx & 0x7FF, blk = in_sb / 384;
+        uint64_t r = p[0] + ((p[1] >> (60 - 12 * blk)) & 0x7FFull);
+        const uint64_t *w = v.data();
+        const int64_t wi = idx >> 6, w0 = ((idx >> 11) << 5) + 6 * blk;        // idx's word; first word of its 384-bit block
+        for (int64_t q = w0; q < wi; q++) r += (uint64_t)__builtin_popcountll(w[q]);
+        if (idx & 63) r += (uint64_t)__builtin_popcountll(w[wi] & ((1ull << (idx & 63)) - 1ull));
+        return (int64_t)r;
     }
     // sdsl::int_vector<64>::serialize: uint64 size in bits, then the words
     int64_t serialize(std::ostream &os) const {

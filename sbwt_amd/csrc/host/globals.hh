@@ -67,9 +67,12 @@ inline std::string load_string(std::istream &in) {
 // throwing_streams.hh:32-35 message
 // (a FIFO, a pipe behind /dev/fd/N or /dev/stdout is not opened for the check: opening and closing a FIFO would cut its
 // writer off before the real reader arrives; the permission bits answer instead)
+// (only FIFOs, character devices and sockets take the shortcut: a directory passes access(W_OK) and must fail here like the
+// reference's stream probe does, not later in the writer)
 inline bool is_regular_or_missing(const std::string &filename) {
     struct stat sb;
-    return ::stat(filename.c_str(), &sb) != 0 || S_ISREG(sb.st_mode);
+    if (::stat(filename.c_str(), &sb) != 0) return true;
+    return !(S_ISFIFO(sb.st_mode) || S_ISCHR(sb.st_mode) || S_ISSOCK(sb.st_mode));
 }
 inline void check_readable(const std::string &filename) {       // globals.cpp:38-40
     if (!is_regular_or_missing(filename)) {
@@ -86,6 +89,16 @@ inline void check_writable(const std::string &filename) {       // globals.cpp:4
     }
     std::ofstream f(filename, std::ofstream::out | std::ofstream::app);
     if (!f.good()) throw std::runtime_error("Error opening file: " + filename);
+}
+// ACGT -> 0123, anything else (lower case included) -> -1 (globals.hh:38-47, SBWT.hh:49-57)
+inline int DNA_to_char_idx(char c) {
+    switch (c) {
+        case 'A': return 0;
+        case 'C': return 1;
+        case 'G': return 2;
+        case 'T': return 3;
+        default: return -1;
+    }
 }
 inline std::vector<std::string> readlines(const std::string &filename) {   // globals.cpp:20-31
     std::ifstream in(filename);

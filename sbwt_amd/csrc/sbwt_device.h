@@ -6,7 +6,7 @@
 //   [ ptab     : 4^p_dev x 16 B  ]   device prefix table, (first,second) int64 pairs
 //   [ ftab     : 4^p_file x 16 B ]   the index file's own table (only if p_file != p_dev, p_file > 0)
 //   [ mega     : 4 x n_mega x 8 B]   absolute (C[c] + rank_c) at every 2^31-column boundary
-//   [ col, pos : n_nodes x 4 B each ]  path order (see k_path_* in sbwt_derived.hip)
+//   [ col, pos : n_nodes x 4 B each ]  path order (see k_path_* in sbwt_derived.hip); col[n_pos] = 0xFFFFFFFF (the "position" of a -1)
 //   [ pq       : (n/32+4) x 16 B ]   path groups of 32 positions: packed chars + two state bits per position
 //   [ trans    : n_tslots x 32 B ]   transition table: one hashed entry per way off a path -- (position, char) -> column,
 //                                    path position and the next 32 steps of its path; sized once the path order is known:
@@ -74,7 +74,7 @@ struct SbwtIndexView {
 
 // Position-independent description of a blob (what index_export_header hands out).
 struct SbwtBlobHeader {
-    uint64_t magic;                 // 'SBWTGPU2'
+    uint64_t magic;                 // 'SBWTGPU3'
     int64_t n_nodes, n_kmers, k, p_file, p_dev;
     int64_t C[4];
     int64_t n_blocks, n_mega;
@@ -106,7 +106,8 @@ struct SbwtBlobHeader {
     int64_t off_stab2;
     int64_t path_lookahead;         // steps the path order looked ahead / behind when it chose successors (0: blind rule)
 };
-#define SBWT_BLOB_MAGIC 0x3255504754574253ull   // "SBWTGPU2" little endian
+#define SBWT_BLOB_MAGIC 0x3355504754574253ull   // "SBWTGPU3" little endian (round 5: col[n_pos] = 0xFFFFFFFF; an image of an
+                                                // earlier layout is refused by sbwtgpu_index_adopt)
 
 // Sparse prefix table entry words
 #define SBWT_SP_EMPTY (1ull << 63)              // the whole word of a free entry

@@ -27,25 +27,30 @@ __device__ __forceinline__ u64 uniform64(u64 v) {
 
 // streaming (read-once / write-once) 16-byte accesses that should not displace the index in L2
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void st_stream(i64 *p, i64 v) { __builtin_nontemporal_store(v, p); }
+#ifdef SBWT_PLAIN_STORES        // experiments: the result stores without the non-temporal hint
+#define SBWT_NT_STORE(v, p) (*(p) = (v))
+#else
+#define SBWT_NT_STORE(v, p) __builtin_nontemporal_store(v, p)
+#endif
+__device__ __forceinline__ void st_stream(i64 *p, i64 v) { SBWT_NT_STORE(v, p); }
 // two consecutive results / columns at their natural (8-byte / 4-byte) alignment
 typedef i64 i64x2_a8 __attribute__((ext_vector_type(2), aligned(8)));
 typedef unsigned u32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));
 __device__ __forceinline__ void st_stream2(i64 *p, i64 a, i64 b) {
     i64x2_a8 v = {a, b};
-    __builtin_nontemporal_store(v, reinterpret_cast<i64x2_a8 *>(p));
+    SBWT_NT_STORE(v, reinterpret_cast<i64x2_a8 *>(p));
 }
 // a result / two consecutive results at slot `at` of the caller's array: int64, or int32 when the call asked for that
 // (o32 is wave-uniform: one launch writes one kind)
 typedef int i32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));
 __device__ __forceinline__ void st_res(i64 *out, i64 at, i64 v, int o32) {
-    if (o32) __builtin_nontemporal_store((int)v, reinterpret_cast<int *>(out) + at);
+    if (o32) SBWT_NT_STORE((int)v, reinterpret_cast<int *>(out) + at);
     else st_stream(out + at, v);
 }
 __device__ __forceinline__ void st_res2(i64 *out, i64 at, i64 a, i64 b, int o32) {
     if (o32) {
         i32x2_a4 v = {(int)a, (int)b};
-        __builtin_nontemporal_store(v, reinterpret_cast<i32x2_a4 *>(reinterpret_cast<int *>(out) + at));
+        SBWT_NT_STORE(v, reinterpret_cast<i32x2_a4 *>(reinterpret_cast<int *>(out) + at));
     } else {
         st_stream2(out + at, a, b);
     }
@@ -159,7 +164,7 @@ __device__ __forceinline__ unsigned sbwt_trans_slot(unsigned t, unsigned c, unsi
 #define SBWT_FUSED_MAXP 3
 __device__ __forceinline__ long long sbwt_fused_limit(int P, int k) {       // the longest read P pieces hold
     const int kpp = SBWT_FUSED_MAXLEN - k + 1;
-    return (P <= 1 || kpp < 16) ? (long long)SBWT_FUSED_MAXLEN : (long long)P * kpp + k - 1;
+    return (P <= 1 || kpp < 64) ? (long long)SBWT_FUSED_MAXLEN : (long long)P * kpp + k - 1;
 }
 // rg_long packs three counters of 20 bits: sampled reads that need more than 1, 2, 3 pieces
 // (rg_sample: the sample's size in bits 0-15, the most pieces a read may be taken as in bits 16-: "fused_pieces", 1 .. 3)

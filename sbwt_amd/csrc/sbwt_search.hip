@@ -1079,23 +1079,21 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
                     if (fm == 0) continue;                       // wave-uniform: unused slots cost nothing
                     const int L = __ffsll((i64)fm) - 1;
                     fm &= fm - 1;
-                    const int ns = __shfl(nseg, L), a = __shfl(i0, L), e = __shfl(i, L);
+                    // (L is wave-uniform: the owner's registers are read with v_readlane)
+                    const int ns = __builtin_amdgcn_readlane(nseg, L), a = __builtin_amdgcn_readlane(i0, L), e = __builtin_amdgcn_readlane(i, L);
                     fL[u] = L;
                     fe[u] = e;
-                    fob[u] = (i64)uniform64((u64)__shfl(obase, L));
+                    fob[u] = (i64)((u64)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u64)obase, L) |
+                                   ((u64)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)((u64)obase >> 32), L) << 32));
                     long_read = long_read || (e - a > 128);
                     const int tl = (tid & ~63) + L;
                     const int j0 = a + 2 * lane, j1 = j0 + 1;
                     fj[u] = j0;
-                    // the segment of result j0: the last one that starts at or before it (bisection over <= 12 starts);
-                    // result j1 is in the same segment or the next
+                    // the segment of result j0: the last one that starts at or before it (lane t holds the start of segment t:
+                    // the starts ascend, so that is a count); result j1 is in the same segment or the next
+                    const int my_at = (int)segs[lane < SBWT_NSEG ? lane : SBWT_NSEG - 1][tl].y;
                     int idx = 0;
-#pragma unroll
-                    for (int step = 8; step > 0; step >>= 1) {
-                        const int t = idx + step;
-                        const unsigned st = segs[t < SBWT_NSEG ? t : SBWT_NSEG - 1][tl].y;
-                        if (t < ns && (int)st <= j0) idx = t;
-                    }
+                    for (int t = 1; t < ns; t++) idx += (__builtin_amdgcn_readlane(my_at, t) <= j0) ? 1 : 0;
                     const uint2 c0 = segs[idx][tl];
                     const uint2 nx = segs[idx + 1 < SBWT_NSEG ? idx + 1 : SBWT_NSEG - 1][tl];
                     const uint2 c1 = (idx + 1 < ns && (int)nx.y <= j1) ? nx : c0;
@@ -1106,13 +1104,21 @@ __global__ void __launch_bounds__(256, WPS) k_search_cert(SbwtIndexView ix, cons
                     w0[u] = (int)ix.col[p0];
                     w1[u] = (int)ix.col[p1];
                 }
+                // every col[] value is consumed before the first store is issued (loads and stores share vmcnt on gfx9: with a
+                // store in flight the wait for a load is a wait for that store's acknowledgement; sbwt_search_fused.hip)
+                int v0[FP], v1[FP];
 #pragma unroll
                 for (int u = 0; u < FP; u++) {
-                    const int v0 = (x0[u] >> 31) ? ((x0[u] == 0xFFFFFFFFu) ? -1 : (int)(x0[u] & 0x7FFFFFFFu)) : w0[u];
-                    const int v1 = (x1[u] >> 31) ? ((x1[u] == 0xFFFFFFFFu) ? -1 : (int)(x1[u] & 0x7FFFFFFFu)) : w1[u];
-                    if (!(ix.debug & 1)) {
-                        if (fj[u] + 1 < fe[u]) st_res2(out, fob[u] + fj[u], (i64)v0, (i64)v1, ix.out32);
-                        else if (fj[u] < fe[u]) st_res(out, fob[u] + fj[u], (i64)v0, ix.out32);
+                    v0[u] = (x0[u] >> 31) ? ((x0[u] == 0xFFFFFFFFu) ? -1 : (int)(x0[u] & 0x7FFFFFFFu)) : w0[u];
+                    v1[u] = (x1[u] >> 31) ? ((x1[u] == 0xFFFFFFFFu) ? -1 : (int)(x1[u] & 0x7FFFFFFFu)) : w1[u];
+                }
+#pragma unroll
+                for (int u = 0; u < FP; u++) asm volatile("" : "+v"(v0[u]), "+v"(v1[u]));
+                if (!(ix.debug & 1)) {
+#pragma unroll
+                    for (int u = 0; u < FP; u++) {
+                        if (fj[u] + 1 < fe[u]) st_res2(out, fob[u] + fj[u], (i64)v0[u], (i64)v1[u], ix.out32);
+                        else if (fj[u] < fe[u]) st_res(out, fob[u] + fj[u], (i64)v0[u], ix.out32);
                     }
                 }
                 if (long_read) {

@@ -162,8 +162,9 @@ extern "C" int sbwtgpu_debug_timeline(unsigned long long *out, int reset) {
 }
 #endif
 
-// 32 ASCII bases (8 dwords) -> 64 bits of 2-bit codes; `bad` collects bit 7 of every byte that is not one of "ACGT"
-// (exact per-byte zero detection, four bases per operation); tm[d] masks the bytes of dword d that belong to the read
+// 32 ASCII bases (8 dwords) -> 64 bits of 2-bit codes; `bad` becomes non-zero when a byte of the read is not one of "ACGT":
+// the codes select the letters they stand for out of "ACGT" (one v_perm_b32 per four bases), and a byte that is not that
+// letter differs from it; tm[d] masks the bytes of dword d that belong to the read (0xFF each)
 __device__ __forceinline__ u64 fz_encode32(const unsigned w[8], const unsigned tm[8], unsigned &bad) {
     u64 codes = 0;
 #pragma unroll
@@ -171,9 +172,8 @@ __device__ __forceinline__ u64 fz_encode32(const unsigned w[8], const unsigned t
         const unsigned x = w[d];
         const unsigned t = ((x >> 1) & 0x03030303u) ^ ((x >> 2) & 0x01010101u);          // dna_code of every byte
         const unsigned c8 = (t * 0x01041040u) >> 24;                                     // 4 x 2 bits -> one byte
-        auto nz = [](unsigned v) { return ((v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | v; };       // bit 7 of a byte set <=> byte != 0
-        const unsigned none = nz(x ^ 0x41414141u) & nz(x ^ 0x43434343u) & nz(x ^ 0x47474747u) & nz(x ^ 0x54545454u);
-        bad |= none & tm[d];
+        const unsigned letters = __builtin_amdgcn_perm(0x54474341u, 0x54474341u, t);     // "ACGT"[code] for every byte
+        bad |= (letters ^ x) & tm[d];
         codes |= (u64)c8 << (8 * d);
     }
     return codes;
@@ -208,6 +208,9 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
     const int last_node = (int)(ix.n_nodes - 1);
 
     int nseg = 0, i0 = 0, last_start = 0;           // segments listed; first result of the read not written yet
+    u64 fm_pend = 0;                // wave-uniform: lanes whose segment list waits for the writer (handed over at the end of an iteration)
+    int pend = 0;                   // ... that list: first result | one past the last << 8 | segments << 16 | piece << 20 | holds a result known by column only << 22
+    unsigned pend_rd = 0;           // ... and its read
     unsigned last_src = 0, emit_pos = 0;
     int wk = 0;                     // how this walk starts (as in k_search_cert): 0 dense table, 1 sparse table, 2 probe filter,
                                     // 3 range probe, 5 second-level sparse lookup
@@ -235,7 +238,8 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
     unsigned c_ext = 0, c_brg = 0;  // per lane: k-mers answered along paths, substitutions bridged
     u64 pool_next = 0, pool_end = 0, pool_bad = 0;  // wave-uniform pool of read tickets; tickets of it that are handed on
     int pool_len = 0;               // varlen: the length of the piece this lane encoded at the last refill (161: too long) | piece << 16
-    // (the piece number of the lane's ticket rides in i0's bits 16..: its first k-mer within its read is piece * kpp)
+    // (the piece number of the lane's ticket rides in i0's bits 16..23: its first k-mer within its read is piece * kpp; bit 24:
+    // the list holds a result known by its column only)
     unsigned c_stream = 0, c_search = 0, c_lf = 0, c_tab = 0;     // wave-uniform work counters
 #ifdef SBWT_STATS
     unsigned it_cnt = 0, tail_it = 0;
@@ -312,7 +316,7 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
                             for (int d = 0; d < 8; d++) {
                                 w[d] = __builtin_amdgcn_alignbyte(raw[d + 1], raw[d], sh);
                                 const int nb = len_e - 32 * g - 4 * d;                 // bytes of this dword inside the read
-                                tm[d] = nb >= 4 ? 0x80808080u : nb <= 0 ? 0u : (0x80808080u & ((1u << (8 * nb)) - 1u));
+                                tm[d] = nb >= 4 ? 0xFFFFFFFFu : nb <= 0 ? 0u : ((1u << (8 * nb)) - 1u);
                             }
                             pool_codes[g][wbase + lane] = fz_encode32(w, tm, bad);
                         }
@@ -384,7 +388,7 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
             //      tests/test_large.hh:104-115), so the taker starts with a full search at its first k-mer.
             const u64 idle = __ballot(mode == F_IDLE);
             const u64 busy_m = __ballot(mode != F_IDLE);
-            if (busy_m == 0) break;                    // everything this wave took is answered and written
+            if (busy_m == 0 && fm_pend == 0) break;    // everything this wave took is answered and written
             u64 donors = __ballot(mode != F_IDLE && mend - i >= FZ_SPLIT_MIN);
             if (idle && donors) {
                 const int n_pairs = min(__popcll(idle), __popcll(donors));
@@ -400,7 +404,7 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
                 }
                 const int d_i = __shfl(i, src), d_end = __shfl(mend, src);
                 const unsigned d_rd = (unsigned)__shfl((int)rd, src);
-                const int d_pc = __shfl(i0, src) & ~0xFFFF;
+                const int d_pc = __shfl(i0, src) & 0x00FF0000;
                 const int mid = d_i + ((d_end - d_i + 1) >> 1);
                 if (giving) mend = i + ((mend - i + 1) >> 1);                        // (the same mid its taker computed)
 #ifdef SBWT_STATS
@@ -541,8 +545,125 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
         c_search = uniform32(c_search + (unsigned)__popcll(__ballot(mode == F_INIT || (p == 0 && mode == F_STEP && j == 0))));
         c_lf = uniform32(c_lf + (unsigned)__popcll(__ballot(mode == F_STEP)));
 
-        const uint4 v1 = *a1;
-        const uint4 v2 = *a2;
+        // ---- the writer: the lists handed over at the end of the last iteration (fm_pend; pend, pend_rd).  Here, behind the
+        //      issue of this iteration's gather and ahead of its use: the col[] loads share the gather's round trip, and the
+        //      stores have the whole iteration to be acknowledged before the next wait (loads and stores share vmcnt on gfx9:
+        //      a wait for a load issued after a store waits for that store).  Up to four reads per trip, the col[] loads of all
+        //      four in flight before the first store ----
+        constexpr int FP = 4;
+        int fL[FP], fe[FP], fa[FP], w0[FP], w1[FP];           // (fL, fe, fa, fob: wave-uniform)
+        i64 fob[FP];
+        const unsigned col_minus1 = (unsigned)ix.n_pos;       // col[n_pos] = 0xFFFFFFFF: the "position" of a -1 (sbwtgpu_index_create)
+        // the source and first k-mer of the segments that hold results j0 and j0 + 1 of lane L's list of ns segments
+        auto seg_of = [&](int tl, int ns, int j0, unsigned &c0s, int &c0a, unsigned &c1s, int &c1a) {
+            // (lane t holds the start of segment t: the starts ascend, so the segment of j0 is a count; j0 + 1 is in it or the next)
+            const int my_at = (int)seg_at[lane < FZ_NSEG ? lane : FZ_NSEG - 1][tl];
+            int idx = 0;
+            for (int t = 1; t < ns; t++) idx += (__builtin_amdgcn_readlane(my_at, t) <= j0) ? 1 : 0;
+            c0s = seg_src[idx][tl];
+            c0a = (int)seg_at[idx][tl];
+            const int nxi = idx + 1 < FZ_NSEG ? idx + 1 : FZ_NSEG - 1;
+            const unsigned nxs = seg_src[nxi][tl];
+            const int nxa = (int)seg_at[nxi][tl];
+            const bool usenx = (idx + 1 < ns && nxa <= j0 + 1);
+            c1s = usenx ? nxs : c0s;
+            c1a = usenx ? nxa : c0a;
+        };
+        // first half of a trip: up to FP lists, the col[] loads of their first 128 results.  A list that holds a result known
+        // by its column only (bit 22 of pend: walks through the blocks -- images without whole k-mers in the tables) and what
+        // lies beyond 128 results is left to the one-read-at-a-time pass of the second half (returns whether there is any)
+        auto flush_issue = [&](u64 &fm) -> bool {
+            bool slow = false;
+#pragma unroll
+            for (int u = 0; u < FP; u++) {
+                fL[u] = -1; fe[u] = 0; fa[u] = 0; fob[u] = 0; w0[u] = w1[u] = 0;
+                if (fm == 0) continue;                 // wave-uniform: unused slots cost nothing
+                const int L = __ffsll((i64)fm) - 1;    // (wave-uniform: the owner's registers are read with v_readlane)
+                fm &= fm - 1;
+                const int pdL = __builtin_amdgcn_readlane(pend, L);
+                const int ns = (pdL >> 16) & 15, a = pdL & 0xFF, e = (pdL >> 8) & 0xFF;
+                const bool direct = (pdL >> 22) & 1;
+                fL[u] = L;
+                fa[u] = a;
+                {
+                    const i64 rdu = (i64)(unsigned)__builtin_amdgcn_readlane((int)pend_rd, L);
+                    fob[u] = (ragged ? out_off[rdu] : u_out0 + rdu * u_stride) + (i64)(((pdL >> 20) & 3) * kpp);
+                }
+                slow = slow || direct || (e - a > 128);
+                if (direct) continue;                  // (fe = 0: the first half writes nothing of it)
+                fe[u] = e;
+                const int j0 = a + 2 * lane, j1 = j0 + 1;
+                unsigned c0s, c1s;
+                int c0a, c1a;
+                seg_of(wbase + L, ns, j0, c0s, c0a, c1s, c1a);
+                const unsigned p0 = (j0 < e && c0s != 0xFFFFFFFFu) ? c0s + (unsigned)(j0 - c0a) : col_minus1;
+                const unsigned p1 = (j1 < e && c1s != 0xFFFFFFFFu) ? c1s + (unsigned)(j1 - c1a) : col_minus1;
+                w0[u] = (int)ix.col[p0];
+                w1[u] = (int)ix.col[p1];
+            }
+            return slow;
+        };
+        auto flush_store = [&](const bool slow) {
+            // Every col[] value has arrived BEFORE the first store is issued: on gfx9 loads and stores share vmcnt, and with a
+            // store in flight the compiler's wait for a load is vmcnt(0) -- a wait for that store's acknowledgement.  With the
+            // stores of a trip between the loads' uses, each store waited for the one before it (round 5: four exposed write
+            // latencies per trip, a quarter of the kernel's time).
+#pragma unroll
+            for (int u = 0; u < FP; u++) asm volatile("" : "+v"(w0[u]), "+v"(w1[u]));
+            if (!(ix.debug & 1)) {
+#pragma unroll
+                for (int u = 0; u < FP; u++) {
+                    const int fj = fa[u] + 2 * lane;
+                    if (fj + 1 < fe[u]) st_res2(out, fob[u] + fj, (i64)w0[u], (i64)w1[u], O32);
+                    else if (fj < fe[u]) st_res(out, fob[u] + fj, (i64)w0[u], O32);
+                }
+            }
+            if (slow) {
+                // (rare) lists with a result known by its column only, from their first result; more than 128 results since the
+                // last flush (reads of up to 160 bases), from the 129th: one read, 128 results at a time
+#pragma unroll
+                for (int u = 0; u < FP; u++) {
+                    if (fL[u] < 0) continue;
+                    const int L = fL[u], pdL = __builtin_amdgcn_readlane(pend, L);
+                    const int ns = (pdL >> 16) & 15, a = pdL & 0xFF, e = (pdL >> 8) & 0xFF;
+                    for (int base = ((pdL >> 22) & 1) ? a : a + 128; base < e; base += 128) {
+                        const int j0 = base + 2 * lane, j1 = j0 + 1;
+                        unsigned c0s, c1s;
+                        int c0a, c1a;
+                        seg_of(wbase + L, ns, j0, c0s, c0a, c1s, c1a);
+                        const unsigned p0 = (j0 < e && !(c0s >> 31)) ? c0s + (unsigned)(j0 - c0a) : col_minus1;
+                        const unsigned p1 = (j1 < e && !(c1s >> 31)) ? c1s + (unsigned)(j1 - c1a) : col_minus1;
+                        const int y0 = (int)ix.col[p0], y1 = (int)ix.col[p1];
+                        const int q0 = (c0s >> 31) ? ((c0s == 0xFFFFFFFFu) ? -1 : (int)(c0s & 0x7FFFFFFFu)) : y0;
+                        const int q1 = (c1s >> 31) ? ((c1s == 0xFFFFFFFFu) ? -1 : (int)(c1s & 0x7FFFFFFFu)) : y1;
+                        if (!(ix.debug & 1)) {
+                            if (j1 < e) st_res2(out, fob[u] + j0, (i64)q0, (i64)q1, O32);
+                            else if (j0 < e) st_res(out, fob[u] + j0, (i64)q0, O32);
+                        }
+                    }
+                }
+            }
+        };
+        // (the gather's two loads are issued BEHIND the first trip's col[] loads: one wait covers both, and the gathered quads
+        // are not live while the writer computes its addresses)
+        uint4 v1, v2;
+        if (fm_pend) {
+            u64 fm = fm_pend;
+            bool lr = flush_issue(fm);
+            v1 = *a1;
+            v2 = *a2;
+            // (the gathered quads have arrived as well before the first store is issued: a wait for them behind the stores
+            // would be a wait for the stores)
+            asm volatile("" : "+v"(v1.x), "+v"(v1.y), "+v"(v1.z), "+v"(v1.w), "+v"(v2.x), "+v"(v2.y), "+v"(v2.z), "+v"(v2.w));
+            flush_store(lr);
+            while (fm) {
+                lr = flush_issue(fm);
+                flush_store(lr);
+            }
+        } else {
+            v1 = *a1;
+            v2 = *a2;
+        }
 
         // ---- consume ----
 #ifdef SBWT_STATS
@@ -1022,6 +1143,7 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
                 nseg++;
                 last_src = src;
                 last_start = at;
+                if ((src >> 31) && src != 0xFFFFFFFFu) i0 |= 1 << 24;     // a result known by its column only: the writer's slow pass
             }
         };
         if (ev == FE_EMIT1) {
@@ -1084,97 +1206,18 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
                 else do_plan = true;
             }
         }
-        // ---- flush: the read is done, or the list could overflow in the next iteration.  Up to four reads per trip: the
-        //      col[] loads of all four are in flight before the first store ----
-        u64 fm = __ballot(nseg > 0 && (i == mend || nseg > FZ_NSEG - 2));
-        while (fm) {
-            constexpr int FP = 4;
-            int fL[FP], fe[FP], fj[FP], w0[FP], w1[FP];
-            i64 fob[FP];
-            unsigned x0[FP], x1[FP];
-            bool long_read = false;
-#pragma unroll
-            for (int u = 0; u < FP; u++) {
-                fL[u] = -1; fe[u] = 0; fj[u] = 0; fob[u] = 0; x0[u] = x1[u] = 0xFFFFFFFFu; w0[u] = w1[u] = 0;
-                if (fm == 0) continue;                 // wave-uniform: unused slots cost nothing
-                const int L = __ffsll((i64)fm) - 1;
-                fm &= fm - 1;
-                const int i0L = __shfl(i0, L);
-                const int ns = __shfl(nseg, L), a = i0L & 0xFFFF, e = __shfl(i, L);
-                fL[u] = L;
-                fe[u] = e;
-                {
-                    const i64 rdu = (i64)uniform32((unsigned)__shfl((int)rd, L));
-                    fob[u] = (ragged ? out_off[rdu] : u_out0 + rdu * u_stride) + (i64)((i0L >> 16) * kpp);
-                }
-                long_read = long_read || (e - a > 128);
-                const int tl = wbase + L;
-                const int j0 = a + 2 * lane, j1 = j0 + 1;
-                fj[u] = j0;
-                // the segment of result j0: the last one that starts at or before it; result j1 is in the same segment or the next
-                int idx = 0;
-#pragma unroll
-                for (int step = 8; step > 0; step >>= 1) {
-                    const int t = idx + step;
-                    const int st = (int)seg_at[t < FZ_NSEG ? t : FZ_NSEG - 1][tl];
-                    if (t < ns && st <= j0) idx = t;
-                }
-                const unsigned c0s = seg_src[idx][tl];
-                const int c0a = (int)seg_at[idx][tl];
-                const int nxi = idx + 1 < FZ_NSEG ? idx + 1 : FZ_NSEG - 1;
-                const unsigned nxs = seg_src[nxi][tl];
-                const int nxa = (int)seg_at[nxi][tl];
-                const bool usenx = (idx + 1 < ns && nxa <= j1);
-                const unsigned c1s = usenx ? nxs : c0s;
-                const int c1a = usenx ? nxa : c0a;
-                x0[u] = c0s;
-                x1[u] = c1s;
-                const unsigned p0 = (j0 < e && !(c0s >> 31)) ? c0s + (unsigned)(j0 - c0a) : 0u;
-                const unsigned p1 = (j1 < e && !(c1s >> 31)) ? c1s + (unsigned)(j1 - c1a) : 0u;
-                w0[u] = (int)ix.col[p0];
-                w1[u] = (int)ix.col[p1];
+        // ---- flush: the read is done, or the list could overflow in the next iteration.  The lane hands its list over (it
+        //      stays in LDS; the next appends come after the writer's pass) and the whole wave writes it in the NEXT iteration,
+        //      between the issue of that iteration's gather and its use (above) ----
+        {
+            const bool want = nseg > 0 && (i == mend || nseg > FZ_NSEG - 2);
+            fm_pend = __ballot(want);
+            if (want) {
+                pend_rd = rd;
+                pend = (i0 & 0xFF) | (i << 8) | (nseg << 16) | (((i0 >> 16) & 3) << 20) | (((i0 >> 24) & 1) << 22);
+                nseg = 0;
+                i0 = i | (i0 & 0x00FF0000);
             }
-#pragma unroll
-            for (int u = 0; u < FP; u++) {
-                const int q0 = (x0[u] >> 31) ? ((x0[u] == 0xFFFFFFFFu) ? -1 : (int)(x0[u] & 0x7FFFFFFFu)) : w0[u];
-                const int q1 = (x1[u] >> 31) ? ((x1[u] == 0xFFFFFFFFu) ? -1 : (int)(x1[u] & 0x7FFFFFFFu)) : w1[u];
-                if (!(ix.debug & 1)) {
-                    if (fj[u] + 1 < fe[u]) st_res2(out, fob[u] + fj[u], (i64)q0, (i64)q1, O32);
-                    else if (fj[u] < fe[u]) st_res(out, fob[u] + fj[u], (i64)q0, O32);
-                }
-            }
-            if (long_read) {
-                // more than 128 results since the last flush (reads of up to 160 bases): the remaining pass, one read at a time
-#pragma unroll
-                for (int u = 0; u < FP; u++) {
-                    if (fL[u] < 0) continue;
-                    const int L = fL[u], ns = __shfl(nseg, L), a = __shfl(i0, L) & 0xFFFF, e = fe[u];
-                    const int tl = wbase + L;
-                    for (int base = a + 128; base < e; base += 128) {
-                        const int j0 = base + 2 * lane, j1 = j0 + 1;
-                        unsigned c0s = seg_src[0][tl], c1s = c0s;
-                        int c0a = (int)seg_at[0][tl], c1a = c0a;
-                        for (int sx = 1; sx < ns; sx++) {
-                            const unsigned ss = seg_src[sx][tl];
-                            const int sa = (int)seg_at[sx][tl];
-                            if (sa <= j0) { c0s = ss; c0a = sa; }
-                            if (sa <= j1) { c1s = ss; c1a = sa; }
-                        }
-                        const unsigned p0 = (j0 < e && !(c0s >> 31)) ? c0s + (unsigned)(j0 - c0a) : 0u;
-                        const unsigned p1 = (j1 < e && !(c1s >> 31)) ? c1s + (unsigned)(j1 - c1a) : 0u;
-                        const int y0 = (int)ix.col[p0], y1 = (int)ix.col[p1];
-                        const int q0 = (c0s >> 31) ? ((c0s == 0xFFFFFFFFu) ? -1 : (int)(c0s & 0x7FFFFFFFu)) : y0;
-                        const int q1 = (c1s >> 31) ? ((c1s == 0xFFFFFFFFu) ? -1 : (int)(c1s & 0x7FFFFFFFu)) : y1;
-                        if (!(ix.debug & 1)) {
-                            if (j1 < e) st_res2(out, fob[u] + j0, (i64)q0, (i64)q1, O32);
-                            else if (j0 < e) st_res(out, fob[u] + j0, (i64)q0, O32);
-                        }
-                    }
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < FP; u++)
-                if (lane == fL[u]) { nseg = 0; i0 = i | (i0 & ~0xFFFF); }
         }
         if (ev == FE_EMIT1 || burst_hi >= 0) {
             if (i == mend) {

@@ -320,7 +320,9 @@ int sbwtgpu_index_create(const sbwtgpu_index_desc *d, int device, sbwtgpu_index 
         h.blob_bytes = align256(h.off_stab + 32 * h.n_sb);
         // second level for 31 < k <= 63 (the remaining k-31 bases fit one 64-bit key): 1.25 two-entry buckets per column, like the
         // first level (round 3: 2 n single 32-byte entries with linear probing -- a miss walked 2.5 of them)
-        if (p_sparse == SBWT_SP_MAX_DEPTH && d->k > p_sparse && d->k - p_sparse <= 32) {
+        // (its entries keep their flags in bit 31 of the column / origin words: columns below 2^31 only -- p_sparse > 0 already
+        // implies one mega block; said again here because a wider first level must not widen this one by accident)
+        if (p_sparse == SBWT_SP_MAX_DEPTH && d->k > p_sparse && d->k - p_sparse <= 32 && n < ((int64_t)1 << 31)) {
             h.n_sb2 = n + n / 4 + 64;
             h.off_stab2 = h.blob_bytes;
             h.blob_bytes = align256(h.off_stab2 + 32 * h.n_sb2);
@@ -498,6 +500,9 @@ int sbwtgpu_index_create(const sbwtgpu_index_desc *d, int device, sbwtgpu_index 
             (void)hipFree(scr);
             if (prc != 0) { e = hipErrorUnknown; break; }
             h.n_pos = n_pos;
+            // col[n_pos] = 0xFFFFFFFF: the "position" whose column is -1 (the fused kernel's writer loads every result, absent
+            // ones included, through col[]; the array has four entries of padding behind the last position)
+            if ((e = hipMemset(idx->blob + h.off_col + (size_t)n_pos * 4, 0xFF, 16)) != hipSuccess) break;
         }
         if (h.p_sparse > 0) {
             void *scr = nullptr;
@@ -829,6 +834,14 @@ static SbwtPieceTab ws_piece_tab(void *d_ws, int64_t total_bases) {
 static const char *RANK_ONLY_MSG =
     "the index columns are not a valid SBWT (set bits != n_nodes - 1): only rank() is available";
 
+// SBWT::search through streaming steps on the device (the marks given with the index, or derived): exact where a streaming step
+// and a full search agree on every k-mer of valid bases (tests/test_large.hh:104-115).  Not for k = 1: there every column is in
+// the root's suffix group while the edges sit on the first k-mer's column (NodeBOSSInMemoryConstructor.hh:98-154), so the
+// reference's own streaming_search misses every second 1-mer that search() finds (round 5, tests/test_gpu_corners.py).
+static bool internal_streaming_ok(const SbwtBlobHeader &h) {
+    return (h.has_ssup || h.ssup_derived) && g_derive_ssup && h.k >= 2;
+}
+
 static int search_dev_check(const sbwtgpu_index *idx, int64_t total_bases, int64_t n_reads, const void *d_ws,
                             int64_t ws_bytes, int streaming) {
     if (!idx) return fail(SBWTGPU_ERR_INVALID_ARG, "idx is NULL");
@@ -891,7 +904,7 @@ int sbwtgpu_search_encoded_dev(const sbwtgpu_index *idx, int64_t total_bases, co
     int variant = g_variant_override >= 0 ? g_variant_override : tuning_variant();
     if (variant < 0) variant = idx->h.has_path ? auto_variant(idx->h) : 2;
     if (variant == 5 || variant == 2 || variant == 3) variant = 4;   // already-encoded bases: the general path kernel
-    const int eff_streaming = (!streaming && (idx->h.has_ssup || idx->h.ssup_derived) && g_derive_ssup) ? 2 : streaming;
+    const int eff_streaming = (!streaming && internal_streaming_ok(idx->h)) ? 2 : streaming;
     // reads sorted by their place in the path order (sbwt_sort.hip): when the batch covers the index a few times
     void *sort_scratch = nullptr;
     long long sort_bytes = 0;
@@ -952,7 +965,7 @@ static int search_dev_common(const sbwtgpu_index *idx, const char *d_bases, int6
         // runs the general kernel behind the fused one for everything that does not.
         int variant = g_variant_override >= 0 ? g_variant_override : tuning_variant();
         if (variant < 0) variant = idx->h.has_path ? auto_variant(idx->h) : 2;
-        const int eff_streaming = (!streaming && (idx->h.has_ssup || idx->h.ssup_derived) && g_derive_ssup) ? 2 : streaming;
+        const int eff_streaming = (!streaming && internal_streaming_ok(idx->h)) ? 2 : streaming;
         const bool path_kernel = idx->h.has_path && eff_streaming &&
                                  idx->h.n_nodes < ((int64_t)1 << 31) - 128 && n_reads < ((int64_t)1 << 31) &&
                                  total_bases / SBWT_GROUP_BASES + 2 < ((int64_t)1 << 31) - 4;

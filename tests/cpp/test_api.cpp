@@ -188,18 +188,55 @@ int main() {
             auto withn = big.partial_search(string("ACNGT"));
             CHECK(withn.second == 2 && withn.first == big.partial_search(string("AC")).first);
         }
-        // cost of the scalar API (batches of one through the small-call path): printed, not asserted
+        // the scalar members answer on the HOST (SubsetMatrixRank.hh:31-48, SBWT.hh:389-437): the same values as
+        // the GPU gives for a batch of one -- every position of the index incl. pos == n_nodes, every symbol incl. non-ACGT;
+        // k-mers that are there, absent ones, lower case (Q1), N inside and outside the prefix table's window (Q3)
+        {
+            const SubsetMatrixRank& mr = big.get_subset_rank_structure();
+            const int64_t n = big.number_of_subsets();
+            vector<int64_t> pos;
+            vector<char> sym;
+            for (int64_t p = 0; p <= n; p += (p < 5000 || p > n - 5000) ? 1 : 37)
+                for (char c : string("ACGTNa$")) { pos.push_back(p); sym.push_back(c); }
+            vector<int64_t> dev(pos.size());
+            mr.rank_batch(pos.data(), sym.data(), (int64_t)pos.size(), dev.data());
+            for (size_t q = 0; q < pos.size(); q++) CHECK(mr.rank(pos[q], sym[q]) == dev[q]);
+            CHECK(mr.rank(n, 'A') + mr.rank(n, 'C') + mr.rank(n, 'G') + mr.rank(n, 'T') == n - 1);
+            for (int t = 0; t < 300; t++) {
+                string kmer = g.substr(rand() % (g.size() - 31), 30);
+                if (t % 3 == 1) kmer[rand() % 30] = "ACGT"[rand() % 4];
+                if (t % 7 == 2) kmer[rand() % 30] = 'N';
+                if (t % 7 == 3) kmer[rand() % 8] = 'N';
+                if (t % 11 == 4) kmer[rand() % 30] = (char)tolower(kmer[5]);
+                CHECK(big.search(kmer) == big.search_on_device(kmer.c_str()));
+                const int64_t cut = rand() % 31;
+                auto I = big.update_sbwt_interval(kmer.c_str(), cut, {0, n - 1});
+                CHECK(I == big.update_sbwt_interval_on_device(kmer.c_str(), cut, {0, n - 1}));
+                CHECK(big.update_sbwt_interval(kmer.c_str() + cut, 30 - cut, I) ==
+                      big.update_sbwt_interval_on_device(kmer.c_str() + cut, 30 - cut, I));
+            }
+        }
+        // cost of the scalar API: on the host (rank, search of one k-mer) and as batches of one through the GPU (what they were
+        // before round 5; streaming_search of one read still is): printed, not asserted
         {
             string kmer = g.substr(4242, 30);
-            auto t0 = std::chrono::steady_clock::now();
-            int64_t acc = 0;
             const int reps = 2000;
-            for (int t = 0; t < reps; t++) acc += big.search(kmer.c_str());
-            double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / reps;
-            auto t1 = std::chrono::steady_clock::now();
-            for (int t = 0; t < reps; t++) acc += big.get_subset_rank_structure().rank(1000 + t, 'C');
-            double us2 = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t1).count() / reps;
-            printf("scalar search(): %.1f us/call, scalar rank(): %.1f us/call (checksum %ld)\n", us, us2, (long)acc);
+            int64_t acc = 0;
+            auto timeit = [&](auto&& f, int n_rep) {
+                auto t0 = std::chrono::steady_clock::now();
+                for (int t = 0; t < n_rep; t++) acc += f(t);
+                return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / n_rep;
+            };
+            const SubsetMatrixRank& mr = big.get_subset_rank_structure();
+            const double us_search = timeit([&](int) { return big.search(kmer.c_str()); }, 100 * reps);
+            const double us_rank = timeit([&](int t) { return mr.rank(1000 + t % 20000, 'C'); }, 100 * reps);
+            const double us_search_dev = timeit([&](int) { return big.search_on_device(kmer.c_str()); }, reps);
+            const double us_rank_dev = timeit([&](int t) { return mr.rank_on_device(1000 + t, 'C'); }, reps);
+            string read = g.substr(5000, 150);
+            const double us_stream = timeit([&](int) { return big.streaming_search(read.c_str(), 150)[0]; }, reps);
+            printf("scalar search(): %.3f us/call on the host (%.1f us as a GPU batch of one), scalar rank(): %.3f us/call "
+                   "(%.1f us), streaming_search of one 150-base read (GPU batch of one): %.1f us (checksum %ld)\n",
+                   us_search, us_search_dev, us_rank, us_rank_dev, us_stream, (long)acc);
         }
         // batch API == scalar API
         vector<int64_t> off = {0, 150, 150, 400}, ooff = {0, 121, 121, 121 + 221}, out(342, -7);

@@ -33,7 +33,7 @@ else:
 idx = capi.Index.create(bits.cols[0], bits.cols[1], bits.cols[2], bits.cols[3], bits.ssup, bits.n_nodes, K, bits.n_kmers, 8)
 print("index: n_nodes", idx.n_nodes, "image MB", idx.blob_bytes / 1e6, "B/col", idx.blob_bytes / idx.n_nodes, "paths", idx.n_paths,
       "branching", idx.n_branch, flush=True)
-d_bases = B.gpu_reads(genomes, n_reads, 42, dev)
+d_bases = B.gpu_reads(genomes, n_reads, 42, dev, in_genome_order=bool(os.environ.get("SORTED")))
 m = L - K + 1
 d_roff = torch.arange(n_reads + 1, dtype=torch.int64, device=dev) * L
 d_ooff = torch.arange(n_reads + 1, dtype=torch.int64, device=dev) * m
@@ -48,6 +48,25 @@ wsb = capi.search_workspace_bytes(d_bases.numel())
 d_ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
 st = torch.cuda.current_stream().cuda_stream
 w = torch.arange(1, m + 1, device=dev, dtype=torch.int64)
+if os.environ.get("SORTED") == "2" and not os.environ.get("RAGGED"):
+    # the batch laid out by the PATH POSITION of each read's first k-mer that the index holds (what a pre-pass could do):
+    # pos[] out of the image (SbwtBlobHeader.off_pos is the int64 at byte 176), one search for the columns
+    import struct
+    off_pos = struct.unpack_from("<q", idx.export_header(), 176)[0]
+    blob = idx.blob_tensor()
+    pos = blob[off_pos:off_pos + 4 * idx.n_nodes].view(torch.int32)
+    idx.streaming_search_dev(d_bases.data_ptr(), d_bases.numel(), d_roff.data_ptr(), n_reads, d_out.data_ptr(), d_ooff.data_ptr(),
+                             d_ws.data_ptr(), wsb, st, bool(streaming))
+    torch.cuda.synchronize()
+    res = d_out.view(n_reads, m)
+    first = (res >= 0).to(torch.int8).argmax(dim=1)
+    col0 = res.gather(1, first[:, None])[:, 0]
+    key = torch.where(col0 >= 0, pos[col0.clamp(min=0)].long() - first, torch.full_like(col0, 1 << 40))
+    shift = int(os.environ.get("SORT_SHIFT", 0))       # SORT_SHIFT=s: only by the key's bits above s (a bucket sort's order)
+    perm = torch.argsort(key >> shift, stable=True)
+    d_bases = d_bases.view(n_reads, L)[perm].contiguous().view(-1)
+    del res, first, col0, key, perm
+    print("reads laid out by path position (shift %d)" % shift, flush=True)
 ref = None
 times = {tuple(c): [] for c in configs}
 ktimes = {tuple(c): [] for c in configs}
