@@ -71,13 +71,34 @@ def log(msg: str) -> None:
 
 
 _T0 = time.time()
+_PHASE = "start-up"             # what this process was doing last: a failure names it (main())
 
 
 def phase(rank: int, world: int, what: str) -> None:
     """Multi-rank runs say where they are (rank 0 always; every rank with SBWT_BENCH_VERBOSE): a stalled 8-GPU run then
     names the phase -- columns, image, broadcast, reads, warm-up, timed loop -- instead of just timing out."""
+    global _PHASE
+    _PHASE = what
     if world > 1 and (rank == 0 or os.environ.get("SBWT_BENCH_VERBOSE")):
         log("rank %d/%d t+%.1fs: %s" % (rank, world, time.time() - _T0, what))
+
+
+def dist_timeout():
+    """Bound on every collective of a multi-rank run (process-group set-up, the image broadcast, the barriers): a rank
+    that never arrives ends the run with an error that names the phase instead of hanging the node.  SBWT_BENCH_DIST_TIMEOUT
+    seconds (default 900: the 13.4 GB image of config 3 moves in well under a minute on any fabric)."""
+    import datetime
+    return datetime.timedelta(seconds=int(os.environ.get("SBWT_BENCH_DIST_TIMEOUT", "900")))
+
+
+def device_memory_check(rank: int, what: str, need_bytes: int, dev) -> None:
+    """Before a large allocation: does it fit next to what this rank already holds (rank 0: the image, and whatever the
+    builders' caches still keep)?  A clear message beats an out-of-memory box (N = 8, config 3: 13.4 GB image + 15 GB reads
+    + 96 GB results + 2 GB workspace per rank)."""
+    free, total = torch.cuda.mem_get_info(dev)
+    if need_bytes > free:
+        raise SystemExit("bench.py: rank %d cannot allocate %s: %.1f GB needed, %.1f GB of %.1f GB free on device %s "
+                         "(smaller --reads, or a lower --image-level)" % (rank, what, need_bytes / 1e9, free / 1e9, total / 1e9, dev))
 
 
 def gpu_reads(genomes, n_reads: int, seed: int, dev: torch.device, in_genome_order: bool = False) -> torch.Tensor:
@@ -316,6 +337,21 @@ def launch_ranks(n: int) -> int:
 
 
 def main() -> int:
+    """Every way out prints either the JSON line (rank 0) or ONE line that names the phase that failed, and a non-zero
+    exit code: a multi-GPU run that dies must say where."""
+    try:
+        return run()
+    except SystemExit as ex:
+        if ex.code not in (0, None):
+            log("FAILED (rank %s) in phase '%s': %s" % (os.environ.get("RANK", "0"), _PHASE, ex.code))
+        raise
+    except BaseException as ex:                # noqa: BLE001 -- anything: the line is the point
+        log("FAILED (rank %s) in phase '%s': %s: %s" % (os.environ.get("RANK", "0"), _PHASE, type(ex).__name__,
+                                                       str(ex).replace("\n", " | ")[:600]))
+        return 1
+
+
+def run() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -406,12 +442,15 @@ def main() -> int:
     backend = os.environ.get("SBWT_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    ctl = None                      # a gloo group beside RCCL's: agreement on failures, and the fall-back route of the replication
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        phase(rank, world, "process group set-up (backend %s)" % backend)
         if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=dist_timeout())
+            ctl = dist.new_group(backend="gloo", timeout=dist_timeout())
         else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+            dist.init_process_group(backend, rank=rank, world_size=world, timeout=dist_timeout())
 
     if args.kernel == "rank":
         return rank_bench(args, rank, world, local_rank, dev)
@@ -443,6 +482,7 @@ def main() -> int:
     capi.set_tuning("image_level", args.image_level)
     build_times = None
     t_bcast = None
+    replicate_fallback = None
     if world > 1 and args.replicate == "rebuild":
         # the five bit vectors travel (RCCL / gloo broadcast of one uint64 tensor), every rank derives its own image
         torch.cuda.synchronize()
@@ -487,15 +527,41 @@ def main() -> int:
         torch.cuda.synchronize()
         dist.barrier()
         tb = time.time()
-        hdr, blob = sdist.broadcast_blob(hdr, blob, dev, src=0)     # RCCL over xGMI, load time only
-        torch.cuda.synchronize()
-        t_bcast = time.time() - tb
-        if rank != 0:
+        phase(rank, world, "image broadcast (RCCL)" if backend == "nccl" else "image broadcast (%s)" % backend)
+        err = None
+        try:
+            if os.environ.get("SBWT_BENCH_FAIL_BCAST") and rank == world - 1:     # test hook: one rank's broadcast fails
+                raise RuntimeError("SBWT_BENCH_FAIL_BCAST")
+            hdr, blob = sdist.broadcast_blob(hdr, blob, dev, src=0)     # RCCL over xGMI, load time only
+            torch.cuda.synchronize()
+        except Exception as ex:                                            # noqa: BLE001
+            err = "%s: %s" % (type(ex).__name__, str(ex).replace("\n", " | ")[:300])
+            log("rank %d: image broadcast failed (%s)" % (rank, err))
+        # every rank learns whether ANY rank failed (over gloo when the data path is RCCL): all of them then take the same
+        # fall-back -- the five bit vectors over the control group, every rank derives its own image (--replicate rebuild's
+        # work, in this process: a rank that has touched the GPU is never re-executed)
+        n_failed = sdist.count_failures(err is not None, ctl)
+        if n_failed > 0:
+            replicate_fallback = "image broadcast failed on %d rank(s)%s; bit vectors over %s, every rank derived its image" % (
+                n_failed, (" (this rank: %s)" % err) if err else "", "gloo" if ctl is not None else backend)
+            phase(rank, world, "fall-back: " + replicate_fallback)
+            blob = None
+            bits = sdist.broadcast_bits_cpu(bits if rank == 0 else None, K, ctl, capi.BuiltBits)
+            if rank != 0:
+                index = capi.Index.create(bits.cols[0], bits.cols[1], bits.cols[2], bits.cols[3], bits.ssup, bits.n_nodes, K,
+                                          bits.n_kmers, PRECALC, None, device=local_rank)
+        elif rank != 0:
             index = capi.Index.adopt(hdr, blob.data_ptr(), blob.numel(), local_rank, keepalive=blob)
-        phase(rank, world, "image broadcast done: %.2f GB in %.2f s" % (index.blob_bytes / 1e9, t_bcast))
+        t_bcast = time.time() - tb
+        phase(rank, world, "image replicated: %.2f GB in %.2f s" % (index.blob_bytes / 1e9, t_bcast))
 
     # ---- this rank's reads, resident in HBM ----
     m = READ_LEN - K + 1
+    phase(rank, world, "allocating reads and results")
+    searched_here = args.reads if args.scaling != "strong" else -(-args.reads // world) + 1     # (strong scaling generates the whole set, searches a shard)
+    device_memory_check(rank, "%d reads, the int64 results of %d of them and the workspace" % (args.reads, searched_here),
+                        args.reads * READ_LEN + searched_here * m * 8 + capi.search_workspace_bytes(searched_here * READ_LEN)
+                        + (1 << 28), dev)
     strong = args.scaling == "strong" and world >= 1
     d_all = None
     if args.scaling == "strong":
@@ -715,6 +781,8 @@ def main() -> int:
         result["int32_results_on_device"] = int32_leg
     if two_in_flight is not None:
         result["two_batches_in_flight"] = two_in_flight
+    if replicate_fallback is not None:
+        result["index_replication_fallback"] = replicate_fallback
     if t_bcast is not None:
         result["index_broadcast_s"] = t_bcast
         result["index_replication"] = args.replicate

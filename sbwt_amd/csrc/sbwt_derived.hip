@@ -1,6 +1,8 @@
 // sbwt_derived.hip -- structures derived from the index on the device when the image is created: suffix-group
 // marks for indexes without streaming support, the sparse prefix table (+ second level), the probe filter, the
 // path order with its packed chars, substitution-safe bits and transition table (DESIGN.md sections 2-3).
+#include <cstdio>
+#include <cstdlib>
 #include "sbwt_kernels_common.h"
 #include "sbwt_scan.h"
 
@@ -100,8 +102,8 @@ __global__ void __launch_bounds__(256) k_sp2_seed(SpItem *items, const u64 *n) {
     reinterpret_cast<SpItem2 *>(items)[t] = SpItem2{0ull, (unsigned)it.l, (unsigned)it.l, (unsigned)it.r, 0u};
 }
 __global__ void __launch_bounds__(256) k_sp2_expand(SbwtIndexView ix, const SpItem2 *__restrict__ in, const u64 *n_in,
-                                                    int d2, SpItem2 *__restrict__ out, u64 *n_out) {
-    u64 t = (u64)blockIdx.x * 256 + threadIdx.x;
+                                                    int d2, SpItem2 *__restrict__ out, u64 *n_out, u64 t0) {
+    u64 t = t0 + (u64)blockIdx.x * 256 + threadIdx.x;
     const bool live = (t >> 2) < *n_in;
     SpItem2 it = SpItem2{0ull, 0u, 0u, 0u, 0u};
     if (live) it = in[t >> 2];
@@ -144,14 +146,17 @@ __global__ void __launch_bounds__(256) k_sp_wide(const SpItem *__restrict__ item
     u64 t = (u64)blockIdx.x * 256 + threadIdx.x;
     if (t < *n && items[t].l != items[t].r) *flag = 1;
 }
-__global__ void __launch_bounds__(256) k_sp_clear(uint4 *table, u64 n_entries) {
-    u64 t = (u64)blockIdx.x * 256 + threadIdx.x;
+// (A launch holds fewer than 2^32 work-items -- the dispatch packet's grid size is 32 bits, and more are dropped SILENTLY: a table
+// of 5.6 x 10^9 entries, or four threads for each of 2.25 x 10^9 items, goes in slices of 2^31 threads that start at t0; round 5)
+#define SBWT_LAUNCH_SLICE ((u64)1 << 31)
+__global__ void __launch_bounds__(256) k_sp_clear(uint4 *table, u64 n_entries, u64 t0) {
+    u64 t = t0 + (u64)blockIdx.x * 256 + threadIdx.x;
     if (t < n_entries) table[t] = make_uint4(0u, (unsigned)(SBWT_SP_EMPTY >> 32), 0u, 0u);
 }
 template <bool MEGA>
 __global__ void __launch_bounds__(256) k_sp_expand(SbwtIndexView ix, const SpItem *__restrict__ in, const u64 *n_in,
-                                                   int depth, SpItem *__restrict__ out, u64 *n_out) {
-    u64 t = (u64)blockIdx.x * 256 + threadIdx.x;
+                                                   int depth, SpItem *__restrict__ out, u64 *n_out, u64 t0) {
+    u64 t = t0 + (u64)blockIdx.x * 256 + threadIdx.x;
     const bool live = (t >> 2) < *n_in;
     SpItem it = SpItem{0, 0, 0};
     if (live) it = in[t >> 2];
@@ -961,6 +966,15 @@ void sbwt_launch_derive_marks(const SbwtIndexView &ix, uint4 *d_blocks, void *d_
     hipLaunchKernelGGL(k_sg_patch, dim3(grid_for(nb)), dim3(256), 0, stream, d_blocks, acc, nb);
 }
 
+// SBWTGPU_VERBOSE=2: the builders below say what they are at (stderr, after a stream synchronise)
+static void derived_log(hipStream_t stream, const char *what, long long a = 0, const u64 *d_count = nullptr) {
+    static const int verbose = [] { const char *e = getenv("SBWTGPU_VERBOSE"); return e ? atoi(e) : 0; }();
+    if (verbose < 2) return;
+    const hipError_t e = hipStreamSynchronize(stream);
+    u64 c = 0;
+    if (d_count) (void)hipMemcpy(&c, d_count, 8, hipMemcpyDeviceToHost);
+    fprintf(stderr, "sbwtgpu:   derived: %s %lld (count %llu)%s\n", what, a, (unsigned long long)c, e == hipSuccess ? "" : " -- STREAM ERROR");
+}
 // scratch of the sparse-table build: two item lists of n_nodes entries + two counters
 long long sbwt_sparse_scratch_bytes(long long n_nodes) { return 2 * (n_nodes + 64) * (long long)sizeof(SpItem) + 256; }
 
@@ -973,7 +987,11 @@ int sbwt_launch_build_sparse(const SbwtIndexView &ix, int p_dense, int p_sparse,
     SpItem *listA = reinterpret_cast<SpItem *>(reinterpret_cast<char *>(d_scratch) + 256);
     SpItem *listB = listA + (ix.n_nodes + 64);
     (void)hipMemsetAsync(counters, 0, 256, stream);
-    hipLaunchKernelGGL(k_sp_clear, dim3(grid_for((i64)2 * n_buckets)), dim3(256), 0, stream, d_table, (u64)2 * (u64)n_buckets);
+    for (u64 t0 = 0; t0 < (u64)2 * (u64)n_buckets; t0 += SBWT_LAUNCH_SLICE) {
+        const u64 left = (u64)2 * (u64)n_buckets - t0;
+        hipLaunchKernelGGL(k_sp_clear, dim3(grid_for((i64)(left < SBWT_LAUNCH_SLICE ? left : SBWT_LAUNCH_SLICE))), dim3(256), 0, stream,
+                           d_table, (u64)2 * (u64)n_buckets, t0);
+    }
     const u64 n_dense = 1ull << (2 * p_dense);
     hipLaunchKernelGGL(k_sp_collect, dim3(grid_for((i64)n_dense)), dim3(256), 0, stream, ix.ptab, n_dense, listA,
                        counters + 0);
@@ -981,15 +999,17 @@ int sbwt_launch_build_sparse(const SbwtIndexView &ix, int p_dense, int p_sparse,
     int ci = 0;
     for (int d = p_dense; d < p_sparse; d++) {
         (void)hipMemsetAsync(counters + (ci ^ 1), 0, 8, stream);
-        const i64 threads = (ix.n_nodes + 64) * 4;
-        if (ix.n_mega > 1)
-            hipLaunchKernelGGL(k_sp_expand<true>, dim3(grid_for(threads)), dim3(256), 0, stream, ix, in, counters + ci, d,
-                               outl, counters + (ci ^ 1));
-        else
-            hipLaunchKernelGGL(k_sp_expand<false>, dim3(grid_for(threads)), dim3(256), 0, stream, ix, in, counters + ci, d,
-                               outl, counters + (ci ^ 1));
+        const u64 threads = (u64)(ix.n_nodes + 64) * 4;
+        for (u64 t0 = 0; t0 < threads; t0 += SBWT_LAUNCH_SLICE) {
+            const unsigned g = grid_for((i64)(threads - t0 < SBWT_LAUNCH_SLICE ? threads - t0 : SBWT_LAUNCH_SLICE));
+            if (ix.n_mega > 1)
+                hipLaunchKernelGGL(k_sp_expand<true>, dim3(g), dim3(256), 0, stream, ix, in, counters + ci, d, outl, counters + (ci ^ 1), t0);
+            else
+                hipLaunchKernelGGL(k_sp_expand<false>, dim3(g), dim3(256), 0, stream, ix, in, counters + ci, d, outl, counters + (ci ^ 1), t0);
+        }
         SpItem *t = in; in = outl; outl = t;
         ci ^= 1;
+        derived_log(stream, "sparse table: prefixes expanded to depth", d + 1, counters + ci);
         if (d_filter && d + 1 == p_filter) {
             (void)hipMemsetAsync(d_filter, 0, (size_t)16 << log2f, stream);
             hipLaunchKernelGGL(k_pf_insert, dim3(grid_for(ix.n_nodes + 64)), dim3(256), 0, stream, in, counters + ci,
@@ -1005,9 +1025,11 @@ int sbwt_launch_build_sparse(const SbwtIndexView &ix, int p_dense, int p_sparse,
         if (hipStreamSynchronize(stream) != hipSuccess) return -1;
         with_pos = h_flag ? 0 : 1;
     }
+    derived_log(stream, "sparse table: items to insert, with positions =", with_pos, counters + ci);
     hipLaunchKernelGGL(k_sp_insert, dim3(grid_for(ix.n_nodes + 64)), dim3(256), 0, stream, in, counters + ci, d_table,
                        (unsigned)n_buckets, with_pos ? d_pos : (const unsigned *)nullptr,
                        (!with_pos && d_pos && d_table2 && ix.k > p_sparse) ? d_pos : (const unsigned *)nullptr);
+    derived_log(stream, "sparse table: inserted", 0);
     if (d_table2 && ix.k > p_sparse) {
         // second level: carry every depth-p_sparse prefix on to depth k, remembering where it started
         (void)hipMemsetAsync(d_table2, 0, (size_t)32 * (size_t)n_entries2, stream);
@@ -1015,8 +1037,10 @@ int sbwt_launch_build_sparse(const SbwtIndexView &ix, int p_dense, int p_sparse,
         SpItem2 *in2 = reinterpret_cast<SpItem2 *>(in), *out2 = reinterpret_cast<SpItem2 *>(outl);
         for (int d = p_sparse; d < ix.k; d++) {
             (void)hipMemsetAsync(counters + (ci ^ 1), 0, 8, stream);
-            hipLaunchKernelGGL(k_sp2_expand, dim3(grid_for((ix.n_nodes + 64) * 4)), dim3(256), 0, stream, ix, in2,
-                               counters + ci, d - p_sparse, out2, counters + (ci ^ 1));
+            const u64 threads = (u64)(ix.n_nodes + 64) * 4;
+            for (u64 t0 = 0; t0 < threads; t0 += SBWT_LAUNCH_SLICE)
+                hipLaunchKernelGGL(k_sp2_expand, dim3(grid_for((i64)(threads - t0 < SBWT_LAUNCH_SLICE ? threads - t0 : SBWT_LAUNCH_SLICE))),
+                                   dim3(256), 0, stream, ix, in2, counters + ci, d - p_sparse, out2, counters + (ci ^ 1), t0);
             SpItem2 *t = in2; in2 = out2; out2 = t;
             ci ^= 1;
         }

@@ -2,6 +2,8 @@
 // (sbwt_search.hip, sbwt_api_kernels.hip, sbwt_derived.hip, sbwt_format.hip).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
 #include "sbwt_device.h"
 
 typedef unsigned long long u64;
@@ -230,4 +232,13 @@ __device__ __forceinline__ void piece_zones_of_wave(i64 r, i64 len, bool valid, 
     }
 }
 
-static inline unsigned grid_for(i64 n) { return (unsigned)((n + 255) / 256); }
+// workgroups of 256 for n threads.  A launch holds fewer than 2^32 work-items (32-bit grid size in the dispatch packet; what is
+// beyond is dropped silently -- it cost the sparse table of a 2.25 x 10^9-column index most of its entries before round 5): a
+// caller with more slices its launch (SBWT_LAUNCH_SLICE, sbwt_derived.hip); one that does not is stopped here.
+static inline unsigned grid_for(i64 n) {
+    if (n + 255 >= ((i64)1 << 32)) {
+        fprintf(stderr, "sbwtgpu: internal error: a launch of %lld threads exceeds the 2^32 work-items of one dispatch\n", (long long)n);
+        abort();
+    }
+    return (unsigned)((n + 255) / 256);
+}

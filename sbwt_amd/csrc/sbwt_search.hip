@@ -1342,9 +1342,21 @@ void sbwt_launch_encode_chained(const char *d_bases, long long total_bases, uint
 // The general kernel's bridge compares the k-1 bases after a substitution in ONE iteration (at most 32 of them): for
 // k > 32 it runs without the safe bits (a safe step is an only-successor step: -1 and the certificates, as before the
 // bits existed); the fused kernel's multi-iteration compare (F_CMP, sbwt_search_fused.hip) uses them for any k <= 64.
+// An index of 2^31 columns or more is served by this file's kernels on its blocks and dense prefix table alone (the 64-bit
+// instantiation, as on a level-2 image): its derived structures hold full 32-bit unsigned columns and positions, which only
+// the fused kernel's BIG instantiation reads (sbwt_search_fused.hip).  Here that is the route of the few reads the fused
+// kernel hands on, of batches it declines, and of the cross-check variants.
+static inline bool view_is_big(const SbwtIndexView &ix) { return ix.n_nodes >= ((1ll << 31) - 128); }
 static inline SbwtIndexView general_view(const SbwtIndexView &ix) {
     SbwtIndexView v = ix;
     if (v.k > 32) v.has_safe = 0;
+    if (view_is_big(v)) {
+        v.stab = nullptr; v.p_sparse = 0; v.n_sb = 0; v.stab_pos = 0;
+        v.stab2 = nullptr; v.n_sb2 = 0;
+        v.pfil = nullptr; v.p_filter = 0; v.log2f = 0;
+        v.col = v.pos = nullptr; v.pq = nullptr; v.trans = nullptr; v.n_tslots = 0; v.has_safe = 0;
+        v.n_pos = v.n_nodes;
+    }
     return v;
 }
 
@@ -1355,8 +1367,12 @@ void sbwt_launch_search_chained(const SbwtIndexView &ix_in, const uint4 *d_packe
     const SbwtIndexView ix = general_view(ix_in);
     const unsigned cap = (ix.debug >> 8) ? (unsigned)(ix.debug >> 8) : 1280u;
     const unsigned g = (unsigned)(want1 < (i64)cap ? want1 : (i64)cap);
-    hipLaunchKernelGGL((k_search_cert<false, 4, true>), dim3(g), dim3(256), 0, stream, ix, d_packed, d_read_off,
-                       d_out_off, d_out, (i64)n_reads, ws, streaming, (const unsigned *)nullptr, d_defer, pt);
+    if (view_is_big(ix))
+        hipLaunchKernelGGL((k_search_cert<true, 4, false>), dim3(g), dim3(256), 0, stream, ix, d_packed, d_read_off,
+                           d_out_off, d_out, (i64)n_reads, ws, streaming, (const unsigned *)nullptr, d_defer, pt);
+    else
+        hipLaunchKernelGGL((k_search_cert<false, 4, true>), dim3(g), dim3(256), 0, stream, ix, d_packed, d_read_off,
+                           d_out_off, d_out, (i64)n_reads, ws, streaming, (const unsigned *)nullptr, d_defer, pt);
 }
 
 void sbwt_launch_piece_bounds(const uint4 *d_packed, const long long *d_read_off, const long long *d_out_off, int k,

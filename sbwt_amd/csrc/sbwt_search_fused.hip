@@ -182,7 +182,11 @@ __device__ __forceinline__ u64 fz_encode32(const unsigned w[8], const unsigned t
 // O32: the results are written as int32 (sbwtgpu_*_dev_i32).  WIDE = false: k <= 31 -- a read follows its path in F_EXT, a substitution-safe step is bridged in one compare (F_BRIDGE):
 // round 3's walk, the leanest code for k-mers that cost one lookup.  WIDE = true: 31 < k <= 63 (and "debug" bit 64) -- both
 // are the one state F_CMP, with anchors, seeds and resumed compares around it.
-template <bool WIDE, bool O32>
+// BIG (round 5): an index of 2^31 .. 2^32 - 2^24 columns (k <= 31, int64 results).  Columns and path positions are then full
+// 32-bit UNSIGNED values: nothing may sign-extend them, bit 31 of a segment's source is part of a position (such an image
+// answers every found k-mer with its position: no result is known by its column only), and the block counts are absolute
+// (C[c] + rank fits 32 bits; the image's mega table is all zero).  0xFFFFFFFF stays "none" / -1.
+template <bool WIDE, bool O32, bool BIG = false>
 __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const unsigned char *__restrict__ bases,
                                                           i64 total_bases, i64 *__restrict__ out, i64 n_reads,
                                                           SbwtWorkHeader *ws, unsigned *__restrict__ defer_list,
@@ -206,6 +210,9 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
     const u64 mk2 = (k - ps >= 32) ? ~0ull : low_mask(2 * ((k - ps) & 31));   // key mask of the second-level window
     const int pw = pfon ? L0 : p;                   // window of a range probe: the filter's when there is one
     const int last_node = (int)(ix.n_nodes - 1);
+    static_assert(!BIG || (!WIDE && !O32), "2^31 columns and more: k <= 31, int64 results");
+    auto zx = [](int v) -> i64 { return BIG ? (i64)(unsigned)v : (i64)v; };                    // a column / position as an index
+    auto is_run = [](unsigned src) -> bool { return BIG ? src != 0xFFFFFFFFu : !(src >> 31); };   // a segment's source is a path position
 
     int nseg = 0, i0 = 0, last_start = 0;           // segments listed; first result of the read not written yet
     u64 fm_pend = 0;                // wave-uniform: lanes whose segment list waits for the writer (handed over at the end of an iteration)
@@ -513,8 +520,8 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
                     a2 = a1;
                 }
             } else {   // F_STEP
-                a1 = ix.blocks + ((((i64)l >> 6) << 2) + c);
-                a2 = ix.blocks + (((((i64)r + 1) >> 6) << 2) + c);
+                a1 = ix.blocks + (((zx(l) >> 6) << 2) + c);
+                a2 = ix.blocks + ((((zx(r) + 1) >> 6) << 2) + c);
             }
         }
 #ifdef SBWT_STATS
@@ -614,8 +621,11 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
 #pragma unroll
                 for (int u = 0; u < FP; u++) {
                     const int fj = fa[u] + 2 * lane;
-                    if (fj + 1 < fe[u]) st_res2(out, fob[u] + fj, (i64)w0[u], (i64)w1[u], O32);
-                    else if (fj < fe[u]) st_res(out, fob[u] + fj, (i64)w0[u], O32);
+                    // (col[] values: int32 columns, -1 from the sentinel; BIG: uint32 columns, 0xFFFFFFFF is the -1)
+                    const i64 r0 = BIG ? (w0[u] == -1 ? -1ll : (i64)(unsigned)w0[u]) : (i64)w0[u];
+                    const i64 r1 = BIG ? (w1[u] == -1 ? -1ll : (i64)(unsigned)w1[u]) : (i64)w1[u];
+                    if (fj + 1 < fe[u]) st_res2(out, fob[u] + fj, r0, r1, O32);
+                    else if (fj < fe[u]) st_res(out, fob[u] + fj, r0, O32);
                 }
             }
             if (slow) {
@@ -631,14 +641,16 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
                         unsigned c0s, c1s;
                         int c0a, c1a;
                         seg_of(wbase + L, ns, j0, c0s, c0a, c1s, c1a);
-                        const unsigned p0 = (j0 < e && !(c0s >> 31)) ? c0s + (unsigned)(j0 - c0a) : col_minus1;
-                        const unsigned p1 = (j1 < e && !(c1s >> 31)) ? c1s + (unsigned)(j1 - c1a) : col_minus1;
+                        const unsigned p0 = (j0 < e && is_run(c0s)) ? c0s + (unsigned)(j0 - c0a) : col_minus1;
+                        const unsigned p1 = (j1 < e && is_run(c1s)) ? c1s + (unsigned)(j1 - c1a) : col_minus1;
                         const int y0 = (int)ix.col[p0], y1 = (int)ix.col[p1];
-                        const int q0 = (c0s >> 31) ? ((c0s == 0xFFFFFFFFu) ? -1 : (int)(c0s & 0x7FFFFFFFu)) : y0;
-                        const int q1 = (c1s >> 31) ? ((c1s == 0xFFFFFFFFu) ? -1 : (int)(c1s & 0x7FFFFFFFu)) : y1;
+                        const int q0 = is_run(c0s) ? y0 : ((c0s == 0xFFFFFFFFu) ? -1 : (int)(c0s & 0x7FFFFFFFu));
+                        const int q1 = is_run(c1s) ? y1 : ((c1s == 0xFFFFFFFFu) ? -1 : (int)(c1s & 0x7FFFFFFFu));
+                        const i64 r0 = BIG ? (q0 == -1 ? -1ll : (i64)(unsigned)q0) : (i64)q0;
+                        const i64 r1 = BIG ? (q1 == -1 ? -1ll : (i64)(unsigned)q1) : (i64)q1;
                         if (!(ix.debug & 1)) {
-                            if (j1 < e) st_res2(out, fob[u] + j0, (i64)q0, (i64)q1, O32);
-                            else if (j0 < e) st_res(out, fob[u] + j0, (i64)q0, O32);
+                            if (j1 < e) st_res2(out, fob[u] + j0, r0, r1, O32);
+                            else if (j0 < e) st_res(out, fob[u] + j0, r0, O32);
                         }
                     }
                 }
@@ -652,9 +664,8 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
             bool lr = flush_issue(fm);
             v1 = *a1;
             v2 = *a2;
-            // (the gathered quads have arrived as well before the first store is issued: a wait for them behind the stores
-            // would be a wait for the stores)
-            asm volatile("" : "+v"(v1.x), "+v"(v1.y), "+v"(v1.z), "+v"(v1.w), "+v"(v2.x), "+v"(v2.y), "+v"(v2.z), "+v"(v2.w));
+            // (measured, round 5: also holding the stores back until the gathered quads have arrived -- so that the wait for
+            // them is not a wait for the stores -- is 1.5 % slower: the stores start a gather's latency later)
             flush_store(lr);
             while (fm) {
                 lr = flush_issue(fm);
@@ -1037,9 +1048,12 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
                 }
             }
         } else if (mode == F_STEP) {
-            l = (int)v1.z + (int)__popcll(quad_bits(v1) & low_mask(l & 63));
-            r = (int)v2.z + (int)__popcll(quad_bits(v2) & low_mask((r + 1) & 63)) - 1;
-            if (l > r) {
+            // (the counts as 64-bit sums: l > r without a signed compare of what may be 32-bit unsigned columns)
+            const u64 Lq = (u64)v1.z + (u64)__popcll(quad_bits(v1) & low_mask(l & 63));
+            const u64 Rq = (u64)v2.z + (u64)__popcll(quad_bits(v2) & low_mask((r + 1) & 63));
+            l = (int)(unsigned)Lq;
+            r = (int)(unsigned)(Rq - 1ull);
+            if (Lq >= Rq) {
                 ev = FE_FAIL;                          // SBWT.hh:433
                 tfail = wstart + j;
             } else if (wstart + (++j) == i + k) {
@@ -1082,7 +1096,7 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
             if (wstart == i) {                         // k chars matched from i: the k-mer is there
                 res = l;
                 if (l != r) ws->status = SBWT_ERR_NOT_SINGLETON;   // SBWT.hh:410-413
-                if (tpos >= 0) { r = tpos; rknown = true; emit_pos = (unsigned)tpos; }
+                if (tpos != -1) { r = tpos; rknown = true; emit_pos = (unsigned)tpos; }
                 ev = FE_EMIT1;
                 b = -1;
                 fl &= ~CF_MISS_MASK;
@@ -1136,17 +1150,20 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
         // ---- append this iteration's results to the lane's segment list (at most two segments; contiguous ones merge) ----
         auto append = [&](int at, unsigned src) {
             const bool merge = nseg > 0 && ((src == 0xFFFFFFFFu && last_src == 0xFFFFFFFFu) ||
-                                            (!(src >> 31) && !(last_src >> 31) && last_src + (unsigned)(at - last_start) == src));
+                                            (is_run(src) && is_run(last_src) && last_src + (unsigned)(at - last_start) == src));
             if (!merge) {
                 seg_src[nseg][tid] = src;
                 seg_at[nseg][tid] = (unsigned char)at;
                 nseg++;
                 last_src = src;
                 last_start = at;
-                if ((src >> 31) && src != 0xFFFFFFFFu) i0 |= 1 << 24;     // a result known by its column only: the writer's slow pass
+                if (!BIG && (src >> 31) && src != 0xFFFFFFFFu) i0 |= 1 << 24;     // a result known by its column only: the writer's slow pass
             }
         };
         if (ev == FE_EMIT1) {
+            // (BIG: a k-mer found without its position cannot be listed -- such an image stores a position with every k-mer,
+            // so that is a damaged image: the call fails)
+            if (BIG && res != -1 && !rknown) ws->status = SBWT_ERR_NOT_SINGLETON;
             append(i, res == -1 ? 0xFFFFFFFFu : (rknown ? emit_pos : (0x80000000u | (unsigned)res)));
             i++;
         }
@@ -1211,7 +1228,7 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
         //      between the issue of that iteration's gather and its use (above) ----
         {
             const bool want = nseg > 0 && (i == mend || nseg > FZ_NSEG - 2);
-            fm_pend = __ballot(want);
+            fm_pend = (ix.debug & 4) ? 0ull : __ballot(want);      // ("debug" bit 4, experiments: no writer at all)
             if (want) {
                 pend_rd = rd;
                 pend = (i0 & 0xFF) | (i << 8) | (nseg << 16) | (((i0 >> 16) & 3) << 20) | (((i0 >> 24) & 1) << 22);
@@ -1373,7 +1390,11 @@ void sbwt_launch_search_fused(const SbwtIndexView &ix, const char *d_bases, long
 #define FZ_LAUNCH(W, O) hipLaunchKernelGGL((k_search_fused<W, O>), dim3(g), dim3(256), 0, stream, ix, \
                                            reinterpret_cast<const unsigned char *>(d_bases), (i64)total_bases, d_out, (i64)n_reads, ws, d_defer, \
                                            d_read_off, d_out_off)
-    if (wide) { if (ix.out32) FZ_LAUNCH(true, true); else FZ_LAUNCH(true, false); }
+    const bool big = ix.n_nodes >= ((i64)1 << 31) - 64;        // (the C ABI sends such an index here only with k <= 31 and int64 results)
+    if (big) hipLaunchKernelGGL((k_search_fused<false, false, true>), dim3(g), dim3(256), 0, stream, ix,
+                                reinterpret_cast<const unsigned char *>(d_bases), (i64)total_bases, d_out, (i64)n_reads, ws, d_defer,
+                                d_read_off, d_out_off);
+    else if (wide) { if (ix.out32) FZ_LAUNCH(true, true); else FZ_LAUNCH(true, false); }
     else      { if (ix.out32) FZ_LAUNCH(false, true); else FZ_LAUNCH(false, false); }
 #undef FZ_LAUNCH
     if (ev_end) (void)hipEventRecord(ev_end, stream);

@@ -6,6 +6,7 @@
 
 #include <dlfcn.h>
 #include <cstdarg>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <algorithm>
@@ -57,6 +58,10 @@ int default_device_precalc(int64_t n_nodes, bool derived) {
         v = 1;
         while (v < 14 && ((int64_t)1 << (2 * v)) < n_nodes) v++;
         if (!derived) v = v + 2 > 14 ? 14 : v + 2;
+        // An image with the sparse table and the filter hardly ever walks from the dense table (0.00 dense lookups per read on
+        // configs 2, 3 and 5: whole k-mers and probe windows have their own structures), so a table of 4^8 entries serves the
+        // rare window that fits neither -- not one entry per column: 21 B per column on config 2, 30 on config 3 (round 5)
+        else if (v > 8) v = 8;
     }
     if (v < 0) v = 0;
     if (v > 14) v = 14;
@@ -107,6 +112,26 @@ static int g_force_mega = 0;    // tests: store every image's block counts relat
 static int g_path_safe = [] { const char *e = getenv("SBWTGPU_PATH_SAFE"); return e ? atoi(e) : 2; }();   // 0 off, 1 narrow rule, 2 wide
 static int g_path_lookahead = [] { const char *e = getenv("SBWTGPU_PATH_LOOKAHEAD"); return e ? atoi(e) : 8; }();   // 0: the blind rule
 static int g_path_order = [] { const char *e = getenv("SBWTGPU_PATH_ORDER"); return e ? atoi(e) : 1; }();
+// the full image (path order, sparse table, filter) for indexes of 2^31 .. 2^32 - 2^24 columns with k <= 31 (round 5): columns
+// and positions as full 32-bit unsigned values, read by k_search_fused<false, false, BIG>.  0: such an index gets blocks +
+// dense table only, as before round 5 (23 G k-mers/s on 2.25 x 10^9 columns)
+// SBWTGPU_VERBOSE=1: index_create says on stderr which part of the image it is building and how long each took (a build of
+// 10^9 columns takes 10-30 s; a stall names its phase)
+static int g_verbose = [] { const char *e = getenv("SBWTGPU_VERBOSE"); return e ? atoi(e) : 0; }();
+struct PhaseLog {
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    void operator()(const char *what) {
+        if (!g_verbose) return;
+        (void)hipDeviceSynchronize();
+        const auto t1 = std::chrono::steady_clock::now();
+        size_t fr = 0, tot = 0;
+        (void)hipMemGetInfo(&fr, &tot);
+        fprintf(stderr, "sbwtgpu: index_create: %-34s %8.2f s   (%.1f GB of device memory free)\n", what,
+                std::chrono::duration<double>(t1 - t0).count(), (double)fr / 1e9);
+        t0 = t1;
+    }
+};
+static int g_big_path = [] { const char *e = getenv("SBWTGPU_BIG_PATH"); return e ? atoi(e) : 1; }();
 // stitched chains (sbwt_derived.hip): 0 = vertex-disjoint paths only; the shortest stretch worth copying
 // long reads are cut into pieces on the device (SbwtPieceTab); 0: one lane per read whatever its length (tests)
 static int g_split_long = [] { const char *e = getenv("SBWTGPU_SPLIT_LONG"); return e ? atoi(e) : 1; }();
@@ -191,6 +216,7 @@ int sbwtgpu_set_tuning(const char *key, int64_t value) {
     if (!strcmp(key, "derive_ssup")) { g_derive_ssup = (int)value; return SBWTGPU_OK; }
     if (!strcmp(key, "poison_results")) { g_poison = (int)value; return SBWTGPU_OK; }
     if (!strcmp(key, "probe_filter")) { g_probe_filter = (int)value; return SBWTGPU_OK; }   // indexes created afterwards
+    if (!strcmp(key, "big_path")) { g_big_path = (int)value; return SBWTGPU_OK; }           // indexes created afterwards
     if (!strcmp(key, "image_level")) { g_image_level = (int)value; return SBWTGPU_OK; }          // indexes created afterwards
     if (!strcmp(key, "max_image_bytes")) { g_max_image_bytes = value; return SBWTGPU_OK; }     // indexes created afterwards
     if (!strcmp(key, "sort_reads")) { g_sort_reads = (int)value; return SBWTGPU_OK; }
@@ -267,13 +293,23 @@ int sbwtgpu_index_create(const sbwtgpu_index_desc *d, int device, sbwtgpu_index 
         // another level)
         if (d_bits.p) { (void)hipFree(d_bits.p); d_bits.p = nullptr; }
         if (d_bscr.p) { (void)hipFree(d_bscr.p); d_bscr.p = nullptr; }
+        // never silently: a stepped-down image answers the same and three to ten times slower
+        fprintf(stderr, "sbwtgpu: the level-%d image of this index (%lld columns, k = %lld) does not fit the device%s: building level %d "
+                        "(%s)\n", level, (long long)n, (long long)d->k, g_max_image_bytes > 0 ? " or \"max_image_bytes\"" : "", level + 1,
+                level + 1 == 1 ? "no path order: the blocks-only search kernel" : "blocks and dense prefix table only");
         t_image_level = level + 1;
         const int rc2 = sbwtgpu_index_create(d, device, out);
         t_image_level = -1;
         return rc2;
     };
-    const bool derived = !t_minimal_image && g_sparse_depth > 0 && g_probe_filter && n < ((int64_t)1 << 31) - 64 &&
-                         n_mega == 1 && d->k > 16;
+    // 2^31 - 64 <= n < 2^32 - 2^24 (round 5): the same derived structures with full 32-bit unsigned columns and positions,
+    // when whole k-mers fit the sparse table (k <= 31: every found k-mer comes with its path position, so no segment source
+    // needs bit 31 as a flag) and the marks are there; absolute 32-bit block counts (the mega table stays zero)
+    const bool big_range = n >= ((int64_t)1 << 31) - 64 && n < ((int64_t)1 << 32) - ((int64_t)1 << 24);
+    const bool big_path = big_range && g_big_path && level == 0 && d->k > 16 && d->k <= SBWT_SP_MAX_DEPTH && g_sparse_depth >= d->k &&
+                          g_probe_filter && g_path_order && (d->suffix_group_starts || g_derive_ssup);
+    const bool derived = !t_minimal_image && g_sparse_depth > 0 && g_probe_filter &&
+                         ((n < ((int64_t)1 << 31) - 64 && n_mega == 1) || big_path) && d->k > 16;
     int64_t p_dev = default_device_precalc(n, derived);
     if (p_dev < p_file) p_dev = p_file;
     if (p_dev > d->k) p_dev = d->k;
@@ -312,7 +348,8 @@ int sbwtgpu_index_create(const sbwtgpu_index_desc *d, int device, sbwtgpu_index 
     int64_t p_sparse = g_sparse_depth < d->k ? g_sparse_depth : d->k;
     if (t_minimal_image) p_sparse = 0;
     if (p_sparse > SBWT_SP_MAX_DEPTH) p_sparse = SBWT_SP_MAX_DEPTH;
-    if (p_sparse <= p_dev || p_dev <= 0 || n >= ((int64_t)1 << 32) || n_mega > 1) p_sparse = 0;
+    if (p_sparse <= p_dev || p_dev <= 0 || n >= ((int64_t)1 << 32) || (n_mega > 1 && !big_path)) p_sparse = 0;
+    if (big_path && p_sparse != d->k) p_sparse = 0;     // (2^31 columns and more: whole k-mers with their positions, or nothing)
     if (p_sparse > 0) {
         h.p_sparse = (int32_t)p_sparse;
         h.n_sb = n + n / 4 + 64;            // 1.25 two-entry buckets per column: 40 % of the entry slots in use, ~6 % of the keys overflow
@@ -341,10 +378,11 @@ int sbwtgpu_index_create(const sbwtgpu_index_desc *d, int device, sbwtgpu_index 
     // path order: needs suffix-group marks (given or derived) and 32-bit columns
     const bool marks = d->suffix_group_starts || (g_derive_ssup && d->k >= 2);
     int64_t pos_cap = n;
-    if (g_path_order && level == 0 && marks && n < ((int64_t)1 << 31) - 64 && n_mega == 1) {
+    if (g_path_order && level == 0 && marks && ((n < ((int64_t)1 << 31) - 64 && n_mega == 1) || (big_path && p_sparse == d->k))) {
         // room for the path order with stitched chains (copies of shared stretches: at most a fifth of the columns, and
-        // positions stay below 2^31); the finished image keeps what was used
-        pos_cap = g_path_stitch ? std::min<int64_t>(n + n / 5 + 64, ((int64_t)1 << 31) - 64) : n;
+        // positions stay below 2^31); the finished image keeps what was used.  (2^31 columns and more: disjoint paths only --
+        // the copies' room and the stitching's temporaries are what such an image has no memory for)
+        pos_cap = (g_path_stitch && !big_path) ? std::min<int64_t>(n + n / 5 + 64, ((int64_t)1 << 31) - 64) : n;
         if (pos_cap < n) pos_cap = n;
         h.has_path = 1;
         h.off_col = h.blob_bytes;
@@ -455,13 +493,15 @@ int sbwtgpu_index_create(const sbwtgpu_index_desc *d, int device, sbwtgpu_index 
     }
     int rc = SBWTGPU_OK;
     unsigned char *alt_safe = nullptr;                 // per-position verdicts of the safe-bit pass, for the transition table
+    PhaseLog plog;
+    plog("upload, counts, allocation");
     do {
         if ((e = hipMemset(idx->blob, 0, (size_t)h.blob_bytes)) != hipSuccess) break;
         {
             const long long Cs[4] = {h.C[0], h.C[1], h.C[2], h.C[3]};
             sbwt_blocks_fill(static_cast<const unsigned long long *>(d_bits.p),
                              d->suffix_group_starts ? static_cast<const unsigned long long *>(d_bits.p) + 4 * nw : nullptr, n,
-                             d_bscr.p, Cs, (n_mega > 1 || h.force_mega) ? 1 : 0, (int)n_mega,
+                             d_bscr.p, Cs, ((n_mega > 1 && !(big_path && consistent)) || h.force_mega) ? 1 : 0, (int)n_mega,
                              reinterpret_cast<uint4 *>(idx->blob + h.off_blocks),
                              reinterpret_cast<unsigned long long *>(idx->blob + h.off_mega), 0);
             if ((e = hipDeviceSynchronize()) != hipSuccess) break;
@@ -479,6 +519,7 @@ int sbwtgpu_index_create(const sbwtgpu_index_desc *d, int device, sbwtgpu_index 
             if (e != hipSuccess) break;
             h.ssup_derived = 1;
         }
+        plog("blocks (+ derived marks)");
         if (p_dev > 0) sbwt_launch_precalc(v, (int)p_dev, reinterpret_cast<longlong2 *>(idx->blob + h.off_ptab), 0);
         if (ftab_bytes) {
             if (d->precalc) {
@@ -489,6 +530,7 @@ int sbwtgpu_index_create(const sbwtgpu_index_desc *d, int device, sbwtgpu_index 
                 sbwt_launch_precalc(v, (int)p_file, reinterpret_cast<longlong2 *>(idx->blob + h.off_ftab), 0);
             }
         }
+        plog("dense prefix table(s)");
         if (h.has_path) {
             void *scr = nullptr;
             if ((e = hipMalloc(&scr, (size_t)sbwt_path_scratch_bytes(n))) != hipSuccess) break;
@@ -504,6 +546,7 @@ int sbwtgpu_index_create(const sbwtgpu_index_desc *d, int device, sbwtgpu_index 
             // ones included, through col[]; the array has four entries of padding behind the last position)
             if ((e = hipMemset(idx->blob + h.off_col + (size_t)n_pos * 4, 0xFF, 16)) != hipSuccess) break;
         }
+        plog("path order");
         if (h.p_sparse > 0) {
             void *scr = nullptr;
             if ((e = hipMalloc(&scr, (size_t)sbwt_sparse_scratch_bytes(n))) != hipSuccess) break;
@@ -520,6 +563,10 @@ int sbwtgpu_index_create(const sbwtgpu_index_desc *d, int device, sbwtgpu_index 
             if (src < 0 && e == hipSuccess) e = hipErrorUnknown;
             if (e != hipSuccess) break;
             h.stab_pos = src > 0 ? 1 : 0;
+            plog("sparse table, second level, filter");
+            // (2^31 columns and more: the fused kernel's BIG instantiation needs every k-mer's position in its table entry;
+            // without them -- the columns are not an SBWT's -- the image steps down like one that does not fit)
+            if (big_path && h.has_path && !h.stab_pos) { e = hipErrorOutOfMemory; break; }
             // substitution-safe bits of the path: need the whole k-mers in the sparse table
             // (31 < k <= 63: whole k-mers live in the two-level table -- the wide kernels, rule 2 only)
             const bool whole_kmers = h.p_sparse == d->k || (h.n_sb2 > 0 && d->k > h.p_sparse);
@@ -546,6 +593,7 @@ int sbwtgpu_index_create(const sbwtgpu_index_desc *d, int device, sbwtgpu_index 
                 h.has_safe = (wide_safe && !had_scratch) ? 0 : 1;    // (no room for the head labels of long k-mers: no safe bits)
             }
         }
+        plog("substitution-safe bits");
         if (h.has_path) {
             // Last: the only-successor bits, the path groups' final encoding, and the transition table.  Its size is known
             // only now -- three entries per branching column and one per successor of a path's last column -- so the image
@@ -579,10 +627,12 @@ int sbwtgpu_index_create(const sbwtgpu_index_desc *d, int device, sbwtgpu_index 
             h.off_pq = new_pq;
             h.off_trans = new_trans;
             h.blob_bytes = full;
+            plog("only-successor bits, final layout");
             sbwt_launch_trans_insert(idx->view(), reinterpret_cast<uint4 *>(idx->blob + h.off_trans), n_slots, alt_safe, 0);
             if ((e = hipDeviceSynchronize()) != hipSuccess) break;
             h.n_paths = sbwt_count_paths(idx->view(), 0);
             if (h.n_paths < 0) { e = hipErrorUnknown; break; }
+            plog("transition table");
         }
         if ((e = hipGetLastError()) != hipSuccess) break;
         e = hipDeviceSynchronize();
@@ -966,8 +1016,11 @@ static int search_dev_common(const sbwtgpu_index *idx, const char *d_bases, int6
         int variant = g_variant_override >= 0 ? g_variant_override : tuning_variant();
         if (variant < 0) variant = idx->h.has_path ? auto_variant(idx->h) : 2;
         const int eff_streaming = (!streaming && internal_streaming_ok(idx->h)) ? 2 : streaming;
+        // (an image of 2^31 columns or more has a path order only in the form the fused kernel's BIG instantiation reads:
+        // k <= 31, whole k-mers with their positions; int64 results -- the int32 calls refuse such an index)
+        const bool big_image = idx->h.n_nodes >= ((int64_t)1 << 31) - 64 && idx->h.stab_pos && idx->h.p_sparse == idx->h.k && !t_out32;
         const bool path_kernel = idx->h.has_path && eff_streaming &&
-                                 idx->h.n_nodes < ((int64_t)1 << 31) - 128 && n_reads < ((int64_t)1 << 31) &&
+                                 (idx->h.n_nodes < ((int64_t)1 << 31) - 128 || big_image) && n_reads < ((int64_t)1 << 31) &&
                                  total_bases / SBWT_GROUP_BASES + 2 < ((int64_t)1 << 31) - 4;
         if (variant == 5 && path_kernel && g_sort_reads <= 0 && !(g_debug & 16)) {
             if (!d_read_off || !d_out_off) return fail(SBWTGPU_ERR_INVALID_ARG, "NULL device pointer");

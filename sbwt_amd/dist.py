@@ -69,3 +69,38 @@ def gather_floats(value: float, device: torch.device):
     out = [torch.empty_like(t) for _ in range(dist.get_world_size())]
     dist.all_gather(out, t)
     return [float(x.item()) for x in out]
+
+
+def count_failures(failed: bool, group=None) -> int:
+    """How many ranks report a failure (all-reduce of one flag over `group`: the gloo control group beside an RCCL data
+    group, or the default group).  Every rank gets the same answer, so every rank takes the same fall-back."""
+    t = torch.tensor([1 if failed else 0], dtype=torch.int64)
+    backend = dist.get_backend(group) if group is not None else dist.get_backend()
+    if backend == "nccl":
+        t = t.cuda()
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return int(t.item())
+
+
+def broadcast_bits_cpu(bits, k: int, group, bits_class):
+    """The fall-back replication: the five bit vectors of the index (0.7 bytes per column) as ONE uint64 CPU tensor from
+    rank 0 over `group` (gloo), for ranks that then derive their own device image.  `bits` is the builder's output on rank 0
+    (None elsewhere); returns a `bits_class` (capi.BuiltBits) on every rank."""
+    rank = dist.get_rank()
+    backend = dist.get_backend(group) if group is not None else dist.get_backend()
+    dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
+    meta = torch.zeros(3, dtype=torch.int64, device=dev)
+    if rank == 0:
+        meta[0], meta[1], meta[2] = bits.n_nodes, bits.n_kmers, 1 if bits.ssup is not None else 0
+    dist.broadcast(meta, src=0, group=group)
+    n_nodes, n_kmers, has_ssup = int(meta[0]), int(meta[1]), int(meta[2])
+    nw = (n_nodes + 63) // 64
+    rows = torch.empty((4 + has_ssup) * nw, dtype=torch.int64, device=dev)
+    if rank == 0:
+        parts = list(bits.cols) + ([bits.ssup] if has_ssup else [])
+        rows.copy_(torch.from_numpy(np.concatenate([np.asarray(p)[:nw] for p in parts]).view(np.int64)))
+    dist.broadcast(rows, src=0, group=group)
+    if rank == 0:
+        return bits
+    h = rows.cpu().numpy().view(np.uint64)
+    return bits_class([h[c * nw:(c + 1) * nw] for c in range(4)], h[4 * nw:5 * nw] if has_ssup else None, n_nodes, n_kmers, k)

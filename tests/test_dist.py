@@ -78,3 +78,53 @@ def test_contiguous_shard_edge_cases():
     off = np.array([0, 0, 0, 100], dtype=np.int64)       # empty reads in front
     parts = [contiguous_shard(off, r, 2) for r in range(2)]
     assert parts[0][0] == 0 and parts[0][1] == parts[1][0] and parts[1][1] == 3
+
+
+class _Bits:
+    def __init__(self, cols, ssup, n_nodes, n_kmers, k):
+        self.cols, self.ssup, self.n_nodes, self.n_kmers, self.k = cols, ssup, n_nodes, n_kmers, k
+
+
+def _fallback_worker(rank, world, port, q):
+    # the control plane of bench.py's replication fall-back: a second (gloo) group beside the data
+    # group, agreement on "did any rank fail", the five bit vectors as one CPU tensor
+    sys.path.insert(0, ROOT)
+    from sbwt_amd import dist as sdist
+    import datetime
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60))
+    ctl = dist.new_group(backend="gloo", timeout=datetime.timedelta(seconds=60))
+    none_failed = sdist.count_failures(False, ctl)
+    one_failed = sdist.count_failures(rank == world - 1, ctl)
+    n_nodes = 1000 * 64 + 17
+    nw = (n_nodes + 63) // 64
+    rng = np.random.default_rng(11)
+    cols = [rng.integers(0, 2**63, size=nw, dtype=np.uint64) for _ in range(4)]
+    ssup = rng.integers(0, 2**63, size=nw, dtype=np.uint64)
+    for with_ssup in (True, False):
+        src = _Bits(cols, ssup if with_ssup else None, n_nodes, 12345, 31) if rank == 0 else None
+        got = sdist.broadcast_bits_cpu(src, 31, ctl, _Bits)
+        ok = (got.n_nodes, got.n_kmers, got.k) == (n_nodes, 12345, 31) and all(np.array_equal(a, b) for a, b in zip(got.cols, cols))
+        ok = ok and ((got.ssup is None) if not with_ssup else np.array_equal(got.ssup, ssup))
+        q.put((rank, with_ssup, ok, none_failed, one_failed))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_replication_fallback_control_plane_world2():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_fallback_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(2 * world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert len(res) == 4
+    for rank, with_ssup, ok, none_failed, one_failed in res:
+        assert ok, (rank, with_ssup)
+        assert none_failed == 0 and one_failed == 1

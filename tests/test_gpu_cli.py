@@ -7,6 +7,7 @@ import gzip
 import json
 import os
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -173,3 +174,15 @@ def test_cli_reads_from_a_fifo_and_writes_to_a_pipe(gpu, tmp_path):
         # (the log lines go to stderr; stdout carries the result text only)
         text = gzip.decompress(out) if zflag else out
         assert text == kat["expected_output"].encode()
+
+
+def test_upstream_index_check_script(gpu):
+    """tools/check_upstream_index.py is the runnable closing step for file-format parity with upstream (no
+    upstream-built index exists offline).  Here it runs on a file of this repository's own writer -- that exercises the script
+    (load, C array, search text, prefix table, byte-identical rewrite, and a corrupted rank support that must fail), it pins
+    nothing."""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_upstream_index.py"), "--self-test"], capture_output=True,
+                       timeout=600)
+    out = p.stdout.decode()
+    assert p.returncode == 0, out[-2000:] + p.stderr.decode()[-2000:]
+    assert out.count("PASS") >= 9 and "rewrite  FAIL" in out and "rank supports" in out, out

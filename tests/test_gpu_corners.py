@@ -108,14 +108,14 @@ def test_file_prefix_tables_with_p_9_to_12(gpu, p):
 
 
 def test_file_table_shallower_than_the_device_table(gpu):
-    # an index file with p = 9 whose image gets a deeper dense table of its own: get_precalc still returns the FILE's table
+    # an index file with p = 5 whose image gets a deeper dense table of its own: get_precalc still returns the FILE's table
     # (SBWT::get_precalc), searches use the device's
     k = 31
     genomes = [synth.random_genome(1_500_000, 41)]
     bits = capi.build_bits_gpu([g.tobytes() for g in genomes], k, False, True)
-    orc = OracleIndex.from_bits(bits.cols[0], bits.cols[1], bits.cols[2], bits.cols[3], bits.ssup, bits.n_nodes, k, bits.n_kmers, 9)
+    orc = OracleIndex.from_bits(bits.cols[0], bits.cols[1], bits.cols[2], bits.cols[3], bits.ssup, bits.n_nodes, k, bits.n_kmers, 5)
     idx = gpu_index_from_oracle(orc, precalc_from_file=True)
-    assert idx.precalc_k == 9 and idx.device_precalc_k > 9, idx.device_precalc_k
+    assert idx.precalc_k == 5 and idx.device_precalc_k > 5, idx.device_precalc_k
     assert np.array_equal(idx.get_precalc(), orc.precalc())
     bases, off = synth.sample_reads(genomes, 800, 150, 0.01, 3)
     for variant in (-1, 1, 0):

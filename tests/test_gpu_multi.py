@@ -110,3 +110,39 @@ def test_index_bcast_distinct_devices(gpu):
     assert rep.device == 1 and rep.n_nodes == root.n_nodes
     got, _ = rep.streaming_search(bases, off)
     assert np.array_equal(got, want)
+
+
+def test_image_broadcast_failure_falls_back_to_rebuild(gpu):
+    """when the image broadcast fails on any rank (here: the last rank raises instead of joining it,
+    SBWT_BENCH_FAIL_BCAST), every rank learns it over the control group and they all take the same fall-back IN PROCESS --
+    the five bit vectors over gloo, every rank derives its own image -- and the line still comes, with parity, and says so."""
+    n_dev = capi.device_count()
+    env = _bench_env(n_dev)
+    env["SBWT_BENCH_FAIL_BCAST"] = "1"
+    env["SBWT_BENCH_DIST_TIMEOUT"] = "120"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--reads", "100000", "--genome-len", "200000",
+           "--steps", "2", "--warmup", "1", "--check-ranks"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    if n_dev < 2:
+        # over gloo the other rank is INSIDE the broadcast when this one raises: it must time out there, and the run must end
+        # with a line that names the phase -- never hang, never print a number
+        assert p.returncode != 0 or "index_replication_fallback" in p.stdout
+        if p.returncode != 0:
+            assert "FAILED" in p.stderr and "image broadcast" in p.stderr, p.stderr[-2000:]
+            return
+    assert p.returncode == 0, p.stderr[-3000:]
+    res = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert "image broadcast failed on 1 rank(s)" in res["index_replication_fallback"]
+    assert res["rank_parity"] == [True, True]
+
+
+def test_a_failing_run_names_its_phase(gpu):
+    """Every way out of bench.py prints the JSON line or ONE line naming the phase, and exits non-zero: a batch that cannot
+    fit says what it needed before anything is allocated."""
+    env = _bench_env(2)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--reads", "2000000000", "--genome-len", "200000", "--steps", "1",
+           "--warmup", "0", "--no-cpu-baseline", "--no-end-to-end"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode != 0
+    assert "FAILED" in p.stderr and "allocating reads and results" in p.stderr and "cannot allocate" in p.stderr, p.stderr[-1500:]
+    assert not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]

@@ -309,34 +309,52 @@ def test_rank_beyond_2_pow_31_columns(gpu):
     idx.close()
 
 
-def test_search_beyond_2_pow_31_columns(gpu):
-    """The reference is int64 throughout (SBWT.hh:36-45); an index of 2^31 columns or more is served by the blocks-only kernel
-    (64-bit instantiation, block counts relative to a table of absolute counts every 2^31 columns) -- the 32-bit path order stops
-    there.  One random 2.25 Gbp sequence, k = 31: columns built on the GPU, streaming_search and search of reads from all over
-    the sequence (substitutions, N) against the oracle, int32 results refused."""
+@pytest.mark.parametrize("L", [1_200_000_000, 2_250_000_000])
+def test_search_on_indexes_of_more_than_2_pow_30_and_2_pow_31_columns(gpu, L):
+    """The reference is int64 throughout (SBWT.hh:36-45).  One random sequence of L bases, k = 31, columns built on the GPU:
+    1.2 x 10^9 columns -- the builders of the derived structures start more than 2^32 threads there (four per item), which one
+    dispatch silently truncates (round 5: sliced launches; before, such an index lost most of its sparse table); 2.25 x 10^9
+    columns -- beyond 2^31 the full image holds 32-bit UNSIGNED columns and positions and the fused kernel runs its BIG
+    instantiation (round 5; before, such an index got the blocks-only kernel: 23 G k-mers/s).  Both must get the FULL image
+    (level 0).  streaming_search and search of reads from all over the sequence (substitutions, N, lower case) on every route
+    against each other and, on a sample, against the oracle; int32 results refused beyond 2^31 columns."""
     import torch
-    if torch.cuda.mem_get_info()[1] < (150 << 30):
-        pytest.skip("needs a GPU with > 150 GB for the builder's sort")
-    L = 2_250_000_000
+    if torch.cuda.mem_get_info()[1] < (250 << 30):
+        pytest.skip("needs a GPU with 288 GB: the image of 2.25e9 columns is 130 GB, its builders' scratch as much again")
     genome = synth.random_genome(L, 7)
     bits = capi.build_bits_gpu([genome.tobytes()], 31, False, True)
-    assert bits.n_nodes >= (1 << 31)
+    big = bits.n_nodes >= (1 << 31)
+    assert big == (L > 2_000_000_000)
     idx = capi.Index.create(bits.cols[0], bits.cols[1], bits.cols[2], bits.cols[3], bits.ssup, bits.n_nodes, 31, bits.n_kmers, 8)
-    assert idx.image_level >= 1                                      # no path order beyond 2^31 columns
+    assert idx.image_level == 0 and idx.default_search_variant == 5, (idx.image_level, idx.default_search_variant)
     bases, off = synth.sample_reads([genome], 3000, 150, 0.01, 5)
     bases = synth.inject(bases, 40, ord("N"), 6)
+    bases = synth.inject(bases, 20, ord("c"), 8)
     got, _ = idx.streaming_search(bases, off)
     got2, _ = idx.search(bases, off)
-    with pytest.raises(capi.SbwtGpuError, match="2\\^31"):
-        idx.search_i32(bases, off)
+    for variant in (1, 0):                                           # the blocks-only kernel, the reference-order kernel
+        capi.set_tuning("search_variant", variant)
+        try:
+            assert np.array_equal(idx.streaming_search(bases, off)[0], got), variant
+            assert np.array_equal(idx.search(bases, off)[0], got2), variant
+        finally:
+            capi.set_tuning("search_variant", -1)
+    if big:
+        with pytest.raises(capi.SbwtGpuError, match="2\\^31"):
+            idx.search_i32(bases, off)
+    else:
+        assert np.array_equal(idx.search_i32(bases, off)[0].astype(np.int64), got)
+    # the device-resident entry point (the fused kernel itself, no host pipeline in between)
+    assert np.array_equal(_search_dev(idx, bases, off, 31, True), got)
     idx.close()
     del genome
     orc = OracleIndex.from_bits(bits.cols[0], bits.cols[1], bits.cols[2], bits.cols[3], bits.ssup, bits.n_nodes, 31, bits.n_kmers, 8)
-    sample = 600
+    sample = 700
     want = oracle_batch(orc, bases[:off[sample]], off[:sample + 1], True)
-    assert np.array_equal(got[:len(want)], want) and np.array_equal(got2[:len(want)], oracle_batch(orc, bases[:off[sample]], off[:sample + 1], False))
-    assert np.array_equal(got, got2)                                 # upper-case and N: search == streaming_search
-    assert (got >= (1 << 31)).any() and 0.6 < (got >= 0).mean() < 0.85
+    assert np.array_equal(got[:len(want)], want)
+    assert np.array_equal(got2[:len(want)], oracle_batch(orc, bases[:off[sample]], off[:sample + 1], False))
+    assert 0.6 < (got >= 0).mean() < 0.85
+    assert (got >= (1 << 31)).any() == big and (got >= (1 << 30)).any()
 
 
 def test_device_side_print_vector(gpu, genome_case):
