@@ -1028,6 +1028,25 @@ def end_to_end_leg(args, index, genomes, d_bases, m, streaming, dev):
                     "cli_fastq_bytes": os.path.getsize(d + "/r.fastq"), "cli_output_bytes": os.path.getsize(d + "/out.txt"),
                     "cli_stage_marks": stages,
                     "cli": "sbwt search -i index -q reads.fastq -o out.txt, process start to exit (index load, parse, search, format on the GPU, write), best of 2"})
+        # ... what ONE call of the reference's scalar API costs through the C++ mirror (host/SBWT.hh): search of
+        # one k-mer and rank of one position answer on the host since round 5, streaming_search of one read is a GPU
+        # batch of one.  tools/scalar_api_bench.cpp, compiled here against the host headers.
+        try:
+            lib = os.path.join(ROOT, "sbwt_amd", "lib")
+            exe = d + "/scalar_api_bench"
+            subprocess.run(["g++", "-O2", "-std=c++17", "-pthread", "-I", os.path.join(ROOT, "sbwt_amd", "csrc", "host"),
+                            os.path.join(ROOT, "tools", "scalar_api_bench.cpp"), "-o", exe, "-L" + lib, "-lsbwtgpu", "-lz",
+                            "-Wl,-rpath," + lib, "-Wl,-rpath,/opt/rocm/lib"], check=True, capture_output=True, timeout=300)
+            one_read = d_bases[:READ_LEN].cpu().numpy().tobytes().decode()
+            p = subprocess.run([exe, d + "/i.sbwt", one_read], capture_output=True, timeout=600)
+            if p.returncode != 0:
+                raise RuntimeError(p.stderr.decode(errors="replace")[-300:])
+            out["scalar_api"] = json.loads(p.stdout.decode().strip().splitlines()[-1])
+            out["scalar_api"]["what"] = ("one call through sbwt_amd/csrc/host/SBWT.hh: SBWT::search(k-mer) and SubsetMatrixRank::rank on "
+                                         "the host (rank_support_v5 directory), the same as GPU batches of one, and "
+                                         "streaming_search of one %d-base read (a GPU batch of one)" % READ_LEN)
+        except Exception as ex:                                            # noqa: BLE001
+            out["scalar_api"] = {"error": repr(ex)[:300]}
         # ... the same command on the whole batch (config 2: 10 M reads, 3 GB of FASTQ in, 8 GB of text out) when the scratch
         # directory has the room: fixed costs (process and HIP start-up, index load) no longer dominate
         big = args.reads

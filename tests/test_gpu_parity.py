@@ -321,6 +321,9 @@ def test_search_on_indexes_of_more_than_2_pow_30_and_2_pow_31_columns(gpu, L):
     import torch
     if torch.cuda.mem_get_info()[1] < (250 << 30):
         pytest.skip("needs a GPU with 288 GB: the image of 2.25e9 columns is 130 GB, its builders' scratch as much again")
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()        # (what earlier tests of this process left in torch's caching allocator: the full-size suites hold 100 GB)
     genome = synth.random_genome(L, 7)
     bits = capi.build_bits_gpu([genome.tobytes()], 31, False, True)
     big = bits.n_nodes >= (1 << 31)
