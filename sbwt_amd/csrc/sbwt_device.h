@@ -19,6 +19,11 @@
 //   [ stab     : n_sb x 32 B     ]   sparse prefix table at depth p_sparse (only non-empty prefixes), hashed:
 //                                    bucket = two 16-byte entries { key | flags (u64), first (u32), second-first (u32) }
 //
+// Indexes of 2^31 .. 2^32 - 2^24 columns (round 5, k <= 31): the same layout with every column and path position a full
+// 32-bit UNSIGNED value (0xFFFFFFFF stays "none"), block counts absolute (C[c] + rank_c < 2^32: the mega table is all zero) and
+// no second-level table; read by k_search_fused<false, false, BIG> (sbwt_search_fused.hip), the general kernels see blocks +
+// ptab only (general_view, sbwt_search.hip).
+//
 // One 64-byte block covers 64 consecutive columns and carries everything both query kinds need,
 // as four 16-byte quads, quad c for symbol c in {A,C,G,T}:
 //

@@ -145,8 +145,10 @@ static int g_fused_pieces = [] { const char *e = getenv("SBWTGPU_FUSED_PIECES");
 static int g_path_stitch = [] { const char *e = getenv("SBWTGPU_PATH_STITCH"); return e ? atoi(e) : 1; }();
 static int g_path_stitch_min = [] { const char *e = getenv("SBWTGPU_PATH_STITCH_MIN"); return e ? atoi(e) : 1; }();
 // buckets of the sparse tables per 100 columns (two 16-byte entries each): 125 = 40 % of the slots in use (~6 % of the keys
-// overflow their bucket), 100 = 50 % (~10 %): 8 bytes per column against 0.1 more probes per read
-static int g_sparse_buckets_pct = [] { const char *e = getenv("SBWTGPU_SPARSE_BUCKETS_PCT"); int v = e ? atoi(e) : 125; return v < 60 ? 60 : v > 400 ? 400 : v; }();
+// overflow their bucket), 100 = 50 % (~10 %): 8 bytes per column against 0.1 more probes per read.  0 (default) = by the index:
+// 100 for k <= 31 (round 5, one box: config 2 4.74 vs 4.90 ms, config 3 6.39 vs 6.54 ms -- the smaller table is no slower), 125 where
+// whole k-mers take two levels (k = 63: 4.18 ms at 125, 4.26 at 110, 4.29 at 100)
+static int g_sparse_buckets_pct = [] { const char *e = getenv("SBWTGPU_SPARSE_BUCKETS_PCT"); int v = e ? atoi(e) : 0; return v <= 0 ? 0 : v < 60 ? 60 : v > 400 ? 400 : v; }();
 static int g_sparse_depth = [] { const char *e = getenv("SBWTGPU_SPARSE_PRECALC"); return e ? atoi(e) : 31; }();
 
 struct sbwtgpu_index {
@@ -355,7 +357,8 @@ int sbwtgpu_index_create(const sbwtgpu_index_desc *d, int device, sbwtgpu_index 
     if (big_path && p_sparse != d->k) p_sparse = 0;     // (2^31 columns and more: whole k-mers with their positions, or nothing)
     if (p_sparse > 0) {
         h.p_sparse = (int32_t)p_sparse;
-        h.n_sb = n * g_sparse_buckets_pct / 100 + 64;   // 1.25 two-entry buckets per column: 40 % of the entry slots in use, ~6 % of the keys overflow
+        const int64_t bpct = g_sparse_buckets_pct > 0 ? g_sparse_buckets_pct : (d->k > SBWT_SP_MAX_DEPTH ? 125 : 100);
+        h.n_sb = n * bpct / 100 + 64;       // two-entry buckets per column
         h.off_stab = h.blob_bytes;
         h.blob_bytes = align256(h.off_stab + 32 * h.n_sb);
         // second level for 31 < k <= 63 (the remaining k-31 bases fit one 64-bit key): 1.25 two-entry buckets per column, like the
@@ -363,7 +366,7 @@ int sbwtgpu_index_create(const sbwtgpu_index_desc *d, int device, sbwtgpu_index 
         // (its entries keep their flags in bit 31 of the column / origin words: columns below 2^31 only -- p_sparse > 0 already
         // implies one mega block; said again here because a wider first level must not widen this one by accident)
         if (p_sparse == SBWT_SP_MAX_DEPTH && d->k > p_sparse && d->k - p_sparse <= 32 && n < ((int64_t)1 << 31)) {
-            h.n_sb2 = n * g_sparse_buckets_pct / 100 + 64;
+            h.n_sb2 = n * bpct / 100 + 64;
             h.off_stab2 = h.blob_bytes;
             h.blob_bytes = align256(h.off_stab2 + 32 * h.n_sb2);
         }

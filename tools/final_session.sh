@@ -1,10 +1,15 @@
 #!/bin/bash
 # The measurements a round's profiles/ are made of (GPU box, from the repo root): the driver's suite, fuzz, bench lines and
 # rocprofv3 summaries (kernel trace + PMC traffic, separate passes) of BASELINE configs 2, 5 and 3, the image levels with
-# their own counters, robustness and batch-size rows.  usage: tools/final_session.sh <tag, e.g. r04>
-TAG=${1:-r04}
+# their own counters, robustness and batch-size rows.  usage: tools/final_session.sh <tag, e.g. r05> [1|2|all]
+#   part 1: the -m gpu suite, fuzz, bench lines, rocprofv3 kernel traces + PMC passes, the committed lines
+#   part 2: robustness and batch-size rows, knob sweep, instrumented builds, two batches in flight, the 10^9- and 2.25 x 10^9-column
+#           indexes, this round's library against last round's (sbwt_amd/lib/lib_prev.so, tools/build_rev_lib.sh)
+TAG=${1:-r05}
+PART=${2:-all}
 O=gpurun_out/final_$TAG
 mkdir -p $O
+if [ "$PART" = 1 ] || [ "$PART" = all ]; then
 ( time timeout 1500 python -m pytest tests/ -q -m gpu ) > $O/gputest.log 2>&1; tail -4 $O/gputest.log
 ( for seed in 1 2 3 4; do SEED=$seed timeout 150 python tools/fuzz_gpu.py 100 2>&1 | tail -1 | sed "s/^/seed $seed: /"; done ) > $O/fuzz.log 2>&1; cat $O/fuzz.log
 timeout 900 python bench.py --steps 25 --warmup 3 > $O/c2_bench.json 2> $O/c2_bench.err
@@ -30,6 +35,8 @@ timeout 400 python bench.py --config 5 --steps 10 --no-cpu-baseline --no-end-to-
 timeout 900 python bench.py --config 3 --steps 5 --no-cpu-baseline --no-end-to-end > $O/c3_line.json 2>/dev/null
 timeout 600 python bench.py --steps 10 --image-level 1 --no-cpu-baseline --no-end-to-end > $O/c2_level1.json 2>/dev/null
 timeout 600 python bench.py --steps 10 --image-level 2 --no-cpu-baseline --no-end-to-end > $O/c2_level2.json 2>/dev/null
+fi   # part 1
+if [ "$PART" = 2 ] || [ "$PART" = all ]; then
 NREADS=10000000 timeout 900 python tools/robustness_bench.py > $O/robustness.jsonl 2> $O/robustness.err
 for n in 1000000 4000000; do NREADS=$n ROUNDS=9 CONFIGS='[[5,0]]' python tools/ab_step.py 2>&1 | grep "^variant" | sed "s/^/config 2, $n reads: /"; done > $O/batch_size.txt 2>&1
 python - <<PY
@@ -62,3 +69,13 @@ fi
 ( NREADS=10000000 python tools/overlap_steps.py 2>&1 | grep "^reads"
   NREADS=1000000 STEPS=50 python tools/overlap_steps.py 2>&1 | grep "^reads"
   K=63 STREAMING=0 NREADS=10000000 python tools/overlap_steps.py 2>&1 | grep "^reads" ) > $O/two_in_flight.txt 2>&1
+# the indexes beyond the Infinity Cache and beyond 2^31 columns (SURVEY 8d "G-hbm")
+timeout 900 python bench.py --config 6 --steps 5 --warmup 1 --no-end-to-end > $O/c6_hbm_bench.json 2> $O/c6_hbm_bench.err
+timeout 1200 python bench.py --config 6 --hbm-genome-len 2250000000 --steps 5 --warmup 1 --no-end-to-end > $O/c6_big_index_bench.json 2> $O/c6_big_index_bench.err
+# this round's library against last round's, interleaved on this box (configs 2, 3's index type, 5)
+if [ -f sbwt_amd/lib/lib_prev.so ]; then
+  ( ROUNDS=5 bash tools/ab_libs5.sh "sbwt_amd/lib/lib_prev.so sbwt_amd/lib/libsbwtgpu.so" 2 | sed "s/^/c2 /"
+    GENOMES=pan64 K=31 ROUNDS=3 bash tools/ab_libs5.sh "sbwt_amd/lib/lib_prev.so sbwt_amd/lib/libsbwtgpu.so" 2 | sed "s/^/c3 /"
+    K=63 STREAMING=0 ROUNDS=3 bash tools/ab_libs5.sh "sbwt_amd/lib/lib_prev.so sbwt_amd/lib/libsbwtgpu.so" 2 | sed "s/^/c5 /" ) > $O/ab_prev_round.txt 2>&1
+fi
+fi   # part 2
