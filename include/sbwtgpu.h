@@ -111,11 +111,20 @@ int         sbwtgpu_device_count(int *count);
  * variables of the same meaning: SBWTGPU_SPARSE_PRECALC, SBWTGPU_PROBE_FILTER, SBWTGPU_PATH_ORDER):
  *   "sparse_depth"    depth of the sparse (hashed) prefix table, 0 = none, default 31 (capped at k)
  *   "probe_filter"    1 (default): Bloom filter over the probe_len-mers of the index for the certificate probes
- *   "path_order"      1 (default): path order + transition table (32-bit indexes with suffix-group marks)
+ *   "path_order"      1 (default): path order + transition table (indexes with suffix-group marks, given or derived)
+ *   "big_path"        1 (default): an index of 2^31 .. 2^32 - 2^24 columns with k <= 31 gets the full image too -- columns and
+ *                     path positions as 32-bit unsigned values, read by the fused kernel's BIG instantiation (2.25 x 10^9
+ *                     columns: 120 GB, 207 G k-mers/s); 0: such an index gets blocks + dense table only, as before round 5
+ *                     (23 G k-mers/s).  k > 31 beyond 2^31 columns always steps down.  SBWTGPU_BIG_PATH.
  *   "image_level"     0 (default): the image carries every derived structure (path order + transition table, sparse
- *                     prefix table, probe filter: 79-94 bytes per column for k <= 31); 1: no path order (about 60 bytes per
- *                     column); 2: blocks + dense prefix table only (1 byte per column + the table).  Results are the
- *                     same at every level; throughput is not.  SBWTGPU_IMAGE_LEVEL.
+ *                     prefix table, probe filter: 50-56 bytes per column for k <= 31, 93 for k = 63); 1: no path order; 2:
+ *                     blocks + dense prefix table only (1 byte per column + the table).  Results are the same at every
+ *                     level; throughput is not.  SBWTGPU_IMAGE_LEVEL.  A step-down that index_create makes by
+ *                     itself (memory) is announced with one line on stderr.
+ *   (environment only) SBWTGPU_SPARSE_BUCKETS_PCT: two-entry buckets of the sparse tables per 100 columns (default: 100 for
+ *                     k <= 31, 125 for 31 < k <= 63); SBWTGPU_DEVICE_PRECALC: depth of the dense device prefix table (default:
+ *                     log4 n, at most 8 on an image with sparse table and filter, at most 14 otherwise); SBWTGPU_VERBOSE=1 / 2:
+ *                     index_create names the parts of the image it builds, with their times, on stderr.
  *   "max_image_bytes" > 0: index_create moves to the next level while the image would be larger than this (and fails
  *                     with SBWTGPU_ERR_OOM if level 2 is still larger); it also steps down by itself when device
  *                     memory runs out.  SBWTGPU_MAX_IMAGE_BYTES.
