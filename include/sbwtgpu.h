@@ -89,8 +89,8 @@ int         sbwtgpu_device_count(int *count);
  *                     offsets); 0: only batches of reads of one length (SBWTGPU_FUSED_RAGGED)
  *   "fused_pieces"    1 .. 3: the fused route takes a read of more than 160 bases as up to this many pieces of 160 bases
  *                     that overlap by k-1 (tickets are (read, piece)); 1: such reads go to the general kernel.  -1 / 0
- *                     (default) = by the index: 3 for 31 < k <= 63 (250-base reads 115 -> 211 G k-mers/s), 1 for k <= 31
- *                     (the two routes measured the same there; NOTES.md).  SBWTGPU_FUSED_PIECES.
+ *                     (default) = 3 (k = 63, 250-base reads: 115 -> 243 G k-mers/s; k = 30: 228 -> 235 G since round 5).
+ *                     SBWTGPU_FUSED_PIECES.
  *   "split_long"      1 (default): the device entry points cut reads of more than two pieces' worth of k-mers (a piece:
  *                     128 .. 1024 k-mers by batch size) into pieces that lanes take separately, at k-mers whose result
  *                     does not depend on history; 0: one lane per read whatever its length (SBWTGPU_SPLIT_LONG)

@@ -138,9 +138,9 @@ static int g_split_long = [] { const char *e = getenv("SBWTGPU_SPLIT_LONG"); ret
 // batches of reads of different lengths through the fused kernel (it fetches their offsets); 0: only reads of one length
 static int g_fused_ragged = [] { const char *e = getenv("SBWTGPU_FUSED_RAGGED"); return e ? atoi(e) : 1; }();
 // reads of more than 160 bases through the fused kernel as up to this many pieces of 160 bases (1: such reads go to the general
-// kernel).  -1 (default) = by the index: 3 where the fused kernel walks with F_CMP (31 < k <= 63: 250-base reads 115 -> 211 G
-// k-mers/s, the general kernel has neither bridges nor anchors there), 1 for k <= 31 (pieces and the two-pass route come out
-// the same, NOTES.md)
+// kernel).  -1 (default) = 3: for 31 < k <= 63 the fused kernel walks with F_CMP (250-base reads 115 -> 243 G k-mers/s, the
+// general kernel has neither bridges nor anchors there); for k <= 31 pieces and the two-pass route came out the same until
+// round 5 made the fused kernel's writer cheaper (250-base reads: 235 vs 228 G, lengths 80-250: 203 vs 200 G, NOTES.md)
 static int g_fused_pieces = [] { const char *e = getenv("SBWTGPU_FUSED_PIECES"); return e ? atoi(e) : -1; }();
 static int g_path_stitch = [] { const char *e = getenv("SBWTGPU_PATH_STITCH"); return e ? atoi(e) : 1; }();
 static int g_path_stitch_min = [] { const char *e = getenv("SBWTGPU_PATH_STITCH_MIN"); return e ? atoi(e) : 1; }();
@@ -1063,7 +1063,7 @@ static int search_dev_common(const sbwtgpu_index *idx, const char *d_bases, int6
                                      ws, eff_streaming, st, defer, e0, e1, ws_piece_tab(d_ws, total_bases),
                                      // (the list of reads handed on has one entry per 32 bases of the batch)
                                      ((g_fused_ragged && n_reads <= total_bases / 32) ? 1 : 0) |
-                                         ((g_fused_pieces > 0 ? g_fused_pieces : (idx->h.n_sb2 > 0 && idx->h.p_sparse < idx->h.k) ? 3 : 1) << 8));
+                                         ((g_fused_pieces > 0 ? g_fused_pieces : 3) << 8));
             hipError_t e = hipGetLastError();
             if (e != hipSuccess) return fail(SBWTGPU_ERR_HIP, "kernel launch: %s", hipGetErrorString(e));
             return SBWTGPU_OK;

@@ -330,7 +330,7 @@ def test_search_on_indexes_of_more_than_2_pow_30_and_2_pow_31_columns(gpu, L):
     assert big == (L > 2_000_000_000)
     idx = capi.Index.create(bits.cols[0], bits.cols[1], bits.cols[2], bits.cols[3], bits.ssup, bits.n_nodes, 31, bits.n_kmers, 8)
     want_level = int(os.environ.get("SBWTGPU_IMAGE_LEVEL", "0"))     # (the knob sweep of tools/final_session.sh forces levels 1 and 2)
-    assert idx.image_level == want_level, (idx.image_level, want_level)
+    assert idx.image_level == 0 if want_level == 0 else idx.image_level >= want_level, (idx.image_level, want_level)
     if want_level == 0 and "SBWTGPU_SEARCH_VARIANT" not in os.environ:
         assert idx.default_search_variant == 5, idx.default_search_variant
     bases, off = synth.sample_reads([genome], 3000, 150, 0.01, 5)
@@ -828,7 +828,7 @@ def test_fused_kernel_takes_batches_of_mixed_lengths(gpu, genome_case):
 
 @pytest.mark.parametrize("k", [30, 63])
 def test_fused_kernel_takes_reads_of_161_to_400_bases_as_pieces(gpu, k):
-    # Round 4, "fused_pieces" = 2 or 3 (the default for k > 31, where it doubles the rate; for k <= 31 the default is 1: no faster
+    # Round 4, "fused_pieces" = 2 or 3 (the default since round 5; before, for k <= 31 the default was 1: no faster
     # than the two-pass route -- NOTES.md): a read of more than
     # 160 bases is taken by the fused kernel as up to three pieces of 160 bases that overlap by k-1 (a ticket is (read, piece);
     # SBWT.hh:556-579 has no length limit).  Reads of ONE length 161 .. 3 * (161 - k) + k - 1

@@ -65,12 +65,13 @@ run("150 bp reads and one of 151", idx0, b, o)
 capi.set_tuning("fused_ragged", 0)
 run("150 bp reads and one of 151, two-pass route", idx0, b, o)
 capi.set_tuning("fused_ragged", 1)
+# reads of more than 160 bases: up to three pieces of the fused kernel by default (round 5; the two-pass route before)
 b, o = synth.sample_reads(base, n_reads, 250, 0.01, 48)
 run("250 bp reads, 1% substitutions", idx0, b, o)
-capi.set_tuning("fused_pieces", 2)
-run("250 bp reads, fused kernel with two pieces per read", idx0, b, o)
+capi.set_tuning("fused_pieces", 1)
+run("250 bp reads, two-pass route (general kernel)", idx0, b, o)
 b2, o2 = synth.ragged_reads(base, n_reads, 80, 250, 0.01, 43)
-run("ragged read lengths 80-250, fused kernel with two pieces per read", idx0, b2, o2)
+run("ragged read lengths 80-250, two-pass route (general kernel)", idx0, b2, o2)
 capi.set_tuning("fused_pieces", -1)
 b, o = synth.indel_reads(base, n_reads, 150, 0.01, 0.002, 44)
 run("0.2% indels + 1% substitutions", idx0, b, o)
