@@ -743,23 +743,40 @@ int sbwtgpu_index_adopt(const void *header, int64_t header_bytes, void *dev_blob
 // RCCL is loaded lazily so that single-GPU use never needs it.
 // devs[] may name a device more than once (several host threads per GPU): the image travels once per DISTINCT
 // device and the duplicates share that device's handle.
+// The plan of a replication, without touching any device (so that a box without GPUs can test it): the DISTINCT devices of
+// devs[] in order of first appearance (uniq_out, n_dev entries of room), slot_out[i] = the index of devs[i] among them, and
+// the root device's index (= its rank in the RCCL group, whose ranks are the distinct devices in that order).
+int sbwtgpu_debug_bcast_plan(int n_dev, const int *devs, int root_device, int n_visible, int *uniq_out, int *slot_out, int *n_uniq,
+                             int *root_rank) {
+    if (n_dev <= 0 || !devs || !uniq_out || !slot_out || !n_uniq || !root_rank) return fail(SBWTGPU_ERR_INVALID_ARG, "NULL/empty argument");
+    int nu = 0;
+    for (int i = 0; i < n_dev; i++) {
+        if (devs[i] < 0 || devs[i] >= n_visible) return fail(SBWTGPU_ERR_NO_DEVICE, "device %d out of range", devs[i]);
+        int u = 0;
+        while (u < nu && uniq_out[u] != devs[i]) u++;
+        if (u == nu) uniq_out[nu++] = devs[i];
+        slot_out[i] = u;
+    }
+    *n_uniq = nu;
+    *root_rank = -1;
+    for (int u = 0; u < nu; u++)
+        if (uniq_out[u] == root_device) *root_rank = u;
+    if (*root_rank < 0) return fail(SBWTGPU_ERR_INVALID_ARG, "the root's device must be in devs[]");
+    return SBWTGPU_OK;
+}
+
 int sbwtgpu_index_bcast(sbwtgpu_index *root, int n_dev, const int *devs, sbwtgpu_index **out) {
     if (!root || n_dev <= 0 || !devs || !out) return fail(SBWTGPU_ERR_INVALID_ARG, "NULL/empty argument");
-    std::vector<int> uniq;                              // distinct devices, in order of first appearance
-    std::vector<int> slot((size_t)n_dev, 0);            // devs[i] -> its index in uniq
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess) ndev = 0;
-    for (int i = 0; i < n_dev; i++) {
-        if (devs[i] < 0 || devs[i] >= ndev) return fail(SBWTGPU_ERR_NO_DEVICE, "device %d out of range", devs[i]);
-        size_t u = 0;
-        while (u < uniq.size() && uniq[u] != devs[i]) u++;
-        if (u == uniq.size()) uniq.push_back(devs[i]);
-        slot[(size_t)i] = (int)u;
+    std::vector<int> uniq((size_t)n_dev, 0);            // distinct devices, in order of first appearance
+    std::vector<int> slot((size_t)n_dev, 0);            // devs[i] -> its index in uniq
+    int n_uniq = 0, root_rank = -1;
+    {
+        const int prc = sbwtgpu_debug_bcast_plan(n_dev, devs, root->device, ndev, uniq.data(), slot.data(), &n_uniq, &root_rank);
+        if (prc != SBWTGPU_OK) return prc;
     }
-    int root_rank = -1;
-    for (size_t u = 0; u < uniq.size(); u++)
-        if (uniq[u] == root->device) root_rank = (int)u;
-    if (root_rank < 0) return fail(SBWTGPU_ERR_INVALID_ARG, "the root's device must be in devs[]");
+    uniq.resize((size_t)n_uniq);
     if (uniq.size() == 1) {
         for (int i = 0; i < n_dev; i++) out[i] = root;
         return SBWTGPU_OK;
@@ -769,8 +786,10 @@ int sbwtgpu_index_bcast(sbwtgpu_index *root, int n_dev, const int *devs, sbwtgpu
     typedef int (*bcast_t)(const void *, void *, size_t, int, int, comm_t, hipStream_t);
     typedef int (*grp_t)(void);
     typedef int (*destroy_t)(comm_t);
-    void *lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-    if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    // (SBWTGPU_RCCL_LIB names another library with RCCL's five entry points: a site's own build, or a stand-in for tests)
+    const char *rccl_name = getenv("SBWTGPU_RCCL_LIB");
+    void *lib = (rccl_name && *rccl_name) ? dlopen(rccl_name, RTLD_NOW | RTLD_GLOBAL) : dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib && !(rccl_name && *rccl_name)) lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
     if (!lib) return fail(SBWTGPU_ERR_HIP, "cannot load librccl.so: %s", dlerror());
     init_all_t init_all = (init_all_t)dlsym(lib, "ncclCommInitAll");
     bcast_t bcast = (bcast_t)dlsym(lib, "ncclBroadcast");

@@ -73,3 +73,34 @@ def test_search_workspace_is_monotone_in_the_batch_size():
         assert w % 256 == 0 and w >= b // 2
         prev = w
     assert capi.search_workspace_bytes(1_500_000_000) < 1_500_000_000      # 0.66 bytes per base + a constant
+
+
+def test_replication_plan_dedups_devices_and_finds_the_root():
+    """sbwtgpu_index_bcast (the single-process RCCL replication of the CLI's --gpus N) sends the image once per DISTINCT device:
+    the ranks of its RCCL group are the distinct devices in order of first appearance, duplicates of a device share its handle,
+    the root's rank is its device's place among them.  The plan is a pure function (sbwtgpu_debug_bcast_plan): tested here
+    without any GPU; the RCCL calls themselves need two devices (tests/test_gpu_multi.py)."""
+    import ctypes as C
+    from sbwt_amd import capi
+    L = capi.lib()
+    fn = L.sbwtgpu_debug_bcast_plan
+    fn.restype = C.c_int
+
+    def plan(devs, root, visible):
+        n = len(devs)
+        a = (C.c_int * n)(*devs)
+        uniq, slot = (C.c_int * n)(), (C.c_int * n)()
+        nu, rr = C.c_int(-5), C.c_int(-5)
+        rc = fn(n, a, root, visible, uniq, slot, C.byref(nu), C.byref(rr))
+        return rc, list(uniq)[: max(nu.value, 0)], list(slot), rr.value
+
+    assert plan([0, 1, 2, 3], 0, 8) == (0, [0, 1, 2, 3], [0, 1, 2, 3], 0)
+    assert plan([0, 0], 0, 1) == (0, [0], [0, 0], 0)                                   # two host threads on one GPU: no RCCL at all
+    assert plan([2, 0, 2, 1, 0, 2], 1, 4) == (0, [2, 0, 1], [0, 1, 0, 2, 1, 0], 2)     # first appearance orders the ranks
+    assert plan([3, 3, 1], 3, 4) == (0, [3, 1], [0, 0, 1], 0)
+    rc, _, _, _ = plan([0, 1], 2, 4)                                                   # the root's device must be listed
+    assert rc != 0 and b"root" in L.sbwtgpu_last_error()
+    rc, _, _, _ = plan([0, 4], 0, 4)                                                   # a device that is not there
+    assert rc != 0 and b"out of range" in L.sbwtgpu_last_error()
+    rc, _, _, _ = plan([-1], 0, 4)
+    assert rc != 0
