@@ -352,6 +352,20 @@ def test_search_on_indexes_of_more_than_2_pow_30_and_2_pow_31_columns(gpu, L):
         assert np.array_equal(idx.search_i32(bases, off)[0].astype(np.int64), got)
     # the device-resident entry point (the fused kernel itself, no host pipeline in between)
     assert np.array_equal(_search_dev(idx, bases, off, 31, True), got)
+    # reads of other lengths: pieces of the fused kernel (161 .. 422 bases), zones of the general kernel beyond, reads shorter than
+    # k; the formatted text of the CLI (values of ten digits) -- against the reference-order kernel
+    b2, o2 = synth.ragged_reads([genome], 600, 20, 700, 0.01, 11)
+    b2 = synth.inject(b2, 30, ord("N"), 12)
+    mixed, _ = idx.streaming_search(b2, o2)
+    text, _ = idx.search_text(b2, o2, True)
+    capi.set_tuning("search_variant", 0)
+    try:
+        ref_mixed, oo2 = idx.streaming_search(b2, o2)
+    finally:
+        capi.set_tuning("search_variant", -1)
+    assert np.array_equal(mixed, ref_mixed)
+    assert np.array_equal(_search_dev(idx, b2, o2, 31, True), ref_mixed)
+    assert text == b"".join(print_vector(ref_mixed[oo2[r]:oo2[r + 1]]) for r in range(len(o2) - 1))
     idx.close()
     del genome
     orc = OracleIndex.from_bits(bits.cols[0], bits.cols[1], bits.cols[2], bits.cols[3], bits.ssup, bits.n_nodes, 31, bits.n_kmers, 8)
