@@ -37,6 +37,9 @@ d_bases = B.gpu_reads(genomes, n_reads, 42, dev, in_genome_order=bool(os.environ
 m = L - K + 1
 d_roff = torch.arange(n_reads + 1, dtype=torch.int64, device=dev) * L
 d_ooff = torch.arange(n_reads + 1, dtype=torch.int64, device=dev) * m
+ostride = int(os.environ.get("OSTRIDE", 0))        # OSTRIDE=128: every read's results start at a multiple of 128 slots (1 KB)
+if ostride:
+    d_ooff = torch.arange(n_reads + 1, dtype=torch.int64, device=dev) * ostride
 if os.environ.get("RAGGED"):       # RAGGED=lo: reads of lo .. READLEN bases (host generator), checksum over a flat view
     hb, ho = synth.ragged_reads(genomes, n_reads, int(os.environ["RAGGED"]), L, 0.01, 43)
     d_bases = torch.from_numpy(hb).to(dev)
@@ -44,6 +47,8 @@ if os.environ.get("RAGGED"):       # RAGGED=lo: reads of lo .. READLEN bases (ho
     d_ooff = torch.from_numpy(capi.out_offsets(ho, K)).to(dev)
 n_kmers = int(d_ooff[-1].item())
 d_out = torch.empty(n_kmers, dtype=torch.int64, device=dev)
+if ostride:
+    n_kmers = n_reads * m                         # (the rate counts k-mers, not slots)
 wsb = capi.search_workspace_bytes(d_bases.numel())
 d_ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
 st = torch.cuda.current_stream().cuda_stream
@@ -85,7 +90,8 @@ for rnd in range(rounds + 1):
             if os.environ.get("RAGGED"):
                 chk = int((d_out * (torch.arange(n_kmers, device=dev) % 1009 + 1)).sum().item())
             else:
-                chk = int(((d_out.view(n_reads, m) * w).sum(dim=1) * torch.arange(1, n_reads + 1, device=dev)).sum().item())
+                dv = d_out.view(n_reads, ostride)[:, :m] if ostride else d_out.view(n_reads, m)
+                chk = int(((dv * w).sum(dim=1) * torch.arange(1, n_reads + 1, device=dev)).sum().item())
             if ref is None: ref = chk
             print("config", c, "checksum", chk, "same" if chk == ref else "DIFFERENT", "stats", idx.workspace_stats(d_ws.data_ptr(), st),
                   "bridges", idx.workspace_bridges(d_ws.data_ptr(), st), flush=True)
