@@ -46,6 +46,12 @@ void sbwthost_free(void *p);
  * threads (0 = automatic) into a multi-member gzip file (-z of `sbwt search`, sbwt_search.cpp:120). */
 int  sbwthost_write_file(const char *path, const char *data, int64_t n, int gzip_output, int n_threads);
 
+/* The host rank directory of the scalar API (host/bitvector.hh: rank_support_v5_blob, the directory an index file carries
+ * beside every bit vector): out[i] = number of set bits in bits[0, pos[i]) for n positions, pos[i] in [0, n_bits].
+ * (SubsetMatrixRank::rank of ONE position through the C++ mirror answers from this structure; batches of the search
+ * path go to the GPU -- this entry point exists so that the directory's arithmetic is tested where there is no GPU.) */
+int  sbwthost_rank_batch(const uint64_t *bits, int64_t n_bits, const int64_t *pos, int64_t n, int64_t *out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -182,4 +182,20 @@ int sbwthost_write_file(const char *path, const char *data, int64_t n, int gzip_
     }
 }
 
+int sbwthost_rank_batch(const uint64_t *bits, int64_t n_bits, const int64_t *pos, int64_t n, int64_t *out) {
+    if (n_bits < 0 || n < 0 || (n_bits > 0 && !bits) || (n > 0 && (!pos || !out))) return fail("invalid argument");
+    try {
+        const sbwt::bit_vector v(bits, n_bits);
+        sbwt::rank_support_v5_blob rs;
+        rs.build(v);
+        for (int64_t i = 0; i < n; i++) {
+            if (pos[i] < 0 || pos[i] > n_bits) return fail("position %lld outside [0, %lld]", (long long)pos[i], (long long)n_bits);
+            out[i] = rs.rank(v, pos[i]);
+        }
+        return 0;
+    } catch (const std::exception &e) {
+        return fail("%s", e.what());
+    }
+}
+
 }  // extern "C"

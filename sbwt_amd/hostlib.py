@@ -16,6 +16,7 @@ EXPORTED_SYMBOLS = [
     "sbwthost_last_error", "sbwthost_build", "sbwthost_bits_free", "sbwthost_bits_info", "sbwthost_bits_words",
     "sbwthost_file_write", "sbwthost_file_read", "sbwthost_file_free", "sbwthost_file_info",
     "sbwthost_file_words", "sbwthost_file_precalc", "sbwthost_read_sequences", "sbwthost_free", "sbwthost_write_file",
+    "sbwthost_rank_batch",
 ]
 
 _lib: Optional[C.CDLL] = None
@@ -50,6 +51,7 @@ def lib() -> C.CDLL:
     L.sbwthost_free.argtypes = [vp]
     L.sbwthost_free.restype = None
     L.sbwthost_write_file.argtypes = [C.c_char_p, C.c_char_p, i64, ci, ci]
+    L.sbwthost_rank_batch.argtypes = [vp, i64, vp, i64, vp]
     _lib = L
     return L
 
@@ -146,3 +148,13 @@ def write_file(path: str, data: bytes, gzip_output: bool = False, n_threads: int
     """Writes bytes through the CLI's buffered writer (parallel multi-member gzip when gzip_output)."""
     if lib().sbwthost_write_file(path.encode(), data, len(data), int(gzip_output), n_threads) != 0:
         raise RuntimeError(_err())
+
+
+def rank_batch(bits: np.ndarray, n_bits: int, pos) -> np.ndarray:
+    """Host rank directory of the scalar API (rank_support_v5 layout): ones in bits[0, pos) for every position."""
+    bits = np.ascontiguousarray(bits, dtype=np.uint64)
+    pos = np.ascontiguousarray(pos, dtype=np.int64)
+    out = np.empty(len(pos), dtype=np.int64)
+    if lib().sbwthost_rank_batch(bits.ctypes.data, n_bits, pos.ctypes.data, len(pos), out.ctypes.data) != 0:
+        raise RuntimeError(_err())
+    return out

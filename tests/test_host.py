@@ -312,3 +312,31 @@ def test_reader_and_writer_on_pipes(tmp_path):
         hostlib.write_file(out, data, gz, 2)
         t.join()
         assert (gzip.decompress(got[0]) if gz else got[0]) == data
+
+
+def test_host_rank_directory_of_the_scalar_api():
+    """The C++ mirror answers SubsetMatrixRank::rank of ONE position on the host from the rank_support_v5 directory it
+    serialises (host/bitvector.hh).  Its arithmetic -- superblock count + 12-bit block field + whole words + masked
+    word -- against a numpy prefix popcount: every position around word, 384-bit block and 2048-bit superblock boundaries,
+    pos == n_bits, vectors whose length is and is not a multiple of 64 / 2048, all-ones and all-zeros."""
+    rng = np.random.default_rng(21)
+    for n_bits in (0, 1, 63, 64, 65, 383, 384, 385, 2047, 2048, 2049, 6 * 64 * 7 + 5, 4096, 100_003, 1 << 17):
+        nw = (n_bits + 63) // 64
+        for kind in ("random", "ones", "zeros"):
+            if kind == "random":
+                w = rng.integers(0, 1 << 63, size=nw, dtype=np.int64).astype(np.uint64) * np.uint64(2) + rng.integers(0, 2, size=nw).astype(np.uint64)
+            elif kind == "ones":
+                w = np.full(nw, np.uint64(0xFFFFFFFFFFFFFFFF))
+            else:
+                w = np.zeros(nw, dtype=np.uint64)
+            if n_bits & 63 and nw:
+                w[-1] &= np.uint64((1 << (n_bits & 63)) - 1)
+            bits = np.unpackbits(w.view(np.uint8), bitorder="little")[:n_bits] if nw else np.zeros(0, np.uint8)
+            prefix = np.concatenate([[0], np.cumsum(bits.astype(np.int64))])
+            pos = np.unique(np.concatenate([np.arange(0, min(n_bits, 5000) + 1), rng.integers(0, n_bits + 1, size=3000),
+                                            np.array([n_bits, max(n_bits - 1, 0), n_bits // 2])]))
+            pos = pos[(pos >= 0) & (pos <= n_bits)]
+            got = hostlib.rank_batch(w, n_bits, pos)
+            assert np.array_equal(got, prefix[pos]), (n_bits, kind)
+    with pytest.raises(RuntimeError):
+        hostlib.rank_batch(np.zeros(1, np.uint64), 10, [11])
