@@ -134,11 +134,25 @@ extern "C" int sbwtgpu_debug_why(unsigned long long *out, int reset) {
     return 0;
 }
 #define FZ_WHY(q, cond) do { const unsigned long long n_ = __popcll(__ballot(cond)); if (lane == 0 && n_) atomicAdd(&g_fz_why[q], n_); } while (0)
+// what the planner starts and what comes of it (tools/lane_stats_fused.py prints the names)
+__device__ unsigned long long g_fz_plan[48];
+extern "C" int sbwtgpu_debug_plan(unsigned long long *out, int reset) {
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fz_plan), sizeof(g_fz_plan)) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[48] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_fz_plan), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#define FZ_PLAN(q, cond) do { const unsigned long long n_ = __popcll(__ballot(cond)); if (lane == 0 && n_) atomicAdd(&g_fz_plan[q], n_); } while (0)
+#define FZ_PLAN_SUM(q, val) do { unsigned long long v_ = (unsigned long long)(val); for (int o_ = 32; o_ > 0; o_ >>= 1) v_ += __shfl_down(v_, o_); if (lane == 0 && v_) atomicAdd(&g_fz_plan[q], v_); } while (0)
 #define FZ_HIST_FLUSH() do { if (it_cnt) { atomicAdd(&g_iter_hist[(it_cnt >> 1) < 63 ? (it_cnt >> 1) : 63], 1ull); \
     if (it_cnt >= SBWT_SLOW_LO && it_cnt < SBWT_SLOW_HI) atomicMax(&g_iter_max[it_cnt & 7u], ((unsigned long long)it_cnt << 32) | rd); it_cnt = 0; } } while (0)
 #else
 #define FZ_HIST_FLUSH() do { } while (0)
 #define FZ_WHY(q, cond) do { } while (0)
+#define FZ_PLAN(q, cond) do { } while (0)
+#define FZ_PLAN_SUM(q, val) do { } while (0)
 #endif
 
 // timeline builds (tools/build_stats_lib.sh timeline): when the waves of one launch start, see the ticket counter run out, and
@@ -396,6 +410,8 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
             const u64 idle = __ballot(mode == F_IDLE);
             const u64 busy_m = __ballot(mode != F_IDLE);
             if (busy_m == 0 && fm_pend == 0) break;    // everything this wave took is answered and written
+            // (round 5: a lower threshold in the thin end of the tail only -- at most 8 / 16 / 32 lanes busy, halves of 2 or 4
+            // k-mers -- moves nothing either: config 2 4.91-4.92 vs 4.91 ms, 1 M reads 0.92-0.94 vs 0.93, config 5 +1 %)
             u64 donors = __ballot(mode != F_IDLE && mend - i >= FZ_SPLIT_MIN);
             if (idle && donors) {
                 const int n_pairs = min(__popcll(idle), __popcll(donors));
@@ -679,6 +695,7 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
         // ---- consume ----
 #ifdef SBWT_STATS
         unsigned why = 0;
+        int pl_kind = -1, oc_kind = -1, cert_n = 0;      // planner statistics (g_fz_plan)
 #define WHY(q) (why |= 1u << (q))
 #else
 #define WHY(q) ((void)0)
@@ -1025,6 +1042,12 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
                 l = (int)(i64)quad_bits(v1);
                 r = (int)(i64)((u64)v1.z | ((u64)v1.w << 32));
             }
+#ifdef SBWT_STATS
+            if (viaf) oc_kind = (wk == 2 ? 10 : wk == 3 ? 12 : 14) + ((again || l != -1) ? 1 : 0);
+            else if (wk == 1 && again && !do_plan) oc_kind = 18;
+            else if (wk == 1) oc_kind = (wstart == i ? 16 : 19) + ((l != -1) ? 0 : 1);
+            if (wk == 1 && !again && i == 0 && wstart == 0) oc_kind = 21 + ((l != -1) ? 0 : 1);
+#endif
             if (!again) {
                 tabhit = (l != -1);
                 if (l == -1) {
@@ -1136,6 +1159,9 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
                 fl &= ~CF_NOCERT;
             }
             fl &= ~CF_WIN31;
+#ifdef SBWT_STATS
+            if (mode == F_INIT && (wk == 2 || wk == 3 || wk == 6)) cert_n = burst_hi >= i ? burst_hi - i + 1 : 0;
+#endif
             if (burst_hi == i) { ev = FE_EMIT1; burst_hi = -1; }
         }
         if (ev == FE_PRES) {                           // no bad base in [wstart, wstart+pw-1]: shrink the range
@@ -1325,12 +1351,20 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
                     if (hinted) { if (nwk == 2) nwk = 6; else { s0 = i; nwk = (ps > 0) ? 1 : 0; b = -1; } }
                 }
             }
+#ifdef SBWT_STATS
+            pl_kind = nwk == 1 ? ((fl & CF_MISS_MASK) >= 2u * CF_MISS ? 2 : force ? 1 : (b >= i && b <= i + k - 1) ? 8 : 0) :
+                      nwk == 2 ? (s0 == b ? 4 : s0 == b - L0 + 1 ? 3 : 9) : nwk == 3 ? 5 : nwk == 6 ? 6 : 7;
+#endif
             wstart = s0;
             j = 0;
             wk = nwk;
             if (p > 0) mode = F_INIT;
             else { mode = F_STEP; l = 0; r = last_node; }
         }
+#ifdef SBWT_STATS
+        for (int q = 0; q < 24; q++) FZ_PLAN(q, pl_kind == q || oc_kind == q);
+        FZ_PLAN_SUM(24, cert_n);
+#endif
     }
 
     FZ_HIST_FLUSH();

@@ -370,11 +370,18 @@ int sbwtgpu_index_create(const sbwtgpu_index_desc *d, int device, sbwtgpu_index 
             h.off_stab2 = h.blob_bytes;
             h.blob_bytes = align256(h.off_stab2 + 32 * h.n_sb2);
         }
-        // probe filter at the certificate probes' length: 128-bit blocks, about 16 bits per column
+        // probe filter at the certificate probes' length: 128-bit blocks of 8 .. 16 windows (8 .. 16 bits per column; round 5:
+        // half of what it was -- config 2 at 12 windows per block runs as at 6, 4.69 vs 4.66 ms; at 24 it is 2.5 % slower).
+        // A filter of more than 128 MB goes up to 20 per block: config 3 (142 M columns) 6.23 ms at 4 per block / 512 MB,
+        // 6.18 at 8 / 256 MB, 6.09 at 17 / 128 MB, 6.23 at 34 -- the smaller filter stays in the Infinity Cache, and that is
+        // worth more than the false positives cost (profiles/r05_experiments.txt)
         const int L0 = idx->probe_len(false);
         if (g_probe_filter && L0 > p_dev && L0 <= p_sparse) {
             int lf = 4;
-            while (((int64_t)8 << lf) < n) lf++;
+            while (((int64_t)16 << lf) < n) lf++;
+            if (((int64_t)16 << lf) > ((int64_t)128 << 20) && n <= ((int64_t)10 << lf)) lf--;
+            // (experiments: SBWTGPU_FILTER_LOG2_ADJ = -1 halves the filter once more, 1 doubles it)
+            { const char *ea = getenv("SBWTGPU_FILTER_LOG2_ADJ"); if (ea) { lf += atoi(ea); if (lf < 4) lf = 4; } }
             h.p_filter = L0;
             h.log2f = lf;
             h.off_pfil = h.blob_bytes;

@@ -60,3 +60,22 @@ try:
                   % tuple(w[q] / launches / nr for q in range(16, 20)))
 except Exception as ex:
     print("no why-counters:", ex)
+
+try:
+    pl = (ctypes.c_ulonglong * 48)()
+    if capi.lib().sbwtgpu_debug_plan(pl, 1) == 0 and any(pl):
+        launches = 2
+        names = {0: "plan: k-mer i's own lookup (nothing known about its window)", 1: "plan: own lookup, forced (a probe was inconclusive)",
+                 2: "plan: own lookup, blind mode", 8: "plan: own lookup although b lies in the window", 3: "plan: filter window ENDING at b",
+                 4: "plan: filter window STARTING at b", 9: "plan: filter window elsewhere", 5: "plan: range probe", 6: "plan: hinted probe",
+                 7: "plan: dense-table walk", 10: "filter window: absent", 11: "filter window: (perhaps) present", 12: "range probe: absent",
+                 13: "range probe: present", 14: "hinted probe: absent", 15: "hinted probe: present", 16: "own lookup (k-mer i): found",
+                 17: "own lookup (k-mer i): not there", 18: "sparse bucket overflow: next bucket", 19: "lookup elsewhere: found",
+                 20: "lookup elsewhere: not there", 21: "a read's first lookup: found", 22: "a read's first lookup: not there"}
+        print("what the planner starts and what comes of it, per read:")
+        for q in sorted(names):
+            print("  %-70s %.3f" % (names[q], pl[q] / launches / nr))
+        nprobe = pl[10] + pl[12] + pl[14]
+        print("  k-mers certified absent per absent filter window: %.2f" % (pl[24] / max(1, nprobe)))
+except Exception as ex:
+    print("no planner counters:", ex)
