@@ -200,7 +200,11 @@ __device__ __forceinline__ u64 fz_encode32(const unsigned w[8], const unsigned t
 // 32-bit UNSIGNED values: nothing may sign-extend them, bit 31 of a segment's source is part of a position (such an image
 // answers every found k-mer with its position: no result is known by its column only), and the block counts are absolute
 // (C[c] + rank fits 32 bits; the image's mega table is all zero).  0xFFFFFFFF stays "none" / -1.
-template <bool WIDE, bool O32, bool BIG = false>
+// UNI (round 5): the instantiation for batches of ONE read length taken as one ticket per read -- sequencing reads, the
+// usual case.  Offsets, lengths and piece numbers are then compile-time facts: no read_off / out_off, no per-ticket lengths,
+// no division of a ticket number by the pieces per read.  Both instantiations are launched; each returns at once from a
+// batch that is the other's ("debug" bit 128: the general one takes everything).
+template <bool WIDE, bool O32, bool BIG = false, bool UNI = false>
 __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const unsigned char *__restrict__ bases,
                                                           i64 total_bases, i64 *__restrict__ out, i64 n_reads,
                                                           SbwtWorkHeader *ws, unsigned *__restrict__ defer_list,
@@ -211,11 +215,13 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
     __shared__ unsigned char seg_at[FZ_NSEG][256];          // ... and first k-mer
     const int fmode = sbwt_fused_mode(ws, ix.k);
     if (fmode == 0) return;                                 // the general route does it all
-    const bool ragged = fmode == 2;                         // reads of any lengths: offsets fetched with every refill
+    const int P_batch = sbwt_fused_pieces(ws, ix.k);
+    if (UNI != (fmode == 1 && P_batch == 1 && !(ix.debug & 128))) return;      // the other instantiation's batch
+    const bool ragged = !UNI && fmode == 2;                 // reads of any lengths: offsets fetched with every refill
     const int tid = threadIdx.x, lane = tid & 63, wbase = tid & ~63;
     const int k = ix.k, p = ix.p_dev, L0 = ix.probe_len, ps = ix.p_sparse;
     // tickets: P per read (reads of more than 160 bases as pieces that overlap by k-1; sbwt_kernels_common.h)
-    const int P = sbwt_fused_pieces(ws, k), kpp = SBWT_FUSED_MAXLEN - k + 1;
+    const int P = UNI ? 1 : P_batch, kpp = SBWT_FUSED_MAXLEN - k + 1;
     const bool varlen = ragged || P > 1;                    // the tickets' lengths differ: each refill notes them
     const i64 n_tickets = n_reads * P;
     const int ulen = ragged ? SBWT_FUSED_MAXLEN : (int)ws->u_len, m = ulen - k + 1, G = varlen ? SBWT_FUSED_MAXG : ((ulen + 31) >> 5);
@@ -610,7 +616,7 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
                 fa[u] = a;
                 {
                     const i64 rdu = (i64)(unsigned)__builtin_amdgcn_readlane((int)pend_rd, L);
-                    fob[u] = (ragged ? out_off[rdu] : u_out0 + rdu * u_stride) + (i64)(((pdL >> 20) & 3) * kpp);
+                    fob[u] = (ragged ? out_off[rdu] : u_out0 + rdu * u_stride) + (UNI ? 0 : (i64)(((pdL >> 20) & 3) * kpp));
                 }
                 slow = slow || direct || (e - a > 128);
                 if (direct) continue;                  // (fe = 0: the first half writes nothing of it)
@@ -1421,16 +1427,18 @@ void sbwt_launch_search_fused(const SbwtIndexView &ix, const char *d_bases, long
     if (ev_begin) (void)hipEventRecord(ev_begin, stream);
     // (k > 31: whole k-mers in the two-level table; "debug" bit 64: the wide walk for every k -- experiments and the fuzzer)
     const bool wide = (ix.stab2 != nullptr && ix.p_sparse < ix.k) || (ix.debug & 64);
-#define FZ_LAUNCH(W, O) hipLaunchKernelGGL((k_search_fused<W, O>), dim3(g), dim3(256), 0, stream, ix, \
+    // (two launches: the instantiation for one read length and one ticket per read, then the one for everything else; the one
+    // whose batch it is not returns at once)
+#define FZ_LAUNCH1(W, O, B, U) hipLaunchKernelGGL((k_search_fused<W, O, B, U>), dim3(g), dim3(256), 0, stream, ix, \
                                            reinterpret_cast<const unsigned char *>(d_bases), (i64)total_bases, d_out, (i64)n_reads, ws, d_defer, \
                                            d_read_off, d_out_off)
+#define FZ_LAUNCH(W, O, B) do { FZ_LAUNCH1(W, O, B, true); FZ_LAUNCH1(W, O, B, false); } while (0)
     const bool big = ix.n_nodes >= ((i64)1 << 31) - 64;        // (the C ABI sends such an index here only with k <= 31 and int64 results)
-    if (big) hipLaunchKernelGGL((k_search_fused<false, false, true>), dim3(g), dim3(256), 0, stream, ix,
-                                reinterpret_cast<const unsigned char *>(d_bases), (i64)total_bases, d_out, (i64)n_reads, ws, d_defer,
-                                d_read_off, d_out_off);
-    else if (wide) { if (ix.out32) FZ_LAUNCH(true, true); else FZ_LAUNCH(true, false); }
-    else      { if (ix.out32) FZ_LAUNCH(false, true); else FZ_LAUNCH(false, false); }
+    if (big) FZ_LAUNCH(false, false, true);
+    else if (wide) { if (ix.out32) FZ_LAUNCH(true, true, false); else FZ_LAUNCH(true, false, false); }
+    else      { if (ix.out32) FZ_LAUNCH(false, true, false); else FZ_LAUNCH(false, false, false); }
 #undef FZ_LAUNCH
+#undef FZ_LAUNCH1
     if (ev_end) (void)hipEventRecord(ev_end, stream);
     // what the fused kernel did not take: everything when the reads are not of one length, else the reads it handed on
     sbwt_launch_encode_chained(d_bases, total_bases, d_packed, ws, d_defer, d_read_off, ix.k, stream);

@@ -24,8 +24,8 @@ kernel_name = bench.dominant_kernel(variant, level)
 vals = {}
 for line in open(summary):
     m = re.match(KERNEL + r".*\s(FETCH_SIZE|WRITE_SIZE|TCC_EA0_RDREQ_sum|TCC_EA0_WRREQ_sum|TCC_HIT_sum|TCC_MISS_sum|SQ_INSTS_VALU|SQ_INSTS_SALU)\s+n=\s*\d+ avg=([0-9.e+]+)", line)
-    if m:
-        vals[m.group(1)] = float(m.group(2))
+    if m:       # (the fused route launches two instantiations, of which one returns at once: a launch = both)
+        vals[m.group(1)] = vals.get(m.group(1), 0.0) + float(m.group(2))
 path = os.path.join(ROOT, "profiles", "traffic.json")
 try:
     allv = json.load(open(path))
