@@ -283,6 +283,26 @@ def test_wide_kernel_instantiation_matches(gpu, genome_case):
     assert np.array_equal(got2, oracle_batch(orc, bases, off, False))
 
 
+def test_fused_kernel_both_instantiations(gpu, genome_case):
+    # batches of one read length run through k_search_fused<.., UNI = true>; "debug" 128 sends them through the general
+    # instantiation (the one ragged batches and pieces use): same bits, both equal to the oracle; int32 results as well
+    genomes, orc = genome_case
+    idx = gpu_index_from_oracle(orc)
+    for length in (150, 100, 33, 160):
+        bases, off = synth.sample_reads(genomes, 4000, length, 0.02, 50 + length)
+        bases = synth.inject(bases, 25, ord("N"), 9)
+        want_s, want_f = oracle_batch(orc, bases, off, True), oracle_batch(orc, bases, off, False)
+        for dbg in (0, 128):
+            capi.set_tuning("debug", dbg)
+            try:
+                got_s, _ = idx.streaming_search(bases, off)
+                got_f, _ = idx.search(bases, off)
+            finally:
+                capi.set_tuning("debug", 0)
+            assert np.array_equal(got_s, want_s), (length, dbg)
+            assert np.array_equal(got_f, want_f), (length, dbg)
+
+
 def test_rank_beyond_2_pow_31_columns(gpu):
     # mega-block path: more than 2^31 columns (random bit matrix; rank() is defined for any bits)
     n = (1 << 31) + 1_000_003
