@@ -117,12 +117,13 @@ int         sbwtgpu_device_count(int *count);
  *                     columns: 120 GB, 207 G k-mers/s); 0: such an index gets blocks + dense table only, as before round 5
  *                     (23 G k-mers/s).  k > 31 beyond 2^31 columns always steps down.  SBWTGPU_BIG_PATH.
  *   "image_level"     0 (default): the image carries every derived structure (path order + transition table, sparse
- *                     prefix table, probe filter: 50-56 bytes per column for k <= 31, 93 for k = 63); 1: no path order; 2:
+ *                     prefix table, probe filter: 43-53 bytes per column for k <= 31, 92 for k = 63); 1: no path order; 2:
  *                     blocks + dense prefix table only (1 byte per column + the table).  Results are the same at every
  *                     level; throughput is not.  SBWTGPU_IMAGE_LEVEL.  A step-down that index_create makes by
  *                     itself (memory) is announced with one line on stderr.
  *   (environment only) SBWTGPU_SPARSE_BUCKETS_PCT: two-entry buckets of the sparse tables per 100 columns (default: 100 for
- *                     k <= 31, 125 for 31 < k <= 63); SBWTGPU_DEVICE_PRECALC: depth of the dense device prefix table (default:
+ *                     k <= 31, 125 for 31 < k <= 63); SBWTGPU_FILTER_LOG2_ADJ: +1 doubles, -1 halves the probe filter (default: 128-bit
+ *                     blocks of 8-16 windows, up to 20 where that keeps a filter of more than 128 MB small); SBWTGPU_DEVICE_PRECALC: depth of the dense device prefix table (default:
  *                     log4 n, at most 8 on an image with sparse table and filter, at most 14 otherwise); SBWTGPU_VERBOSE=1 / 2:
  *                     index_create names the parts of the image it builds, with their times, on stderr.
  *   "max_image_bytes" > 0: index_create moves to the next level while the image would be larger than this (and fails
