@@ -1422,7 +1422,22 @@ void sbwt_launch_search_fused(const SbwtIndexView &ix, const char *d_bases, long
     hipLaunchKernelGGL(k_check_uniform2, dim3(grid_for(n_reads)), dim3(256), 0, stream, d_read_off, d_out_off, (i64)n_reads, ws,
                        ix.k, pt, ragged_ok);
     const i64 want = (n_reads + 255) / 256;
-    const unsigned cap = (ix.debug >> 8) ? (unsigned)(ix.debug >> 8) : 1280u;
+    // Workgroups: five per CU fill the chip and give the most k-mers per second -- and the slowest iterations (the vector ALU is
+    // shared by five waves per SIMD), which is what a launch's END is made of: the last reads' chains of 20-40 iterations.  A
+    // small batch is mostly end, so it gets fewer, faster waves (measured in one process, config 2, kernel ms at 1280 workgroups
+    // and at the best number: 200 K reads 0.447 -> 0.357 at 512, 1 M reads 0.895 -> 0.792 at 768, 4 M and 10 M reads: 1024 and
+    // 1280 the same, 896 +2-3 %; config 5, 1 M reads: 0.882 -> 0.816 at 768; with the steps below against 1280 throughout:
+    // 400 K reads 73 -> 93 G k-mers/s, 1 M reads 129 -> 144, 2 M reads 174 -> 179, from 4 M reads on the same).
+    // "debug" >> 8 sets the number.
+    unsigned cap = 1280u;
+    if (ix.debug >> 8) cap = (unsigned)(ix.debug >> 8);
+    else if (total_bases < 8000000ll) cap = 256u;
+    else if (total_bases < 20000000ll) cap = 384u;
+    else if (total_bases < 60000000ll) cap = 512u;
+    else if (total_bases < 110000000ll) cap = 640u;
+    else if (total_bases < 170000000ll) cap = 768u;
+    else if (total_bases < 250000000ll) cap = 896u;
+    else if (total_bases < 500000000ll) cap = 1024u;
     const unsigned g = (unsigned)(want < (i64)cap ? want : (i64)cap);
     if (ev_begin) (void)hipEventRecord(ev_begin, stream);
     // (k > 31: whole k-mers in the two-level table; "debug" bit 64: the wide walk for every k -- experiments and the fuzzer)
