@@ -129,7 +129,9 @@ def _fuzz(budget, seed, max_cases):
             capi.set_tuning("sort_reads", int(rng.integers(0, 2)) if v == 4 else -1)
             # the fused kernel's alignments (anchors, seeds, resumed compares): off / as shipped / for every k
             # (+128, at random: the general instantiation instead of the one for batches of one read length)
-            capi.set_tuning("debug", (int(rng.choice([0, 0, 32, 64])) | int(rng.choice([0, 128]))) if v == 5 else 0)
+            # (+ workgroups << 8, at random: the launcher's choice by batch size, one workgroup, a few, many)
+            capi.set_tuning("debug", (int(rng.choice([0, 0, 32, 64])) | int(rng.choice([0, 128])) |
+                                      (int(rng.choice([0, 0, 1, 3, 40, 1280])) << 8)) if v == 5 else 0)
             capi.set_tuning("fused_pieces", int(rng.choice([-1, 1, 2, 3])) if v == 5 else -1)
             a = idx.streaming_search(bases, off)[0] if ssup else None
             b = idx.search(bases, off)[0]
