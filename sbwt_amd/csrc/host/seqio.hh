@@ -260,8 +260,19 @@ private:
 class Buffered_ofstream {
 public:
     Buffered_ofstream(const std::string &filename, bool gzip, int n_threads = 0) : filename_(filename), gzip_(gzip) {
-        fd_ = ::open(filename.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0666);
+        // No O_TRUNC: truncating a file to nothing marks it for ext4's "replace via truncate" heuristic (auto_da_alloc), which
+        // allocates and starts writing back ALL of its dirty pages inside close() -- 0.77 s for the 8 GB a 10 M-read search
+        // writes, a third of the whole run, and it strikes every run because check_writable() has just created the file
+        // (truncating an EMPTY file counts).  An existing regular file is overwritten in place from offset 0 and cut to
+        // what was written when it is closed (ftruncate to a length > 0 does not set the mark); the result is the same file
+        // the reference's ofstream would leave, same inode, same contents.
+        fd_ = ::open(filename.c_str(), O_WRONLY | O_CREAT, 0666);
         if (fd_ < 0) throw std::runtime_error("Error opening file: " + filename);
+        struct stat sb;
+        if (::fstat(fd_, &sb) == 0 && S_ISREG(sb.st_mode)) {
+            regular_ = true;
+            old_size_ = (int64_t)sb.st_size;
+        }
         if (n_threads <= 0) {
             n_threads = (int)std::thread::hardware_concurrency();
             if (n_threads > 16) n_threads = 16;
@@ -306,6 +317,10 @@ public:
         flush_small();
         const int f = fd_;
         fd_ = -1;
+        if (regular_ && old_size_ > written_ && ::ftruncate(f, (off_t)written_) != 0) {
+            ::close(f);
+            throw std::runtime_error("Error writing to file " + filename_);
+        }
         if (::close(f) != 0) throw std::runtime_error("Error writing to file " + filename_);
     }
 
@@ -363,6 +378,7 @@ private:
             if (w <= 0) throw std::runtime_error("Error writing to file " + filename_);
             p += w;
             n -= (size_t)w;
+            written_ += (int64_t)w;
         }
     }
     void flush_small() {
@@ -377,6 +393,8 @@ private:
     std::vector<char> small_;
     std::vector<char> pending_;
     bool wrote_member_ = false;
+    bool regular_ = false;          // a regular file: cut to written_ bytes at close if it was longer before
+    int64_t old_size_ = 0, written_ = 0;
 };
 
 // FASTA writer used by tests and `sbwt build --add-reverse-complements`
