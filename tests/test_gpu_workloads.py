@@ -108,3 +108,43 @@ def test_reads_without_a_single_kmer_in_shared_stretches(gpu):
     off = np.arange(n + 1, dtype=np.int64) * L
     want = check(genomes, 63, bases, off)
     assert (want >= 0).mean() < 0.05
+
+
+def test_batch_sizes_around_the_pool_and_workgroup_boundaries(gpu):
+    """Batches of 1 .. 70 000 reads (a wave's pool is 64 tickets, a workgroup 256 lanes; the launcher picks the number of
+    workgroups by the batch's bases, `sbwt_launch_search_fused`) and the same batch on 1, 2 and 1280 workgroups ("debug" >> 8):
+    the fused route against the oracle, int64 results."""
+    genomes = [synth.random_genome(200_000, 21)]
+    genomes.append(synth.mutate(genomes[0], 0.04, 22))
+    k = 30
+    bits = capi.build_bits_gpu([g.tobytes() for g in genomes], k, False, True)
+    orc = OracleIndex.from_bits(bits.cols[0], bits.cols[1], bits.cols[2], bits.cols[3], bits.ssup, bits.n_nodes, k,
+                                bits.n_kmers, 8)
+    idx = capi.Index.create(bits.cols[0], bits.cols[1], bits.cols[2], bits.cols[3], bits.ssup, bits.n_nodes, k,
+                            bits.n_kmers, 8)
+    bases_all, off_all = synth.sample_reads(genomes, 70_000, 150, 0.015, 47)
+    bases_all = synth.inject(bases_all, 20, ord("N"), 5)
+    want_all = np.concatenate([orc.streaming_search(bases_all[off_all[r]:off_all[r + 1]].tobytes()) for r in range(6000)])
+    m = 150 - k + 1
+    for n in (1, 2, 63, 64, 65, 127, 128, 129, 255, 256, 257, 1000, 4097, 6000):
+        got, _ = idx.streaming_search(bases_all[:off_all[n]], off_all[:n + 1])
+        assert np.array_equal(got, want_all[:n * m]), n
+    for wgs in (1, 2, 1280):
+        capi.set_tuning("debug", wgs << 8)
+        try:
+            got, _ = idx.streaming_search(bases_all[:off_all[6000]], off_all[:6001])
+        finally:
+            capi.set_tuning("debug", 0)
+        assert np.array_equal(got, want_all), wgs
+    # the whole batch: every route agrees (the oracle has vouched for the first 6000 reads)
+    ref = None
+    for variant in (5, 4):
+        capi.set_tuning("search_variant", variant)
+        try:
+            got, _ = idx.streaming_search(bases_all, off_all)
+        finally:
+            capi.set_tuning("search_variant", -1)
+        assert np.array_equal(got[:6000 * m], want_all), variant
+        if ref is None:
+            ref = got
+        assert np.array_equal(got, ref), variant
