@@ -106,6 +106,20 @@ def test_cli_non_streaming_index_and_batches(gpu, tmp_path):
     assert open(d + "/g1.out", "rb").read() == want
     p = run("search", "-o", d + "/g9.out", "-i", d + "/st.sbwt", "-q", d + "/r.fastq", "--gpus", "9", check=False)
     assert p.returncode == 1 and b"Runtime error" in p.stderr        # more GPUs than the box has
+    # an output file that exists already -- longer, then a hard link's other name -- is replaced in place (the writer opens
+    # without O_TRUNC and cuts the file when it closes it; host/seqio.hh): same bytes, same inode, plain and gzipped
+    few = reads[:40]
+    write_fastq(d + "/few.fastq", few)
+    want_few = b"".join(print_vector(orc.streaming_search(r)) for r in few)
+    ino = os.stat(d + "/st.out").st_ino
+    os.link(d + "/st.out", d + "/st_link.out")
+    run("search", "-o", d + "/st.out", "-i", d + "/st.sbwt", "-q", d + "/few.fastq")
+    assert open(d + "/st.out", "rb").read() == want_few and os.stat(d + "/st.out").st_ino == ino
+    assert open(d + "/st_link.out", "rb").read() == want_few
+    run("search", "-o", d + "/st.out", "-i", d + "/st.sbwt", "-q", d + "/r.fastq", "-z")
+    assert gzip.open(d + "/st.out", "rb").read() == want
+    run("search", "-o", d + "/st.out", "-i", d + "/st.sbwt", "-q", d + "/few.fastq")
+    assert open(d + "/st.out", "rb").read() == want_few
 
 
 def test_cli_error_conventions(gpu, tmp_path):
