@@ -233,6 +233,75 @@ QueryStats run_file(const string &infile, const string &outfile, const std::func
                       " to output file " + outfile,
                   LogLevel::MAJOR);
         const int64_t k = index.get_k();
+        if (!host_format && index.number_of_devices_in_use() <= 1 && !gzip_output) {
+            // The default: search + print_vector on the GPU, pipelined over PCIe; the text goes from the pinned
+            // staging buffers straight into the output file (one copy, into the page cache).  TWO threads take the batches
+            // in turn: while one copies its batch's text into the file -- the longest stage, one thread's write(2) at the
+            // page cache's rate -- the other's batch is already on the GPU and its first pieces of text are waiting; its
+            // sink blocks until the batch before it is written.  The output is in input order, piece by piece.
+            std::mutex pop_m, turn_m;
+            std::condition_variable turn_cv;
+            int64_t next_seq = 0, turn = 0;
+            bool failed = false;
+            std::exception_ptr worker_err[2];
+            auto worker = [&](int w) {
+                try {
+                    for (;;) {
+                        ReadBatch rb;
+                        int64_t seq;
+                        {
+                            std::lock_guard<std::mutex> lk(pop_m);
+                            if (!to_search.pop(rb)) break;
+                            seq = next_seq++;
+                        }
+                        const int64_t n_reads = (int64_t)rb.read_off.size() - 1;
+                        bool mine = false;
+                        int64_t t_sink = 0, t_wait = 0, nq = 0;
+                        auto take_turn = [&] {
+                            if (mine) return;
+                            const int64_t w0 = cur_time_micros();
+                            std::unique_lock<std::mutex> lk(turn_m);
+                            turn_cv.wait(lk, [&] { return turn == seq || failed; });
+                            if (failed && turn != seq) throw std::runtime_error("search stopped: another batch failed");
+                            mine = true;
+                            t_wait += cur_time_micros() - w0;
+                        };
+                        const int64_t t0 = cur_time_micros();
+                        try {
+                            nq = index.search_text_stream(rb.bases.data(), rb.read_off.data(), n_reads,
+                                                          [&](const char *text, int64_t bytes) {
+                                                              take_turn();
+                                                              const int64_t w0 = cur_time_micros();
+                                                              writer.write(text, bytes);
+                                                              t_sink += cur_time_micros() - w0;
+                                                          });
+                            take_turn();                       // (a batch without any text still waits for its turn)
+                        } catch (...) {
+                            std::lock_guard<std::mutex> lk(turn_m);
+                            failed = true;
+                            turn_cv.notify_all();
+                            throw;
+                        }
+                        {
+                            std::lock_guard<std::mutex> lk(turn_m);
+                            st.queries += nq;
+                            st.micros += cur_time_micros() - t0 - t_sink - t_wait;
+                            t_write += t_sink;
+                            turn = seq + 1;
+                        }
+                        turn_cv.notify_all();
+                        timing_mark("a batch searched and written");
+                    }
+                } catch (...) {
+                    worker_err[w] = std::current_exception();
+                }
+            };
+            std::thread second([&] { worker(1); });
+            worker(0);
+            second.join();
+            for (auto &e : worker_err)
+                if (e) std::rethrow_exception(e);
+        }
         ReadBatch rb;
         vector<int64_t> out;
         while (to_search.pop(rb)) {
@@ -251,23 +320,6 @@ QueryStats run_file(const string &infile, const string &outfile, const std::func
                 st.queries += rb.out_off.back();
                 for (int64_t r = 0; r < n_reads; r++)
                     print_vector(out.data() + rb.out_off[(size_t)r], rb.out_off[(size_t)r + 1] - rb.out_off[(size_t)r], tb.host_text);
-            } else if (index.number_of_devices_in_use() <= 1 && !gzip_output) {
-                // default: search + print_vector on the GPU, pipelined over PCIe; the text goes from the
-                // pinned staging buffers straight into the output file (one copy, into the page cache), in order, while
-                // the next chunk is on the GPU.  Batches before this one must be on disk first.
-                to_write.push(std::move(tb));
-                to_write.drain();
-                int64_t t0 = cur_time_micros(), t_sink = 0;
-                st.queries += index.search_text_stream(rb.bases.data(), rb.read_off.data(), n_reads,
-                                                       [&](const char *text, int64_t bytes) {
-                                                           const int64_t w0 = cur_time_micros();
-                                                           writer.write(text, bytes);
-                                                           t_sink += cur_time_micros() - w0;
-                                                       });
-                st.micros += cur_time_micros() - t0 - t_sink;
-                t_write += t_sink;
-                timing_mark("a batch searched and written");
-                continue;
             } else {
                 // several devices (every device's text is a piece of its own), or compressed output (a writer thread)
                 int64_t t0 = cur_time_micros();
