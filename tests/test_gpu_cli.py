@@ -122,6 +122,35 @@ def test_cli_non_streaming_index_and_batches(gpu, tmp_path):
     assert open(d + "/st.out", "rb").read() == want_few
 
 
+def test_cli_many_batches_keep_their_order(gpu, tmp_path):
+    # two threads take the batches in turn and write their text in input order (host/sbwt_cli.cpp run_file): hundreds of
+    # batches of uneven cost -- stretches of reads that are absent, reads with N, short reads -- against one batch, the
+    # host-formatted output and the oracle
+    d = str(tmp_path)
+    genomes = [synth.random_genome(60_000, 8)]
+    genomes.append(synth.mutate(genomes[0], 0.03, 9))
+    write_fasta(d + "/g.fna", [g.tobytes() for g in genomes])
+    run("build", "-i", d + "/g.fna", "-o", d + "/i.sbwt", "-k", "30", "-t", "4")
+    bases, off = synth.sample_reads(genomes, 30_000, 150, 0.02, 10)
+    bases = synth.inject(bases, 300, ord("N"), 2)
+    rb, ro = synth.random_reads(3_000, 150, 11)
+    reads = [bases[off[r]:off[r + 1]].tobytes() for r in range(30_000)]
+    absent = [rb[ro[r]:ro[r + 1]].tobytes() for r in range(3_000)]
+    mixed = reads[:10_000] + absent + [b"ACGT", b"A" * 29] + reads[10_000:]
+    write_fastq(d + "/r.fastq", mixed)
+    run("search", "-o", d + "/one.out", "-i", d + "/i.sbwt", "-q", d + "/r.fastq", "--batch-bases", "100000000")
+    run("search", "-o", d + "/many.out", "-i", d + "/i.sbwt", "-q", d + "/r.fastq", "--batch-bases", "20000")
+    run("search", "-o", d + "/host.out", "-i", d + "/i.sbwt", "-q", d + "/r.fastq", "--host-format", "--batch-bases", "300000")
+    one = open(d + "/one.out", "rb").read()
+    assert open(d + "/many.out", "rb").read() == one
+    assert open(d + "/host.out", "rb").read() == one
+    orc = OracleIndex.build([g.tobytes() for g in genomes], 30, True, False, 8)
+    lines = one.split(b"\n")
+    assert len(lines) == len(mixed) + 1
+    for r in list(range(0, 300)) + list(range(9_990, 10_010)) + list(range(13_000, 13_010)):
+        assert lines[r] + b"\n" == print_vector(orc.streaming_search(mixed[r])), r
+
+
 def test_cli_error_conventions(gpu, tmp_path):
     d = str(tmp_path)
     p = run("search", "-o", d + "/o.txt", "-i", d + "/missing.sbwt", "-q", d + "/q.fna", check=False)
