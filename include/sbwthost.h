@@ -42,6 +42,11 @@ const int64_t  *sbwthost_file_precalc(const sbwthost_file *f);
  * *bases / *read_off are malloc'ed; free with sbwthost_free. */
 int  sbwthost_read_sequences(const char *path, char **bases, int64_t **read_off, int64_t *n_reads);
 void sbwthost_free(void *p);
+/* The same reads by the CLI's reader for plain regular files: the file cut at record starts about chunk_bytes apart,
+ * the pieces parsed by n_threads threads and put together in file order (seqio.hh read_file_chunked).  Returns 1 (and
+ * reads nothing) when the file is not one that can be cut: gzip data, a pipe, an unknown extension. */
+int  sbwthost_read_sequences_chunked(const char *path, int64_t chunk_bytes, int n_threads, char **bases, int64_t **read_off,
+                                     int64_t *n_reads);
 /* Writes n bytes through the CLI's buffered writer; gzip_output != 0 compresses 1 MiB blocks on n_threads
  * threads (0 = automatic) into a multi-member gzip file (-z of `sbwt search`, sbwt_search.cpp:120). */
 int  sbwthost_write_file(const char *path, const char *data, int64_t n, int gzip_output, int n_threads);

@@ -168,6 +168,31 @@ int sbwthost_read_sequences(const char *path, char **bases, int64_t **read_off, 
         return fail("%s", e.what());
     }
 }
+int sbwthost_read_sequences_chunked(const char *path, int64_t chunk_bytes, int n_threads, char **bases, int64_t **read_off,
+                                    int64_t *n_reads) {
+    if (!path || !bases || !read_off || !n_reads) return fail("invalid argument");
+    try {
+        int64_t size = 0;
+        if (!sbwt::seq_io::chunkable_file(path, &size)) return 1;
+        std::vector<char> b;
+        std::vector<int64_t> off{0};
+        sbwt::seq_io::read_file_chunked(path, size, chunk_bytes, n_threads,
+                                        [&](std::vector<char> &&pb, std::vector<int64_t> &&po, bool) {
+                                            const int64_t base = (int64_t)b.size();
+                                            b.insert(b.end(), pb.begin(), pb.end());
+                                            for (size_t r = 1; r < po.size(); r++) off.push_back(base + po[r]);
+                                        });
+        *bases = (char *)malloc(b.size() ? b.size() : 1);
+        *read_off = (int64_t *)malloc(off.size() * 8);
+        if (!*bases || !*read_off) return fail("out of memory");
+        if (!b.empty()) memcpy(*bases, b.data(), b.size());
+        memcpy(*read_off, off.data(), off.size() * 8);
+        *n_reads = (int64_t)off.size() - 1;
+        return 0;
+    } catch (const std::exception &e) {
+        return fail("%s", e.what());
+    }
+}
 void sbwthost_free(void *p) { free(p); }
 
 int sbwthost_write_file(const char *path, const char *data, int64_t n, int gzip_output, int n_threads) {

@@ -15,6 +15,10 @@
 #include <cstring>
 #include <algorithm>
 #include <cstdio>
+#include <condition_variable>
+#include <deque>
+#include <exception>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <thread>
@@ -100,10 +104,25 @@ public:
         }
         seq_.reserve(1 << 10);
     }
+    // A byte range [begin, end) of a plain (not gzipped) regular file that starts at a record's first byte and ends at one:
+    // the same parser on a piece of the file (read_file_chunked below); bytes are fetched with pread.
+    Reader(const std::string &filename, int64_t begin, int64_t end) : filename_(filename) {
+        fmt_ = figure_out_file_format(filename).format;
+        plain_fd_ = ::open(filename.c_str(), O_RDONLY);
+        if (plain_fd_ < 0) throw std::runtime_error("Error opening file: " + filename);
+        ranged_ = true;
+        range_pos_ = begin;
+        range_end_ = end;
+        buf_.resize((size_t)8 << 20);
+        seq_.reserve(1 << 10);
+    }
     ~Reader() {
         if (f_) gzclose(f_);
         if (plain_fd_ >= 0) ::close(plain_fd_);
     }
+    // read_batch() / get_next_read_to_buffer() ended at a record without bases (which ends the stream like EOF does), not at
+    // the end of the input
+    bool stopped_at_empty_record() const { return empty_record_; }
     Reader(const Reader &) = delete;
     Reader &operator=(const Reader &) = delete;
 
@@ -163,7 +182,8 @@ public:
                 }
             }
             if (bases.size() == before) {      // a record without bases ends the stream like a zero-length read does
-                return false;                   // (get_next_read_to_buffer() returns 0 for it, which callers take as EOF)
+                empty_record_ = true;           // (get_next_read_to_buffer() returns 0 for it, which callers take as EOF)
+                return false;
             }
             char *p = bases.data() + before;
             const size_t n = bases.size() - before;
@@ -190,7 +210,14 @@ private:
     }
     bool fill() {
         int n;
-        if (plain_fd_ >= 0) {        // not compressed: straight read(2) into the parse buffer (gzread copies twice)
+        if (ranged_) {               // a piece of a plain regular file
+            const int64_t want = std::min<int64_t>((int64_t)buf_.size(), range_end_ - range_pos_);
+            if (want <= 0) { pos_ = end_ = 0; return false; }
+            do {
+                n = (int)::pread(plain_fd_, buf_.data(), (size_t)want, (off_t)range_pos_);
+            } while (n < 0 && errno == EINTR);
+            if (n > 0) range_pos_ += n;
+        } else if (plain_fd_ >= 0) {        // not compressed: straight read(2) into the parse buffer (gzread copies twice)
             do {
                 n = (int)::read(plain_fd_, buf_.data(), std::min(buf_.size(), (size_t)1 << 30));
             } while (n < 0 && errno == EINTR);
@@ -251,7 +278,156 @@ private:
     std::vector<char> buf_;
     size_t pos_ = 0, end_ = 0;
     std::vector<char> seq_;
+    bool ranged_ = false;           // a byte range of a regular file (pread)
+    int64_t range_pos_ = 0, range_end_ = 0;
+    bool empty_record_ = false;
 };
+
+// ---- a plain regular file parsed by several threads, piece by piece --------------------------------------------------
+// The file is cut at record starts about chunk_bytes apart; every piece is parsed by Reader's own code (range mode), the
+// pieces' reads are handed to `emit(bases, read_off, last)` in file order, one piece at a time.  What ends the stream for
+// the sequential reader ends it here: a record without bases in piece i means pieces i+1 .. are dropped.
+//
+// Where a record starts, seen from the middle of a file: FASTA -- a line that begins with '>' (sequence lines cannot hold
+// one).  FASTQ (four lines per record, as the sequential reader requires) -- a line that begins with '@' whose next line but
+// one begins with '+': a quality line may begin with '@' too, but the line two below a quality line is a sequence line, and
+// those begin with a base.
+inline bool chunkable_file(const std::string &filename, int64_t *size) {
+    FileFormat ff;
+    try { ff = figure_out_file_format(filename); } catch (...) { return false; }
+    if (ff.gzipped) return false;
+    struct stat sb;
+    if (::stat(filename.c_str(), &sb) != 0 || !S_ISREG(sb.st_mode)) return false;
+    const int fd = ::open(filename.c_str(), O_RDONLY);
+    if (fd < 0) return false;
+    unsigned char magic[2] = {0, 0};
+    const ssize_t got = ::pread(fd, magic, 2, 0);
+    ::close(fd);
+    if (got == 2 && magic[0] == 0x1f && magic[1] == 0x8b) return false;       // gzip data under a plain name
+    *size = (int64_t)sb.st_size;
+    return true;
+}
+// first record start at or after `from` (file_size if there is none; -1 if it cannot be told within 64 MB)
+inline int64_t find_record_start(int fd, Format fmt, int64_t from, int64_t file_size) {
+    if (from <= 0) return 0;
+    if (from >= file_size) return file_size;
+    std::vector<char> w;
+    for (size_t span = (size_t)1 << 20; span <= ((size_t)64 << 20); span <<= 2) {
+        const int64_t lo = from - 1;                                        // (the byte before: is `from` itself a line start?)
+        const int64_t len = std::min<int64_t>((int64_t)span, file_size - lo);
+        w.resize((size_t)len);
+        int64_t got = 0;
+        while (got < len) {
+            const ssize_t r = ::pread(fd, w.data() + got, (size_t)(len - got), (off_t)(lo + got));
+            if (r < 0 && errno == EINTR) continue;
+            if (r <= 0) break;
+            got += r;
+        }
+        if (got < len) return -1;
+        const bool whole = lo + len == file_size;                            // the window reaches the end of the file
+        // line starts inside the window: index i such that w[i - 1] == '\n'
+        size_t i = 0;
+        const char *nl0 = (const char *)memchr(w.data(), '\n', (size_t)len);
+        if (!nl0) { if (whole) return file_size; continue; }
+        i = (size_t)(nl0 - w.data()) + 1;
+        while (i < (size_t)len) {
+            if (fmt == FASTA) {
+                if (w[i] == '>') return lo + (int64_t)i;
+            } else if (w[i] == '@') {
+                const char *a = (const char *)memchr(w.data() + i, '\n', (size_t)len - i);
+                const char *b = a ? (const char *)memchr(a + 1, '\n', (size_t)(w.data() + len - (a + 1))) : nullptr;
+                if (b && b + 1 < w.data() + len) {
+                    if (b[1] == '+') return lo + (int64_t)i;
+                } else if (!whole) {
+                    break;                                                   // the next lines are beyond the window: a wider one
+                }
+            }
+            const char *nl = (const char *)memchr(w.data() + i, '\n', (size_t)len - i);
+            if (!nl) { i = (size_t)len; break; }
+            i = (size_t)(nl - w.data()) + 1;
+        }
+        if (i >= (size_t)len && whole) return file_size;
+        if (whole) return file_size;
+    }
+    return -1;
+}
+template <typename Emit>
+inline void read_file_chunked(const std::string &filename, int64_t file_size, int64_t chunk_bytes, int n_threads, Emit &&emit) {
+    const Format fmt = figure_out_file_format(filename).format;
+    const int fd = ::open(filename.c_str(), O_RDONLY);
+    if (fd < 0) throw std::runtime_error("Error opening file: " + filename);
+    if (chunk_bytes < 4096) chunk_bytes = 4096;
+    if (n_threads < 1) n_threads = 1;
+    struct Piece { std::vector<char> bases; std::vector<int64_t> read_off{0}; bool ready = false, stop = false; std::exception_ptr err; };
+    // pieces are planned one after the other (a cut needs the cut before it), parsed by whoever is free, emitted in order
+    std::mutex m;
+    std::condition_variable cv;
+    int64_t next_begin = 0, planned = 0, emitted = 0;
+    bool plan_done = false, stopped = false, emitting = false;
+    std::deque<Piece> window;                       // pieces emitted .. planned - 1
+    auto work = [&] {
+        for (;;) {
+            int64_t idx, b, e;
+            {
+                std::unique_lock<std::mutex> lk(m);
+                cv.wait(lk, [&] { return stopped || plan_done || planned - emitted < (int64_t)n_threads + 1; });
+                if (stopped || plan_done) return;
+                b = next_begin;
+                e = b + chunk_bytes >= file_size ? file_size : find_record_start(fd, fmt, b + chunk_bytes, file_size);
+                if (e < 0 || e <= b) e = file_size;       // no cut to be found: the rest is one piece
+                next_begin = e;
+                if (e >= file_size) plan_done = true;
+                idx = planned++;
+                window.emplace_back();
+            }
+            Piece pc;
+            try {
+                Reader r(filename, b, e);
+                pc.bases.reserve((size_t)((e - b) / (fmt == FASTQ ? 2 : 1)) + 4096);     // (no regrowing: bases are < half of a FASTQ piece)
+                r.read_batch(pc.bases, pc.read_off, INT64_MAX);
+                pc.stop = r.stopped_at_empty_record();
+            } catch (...) {
+                pc.err = std::current_exception();
+            }
+            pc.ready = true;
+            std::unique_lock<std::mutex> lk(m);
+            window[(size_t)(idx - emitted)] = std::move(pc);
+            // whoever completes the piece that is next in line emits it and what is ready behind it
+            while (!emitting && !stopped && !window.empty() && window.front().ready) {
+                emitting = true;                    // (one emitter at a time: the front stays in place until it is handed over)
+                Piece out = std::move(window.front());
+                const bool last = out.stop || out.err || (plan_done && emitted + 1 == planned);
+                if (out.stop || out.err) stopped = true;
+                lk.unlock();
+                // (emitting outside the lock: the other threads go on parsing; order is kept because only the front is taken,
+                // and the front is not popped until it has been handed over)
+                if (out.err) std::rethrow_exception(out.err);           // (the thread's handler sets `stopped`)
+                emit(std::move(out.bases), std::move(out.read_off), last);
+                lk.lock();
+                window.pop_front();
+                emitted++;
+                emitting = false;
+                cv.notify_all();
+            }
+            cv.notify_all();
+        }
+    };
+    std::vector<std::thread> th;
+    std::vector<std::exception_ptr> errs((size_t)n_threads);
+    for (int t = 0; t < n_threads; t++)
+        th.emplace_back([&, t] {
+            try { work(); } catch (...) {
+                errs[(size_t)t] = std::current_exception();
+                std::lock_guard<std::mutex> lk(m);
+                stopped = true;
+                cv.notify_all();
+            }
+        });
+    for (auto &t : th) t.join();
+    ::close(fd);
+    for (auto &e : errs)
+        if (e) std::rethrow_exception(e);
+}
 
 // Buffered output, optionally gzip-compressed (-z of `sbwt search`, sbwt_search.cpp:120,126-137).
 // Compression runs on several threads: the data is cut into 1 MiB blocks, every block becomes a gzip

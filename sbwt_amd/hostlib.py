@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("SBWT_HOST_LIB", os.path.join(_HERE, "lib", "libsbwtho
 EXPORTED_SYMBOLS = [
     "sbwthost_last_error", "sbwthost_build", "sbwthost_bits_free", "sbwthost_bits_info", "sbwthost_bits_words",
     "sbwthost_file_write", "sbwthost_file_read", "sbwthost_file_free", "sbwthost_file_info",
-    "sbwthost_file_words", "sbwthost_file_precalc", "sbwthost_read_sequences", "sbwthost_free", "sbwthost_write_file",
+    "sbwthost_file_words", "sbwthost_file_precalc", "sbwthost_read_sequences", "sbwthost_read_sequences_chunked", "sbwthost_free", "sbwthost_write_file",
     "sbwthost_rank_batch",
 ]
 
@@ -48,6 +48,7 @@ def lib() -> C.CDLL:
     L.sbwthost_file_precalc.argtypes = [vp]
     L.sbwthost_file_precalc.restype = C.POINTER(i64)
     L.sbwthost_read_sequences.argtypes = [C.c_char_p, C.POINTER(vp), C.POINTER(vp), C.POINTER(i64)]
+    L.sbwthost_read_sequences_chunked.argtypes = [C.c_char_p, i64, ci, C.POINTER(vp), C.POINTER(vp), C.POINTER(i64)]
     L.sbwthost_free.argtypes = [vp]
     L.sbwthost_free.restype = None
     L.sbwthost_write_file.argtypes = [C.c_char_p, C.c_char_p, i64, ci, ci]
@@ -125,6 +126,26 @@ def read_index_file(path: str) -> IndexFile:
         return IndexFile(cols, ssup, [Carr[i] for i in range(4)], precalc, p.value, n.value, nk.value, k.value)
     finally:
         L.sbwthost_file_free(h)
+
+
+def read_sequences_chunked(path: str, chunk_bytes: int, n_threads: int):
+    """The same reads through the CLI's chunked reader for plain regular files; None when the file cannot be cut."""
+    L = lib()
+    pb, po, n = C.c_void_p(), C.c_void_p(), C.c_int64()
+    rc = L.sbwthost_read_sequences_chunked(path.encode(), chunk_bytes, n_threads, C.byref(pb), C.byref(po), C.byref(n))
+    if rc == 1:
+        return None
+    if rc != 0:
+        raise RuntimeError(_err())
+    try:
+        off = np.ctypeslib.as_array(C.cast(po, C.POINTER(C.c_int64)), shape=(n.value + 1,)).copy()
+        total = int(off[-1])
+        bases = (np.ctypeslib.as_array(C.cast(pb, C.POINTER(C.c_uint8)), shape=(total,)).copy()
+                 if total else np.zeros(0, np.uint8))
+        return bases, off
+    finally:
+        L.sbwthost_free(pb)
+        L.sbwthost_free(po)
 
 
 def read_sequences(path: str):

@@ -22,8 +22,8 @@ SBWT = os.path.join(ROOT, "sbwt_amd", "bin", "sbwt")
 KATS = json.load(open(os.path.join(ROOT, "tests", "golden", "ref_kats.json")))
 
 
-def run(*args, check=True):
-    p = subprocess.run([SBWT] + list(args), capture_output=True, timeout=300)
+def run(*args, check=True, env=None):
+    p = subprocess.run([SBWT] + list(args), capture_output=True, timeout=300, env=dict(os.environ, **env) if env else None)
     if check:
         assert p.returncode == 0, p.stderr.decode()
     return p
@@ -141,8 +141,16 @@ def test_cli_many_batches_keep_their_order(gpu, tmp_path):
     run("search", "-o", d + "/one.out", "-i", d + "/i.sbwt", "-q", d + "/r.fastq", "--batch-bases", "100000000")
     run("search", "-o", d + "/many.out", "-i", d + "/i.sbwt", "-q", d + "/r.fastq", "--batch-bases", "20000")
     run("search", "-o", d + "/host.out", "-i", d + "/i.sbwt", "-q", d + "/r.fastq", "--host-format", "--batch-bases", "300000")
+    # ... and with the input parsed piece by piece by several threads (SBWT_CLI_PARSER_THREADS: off by default)
+    run("search", "-o", d + "/chunked.out", "-i", d + "/i.sbwt", "-q", d + "/r.fastq", "--batch-bases", "20000",
+        env={"SBWT_CLI_CHUNK_MIN_BYTES": "0", "SBWT_CLI_PARSER_THREADS": "3"})
+    write_fasta(d + "/r.fna", mixed)
+    run("search", "-o", d + "/chunked_fa.out", "-i", d + "/i.sbwt", "-q", d + "/r.fna", "--batch-bases", "50000",
+        env={"SBWT_CLI_CHUNK_MIN_BYTES": "0", "SBWT_CLI_PARSER_THREADS": "2"})
     one = open(d + "/one.out", "rb").read()
     assert open(d + "/many.out", "rb").read() == one
+    assert open(d + "/chunked.out", "rb").read() == one
+    assert open(d + "/chunked_fa.out", "rb").read() == one
     assert open(d + "/host.out", "rb").read() == one
     orc = OracleIndex.build([g.tobytes() for g in genomes], 30, True, False, 8)
     lines = one.split(b"\n")

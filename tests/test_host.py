@@ -291,6 +291,65 @@ def test_writer_replaces_existing_files_without_truncating_on_open(tmp_path):
                 assert gzip.open(p, "rb").read() == new
 
 
+def test_chunked_reader_equals_the_sequential_one(tmp_path):
+    """read_file_chunked (the CLI's reader for plain regular files: pieces cut at record starts, parsed by several threads,
+    put together in order) against the sequential Reader on files made to confuse the cut: quality lines that begin with
+    '@' or '+', headers with '+' and '@' inside, CRLF line ends, lower case, N, no newline at the end, long and short
+    records, multi-line FASTA -- and a record without bases, which ends the stream for both."""
+    rng = random.Random(11)
+
+    def fastq(n, crlf=False, empty_at=None, final_newline=True):
+        nl = b"\r\n" if crlf else b"\n"
+        out = []
+        for i in range(n):
+            ln = rng.choice([1, 5, 30, 31, 150, 151, 400]) if i != empty_at else 0
+            seq = bytes(rng.choice(b"ACGTacgtN") for _ in range(ln))
+            qual = bytes(rng.choice(b"@+I#5>") for _ in range(ln))
+            if ln and rng.random() < 0.3:
+                qual = rng.choice([b"@", b"+"]) + qual[1:]
+            hdr = b"@r%d %s" % (i, rng.choice([b"", b"+x", b"@y", b"a b+c@d"]))
+            out.append(hdr + nl + seq + nl + b"+" + rng.choice([b"", b"r%d" % i]) + nl + qual + nl)
+        data = b"".join(out)
+        return data if final_newline else data.rstrip(b"\r\n")
+
+    def fasta(n, crlf=False):
+        nl = b"\r\n" if crlf else b"\n"
+        out = []
+        for i in range(n):
+            ln = rng.choice([1, 60, 61, 500, 5000])
+            seq = bytes(rng.choice(b"ACGTacgtN") for _ in range(ln))
+            width = rng.choice([60, 70, 100000])
+            lines = [seq[j:j + width] for j in range(0, ln, width)]
+            out.append(b">s%d @x +y" % i + nl + nl.join(lines) + nl)
+        return b"".join(out)
+
+    cases = [("a.fastq", fastq(3000)), ("b.fq", fastq(2000, crlf=True)), ("c.fastq", fastq(1500, final_newline=False)),
+             ("d.fastq", fastq(2500, empty_at=1700)), ("e.fastq", fastq(1)), ("f.fastq", b""),
+             ("g.fna", fasta(400)), ("h.fasta", fasta(300, crlf=True)), ("i.fa", fasta(1))]
+    for name, data in cases:
+        p = str(tmp_path / name)
+        open(p, "wb").write(data)
+        want_b, want_off = hostlib.read_sequences(p)
+        for chunk, threads in ((4096, 1), (5000, 3), (70_000, 4), (1 << 20, 2), (1 << 30, 2)):
+            got = hostlib.read_sequences_chunked(p, chunk, threads)
+            assert got is not None, name
+            assert np.array_equal(got[1], want_off), (name, chunk, threads)
+            assert np.array_equal(got[0], want_b), (name, chunk, threads)
+    # (pieces of 4 KB .. 1 GB: hundreds of cuts per file, a few, none; then a larger file with pieces of 1 MiB)
+    p = str(tmp_path / "big.fastq")
+    open(p, "wb").write(fastq(40000))
+    want_b, want_off = hostlib.read_sequences(p)
+    got = hostlib.read_sequences_chunked(p, 1 << 20, 4)
+    assert np.array_equal(got[1], want_off) and np.array_equal(got[0], want_b)
+    # what cannot be cut is refused (the CLI then reads it sequentially): gzip files, gzip data under a plain name
+    pz = str(tmp_path / "z.fastq.gz")
+    gzip.open(pz, "wb").write(fastq(10))
+    assert hostlib.read_sequences_chunked(pz, 1 << 20, 2) is None
+    pz2 = str(tmp_path / "z2.fastq")
+    open(pz2, "wb").write(open(pz, "rb").read())
+    assert hostlib.read_sequences_chunked(pz2, 1 << 20, 2) is None
+
+
 def test_reader_and_writer_on_pipes(tmp_path):
     """Non-seekable input and output: `-q <(zcat reads.fq.gz)`-style FIFOs feed the reader, and the writer
     appends to a pipe (`-o /dev/stdout | ...`), like the reference's ifstream / ofstream do.  The reader's gzip probe

@@ -16,13 +16,19 @@ int main(int argc, char **argv) {
     const int T = atoi(argv[2]);
     const size_t piece = (size_t)32 << 20, total = (size_t)3 << 30;
     std::vector<char> src(piece, 'x');
-    for (int mode = 0; mode < 3; mode++) {        // 0 write(), 1 mmap + T threads, 2 fallocate + mmap + T threads
+    for (int mode = 0; mode < 5; mode++) {        // 0 write(), 1 mmap + T threads, 2 fallocate + mmap + T threads, 3 fallocate(all) + write(), 4 write() of 4 MiB pieces
         unlink(path);
         int fd = open(path, O_RDWR | O_CREAT, 0666);
         double t0 = now();
         size_t pos = 0;
+        if (mode == 3 && posix_fallocate(fd, 0, (off_t)total) != 0) { perror("fallocate"); return 1; }
         while (pos < total) {
-            if (mode == 0) {
+            if (mode == 4) {
+                for (size_t o = 0; o < piece; o += (size_t)4 << 20) {
+                    size_t done = 0, n = (size_t)4 << 20;
+                    while (done < n) done += (size_t)write(fd, src.data() + o + done, n - done);
+                }
+            } else if (mode == 0 || mode == 3) {
                 size_t done = 0;
                 while (done < piece) done += (size_t)write(fd, src.data() + done, piece - done);
             } else {
@@ -44,7 +50,7 @@ int main(int argc, char **argv) {
         double t1 = now();
         close(fd);
         double t2 = now();
-        printf("mode %d (%s): write %.2f s (%.1f GB/s) close %.2f s\n", mode, mode == 0 ? "write()" : mode == 1 ? "ftruncate + mmap" : "fallocate + mmap", t1 - t0, total / (t1 - t0) / 1e9, t2 - t1);
+        printf("mode %d (%s): write %.2f s (%.1f GB/s) close %.2f s\n", mode, mode == 0 ? "write()" : mode == 1 ? "ftruncate + mmap" : mode == 2 ? "fallocate + mmap" : mode == 3 ? "fallocate(all) + write()" : "write() of 4 MiB pieces", t1 - t0, total / (t1 - t0) / 1e9, t2 - t1);
     }
     unlink(path);
     return 0;
