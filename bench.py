@@ -528,30 +528,38 @@ def run() -> int:
         dist.barrier()
         tb = time.time()
         phase(rank, world, "image broadcast (RCCL)" if backend == "nccl" else "image broadcast (%s)" % backend)
-        err = None
-        try:
-            if os.environ.get("SBWT_BENCH_FAIL_BCAST") and rank == world - 1:     # test hook: one rank's broadcast fails
-                raise RuntimeError("SBWT_BENCH_FAIL_BCAST")
-            hdr, blob = sdist.broadcast_blob(hdr, blob, dev, src=0)     # RCCL over xGMI, load time only
+        # Pre-flight over the CONTROL group (gloo beside RCCL): header and length travel there, every rank allocates its
+        # receiving tensor, the test hook fires, and all ranks count the failures BEFORE anyone enters the data collective --
+        # a rank that fails on its own can then never leave the others blocked inside RCCL.  With any failure all
+        # ranks take the same fall-back in process: the five bit vectors over the control group, every rank derives its own
+        # image (--replicate rebuild's work; a rank that has touched the GPU is never re-executed).
+        hook = bool(os.environ.get("SBWT_BENCH_FAIL_BCAST")) and rank == world - 1     # test hook: one rank cannot take part
+        if hook:
+            log("rank %d: image broadcast failed (SBWT_BENCH_FAIL_BCAST)" % rank)
+        hdr, blob, n_failed = sdist.blob_preflight(hdr, blob, dev, ctl, src=0, fail=hook)
+        why = "image broadcast failed on %d rank(s)" % n_failed
+        if n_failed == 0:
+            # the data collective itself: ONE broadcast of the image (RCCL over xGMI, load time only).  A failure INSIDE it is
+            # fatal -- the other ranks are in the same collective and cannot be told: main() prints the phase, exit non-zero
+            dist.broadcast(blob, src=0)
             torch.cuda.synchronize()
-        except Exception as ex:                                            # noqa: BLE001
-            err = "%s: %s" % (type(ex).__name__, str(ex).replace("\n", " | ")[:300])
-            log("rank %d: image broadcast failed (%s)" % (rank, err))
-        # every rank learns whether ANY rank failed (over gloo when the data path is RCCL): all of them then take the same
-        # fall-back -- the five bit vectors over the control group, every rank derives its own image (--replicate rebuild's
-        # work, in this process: a rank that has touched the GPU is never re-executed)
-        n_failed = sdist.count_failures(err is not None, ctl)
+            adopt_err = None
+            if rank != 0:
+                try:
+                    index = capi.Index.adopt(hdr, blob.data_ptr(), blob.numel(), local_rank, keepalive=blob)
+                except Exception as ex:                                        # noqa: BLE001
+                    adopt_err = "%s: %s" % (type(ex).__name__, str(ex).replace("\n", " | ")[:300])
+                    log("rank %d: adopting the image failed (%s)" % (rank, adopt_err))
+            n_failed = sdist.count_failures(adopt_err is not None, ctl)    # (every rank is out of the collective: safe)
+            why = "adopting the image failed on %d rank(s)" % n_failed
         if n_failed > 0:
-            replicate_fallback = "image broadcast failed on %d rank(s)%s; bit vectors over %s, every rank derived its image" % (
-                n_failed, (" (this rank: %s)" % err) if err else "", "gloo" if ctl is not None else backend)
+            replicate_fallback = "%s; bit vectors over %s, every rank derived its image" % (why, "gloo" if ctl is not None else backend)
             phase(rank, world, "fall-back: " + replicate_fallback)
             blob = None
             bits = sdist.broadcast_bits_cpu(bits if rank == 0 else None, K, ctl, capi.BuiltBits)
             if rank != 0:
                 index = capi.Index.create(bits.cols[0], bits.cols[1], bits.cols[2], bits.cols[3], bits.ssup, bits.n_nodes, K,
                                           bits.n_kmers, PRECALC, None, device=local_rank)
-        elif rank != 0:
-            index = capi.Index.adopt(hdr, blob.data_ptr(), blob.numel(), local_rank, keepalive=blob)
         t_bcast = time.time() - tb
         phase(rank, world, "image replicated: %.2f GB in %.2f s" % (index.blob_bytes / 1e9, t_bcast))
 

@@ -311,7 +311,13 @@ int  sbwtgpu_search_text_batch(const sbwtgpu_index *idx, const char *bases, cons
                                int64_t *n_queries);
 /* The same, streamed: `sink` is called from the calling thread with consecutive pieces of the output text, in order, each
  * straight out of a pinned staging buffer that is only valid during the call (what `sbwt search` writes to its output
- * file: no copy of the whole text is ever made).  A non-zero return of the sink aborts the call. */
+ * file: no copy of the whole text is ever made).  A non-zero return of the sink aborts the call.
+ * Concurrency: several host threads may call this (and every other search entry point) on ONE index at the same time --
+ * the handle is immutable and a call owns its stream, its staging slots (three per call here: pinned text, pinned input and
+ * device buffers sized by the batch; at most eight are parked between calls) and its workspace; `sbwt search` drives two
+ * such calls in turn (SBWT_CLI_SEARCH_THREADS=1: one).  NOT thread-safe: sbwtgpu_set_tuning() and the measurement aids
+ * behind it ("kernel_events" / sbwtgpu_kernel_times: one unsynchronised event ring per process) -- set them before the
+ * threads start and keep "kernel_events" off while calls overlap. */
 typedef int (*sbwtgpu_text_sink)(void *ctx, const char *text, int64_t bytes);
 int  sbwtgpu_search_text_stream(const sbwtgpu_index *idx, const char *bases, const int64_t *read_off,
                                 int64_t n_reads, int streaming, sbwtgpu_text_sink sink, void *sink_ctx,

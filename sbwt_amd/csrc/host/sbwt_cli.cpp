@@ -326,9 +326,13 @@ QueryStats run_file(const string &infile, const string &outfile, const std::func
                     worker_err[w] = std::current_exception();
                 }
             };
-            std::thread second([&] { worker(1); });
+            // SBWT_CLI_SEARCH_THREADS=1: one worker (three staging slots instead of six: pinned and device memory are tight)
+            const char *st_env = getenv("SBWT_CLI_SEARCH_THREADS");
+            const bool one_worker = st_env && atoi(st_env) == 1;
+            std::thread second;
+            if (!one_worker) second = std::thread([&] { worker(1); });
             worker(0);
-            second.join();
+            if (second.joinable()) second.join();
             for (auto &e : worker_err)
                 if (e) std::rethrow_exception(e);
         }

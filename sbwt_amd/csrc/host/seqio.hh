@@ -363,22 +363,29 @@ inline void read_file_chunked(const std::string &filename, int64_t file_size, in
     std::mutex m;
     std::condition_variable cv;
     int64_t next_begin = 0, planned = 0, emitted = 0;
-    bool plan_done = false, stopped = false, emitting = false;
+    bool plan_done = false, stopped = false, emitting = false, planning = false;
     std::deque<Piece> window;                       // pieces emitted .. planned - 1
     auto work = [&] {
         for (;;) {
             int64_t idx, b, e;
             {
                 std::unique_lock<std::mutex> lk(m);
-                cv.wait(lk, [&] { return stopped || plan_done || planned - emitted < (int64_t)n_threads + 1; });
+                cv.wait(lk, [&] { return stopped || plan_done || (!planning && planned - emitted < (int64_t)n_threads + 1); });
                 if (stopped || plan_done) return;
                 b = next_begin;
+                // the cut is looked for WITHOUT the lock (find_record_start reads and scans 1 .. 64 MB windows: the other
+                // workers go on storing and emitting their pieces meanwhile); `planning` keeps the plans one after the other
+                planning = true;
+                lk.unlock();
                 e = b + chunk_bytes >= file_size ? file_size : find_record_start(fd, fmt, b + chunk_bytes, file_size);
                 if (e < 0 || e <= b) e = file_size;       // no cut to be found: the rest is one piece
+                lk.lock();
+                planning = false;
                 next_begin = e;
                 if (e >= file_size) plan_done = true;
                 idx = planned++;
                 window.emplace_back();
+                cv.notify_all();
             }
             Piece pc;
             try {
@@ -448,6 +455,13 @@ public:
         if (::fstat(fd_, &sb) == 0 && S_ISREG(sb.st_mode)) {
             regular_ = true;
             old_size_ = (int64_t)sb.st_size;
+            // An existing file with contents is cut to ONE byte at once (a length > 0 does not set the ext4 mark): a process
+            // that dies before close() -- SIGKILL, the OOM killer, exit() from an error path -- then leaves a visibly short
+            // file like the reference's ofstream would, not the new text followed by the old file's tail.
+            if (old_size_ > 1) {
+                if (::ftruncate(fd_, 1) != 0) { ::close(fd_); fd_ = -1; throw std::runtime_error("Error opening file: " + filename); }
+                old_size_ = 1;
+            }
         }
         if (n_threads <= 0) {
             n_threads = (int)std::thread::hardware_concurrency();

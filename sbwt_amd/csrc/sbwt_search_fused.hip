@@ -1195,8 +1195,11 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
         if (ev == FE_EMIT1) {
             // (BIG: a k-mer found without its position cannot be listed -- such an image stores a position with every k-mer,
             // so that is a damaged image: the call fails)
-            if (BIG && res != -1 && !rknown) ws->status = SBWT_ERR_NOT_SINGLETON;
-            append(i, res == -1 ? 0xFFFFFFFFu : (rknown ? emit_pos : (0x80000000u | (unsigned)res)));
+            // (... and the k-mer is listed as "none": for BIG every source but 0xFFFFFFFF is a position, and col[0x80000000 | res]
+            // would be a read far outside col[]; the status fails the call either way)
+            const bool big_lost = BIG && res != -1 && !rknown;
+            if (big_lost) ws->status = SBWT_ERR_NOT_SINGLETON;
+            append(i, (res == -1 || big_lost) ? 0xFFFFFFFFu : (rknown ? emit_pos : (0x80000000u | (unsigned)res)));
             i++;
         }
         {

@@ -51,6 +51,35 @@ def broadcast_blob(header: Optional[bytes], blob: Optional[torch.Tensor], device
     return bytes(hdr.cpu().numpy().tobytes()), out
 
 
+def blob_preflight(header: Optional[bytes], blob: Optional[torch.Tensor], device: torch.device, group=None, src: int = 0,
+                   fail: bool = False) -> Tuple[Optional[bytes], Optional[torch.Tensor], int]:
+    """What every rank must get right BEFORE the data collective is entered, agreed over `group` (the gloo control group
+    beside an RCCL data group): the header and the image's length travel as CPU tensors, every other rank allocates its
+    receiving tensor, and all ranks count the failures (`fail`: a test hook's, an allocation's).  Returns (header, tensor to
+    broadcast into, failures): with failures > 0 NO rank enters the data collective -- a rank that fails on its own can
+    therefore never leave the others blocked inside RCCL."""
+    rank = dist.get_rank()
+    backend = dist.get_backend(group) if group is not None else dist.get_backend()
+    cdev = device if backend == "nccl" else torch.device("cpu")
+    meta = torch.zeros(2, dtype=torch.int64, device=cdev)
+    if rank == src:
+        meta[0], meta[1] = len(header), blob.numel()
+    dist.broadcast(meta, src=src, group=group)
+    hlen, blen = int(meta[0].item()), int(meta[1].item())
+    hdr = torch.zeros(hlen, dtype=torch.uint8, device=cdev)
+    if rank == src:
+        hdr.copy_(torch.frombuffer(bytearray(header), dtype=torch.uint8))
+    dist.broadcast(hdr, src=src, group=group)
+    out, failed = blob, fail
+    if rank != src and not failed:
+        try:
+            out = torch.empty(blen, dtype=torch.uint8, device=device)
+        except Exception:                                                  # noqa: BLE001 (out of memory on this rank only)
+            out, failed = None, True
+    n_failed = count_failures(failed, group)
+    return bytes(hdr.cpu().numpy().tobytes()), out, n_failed
+
+
 def max_over_ranks(value: float, device: torch.device) -> float:
     t = torch.tensor([value], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -97,6 +97,18 @@ def _fallback_worker(rank, world, port, q):
     ctl = dist.new_group(backend="gloo", timeout=datetime.timedelta(seconds=60))
     none_failed = sdist.count_failures(False, ctl)
     one_failed = sdist.count_failures(rank == world - 1, ctl)
+    # the pre-flight of the image broadcast: header, length and the receiving tensor are agreed over the control
+    # group, and a rank that fails on its own is counted BEFORE anyone enters the data collective
+    hdr0 = bytes(range(100)) + b"SBWTGPU3"
+    blob0 = torch.arange(5003, dtype=torch.int64).to(torch.uint8)
+    for fail_last in (False, True):
+        h, out, nf = sdist.blob_preflight(hdr0 if rank == 0 else None, blob0 if rank == 0 else None, torch.device("cpu"), ctl,
+                                          src=0, fail=fail_last and rank == world - 1)
+        assert h == hdr0 and nf == (1 if fail_last else 0)
+        if not fail_last:
+            assert out.numel() == 5003 and out.dtype == torch.uint8
+            dist.broadcast(out, src=0)                 # the data collective, entered by every rank or by none
+            assert torch.equal(out, blob0)
     n_nodes = 1000 * 64 + 17
     nw = (n_nodes + 63) // 64
     rng = np.random.default_rng(11)

@@ -15,12 +15,8 @@ for f in find("trace/**/*kernel_trace.csv"):
         agg[name].append((int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e6)
     for name, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
         print(f"{name[:90]:90s} n={len(v):4d} total={sum(v):10.3f} avg={sum(v)/len(v):9.4f} min={min(v):9.4f} max={max(v):9.4f}")
-    rows = list(csv.DictReader(open(f)))
-    if rows:
-        r = [x for x in rows if "k_search_fused" in x.get("Kernel_Name", "")] or [x for x in rows if "k_search" in x.get("Kernel_Name", "")]
-        if r:
-            x = r[-1]
-            print("k_search resources:", {k: x[k] for k in x if k in ("VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Scratch_Size", "Workgroup_Size", "Grid_Size")})
+    # (the trace's VGPR_Count / SGPR_Count columns are allocation granules of a dispatch, not the code object's numbers: the
+    # table at the end of this summary is read from the code objects themselves, every instantiation by name)
 print("== kernel stats csv ==")
 for f in find("trace/**/*kernel_stats.csv"):
     print(open(f).read()[:3000])
@@ -33,3 +29,10 @@ for f in find("pmc_*/**/*counter_collection.csv"):
         if "k_search" in name or "k_encode" in name or "k_rank" in name:
             for c, v in cs.items():
                 print(f"{name[:60]:60s} {c:28s} n={len(v):3d} avg={sum(v)/len(v):.6g}")
+# registers, spills, LDS and scratch of every search-kernel instantiation, from the code objects inside the library that ran
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import kernel_resources
+lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "sbwt_amd", "lib", "libsbwtgpu.so")
+print("== code-object resources of %s (llvm-readelf --notes; per kernel instantiation) ==" % os.path.relpath(lib))
+for ln in kernel_resources.table(lib, "k_search|k_rank|k_encode"):
+    print(ln)
