@@ -44,6 +44,9 @@
 #define SBWT_MEGA_SHIFT 31          // columns per mega block = 2^31
 #define SBWT_GROUP_BASES 32         // bases per packed read group
 
+#ifndef SBWT_FUSED_SORT_DEFAULT
+#define SBWT_FUSED_SORT_DEFAULT 0
+#endif
 struct SbwtIndexView {
     const uint4 *blocks;            // n_blocks * 4 quads
     const longlong2 *ptab;          // device prefix table, depth p_dev (nullptr if p_dev == 0)
@@ -73,6 +76,7 @@ struct SbwtIndexView {
     int stab_pos;                   // sparse entries are whole k-mers stored with their path position
     int debug;                      // experiments only: bit0 = skip result stores
     int out32 = 0;                  // results are written as int32 (the *_i32 entry points; n_nodes < 2^31): the result pointer is an int32 array
+    int fused_sort = 0;             // the fused kernel's SORT instantiation (lanes sorted by state; sbwt_search_fused.hip)
     int force_mega;                 // one mega block whose counts do not fit 32 bits (dense rank-only images): cnt is relative
                                     // to mega[c][0] although n_mega == 1
 };

@@ -40,6 +40,7 @@
 #define F_POS 9
 #define F_BRIDGE 10             // entry of F_CMP from a substitution-safe step (set up at the top of the next iteration)
 #define F_CMP 11                // the read against its path's chars, 33 .. 64 bases per iteration: bridges and anchors (below)
+#define F_PLAN 12               // SORT: the planner has to choose this read's next walk (it runs at the top of a searcher wave's iteration)
 #define FE_NONE 0
 #define FE_EMIT1 1
 #define FE_FAIL 2
@@ -75,6 +76,7 @@
 #define CF_SEED2 16384u          // k > 31: the seed's 31-prefix has TWO columns (l, l + 1): after the position lookup l holds the second
                                  // one's path position -- tried when the compare on the first answers nothing
 #define CF_NOCERT 4096u          // since the last own lookup: windows were probed, and every one of them is (perhaps) in the index
+#define CF_FORCE (1u << 30)      // SORT: the planner is to start k-mer i's own search (a probe was inconclusive)
 #define CF_ANC_LEFT(f) (((f) >> 16) & 3u)
 #define CF_CMP_LEFT(f) (((f) >> 18) & 7u)
 #define CF_ANC_TRIED(f) ((int)(((f) >> 21) & 511u) - 1)
@@ -204,21 +206,60 @@ __device__ __forceinline__ u64 fz_encode32(const unsigned w[8], const unsigned t
 // usual case.  Offsets, lengths and piece numbers are then compile-time facts: no read_off / out_off, no per-ticket lengths,
 // no division of a ticket number by the pieces per read.  Both instantiations are launched; each returns at once from a
 // batch that is the other's ("debug" bit 128: the general one takes everything).
-template <bool WIDE, bool O32, bool BIG = false, bool UNI = false>
+// SORT (round 6): lanes sorted by state.  Waves 0-1 of a workgroup are SEARCHERS (they take the tickets and run F_INIT / F_STEP /
+// F_POS, the events and the planner), waves 2-3 are PATH FOLLOWERS (F_EXT / F_TRANS / F_BRIDGE); every wave runs the writer for
+// the lists its own lanes finished.  A read lives in a SLOT of the workgroup's LDS (its codes, its segment list, four words of
+// state); a lane whose read changes class writes the state, pushes the slot's number into the other class's ring and goes
+// idle; idle lanes hold a place in their class's ring and take what arrives there.  Each wave then executes only its class's
+// blocks of the state machine (the rest are skipped by wave-uniform branches).  See DESIGN.md section 3.
+template <bool WIDE, bool O32, bool BIG = false, bool UNI = false, bool SORT = false>
 __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const unsigned char *__restrict__ bases,
                                                           i64 total_bases, i64 *__restrict__ out, i64 n_reads,
                                                           SbwtWorkHeader *ws, unsigned *__restrict__ defer_list,
                                                           const i64 *__restrict__ read_off, const i64 *__restrict__ out_off) {
-    __shared__ u64 pool_codes[SBWT_FUSED_MAXG][256];        // the wave's pool of 64 tickets, encoded ([group][wave * 64 + ticket])
-    __shared__ u64 cur_codes[SBWT_FUSED_MAXG][256];         // the read this lane is working on
+    static_assert(!SORT || (!WIDE && !BIG), "lanes sorted by state: k <= 31, fewer than 2^31 columns (so far)");
+    __shared__ u64 pool_codes[SBWT_FUSED_MAXG][SORT ? 128 : 256];   // the wave's pool of 64 tickets, encoded ([group][wave * 64 + ticket]; SORT: searcher waves only)
+    __shared__ u64 cur_codes[SBWT_FUSED_MAXG][256];         // the read this lane is working on (SORT: by slot)
     __shared__ unsigned seg_src[FZ_NSEG][256];              // segment lists: source ...
     __shared__ unsigned char seg_at[FZ_NSEG][256];          // ... and first k-mer
+    // SORT: a slot's state while it waits in a ring -- [0] read, [1] path position r (to a follower) / b+1 | blo+1 << 8 (to a
+    // searcher), [2] i | mend << 8 | nseg << 16 | kind << 20 (0 free slot, 1 F_EXT, 2 F_PLAN) | force << 22 | fl's miss and nocert
+    // bits << 23 | piece << 26 | list holds a column-only result << 28, [3] first result not written | bnext+1 << 8
+    __shared__ unsigned st_w[SORT ? 4 : 1][SORT ? 256 : 1];
+    __shared__ unsigned short q_ring[SORT ? 2 : 1][SORT ? 256 : 1];   // the rings: [0] to the searchers, [1] to the followers; slot + 1, 0 = not written yet
+    __shared__ unsigned q_ctl[8];                           // [0], [1] places handed out in ring 0 / 1; [2], [3] entries written; [4] reads in flight; [5] searcher waves drained
     const int fmode = sbwt_fused_mode(ws, ix.k);
     if (fmode == 0) return;                                 // the general route does it all
     const int P_batch = sbwt_fused_pieces(ws, ix.k);
     if (UNI != (fmode == 1 && P_batch == 1 && !(ix.debug & 128))) return;      // the other instantiation's batch
     const bool ragged = !UNI && fmode == 2;                 // reads of any lengths: offsets fetched with every refill
     const int tid = threadIdx.x, lane = tid & 63, wbase = tid & ~63;
+    const bool isP = SORT && __builtin_amdgcn_readfirstlane(tid) >= 128;     // a path-follower wave (wave-uniform, in a scalar register)
+    const bool runS = !SORT || !isP, runP = !SORT || isP;   // (wave-uniform: which blocks of the state machine this wave executes)
+    const int qc = isP ? 1 : 0;                             // this wave's ring
+    int slot = SORT ? (isP ? -1 : tid) : tid;               // SORT: the slot this lane holds (-1: none)
+    int qpos = -1;                                          // SORT: this lane's place in its ring (-1: none)
+    if (SORT) {
+        // slots 0 .. 127 start with the searcher lanes, 128 .. 255 wait in the searchers' ring as free slots
+        if (tid < 8) q_ctl[tid] = (tid == 2) ? 128u : 0u;
+        if (tid < 128) { q_ring[0][tid] = (unsigned short)(128 + tid + 1); q_ring[0][128 + tid] = 0; st_w[2][128 + tid] = 0u; }
+        else { q_ring[1][tid - 128] = 0; q_ring[1][tid] = 0; }
+        __syncthreads();
+    }
+    volatile unsigned *const vctl = q_ctl;
+    // entries of a ring: written after the slot's state (LDS operations of a wave complete in order; the wait keeps the compiler
+    // and the hardware from letting the entry pass the state), read before it (the state's address depends on the entry)
+    auto ring_push = [&](const u64 mask, const int ring, const int s) {
+        // (wave-uniform call: every lane of `mask` appends slot s to `ring`)
+        unsigned base = 0;
+        if (lane == 0) base = __hip_atomic_fetch_add(&q_ctl[2 + ring], (unsigned)__popcll(mask), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        base = uniform32(base);
+        if ((mask >> lane) & 1ull) {
+            const unsigned at = (base + (unsigned)__popcll(mask & low_mask(lane))) & 255u;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            *(volatile unsigned short *)&q_ring[SORT ? ring : 0][SORT ? at : 0] = (unsigned short)(s + 1);
+        }
+    };
     const int k = ix.k, p = ix.p_dev, L0 = ix.probe_len, ps = ix.p_sparse;
     // tickets: P per read (reads of more than 160 bases as pieces that overlap by k-1; sbwt_kernels_common.h)
     const int P = UNI ? 1 : P_batch, kpp = SBWT_FUSED_MAXLEN - k + 1;
@@ -279,8 +320,116 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
 #endif
 
     for (;;) {
+#ifdef SBWT_STATS
+        int pl_kind = -1, oc_kind = -1, cert_n = 0;      // planner statistics (g_fz_plan)
+#endif
+        bool force = false;                            // the planner starts k-mer i's own search
+        bool w31 = false;                              // k > 31: a filter window was (perhaps) present: try the 31-base window around b
+        // the planner: where the next walk of this lane's read starts (SORT: called at the top of a searcher wave's iteration,
+        // otherwise at the end of the iteration that asked for it)
+        auto plan_walk = [&](bool force, const bool w31) {
+            // where the next walk starts (see k_search_cert): at k-mer i itself, or close to the last failure position b
+            // when b lies inside k-mer i's window
+            int s0 = i, nwk = (ps > 0) ? 1 : 0;
+            // k > 31: the 16-base window at b is (perhaps) in the index -- as another strain's variant, usually.  The 31-base
+            // window that holds b and starts as late as k-mer i allows is an exact lookup in the sparse table, and absent far
+            // more often; it answers up to k - 30 k-mers.
+            bool win31 = false;
+            if (w31 && (fl & CF_MISS_MASK) < 2u * CF_MISS && b >= i && b <= i + k - 1) {
+                const int ws = b < i + k - ps ? b : i + k - ps;
+                if (ws > i) { win31 = true; force = false; s0 = ws; }
+            }
+            if ((fl & CF_MISS_MASK) >= 2u * CF_MISS) force = true;      // blind: the k-mer's own search
+            // nothing known about k-mer i's window, but a bridge compare has seen the read's next difference inside it: two
+            // substitutions within k-1 bases -- start the certificates there instead of bisecting for it (a hint like b
+            // itself: the probes prove what they prove wherever they start)
+            bool hinted = false;
+            if (!force && pfon && !(b >= i && b <= i + k - 1) && bnext >= i && bnext <= i + k - 1) { b = blo = bnext; bnext = -1; hinted = true; }
+            if (win31) {
+                nwk = 1;
+                fl |= CF_WIN31;
+            } else if (!force && L0 > 0 && b >= i && b <= i + k - 1) {
+                const int lo = blo > i ? blo : i;
+                if (lo < b && anch_ok && CF_ANC_LEFT(fl) > 0 && b + 1 != CF_ANC_TRIED(fl) && b + 1 <= mend - 1) {
+                    // the bad base is somewhere in [lo, b]: the k-mer just past the range as an anchor (F_CMP) instead of
+                    // halving the range probe by probe
+                    s0 = b + 1;
+                    nwk = 1;
+                    fl |= CF_ANCH;
+                    fl -= 1u << 16;
+                } else if (lo < b && p > 0 && k - pw >= 1) {
+                    // the bad base is somewhere in [lo, b]: halve the range with a window that starts inside it
+                    int x = lo + ((b - lo + 1) >> 1);
+                    if (x > i + k - pw) x = i + k - pw;
+                    if (x <= i) x = i + 1;
+                    s0 = x;
+                    nwk = 3;
+                } else {
+                    s0 = (b - i >= L0 - 1) ? (b - L0 + 1) : b;
+                    // a window that starts at b but runs past k-mer i (k = 31 with probes of 18 bases: three windows per bad
+                    // base, not two): the last window inside k-mer i holds b as well
+                    if (pfon && s0 == b && b + L0 - 1 > i + k - 1 && k > L0) s0 = i + k - L0;
+                    if (s0 + p - 1 > i + k - 1) s0 = i;
+                    if (s0 != i) nwk = (pfon && s0 + L0 - 1 <= i + k - 1) ? 2 : 0;
+                    // a hinted probe that finds its window in the index gives up the hint instead of walking the window
+                    if (hinted) { if (nwk == 2) nwk = 6; else { s0 = i; nwk = (ps > 0) ? 1 : 0; b = -1; } }
+                }
+            }
+#ifdef SBWT_STATS
+            pl_kind = nwk == 1 ? ((fl & CF_MISS_MASK) >= 2u * CF_MISS ? 2 : force ? 1 : (b >= i && b <= i + k - 1) ? 8 : 0) :
+                      nwk == 2 ? (s0 == b ? 4 : s0 == b - L0 + 1 ? 3 : 9) : nwk == 3 ? 5 : nwk == 6 ? 6 : 7;
+#endif
+            wstart = s0;
+            j = 0;
+            wk = nwk;
+            if (p > 0) mode = F_INIT;
+            else { mode = F_STEP; l = 0; r = last_node; }
+                };
+        if (SORT) {
+            // ---- the workgroup is done when both searcher waves have seen the tickets run out and no read is in flight ----
+            const unsigned n_drained = vctl[5], n_live = vctl[4];
+            if (isP) drained = n_drained >= 2u;
+            if (n_drained >= 2u && n_live == 0u && fm_pend == 0) break;
+            // ---- idle lanes without a slot hold a place in their class's ring and take what arrives there: a read that changed
+            //      class (with its state), or -- searchers -- a free slot for the next ticket ----
+            const u64 wantq = __ballot(mode == F_IDLE && slot < 0 && qpos < 0);
+            if (wantq) {
+                unsigned base = 0;
+                if (lane == 0) base = __hip_atomic_fetch_add(&q_ctl[qc], (unsigned)__popcll(wantq), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                base = uniform32(base);
+                if ((wantq >> lane) & 1ull) qpos = (int)((base + (unsigned)__popcll(wantq & low_mask(lane))) & 0x7FFFFFFFu);
+            }
+            if (qpos >= 0) {
+                volatile unsigned short *const e = &q_ring[SORT ? qc : 0][SORT ? (qpos & 255) : 0];
+                const unsigned v = *e;
+                if (v) {
+                    *e = 0;
+                    qpos = -1;
+                    slot = (int)v - 1;
+                    const int sx = SORT ? slot : 0;
+                    const unsigned w2 = st_w[SORT ? 2 : 0][sx];
+                    const unsigned kind = (w2 >> 20) & 3u;
+                    if (kind != 0u) {
+                        const unsigned w1 = st_w[SORT ? 1 : 0][sx], w3 = st_w[SORT ? 3 : 0][sx];
+                        rd = st_w[0][sx];
+                        i = (int)(w2 & 255u);
+                        mend = (int)((w2 >> 8) & 255u);
+                        nseg = (int)((w2 >> 16) & 15u);
+                        i0 = (int)(w3 & 255u) | (int)(((w2 >> 26) & 3u) << 16) | (int)(((w2 >> 28) & 1u) << 24);
+                        fl = CF_BUDGETS | (((w2 >> 23) & 7u) << 10) | (((w2 >> 22) & 1u) ? CF_FORCE : 0u);
+                        bnext = (int)((w3 >> 8) & 255u) - 1;
+                        const int nl = nseg > 0 ? nseg - 1 : 0;
+                        last_src = seg_src[nl][slot];
+                        last_start = (int)seg_at[nl][slot];
+                        j = 0;
+                        if (kind == 1u) { mode = F_EXT; r = (int)w1; b = -1; blo = -1; }
+                        else { mode = F_PLAN; b = (int)(w1 & 255u) - 1; blo = (int)((w1 >> 8) & 255u) - 1; }
+                    }
+                }
+            }
+        }
         // ---- hand out reads to idle lanes from the wave's ticket pool; an empty pool is refilled with 64 encoded reads ----
-        const u64 need = __ballot(mode == F_IDLE);
+        const u64 need = SORT ? (isP ? 0ull : __ballot(mode == F_IDLE && slot >= 0)) : __ballot(mode == F_IDLE);
         if (need && !drained) {
             if (pool_next == pool_end) {
                 u64 t = 0;
@@ -364,6 +513,7 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
                     }
                 } else {
                     drained = true;                    // no read left anywhere: from now on idle lanes help busy ones (below)
+                    if (SORT && lane == 0) (void)__hip_atomic_fetch_add(&q_ctl[5], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #ifdef SBWT_TIMELINE
                     tl_drain = wall_clock64();
 #endif
@@ -378,7 +528,8 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
             const int qsrc = (int)((pool_next + rank) & 63ull);
             const int plq = varlen ? __shfl(pool_len, qsrc) : 0;
             const int mq_r = varlen ? (plq & 0xFFFF) - k + 1 : m;
-            if (mode == F_IDLE && rank < avail) {
+            bool started = false;
+            if (((need >> lane) & 1ull) && rank < avail) {
                 const u64 tk = pool_next + rank;
                 const int q = (int)(tk & 63ull);
                 const int mq = mq_r;                   // (a read shorter than k: nothing to answer)
@@ -387,7 +538,8 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
                     rd = (unsigned)(P == 1 ? tk : P == 2 ? (tk >> 1) : tk / 3ull);
 #pragma unroll
                     for (int g = 0; g < SBWT_FUSED_MAXG; g++)
-                        if (g < G) cur_codes[g][tid] = pool_codes[g][wbase + q];
+                        if (g < G) cur_codes[g][slot] = pool_codes[g][wbase + q];
+                    started = true;
                     i = 0;
                     mend = mq;
                     nseg = 0;
@@ -404,18 +556,23 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
                 }                                      // else: past the last read, or handed on -- the lane stays idle
             }
             pool_next = uniform64(pool_next + ((n < avail) ? n : avail));
+            if (SORT) {
+                const u64 st_m = __ballot(started);
+                if (st_m && lane == 0) (void)__hip_atomic_fetch_add(&q_ctl[4], (unsigned)__popcll(st_m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
         }
 #ifdef SBWT_TIMELINE
         if (!drained) tl_n++;
 #endif
-        if (drained) {
+        if (drained && runS) {
             // ---- the tail of the batch: one lane per read means a wave waits for its slowest read.  An idle lane takes over
             //      the second half of what a busy lane still has to answer.  Exact: this kernel only walks reads of upper-case
             //      ACGT, where a k-mer's result does not depend on what came before it (streaming step and full search agree,
             //      tests/test_large.hh:104-115), so the taker starts with a full search at its first k-mer.
-            const u64 idle = __ballot(mode == F_IDLE);
+            // (SORT: among the searcher lanes of a wave -- a taker needs a slot; reads that are with the followers are not split)
+            const u64 idle = __ballot(mode == F_IDLE && slot >= 0);
             const u64 busy_m = __ballot(mode != F_IDLE);
-            if (busy_m == 0 && fm_pend == 0) break;    // everything this wave took is answered and written
+            if (!SORT && busy_m == 0 && fm_pend == 0) break;    // everything this wave took is answered and written
             // (round 5: a lower threshold in the thin end of the tail only -- at most 8 / 16 / 32 lanes busy, halves of 2 or 4
             // k-mers -- moves nothing either: config 2 4.91-4.92 vs 4.91 ms, 1 M reads 0.92-0.94 vs 0.93, config 5 +1 %)
             u64 donors = __ballot(mode != F_IDLE && mend - i >= FZ_SPLIT_MIN);
@@ -434,6 +591,7 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
                 const int d_i = __shfl(i, src), d_end = __shfl(mend, src);
                 const unsigned d_rd = (unsigned)__shfl((int)rd, src);
                 const int d_pc = __shfl(i0, src) & 0x00FF0000;
+                const int d_slot = SORT ? __shfl(slot, src) : wbase + src;
                 const int mid = d_i + ((d_end - d_i + 1) >> 1);
                 if (giving) mend = i + ((mend - i + 1) >> 1);                        // (the same mid its taker computed)
 #ifdef SBWT_STATS
@@ -443,7 +601,7 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
                     FZ_HIST_FLUSH();
 #pragma unroll
                     for (int g = 0; g < SBWT_FUSED_MAXG; g++)
-                        if (g < G) cur_codes[g][tid] = cur_codes[g][wbase + src];
+                        if (g < G) cur_codes[g][slot] = cur_codes[g][d_slot];
                     rd = d_rd;
                     i = mid;
                     mend = d_end;
@@ -459,8 +617,23 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
                     if (p > 0) mode = F_INIT;
                     else { mode = F_STEP; l = 0; r = last_node; }
                 }
+                if (SORT && lane == 0) (void)__hip_atomic_fetch_add(&q_ctl[4], (unsigned)n_pairs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 __builtin_amdgcn_wave_barrier();
             }
+            if (SORT) {
+                // entries wait in the searchers' ring and nobody holds a place for them: idle lanes give up their (empty) slots,
+                // take places in the next iteration, and the reads that came back from the followers go on
+                const int backlog = (int)(vctl[2] - vctl[0]);
+                const u64 still = __ballot(mode == F_IDLE && slot >= 0);
+                if (backlog > 0 && ((still >> lane) & 1ull) && __popcll(still & low_mask(lane)) < backlog) slot = -1;
+            }
+        }
+        // SORT: the planner runs here, at the top of a searcher wave's iteration, for the reads whose last iteration (in this
+        // wave or in a follower wave) asked for it
+        if (SORT && runS && mode == F_PLAN) {
+            force = (fl & CF_FORCE) != 0;
+            fl &= ~CF_FORCE;
+            plan_walk(force, w31);
         }
 
 
@@ -487,9 +660,13 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
         int ev = FE_NONE, tfail = 0, c = 0;
         const uint4 *a1 = ix.blocks, *a2 = ix.blocks;
         int res = -1;
-        const bool trn = (mode == F_TRANS), cmp = WIDE && (mode == F_CMP);
-        const bool ext = !WIDE && (mode == F_EXT), brg = !WIDE && (mode == F_BRIDGE);
-        const bool busy = (mode != F_IDLE && mode != F_DEAD);
+        const bool trn = runP && (mode == F_TRANS), cmp = WIDE && (mode == F_CMP);
+        const bool ext = runP && !WIDE && (mode == F_EXT), brg = runP && !WIDE && (mode == F_BRIDGE);
+        // (SORT: a lane whose read is of the other class by now -- its hand-over waits for the writer, below -- does nothing)
+        const bool own = !SORT || (isP ? (mode == F_EXT || mode == F_TRANS || mode == F_BRIDGE) : (mode == F_INIT || mode == F_STEP || mode == F_POS));
+        const bool busy = own && (mode != F_IDLE && mode != F_DEAD);
+        const int mode0 = mode;                        // (the state this iteration's gather is for)
+        const int sli = SORT ? (slot < 0 ? tid : slot) : tid;      // this lane's slot in LDS (a lane without one reads its own number's: unused)
         bool rknown = false, ext_absent = false;
         int tnext = F_EXT;
         int tpos = -1;
@@ -499,11 +676,11 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
         const int woff5 = (mode == F_INIT && wk == 5) ? ps : 0;       // the second-level window starts after the prefix
         const int P = (ext || trn) ? (i + k - 1) : brg ? (i + k) : cmp ? cP : ((mode == F_INIT) ? (wstart + woff5) : (wstart + j));
         const int s = P & 31, pg = busy ? (P >> 5) : 0;
-        const u64 cw0 = cur_codes[pg < SBWT_FUSED_MAXG ? pg : SBWT_FUSED_MAXG - 1][tid];
-        const u64 cw1 = cur_codes[pg + 1 < SBWT_FUSED_MAXG ? pg + 1 : SBWT_FUSED_MAXG - 1][tid];
-        const u64 cw2 = cur_codes[pg + 2 < SBWT_FUSED_MAXG ? pg + 2 : SBWT_FUSED_MAXG - 1][tid];
+        const u64 cw0 = cur_codes[pg < SBWT_FUSED_MAXG ? pg : SBWT_FUSED_MAXG - 1][sli];
+        const u64 cw1 = cur_codes[pg + 1 < SBWT_FUSED_MAXG ? pg + 1 : SBWT_FUSED_MAXG - 1][sli];
+        const u64 cw2 = cur_codes[pg + 2 < SBWT_FUSED_MAXG ? pg + 2 : SBWT_FUSED_MAXG - 1][sli];
         const u64 rw = s ? ((cw0 >> (2 * s)) | (cw1 << (64 - 2 * s))) : cw0;      // bases P .. P+31
-        if (mode == F_POS) {
+        if (runS && busy && mode == F_POS) {
             a1 = reinterpret_cast<const uint4 *>(ix.pos + ((unsigned)l & ~3u));  // the aligned 16 bytes holding pos[l]
             a2 = a1 + ((((unsigned)l & 3u) == 3u && (fl & CF_SEED2)) ? 1 : 0);   // (a seed of two columns: pos[l + 1] as well)
         } else if (busy) {
@@ -519,6 +696,8 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
                 // the entry of (position r, char c); j counts the slots probed
                 a1 = ix.trans + 2 * (size_t)sbwt_trans_slot((unsigned)r, (unsigned)c, ix.n_tslots, (unsigned)j);
                 a2 = a1 + 1;
+            } else if (!runS) {
+                // (SORT, a follower wave: no other state)
             } else if (mode == F_INIT) {
                 (void)wl;
                 if (wk == 1) {                 // bucket (hash + j) of the sparse table: two entries
@@ -624,7 +803,7 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
                 const int j0 = a + 2 * lane, j1 = j0 + 1;
                 unsigned c0s, c1s;
                 int c0a, c1a;
-                seg_of(wbase + L, ns, j0, c0s, c0a, c1s, c1a);
+                seg_of(SORT ? (int)((unsigned)pdL >> 24) : wbase + L, ns, j0, c0s, c0a, c1s, c1a);
                 const unsigned p0 = (j0 < e && c0s != 0xFFFFFFFFu) ? c0s + (unsigned)(j0 - c0a) : col_minus1;
                 const unsigned p1 = (j1 < e && c1s != 0xFFFFFFFFu) ? c1s + (unsigned)(j1 - c1a) : col_minus1;
                 w0[u] = (int)ix.col[p0];
@@ -662,7 +841,7 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
                         const int j0 = base + 2 * lane, j1 = j0 + 1;
                         unsigned c0s, c1s;
                         int c0a, c1a;
-                        seg_of(wbase + L, ns, j0, c0s, c0a, c1s, c1a);
+                        seg_of(SORT ? (int)((unsigned)pdL >> 24) : wbase + L, ns, j0, c0s, c0a, c1s, c1a);
                         const unsigned p0 = (j0 < e && is_run(c0s)) ? c0s + (unsigned)(j0 - c0a) : col_minus1;
                         const unsigned p1 = (j1 < e && is_run(c1s)) ? c1s + (unsigned)(j1 - c1a) : col_minus1;
                         const int y0 = (int)ix.col[p0], y1 = (int)ix.col[p1];
@@ -693,6 +872,19 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
                 lr = flush_issue(fm);
                 flush_store(lr);
             }
+            if (SORT) {
+                // the lists are written (their stores are issued): the last list of a read ends it -- the workgroup counts its
+                // reads in flight -- and a follower lane's slot goes back to the searchers as a free one
+                const u64 fin = fm_pend & __ballot((pend >> 23) & 1);
+                if (fin) {
+                    if (lane == 0) (void)__hip_atomic_fetch_sub(&q_ctl[4], (unsigned)__popcll(fin), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (isP) {
+                        const int ps_ = (int)((unsigned)pend >> 24);
+                        if ((fin >> lane) & 1ull) st_w[SORT ? 2 : 0][SORT ? ps_ : 0] = 0u;       // kind 0: a free slot
+                        ring_push(fin, 0, ps_);
+                    }
+                }
+            }
         } else {
             v1 = *a1;
             v2 = *a2;
@@ -701,13 +893,11 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
         // ---- consume ----
 #ifdef SBWT_STATS
         unsigned why = 0;
-        int pl_kind = -1, oc_kind = -1, cert_n = 0;      // planner statistics (g_fz_plan)
 #define WHY(q) (why |= 1u << (q))
 #else
 #define WHY(q) ((void)0)
 #endif
-        bool tabhit = false, do_plan = false, force = false;
-        bool w31 = false;                              // k > 31: a filter window was (perhaps) present: try the 31-base window around b
+        bool tabhit = false, do_plan = false;
         int m2 = -1;                                   // F_CMP: the second difference (this iteration's)
         int seed_col = -1;                             // k > 31: the column of a unique 31-mer whose k-mer was not there: a SEED for an alignment
         bool seed_is_pos = false;                      // ... seed_col is that column's path position already (the table entry carried it)
@@ -716,7 +906,7 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
         int cact = 0, ctr = 0;                         // ... and what follows (CA_*)
         int burst_to = -1;                             // F_BRIDGE: k-mers i .. burst_to are certified absent
         bool bridged = false;                          // F_BRIDGE: ... and the read goes on along the path
-        if (mode == F_POS) {
+        if (runS && busy && mode0 == F_POS) {
             const unsigned sel = (unsigned)l & 3u;
             r = (int)(sel == 0 ? v1.x : sel == 1 ? v1.y : sel == 2 ? v1.z : v1.w);
             if (fl & CF_SEED) {
@@ -970,7 +1160,7 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
             }
             fl = onp ? (fl | CF_ONP) : (fl & ~CF_ONP);
             if (cact == CA_ABSENT) ext_absent = true;
-        } else if (mode == F_INIT) {
+        } else if (runS && mode0 == F_INIT) {
             int wl = p;
             bool again = false;
             const bool viaf = (wk == 2) || (wk == 6) || (wk == 3 && pfon);
@@ -1076,7 +1266,7 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
                     else mode = F_STEP;
                 }
             }
-        } else if (mode == F_STEP) {
+        } else if (runS && mode0 == F_STEP) {
             // (the counts as 64-bit sums: l > r without a signed compare of what may be 32-bit unsigned columns)
             const u64 Lq = (u64)v1.z + (u64)__popcll(quad_bits(v1) & low_mask(l & 63));
             const u64 Rq = (u64)v2.z + (u64)__popcll(quad_bits(v2) & low_mask((r + 1) & 63));
@@ -1103,6 +1293,15 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
 #endif
         // ---- events: results, certificates, next state ----
         int burst_hi = -1;                             // >= i: k-mers i..burst_hi are certified absent
+        if (!runS) {
+            // (SORT, a follower wave: the only event beside FE_EMIT1 is a bridge's burst)
+            if (ev == FE_FAIL) {
+                burst_hi = burst_to;
+                b = -1;
+                if (burst_hi > i) fl &= ~(CF_MISS_MASK | CF_NOCERT);
+                if (burst_hi == i) { ev = FE_EMIT1; burst_hi = -1; }
+            }
+        } else {
         if ((fl & CF_ANCH) && (ev == FE_FAIL || ev == FE_ANCH)) {
             // an anchor lookup is over.  Its window is NOT inside k-mer i's, so a miss certifies nothing here: the
             // certificates go on as if it had not been tried (or a seed it left is taken up).  A hit aligns the read.
@@ -1178,14 +1377,15 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
             if (blo > b) b = -1;
             do_plan = true;
         }
+        }
 
         // ---- append this iteration's results to the lane's segment list (at most two segments; contiguous ones merge) ----
         auto append = [&](int at, unsigned src) {
             const bool merge = nseg > 0 && ((src == 0xFFFFFFFFu && last_src == 0xFFFFFFFFu) ||
                                             (is_run(src) && is_run(last_src) && last_src + (unsigned)(at - last_start) == src));
             if (!merge) {
-                seg_src[nseg][tid] = src;
-                seg_at[nseg][tid] = (unsigned char)at;
+                seg_src[nseg][sli] = src;
+                seg_at[nseg][sli] = (unsigned char)at;
                 nseg++;
                 last_src = src;
                 last_start = at;
@@ -1261,12 +1461,16 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
         // ---- flush: the read is done, or the list could overflow in the next iteration.  The lane hands its list over (it
         //      stays in LDS; the next appends come after the writer's pass) and the whole wave writes it in the NEXT iteration,
         //      between the issue of that iteration's gather and its use (above) ----
+        bool want_flush;
         {
             const bool want = nseg > 0 && (i == mend || nseg > FZ_NSEG - 2);
-            fm_pend = (ix.debug & 4) ? 0ull : __ballot(want);      // ("debug" bit 4, experiments: no writer at all)
+            want_flush = want;
+            fm_pend = (!SORT && (ix.debug & 4)) ? 0ull : __ballot(want);      // ("debug" bit 4, experiments: no writer at all)
             if (want) {
                 pend_rd = rd;
-                pend = (i0 & 0xFF) | (i << 8) | (nseg << 16) | (((i0 >> 16) & 3) << 20) | (((i0 >> 24) & 1) << 22);
+                // (SORT: bit 23 = the read's last list -- the writer then counts the read as done -- and the list's slot in bits 24 ..)
+                pend = (i0 & 0xFF) | (i << 8) | (nseg << 16) | (((i0 >> 16) & 3) << 20) | (((i0 >> 24) & 1) << 22) |
+                       (SORT ? (((i == mend) ? 1 : 0) << 23) | (int)((unsigned)slot << 24) : 0);
                 nseg = 0;
                 i0 = i | (i0 & 0x00FF0000);
             }
@@ -1313,62 +1517,30 @@ __global__ void __launch_bounds__(256, 5) k_search_fused(SbwtIndexView ix, const
             do_plan = keep_plan;
         }
         if (do_plan) {
-            // where the next walk starts (see k_search_cert): at k-mer i itself, or close to the last failure position b
-            // when b lies inside k-mer i's window
-            int s0 = i, nwk = (ps > 0) ? 1 : 0;
-            // k > 31: the 16-base window at b is (perhaps) in the index -- as another strain's variant, usually.  The 31-base
-            // window that holds b and starts as late as k-mer i allows is an exact lookup in the sparse table, and absent far
-            // more often; it answers up to k - 30 k-mers.
-            bool win31 = false;
-            if (w31 && (fl & CF_MISS_MASK) < 2u * CF_MISS && b >= i && b <= i + k - 1) {
-                const int ws = b < i + k - ps ? b : i + k - ps;
-                if (ws > i) { win31 = true; force = false; s0 = ws; }
-            }
-            if ((fl & CF_MISS_MASK) >= 2u * CF_MISS) force = true;      // blind: the k-mer's own search
-            // nothing known about k-mer i's window, but a bridge compare has seen the read's next difference inside it: two
-            // substitutions within k-1 bases -- start the certificates there instead of bisecting for it (a hint like b
-            // itself: the probes prove what they prove wherever they start)
-            bool hinted = false;
-            if (!force && pfon && !(b >= i && b <= i + k - 1) && bnext >= i && bnext <= i + k - 1) { b = blo = bnext; bnext = -1; hinted = true; }
-            if (win31) {
-                nwk = 1;
-                fl |= CF_WIN31;
-            } else if (!force && L0 > 0 && b >= i && b <= i + k - 1) {
-                const int lo = blo > i ? blo : i;
-                if (lo < b && anch_ok && CF_ANC_LEFT(fl) > 0 && b + 1 != CF_ANC_TRIED(fl) && b + 1 <= mend - 1) {
-                    // the bad base is somewhere in [lo, b]: the k-mer just past the range as an anchor (F_CMP) instead of
-                    // halving the range probe by probe
-                    s0 = b + 1;
-                    nwk = 1;
-                    fl |= CF_ANCH;
-                    fl -= 1u << 16;
-                } else if (lo < b && p > 0 && k - pw >= 1) {
-                    // the bad base is somewhere in [lo, b]: halve the range with a window that starts inside it
-                    int x = lo + ((b - lo + 1) >> 1);
-                    if (x > i + k - pw) x = i + k - pw;
-                    if (x <= i) x = i + 1;
-                    s0 = x;
-                    nwk = 3;
-                } else {
-                    s0 = (b - i >= L0 - 1) ? (b - L0 + 1) : b;
-                    // a window that starts at b but runs past k-mer i (k = 31 with probes of 18 bases: three windows per bad
-                    // base, not two): the last window inside k-mer i holds b as well
-                    if (pfon && s0 == b && b + L0 - 1 > i + k - 1 && k > L0) s0 = i + k - L0;
-                    if (s0 + p - 1 > i + k - 1) s0 = i;
-                    if (s0 != i) nwk = (pfon && s0 + L0 - 1 <= i + k - 1) ? 2 : 0;
-                    // a hinted probe that finds its window in the index gives up the hint instead of walking the window
-                    if (hinted) { if (nwk == 2) nwk = 6; else { s0 = i; nwk = (ps > 0) ? 1 : 0; b = -1; } }
+            if (SORT) { mode = F_PLAN; if (force) fl |= CF_FORCE; }      // (the planner runs at the top of a searcher wave's next iteration)
+            else plan_walk(force, w31);
+        }
+        if (SORT) {
+            // a follower lane whose read is done lets go of its slot: it travels in `pend` to the writer, which frees it
+            if (isP && want_flush && mode == F_IDLE) slot = -1;
+            // ---- hand-over: the read is of the other class now.  Its state goes into the slot, the slot's number into the other
+            //      class's ring, the lane is idle.  (A list handed to the writer in this very iteration is written first -- the
+            //      receiver appends to the same list -- so such a lane waits one iteration.) ----
+            const bool foreign = slot >= 0 && (isP ? (mode == F_PLAN) : (mode == F_EXT || mode == F_TRANS || mode == F_BRIDGE));
+            const u64 pm = __ballot(foreign && !want_flush);
+            if (pm) {
+                if ((pm >> lane) & 1ull) {
+                    const int sx = SORT ? slot : 0;
+                    st_w[0][sx] = rd;
+                    st_w[SORT ? 1 : 0][sx] = isP ? ((unsigned)(b + 1) | ((unsigned)(blo + 1) << 8)) : (unsigned)r;
+                    st_w[SORT ? 2 : 0][sx] = (unsigned)i | ((unsigned)mend << 8) | ((unsigned)nseg << 16) | ((isP ? 2u : 1u) << 20) |
+                                             (((fl & CF_FORCE) ? 1u : 0u) << 22) | (((fl >> 10) & 7u) << 23) |
+                                             ((unsigned)((i0 >> 16) & 3) << 26) | ((unsigned)((i0 >> 24) & 1) << 28);
+                    st_w[SORT ? 3 : 0][sx] = (unsigned)(i0 & 0xFF) | ((unsigned)(bnext + 1) << 8);
                 }
+                ring_push(pm, isP ? 0 : 1, slot);
+                if ((pm >> lane) & 1ull) { slot = -1; mode = F_IDLE; }
             }
-#ifdef SBWT_STATS
-            pl_kind = nwk == 1 ? ((fl & CF_MISS_MASK) >= 2u * CF_MISS ? 2 : force ? 1 : (b >= i && b <= i + k - 1) ? 8 : 0) :
-                      nwk == 2 ? (s0 == b ? 4 : s0 == b - L0 + 1 ? 3 : 9) : nwk == 3 ? 5 : nwk == 6 ? 6 : 7;
-#endif
-            wstart = s0;
-            j = 0;
-            wk = nwk;
-            if (p > 0) mode = F_INIT;
-            else { mode = F_STEP; l = 0; r = last_node; }
         }
 #ifdef SBWT_STATS
         for (int q = 0; q < 24; q++) FZ_PLAN(q, pl_kind == q || oc_kind == q);
@@ -1451,10 +1623,18 @@ void sbwt_launch_search_fused(const SbwtIndexView &ix, const char *d_bases, long
                                            reinterpret_cast<const unsigned char *>(d_bases), (i64)total_bases, d_out, (i64)n_reads, ws, d_defer, \
                                            d_read_off, d_out_off)
 #define FZ_LAUNCH(W, O, B) do { FZ_LAUNCH1(W, O, B, true); FZ_LAUNCH1(W, O, B, false); } while (0)
+#define FZ_LAUNCH_S(O) do { hipLaunchKernelGGL((k_search_fused<false, O, false, true, true>), dim3(g), dim3(256), 0, stream, ix, \
+                                           reinterpret_cast<const unsigned char *>(d_bases), (i64)total_bases, d_out, (i64)n_reads, ws, d_defer, \
+                                           d_read_off, d_out_off); \
+                            hipLaunchKernelGGL((k_search_fused<false, O, false, false, true>), dim3(g), dim3(256), 0, stream, ix, \
+                                           reinterpret_cast<const unsigned char *>(d_bases), (i64)total_bases, d_out, (i64)n_reads, ws, d_defer, \
+                                           d_read_off, d_out_off); } while (0)
     const bool big = ix.n_nodes >= ((i64)1 << 31) - 64;        // (the C ABI sends such an index here only with k <= 31 and int64 results)
     if (big) FZ_LAUNCH(false, false, true);
     else if (wide) { if (ix.out32) FZ_LAUNCH(true, true, false); else FZ_LAUNCH(true, false, false); }
+    else if (ix.fused_sort > 0) { if (ix.out32) FZ_LAUNCH_S(true); else FZ_LAUNCH_S(false); }      // lanes sorted by state (k <= 31)
     else      { if (ix.out32) FZ_LAUNCH(false, true, false); else FZ_LAUNCH(false, false, false); }
+#undef FZ_LAUNCH_S
 #undef FZ_LAUNCH
 #undef FZ_LAUNCH1
     if (ev_end) (void)hipEventRecord(ev_end, stream);

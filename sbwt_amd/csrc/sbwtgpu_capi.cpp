@@ -97,6 +97,8 @@ static int tuning_variant() {
     return v;
 }
 static int g_variant_override = -1, g_probe_override = -1, g_debug = 0, g_derive_ssup = 1, g_kernel_events = 0;
+// the fused kernel with its lanes sorted by state ("fused_sort": 0 off, 1 on; env SBWTGPU_FUSED_SORT; sbwt_search_fused.hip)
+static int g_fused_sort = [] { const char *e = getenv("SBWTGPU_FUSED_SORT"); return e ? atoi(e) : SBWT_FUSED_SORT_DEFAULT; }();
 // set around a search call by the *_i32 entry points: the kernels of this call write int32 results (SbwtIndexView::out32)
 static thread_local int t_out32 = 0;
 static int64_t g_ev_count = 0;
@@ -182,6 +184,7 @@ struct sbwtgpu_index {
         v.has_ssup = h.has_ssup;
         v.probe_len = probe_len();
         v.debug = g_debug;
+        v.fused_sort = g_fused_sort;
         v.out32 = t_out32;
         v.force_mega = h.force_mega;
         v.p_sparse = (int)h.p_sparse;
@@ -231,6 +234,7 @@ int sbwtgpu_set_tuning(const char *key, int64_t value) {
     if (!strcmp(key, "path_safe")) { g_path_safe = (int)value; return SBWTGPU_OK; }   // indexes created afterwards
     if (!strcmp(key, "path_lookahead")) { g_path_lookahead = value < 0 ? 0 : value > 64 ? 64 : (int)value; return SBWTGPU_OK; }
     if (!strcmp(key, "path_order")) { g_path_order = (int)value; return SBWTGPU_OK; }   // indexes created afterwards
+    if (!strcmp(key, "fused_sort")) { g_fused_sort = (int)value; return SBWTGPU_OK; }
     if (!strcmp(key, "fused_ragged")) { g_fused_ragged = (int)value; return SBWTGPU_OK; }
     if (!strcmp(key, "fused_pieces")) { g_fused_pieces = value < 1 ? -1 : value > 3 ? 3 : (int)value; return SBWTGPU_OK; }
     if (!strcmp(key, "split_long")) { g_split_long = (int)value; return SBWTGPU_OK; }
@@ -782,6 +786,19 @@ int sbwtgpu_index_bcast(sbwtgpu_index *root, int n_dev, const int *devs, sbwtgpu
     {
         const int prc = sbwtgpu_debug_bcast_plan(n_dev, devs, root->device, ndev, uniq.data(), slot.data(), &n_uniq, &root_rank);
         if (prc != SBWTGPU_OK) return prc;
+    }
+    // SBWTGPU_BCAST_NO_DEDUP=1 (tests): every entry of devs[] is a rank of its own, duplicates included -- the RCCL call
+    // sequence below then runs on a one-GPU box (with a stand-in library behind SBWTGPU_RCCL_LIB: RCCL itself refuses two
+    // ranks on one device); the root's rank is its device's first entry
+    const char *nd_env = getenv("SBWTGPU_BCAST_NO_DEDUP");
+    if (nd_env && *nd_env == '1' && n_dev > 1) {
+        n_uniq = n_dev;
+        root_rank = -1;
+        for (int i = 0; i < n_dev; i++) {
+            uniq[(size_t)i] = devs[i];
+            slot[(size_t)i] = i;
+            if (root_rank < 0 && devs[i] == root->device) root_rank = i;
+        }
     }
     uniq.resize((size_t)n_uniq);
     if (uniq.size() == 1) {
