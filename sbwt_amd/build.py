@@ -45,7 +45,7 @@ def build_gpu(force=False) -> str:
     out = os.path.join(LIB, "libsbwtgpu.so")
     srcs = [os.path.join(CSRC, f) for f in ("sbwt_search.hip", "sbwt_search_fused.hip", "sbwt_api_kernels.hip", "sbwt_derived.hip", "sbwt_build.hip", "sbwt_sort.hip",
                                             "sbwt_format.hip", "sbwtgpu_capi.cpp")]
-    deps = srcs + [os.path.join(CSRC, f) for f in ("sbwt_device.h", "sbwt_kernels_common.h", "sbwt_scan.h")] + \
+    deps = srcs + [os.path.join(CSRC, f) for f in ("sbwt_device.h", "sbwt_kernels_common.h", "sbwt_scan.h", "sbwt_search_fused_loop.inc")] + \
         [os.path.join(INC, "sbwtgpu.h")]
     if force or _newer(out, deps):
         _run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", out] + srcs + ["-ldl"])

@@ -45,7 +45,7 @@
 #define SBWT_GROUP_BASES 32         // bases per packed read group
 
 #ifndef SBWT_FUSED_SORT_DEFAULT
-#define SBWT_FUSED_SORT_DEFAULT 0
+#define SBWT_FUSED_SORT_DEFAULT 3632       // waves wait for 48 busy lanes | 14 << 8: the followers' finished reads go to the searchers while more than 40 reads wait in the followers' ring
 #endif
 struct SbwtIndexView {
     const uint4 *blocks;            // n_blocks * 4 quads

@@ -1,5 +1,5 @@
 """A/B timing of whole search STEPS (sbwtgpu_streaming_search_dev: every kernel of the route, encode included) in ONE
-process, interleaved rounds.  Env: NREADS, GLEN, ROUNDS, READLEN, K, CONFIGS = json list of [variant, debug] pairs,
+process, interleaved rounds.  Env: NREADS, GLEN, ROUNDS, READLEN, K, CONFIGS = json list of [variant, debug(, fused_sort)] entries,
 GENOMES = coli3 | pan<N> | single.  Prints per config: median / min step ms, the fused kernel's own ms (variant 5), the
 work counters, and a checksum that must be the same for every config."""
 import os, sys, json
@@ -46,7 +46,8 @@ if os.environ.get("RAGGED"):       # RAGGED=lo: reads of lo .. READLEN bases (ho
     d_roff = torch.from_numpy(ho).to(dev)
     d_ooff = torch.from_numpy(capi.out_offsets(ho, K)).to(dev)
 n_kmers = int(d_ooff[-1].item())
-d_out = torch.empty(n_kmers, dtype=torch.int64, device=dev)
+I32 = bool(os.environ.get("I32"))               # I32=1: the int32-result entry point (sbwtgpu_*_dev_i32)
+d_out = torch.empty(n_kmers, dtype=torch.int32 if I32 else torch.int64, device=dev)
 if ostride:
     n_kmers = n_reads * m                         # (the rate counts k-mers, not slots)
 wsb = capi.search_workspace_bytes(d_bases.numel())
@@ -79,20 +80,30 @@ capi.set_tuning("kernel_events", 1)
 for rnd in range(rounds + 1):
     for c in configs:
         capi.set_tuning("search_variant", c[0]); capi.set_tuning("debug", c[1] if len(c) > 1 else 0)
+        try:
+            capi.set_tuning("fused_sort", c[2] if len(c) > 2 else 0)   # (third entry: the fused kernel with its lanes sorted by state)
+        except capi.SbwtGpuError:
+            pass                                                       # (a library of an earlier round)
         if rnd == 0:
             d_out.fill_(-7)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        idx.streaming_search_dev(d_bases.data_ptr(), d_bases.numel(), d_roff.data_ptr(), n_reads, d_out.data_ptr(), d_ooff.data_ptr(),
-                                 d_ws.data_ptr(), wsb, st, bool(streaming))
+        (idx.streaming_search_dev_i32 if I32 else idx.streaming_search_dev)(
+            d_bases.data_ptr(), d_bases.numel(), d_roff.data_ptr(), n_reads, d_out.data_ptr(), d_ooff.data_ptr(),
+            d_ws.data_ptr(), wsb, st, bool(streaming))
         e1.record(); torch.cuda.synchronize()
         if rnd == 0:
             if os.environ.get("RAGGED"):
-                chk = int((d_out * (torch.arange(n_kmers, device=dev) % 1009 + 1)).sum().item())
+                chk = int((d_out.long() * (torch.arange(n_kmers, device=dev) % 1009 + 1)).sum().item())
             else:
                 dv = d_out.view(n_reads, ostride)[:, :m] if ostride else d_out.view(n_reads, m)
-                chk = int(((dv * w).sum(dim=1) * torch.arange(1, n_reads + 1, device=dev)).sum().item())
+                chk = int(((dv.long() * w).sum(dim=1) * torch.arange(1, n_reads + 1, device=dev)).sum().item())
             if ref is None: ref = chk
+            if len(c) > 2 and c[2]:
+                hdr = d_ws[:256].cpu().numpy().view("uint64")      # ws->pad[11..14]: wave-iterations and busy lanes per wave class
+                it_s, b_s, it_p, b_p = (int(hdr[16 + q]) for q in (11, 12, 13, 14))
+                print("   SORT: searcher waves %d iterations x %.1f busy lanes, follower waves %d x %.1f; lists written %d, not a read's last %d" % (
+                    it_s, b_s / max(1, it_s), it_p, b_p / max(1, it_p), int(hdr[16 + 9]), int(hdr[16 + 10])), flush=True)
             print("config", c, "checksum", chk, "same" if chk == ref else "DIFFERENT", "stats", idx.workspace_stats(d_ws.data_ptr(), st),
                   "bridges", idx.workspace_bridges(d_ws.data_ptr(), st), flush=True)
         else:
@@ -103,5 +114,5 @@ for c, v in times.items():
     kt = ktimes[c]
     if os.environ.get("PRINT_ALL"):      # the steps in order: does the box slow down while it runs?
         print("steps ms:", " ".join("%.2f" % x for x in v))
-    print(f"variant={c[0]} debug={c[1] if len(c) > 1 else 0}: step median {np.median(v):.3f} ms min {min(v):.3f} ms -> "
+    print(f"variant={c[0]} debug={c[1] if len(c) > 1 else 0} sort={c[2] if len(c) > 2 else 0}: step median {np.median(v):.3f} ms min {min(v):.3f} ms -> "
           f"{n_kmers / np.median(v) / 1e6:.2f} G kmers/s" + (f"; fused kernel median {np.median(kt):.3f} ms" if kt else ""))

@@ -37,6 +37,7 @@ def reset_tuning():
     capi.set_tuning("sort_reads", -1)
     capi.set_tuning("debug", 0)
     capi.set_tuning("fused_pieces", -1)
+    capi.set_tuning("fused_sort", 3632)
     capi.set_tuning("path_lookahead", 8); capi.set_tuning("path_safe", 2); capi.set_tuning("image_level", 0)
     capi.set_tuning("path_stitch", 1); capi.set_tuning("path_stitch_min", 1)
 
@@ -133,6 +134,9 @@ def _fuzz(budget, seed, max_cases):
             capi.set_tuning("debug", (int(rng.choice([0, 0, 32, 64])) | int(rng.choice([0, 128])) |
                                       (int(rng.choice([0, 0, 1, 3, 40, 1280])) << 8)) if v == 5 else 0)
             capi.set_tuning("fused_pieces", int(rng.choice([-1, 1, 2, 3])) if v == 5 else -1)
+            # the fused kernel with its lanes sorted by state (k <= 31): off / no waiting, no shipping / waves wait for 48 busy lanes,
+            # two finished reads in eight written by the searchers / ... by the followers' load (the default) / every one shipped
+            capi.set_tuning("fused_sort", int(rng.choice([0, 1, 560, 3632, 3632, 2096, 2352])) if v == 5 else 0)
             a = idx.streaming_search(bases, off)[0] if ssup else None
             b = idx.search(bases, off)[0]
             res[(v, -1)] = (a, b)

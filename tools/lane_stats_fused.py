@@ -79,3 +79,16 @@ try:
         print("  k-mers certified absent per absent filter window: %.2f" % (pl[24] / max(1, nprobe)))
 except Exception as ex:
     print("no planner counters:", ex)
+
+try:
+    t = (ctypes.c_ulonglong * 16)()
+    if capi.lib().sbwtgpu_debug_sort_stats(t, 1) == 0 and t[0]:
+        nm = ["searcher", "follower"]
+        for c in (0, 1):
+            it = max(1, t[4 * c])
+            print("SORT %s waves: %d wave-iterations, per iteration %.1f lanes busy, %.1f waiting at the ring, %.1f idle with a slot" % (
+                nm[c], t[4 * c], t[4 * c + 1] / it, t[4 * c + 2] / it, t[4 * c + 3] / it))
+        print("SORT per read: %.2f hand-overs to the followers, %.2f to the searchers, %.2f free slots returned, %.3f hand-overs that waited "
+              "for the writer; %d skipped wave-iterations" % (t[8] / nr, t[9] / nr, t[10] / nr, t[11] / nr, t[12]))
+except Exception as ex:
+    print("no SORT statistics:", ex)

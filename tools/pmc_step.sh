@@ -23,7 +23,7 @@ for f in sorted(glob.glob(os.path.join(root, "g*/**/*counter_collection.csv"), r
     for name, cs in agg.items():
         if "k_search" in name or "k_presort" in name:
             for c, v in cs.items():
-                print(f"{name[:56]:56s} {c:28s} n={len(v):3d} avg={sum(v)/len(v):.6g}")
+                print(f"{name[:72]:72s} {c:28s} n={len(v):3d} avg={sum(v)/len(v):.6g}")
 PY
 rm -rf $OUT/g*/
 cat $OUT/summary.txt; cat $OUT/errors.txt 2>/dev/null
