@@ -119,13 +119,15 @@ __global__ void __launch_bounds__(256) k_sp2_expand(SbwtIndexView ix, const SpIt
     if (slot != ~0ull) out[slot] = SpItem2{it.key2 | ((u64)c << (2 * d2)), it.origin, (unsigned)l, (unsigned)r, 0u};
 }
 __global__ void __launch_bounds__(256) k_sp2_insert(const SpItem2 *__restrict__ items, const u64 *n, uint4 *table,
-                                                    unsigned n_entries, const unsigned *__restrict__ pos, int *wide_flag) {
+                                                    unsigned n_entries, const unsigned *__restrict__ pos, int *wide_flag, int big) {
     u64 t = (u64)blockIdx.x * 256 + threadIdx.x;
     if (t >= *n) return;
     const SpItem2 it = items[t];
     if (it.l != it.r) *wide_flag = 1;                  // a k-mer's interval is one column in an SBWT
     // payload: the k-mer's path position when there is a path order (its column is col[position]), else its column
-    const unsigned payload = SBWT_SP2_USED | (pos ? pos[it.l] : it.l);
+    // (big layout: position + 1, every bit of the word is the position's; no overflow flag either -- the origin word is a
+    // full 32-bit column -- so a lookup goes on past every full bucket)
+    const unsigned payload = big ? (pos ? pos[it.l] : it.l) + 1u : (SBWT_SP2_USED | (pos ? pos[it.l] : it.l));
     size_t bkt = sbwt_sp2_entry(it.origin, it.key2, n_entries, 0u);
     for (;;) {
         unsigned *b0 = reinterpret_cast<unsigned *>(&table[2 * bkt]);
@@ -138,7 +140,7 @@ __global__ void __launch_bounds__(256) k_sp2_insert(const SpItem2 *__restrict__ 
                 return;
             }
         }
-        atomicOr(&b0[2], SBWT_SP2_OVERFLOW);               // both entries taken: mark and move on
+        if (!big) atomicOr(&b0[2], SBWT_SP2_OVERFLOW);     // both entries taken: mark and move on
         bkt = bkt + 1 < n_entries ? bkt + 1 : 0;
     }
 }
@@ -743,9 +745,15 @@ __device__ __forceinline__ bool sp2_present(const SbwtIndexView &ix, unsigned or
     unsigned e = sbwt_sp2_entry(origin, key2, ix.n_sb2, 0u);
     for (;;) {
         const uint4 a = ix.stab2[2 * (size_t)e], b = ix.stab2[2 * (size_t)e + 1];
-        if ((a.w & SBWT_SP2_USED) && quad_bits(a) == key2 && (a.z & ~SBWT_SP2_OVERFLOW) == origin) return true;
-        if ((b.w & SBWT_SP2_USED) && quad_bits(b) == key2 && b.z == origin) return true;
-        if (!(a.z & SBWT_SP2_OVERFLOW)) return false;
+        if (ix.big) {
+            if (a.w != 0u && quad_bits(a) == key2 && a.z == origin) return true;
+            if (b.w != 0u && quad_bits(b) == key2 && b.z == origin) return true;
+            if (a.w == 0u || b.w == 0u) return false;           // (a bucket with a free entry ends the search)
+        } else {
+            if ((a.w & SBWT_SP2_USED) && quad_bits(a) == key2 && (a.z & ~SBWT_SP2_OVERFLOW) == origin) return true;
+            if ((b.w & SBWT_SP2_USED) && quad_bits(b) == key2 && b.z == origin) return true;
+            if (!(a.z & SBWT_SP2_OVERFLOW)) return false;
+        }
         e = e + 1 < ix.n_sb2 ? e + 1 : 0;
     }
 }
@@ -1028,7 +1036,7 @@ int sbwt_launch_build_sparse(const SbwtIndexView &ix, int p_dense, int p_sparse,
     derived_log(stream, "sparse table: items to insert, with positions =", with_pos, counters + ci);
     hipLaunchKernelGGL(k_sp_insert, dim3(grid_for(ix.n_nodes + 64)), dim3(256), 0, stream, in, counters + ci, d_table,
                        (unsigned)n_buckets, with_pos ? d_pos : (const unsigned *)nullptr,
-                       (!with_pos && d_pos && d_table2 && ix.k > p_sparse) ? d_pos : (const unsigned *)nullptr);
+                       (!with_pos && d_pos && d_table2 && ix.k > p_sparse && !ix.big) ? d_pos : (const unsigned *)nullptr);
     derived_log(stream, "sparse table: inserted", 0);
     if (d_table2 && ix.k > p_sparse) {
         // second level: carry every depth-p_sparse prefix on to depth k, remembering where it started
@@ -1046,7 +1054,7 @@ int sbwt_launch_build_sparse(const SbwtIndexView &ix, int p_dense, int p_sparse,
         }
         int *flag = reinterpret_cast<int *>(counters + 9);
         hipLaunchKernelGGL(k_sp2_insert, dim3(grid_for(ix.n_nodes + 64)), dim3(256), 0, stream, in2, counters + ci, d_table2,
-                           (unsigned)n_entries2, d_pos, flag);
+                           (unsigned)n_entries2, d_pos, flag, ix.big);
         int h_flag = 1;
         if (hipMemcpyAsync(&h_flag, flag, 4, hipMemcpyDeviceToHost, stream) != hipSuccess) return -1;
         if (hipStreamSynchronize(stream) != hipSuccess) return -1;
@@ -1342,7 +1350,9 @@ int sbwt_launch_build_path(const SbwtIndexView &ix, unsigned *d_col, unsigned *d
 }
 // The ONLY bits, then the path groups' final encoding (k_path_reencode); returns the number of transition entries
 // (*n_branch: columns with two or more successors).  Synchronises the stream.  -1 on error.
-long long sbwt_launch_path_oth(const SbwtIndexView &ix, uint4 *d_pq, long long *n_branch, hipStream_t stream) {
+// count_only: the entries and the branching columns only (the table's size, which the image's final layout needs before the sparse
+// tables are built); the path groups stay in their build-time encoding
+long long sbwt_launch_path_oth(const SbwtIndexView &ix, uint4 *d_pq, long long *n_branch, hipStream_t stream, int count_only) {
     unsigned long long *d = nullptr, h[2] = {0, 0};
     unsigned *only = nullptr;
     const i64 n_quads = sbwt_path_quads(ix.n_pos);
@@ -1351,7 +1361,7 @@ long long sbwt_launch_path_oth(const SbwtIndexView &ix, uint4 *d_pq, long long *
     (void)hipMemsetAsync(d, 0, 16, stream);
     (void)hipMemsetAsync(only, 0, (size_t)n_quads * 4, stream);
     hipLaunchKernelGGL(k_path_oth, dim3(grid_for(ix.n_pos)), dim3(256), 0, stream, ix, only, d);
-    hipLaunchKernelGGL(k_path_reencode, dim3(grid_for(n_quads)), dim3(256), 0, stream, d_pq, n_quads, only);
+    if (!count_only) hipLaunchKernelGGL(k_path_reencode, dim3(grid_for(n_quads)), dim3(256), 0, stream, d_pq, n_quads, only);
     hipError_t e = hipMemcpyAsync(h, d, 16, hipMemcpyDeviceToHost, stream);
     if (e == hipSuccess) e = hipStreamSynchronize(stream);
     (void)hipFree(d);

@@ -76,6 +76,8 @@ struct SbwtIndexView {
     int stab_pos;                   // sparse entries are whole k-mers stored with their path position
     int debug;                      // experiments only: bit0 = skip result stores
     int out32 = 0;                  // results are written as int32 (the *_i32 entry points; n_nodes < 2^31): the result pointer is an int32 array
+    int big = 0;                    // the image has the layout of 2^31 .. 2^32 columns (SbwtBlobHeader::big_layout): full 32-bit unsigned
+                                    // columns and positions, no flag in bit 31 of any of them
     int fused_sort = 0;             // the fused kernel's SORT instantiation (lanes sorted by state; sbwt_search_fused.hip)
     int force_mega;                 // one mega block whose counts do not fit 32 bits (dense rank-only images): cnt is relative
                                     // to mega[c][0] although n_mega == 1
@@ -93,7 +95,10 @@ struct SbwtBlobHeader {
     int32_t ssup_derived;           // no suffix_group_starts given: marks derived on the device (internal use)
     int32_t p_sparse;               // depth of the sparse prefix table (0 = none)
     int64_t off_stab;
-    int32_t log2b_unused;
+    int32_t big_layout;             // the derived structures hold full 32-bit UNSIGNED columns and positions (2^31 <= n < 2^32 - 2^24, or
+                                    // "big_path" 2: forced, for tests): no stitched chains; sparse entries of depth < k carry no position
+                                    // (SBWT_SP_UNIQ is bit 31); second-level entries hold position + 1 (0 = free) and no overflow flag (a
+                                    // lookup goes on past a full bucket)
     int32_t has_path;               // path order present (col, pos, pq)
     int64_t off_col, off_pos, off_pq, off_trans;
     int32_t stab_pos;
@@ -232,7 +237,7 @@ long long sbwt_count_paths(const SbwtIndexView &ix, hipStream_t stream);
 void sbwt_launch_path_safe(const SbwtIndexView &ix, uint4 *d_pq, int rule, void *d_hlab, unsigned char *d_alt_safe,
                            hipStream_t stream);
 long long sbwt_path_safe_scratch_bytes(long long n_pos, int k);
-long long sbwt_launch_path_oth(const SbwtIndexView &ix, uint4 *d_pq, long long *n_branch, hipStream_t stream);
+long long sbwt_launch_path_oth(const SbwtIndexView &ix, uint4 *d_pq, long long *n_branch, hipStream_t stream, int count_only = 0);
 void sbwt_launch_trans_insert(const SbwtIndexView &ix, uint4 *d_trans, long long n_slots, const unsigned char *d_alt_safe,
                               hipStream_t stream);
 int sbwt_launch_build_path(const SbwtIndexView &ix, unsigned *d_col, unsigned *d_pos, uint4 *d_pq, long long pos_cap,

@@ -1346,7 +1346,7 @@ void sbwt_launch_encode_chained(const char *d_bases, long long total_bases, uint
 // instantiation, as on a level-2 image): its derived structures hold full 32-bit unsigned columns and positions, which only
 // the fused kernel's BIG instantiation reads (sbwt_search_fused.hip).  Here that is the route of the few reads the fused
 // kernel hands on, of batches it declines, and of the cross-check variants.
-static inline bool view_is_big(const SbwtIndexView &ix) { return ix.n_nodes >= ((1ll << 31) - 128); }
+static inline bool view_is_big(const SbwtIndexView &ix) { return ix.big || ix.n_nodes >= ((1ll << 31) - 128); }
 static inline SbwtIndexView general_view(const SbwtIndexView &ix) {
     SbwtIndexView v = ix;
     if (v.k > 32) v.has_safe = 0;
@@ -1400,7 +1400,7 @@ void sbwt_launch_search(const SbwtIndexView &ix_in, const uint4 *d_packed, const
         sbwt_launch_piece_bounds(d_packed, d_read_off, d_out_off, ix.k, ws, pt, 0, stream);
         unsigned grid1 = (unsigned)(want1 < 2048 ? want1 : 2048);
         // 32-bit positions need every column index (and n_nodes + 64) below 2^31 and < 2^31 packed groups
-        const bool wide = ix.n_nodes >= ((1ll << 31) - 128) || total_groups >= (1ll << 31) - 4 || (ix.debug & 16);
+        const bool wide = view_is_big(ix) || total_groups >= (1ll << 31) - 4 || (ix.debug & 16);
         // no-spill build: 72 VGPRs (7 waves/SIMD max); 4 workgroups per CU measured best (tools/ab_bench.py)
         unsigned cap = (ix.debug >> 8) ? (unsigned)(ix.debug >> 8) : (variant >= 2 ? 1280u : 1024u);
         unsigned g = grid1 < cap ? grid1 : cap;

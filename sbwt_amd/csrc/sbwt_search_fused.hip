@@ -303,7 +303,7 @@ __global__ void __launch_bounds__(256, SORT ? FZ_SORT_WGS : 5) k_search_fused(Sb
     const u64 mk2 = (k - ps >= 32) ? ~0ull : low_mask(2 * ((k - ps) & 31));   // key mask of the second-level window
     const int pw = pfon ? L0 : p;                   // window of a range probe: the filter's when there is one
     const int last_node = (int)(ix.n_nodes - 1);
-    static_assert(!BIG || (!WIDE && !O32), "2^31 columns and more: k <= 31, int64 results");
+    static_assert(!BIG || !O32, "2^31 columns and more: int64 results");
     auto zx = [](int v) -> i64 { return BIG ? (i64)(unsigned)v : (i64)v; };                    // a column / position as an index
     auto is_run = [](unsigned src) -> bool { return BIG ? src != 0xFFFFFFFFu : !(src >> 31); };   // a segment's source is a path position
 
@@ -334,7 +334,7 @@ __global__ void __launch_bounds__(256, SORT ? FZ_SORT_WGS : 5) k_search_fused(Sb
     // "debug" bits: 32 = no anchors / seeds / resumes, 64 = all of them for k <= 31 as well.
     const bool wide_k = WIDE && ((ix.stab2 != nullptr && ps < k) || (ix.stab_pos && ps == k)) && !(ix.debug & 32);
     const bool anch_ok = wide_k;
-    const bool seed_ok = wide_k && ps < k;
+    const bool seed_ok = wide_k && ps < k && !BIG;       // (seeds travel as signed columns / positions: not in the 32-bit unsigned layout)
     int bnext = -1;                 // a hint: the read's next difference from its path after b (a failed bridge's compare saw it)
     int mode = F_IDLE;
     unsigned rd = 0;                // the read this lane works on
@@ -447,7 +447,7 @@ void sbwt_launch_search_fused(const SbwtIndexView &ix, const char *d_bases, long
     else if (total_bases < 170000000ll) cap = 768u;
     else if (total_bases < 250000000ll) cap = 896u;
     else if (total_bases < 500000000ll) cap = 1024u;
-    const bool sorted = !(ix.n_nodes >= ((i64)1 << 31) - 64) && !((ix.stab2 != nullptr && ix.p_sparse < ix.k) || (ix.debug & 64)) && ix.fused_sort > 0;
+    const bool sorted = !ix.big && !(ix.n_nodes >= ((i64)1 << 31) - 64) && !((ix.stab2 != nullptr && ix.p_sparse < ix.k) || (ix.debug & 64)) && ix.fused_sort > 0;
     if (sorted && cap > 256u * FZ_SORT_WGS) cap = 256u * FZ_SORT_WGS;      // (the SORT instantiation: four workgroups per CU)
     const unsigned g = (unsigned)(want < (i64)cap ? want : (i64)cap);
     if (ev_begin) (void)hipEventRecord(ev_begin, stream);
@@ -465,8 +465,8 @@ void sbwt_launch_search_fused(const SbwtIndexView &ix, const char *d_bases, long
                             hipLaunchKernelGGL((k_search_fused<false, O, false, false, true>), dim3(g), dim3(256), 0, stream, ix, \
                                            reinterpret_cast<const unsigned char *>(d_bases), (i64)total_bases, d_out, (i64)n_reads, ws, d_defer, \
                                            d_read_off, d_out_off); } while (0)
-    const bool big = ix.n_nodes >= ((i64)1 << 31) - 64;        // (the C ABI sends such an index here only with k <= 31 and int64 results)
-    if (big) FZ_LAUNCH(false, false, true);
+    const bool big = ix.big || ix.n_nodes >= ((i64)1 << 31) - 64;     // (the C ABI sends such an index here only with int64 results)
+    if (big) { if (wide) FZ_LAUNCH(true, false, true); else FZ_LAUNCH(false, false, true); }
     else if (wide) { if (ix.out32) FZ_LAUNCH(true, true, false); else FZ_LAUNCH(true, false, false); }
     else if (ix.fused_sort > 0) { if (ix.out32) FZ_LAUNCH_S(true); else FZ_LAUNCH_S(false); }      // lanes sorted by state (k <= 31)
     else      { if (ix.out32) FZ_LAUNCH(false, true, false); else FZ_LAUNCH(false, false, false); }

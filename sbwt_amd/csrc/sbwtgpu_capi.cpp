@@ -185,6 +185,7 @@ struct sbwtgpu_index {
         v.probe_len = probe_len();
         v.debug = g_debug;
         v.fused_sort = g_fused_sort;
+        v.big = h.big_layout;
         v.out32 = t_out32;
         v.force_mega = h.force_mega;
         v.p_sparse = (int)h.p_sparse;
@@ -314,8 +315,12 @@ int sbwtgpu_index_create(const sbwtgpu_index_desc *d, int device, sbwtgpu_index 
     // 2^31 - 64 <= n < 2^32 - 2^24 (round 5): the same derived structures with full 32-bit unsigned columns and positions,
     // when whole k-mers fit the sparse table (k <= 31: every found k-mer comes with its path position, so no segment source
     // needs bit 31 as a flag) and the marks are there; absolute 32-bit block counts (the mega table stays zero)
-    const bool big_range = n >= ((int64_t)1 << 31) - 64 && n < ((int64_t)1 << 32) - ((int64_t)1 << 24);
-    const bool big_path = big_range && g_big_path && level == 0 && d->k > 16 && d->k <= SBWT_SP_MAX_DEPTH && g_sparse_depth >= d->k &&
+    // (round 6: 31 < k <= 63 as well -- the second-level table's entries hold position + 1 and no flags in that layout.
+    // "big_path" 2 gives ANY index that layout: the BIG instantiations are tested on small indexes)
+    const bool big_range = (n >= ((int64_t)1 << 31) - 64 || g_big_path == 2) && n < ((int64_t)1 << 32) - ((int64_t)1 << 24);
+    const bool big_k = d->k <= SBWT_SP_MAX_DEPTH ? g_sparse_depth >= d->k
+                                                 : (d->k - SBWT_SP_MAX_DEPTH <= 32 && g_sparse_depth >= SBWT_SP_MAX_DEPTH);
+    const bool big_path = big_range && g_big_path && level == 0 && d->k > 16 && big_k &&
                           g_probe_filter && g_path_order && (d->suffix_group_starts || g_derive_ssup);
     const bool derived = !t_minimal_image && g_sparse_depth > 0 && g_probe_filter &&
                          ((n < ((int64_t)1 << 31) - 64 && n_mega == 1) || big_path) && d->k > 16;
@@ -358,10 +363,14 @@ int sbwtgpu_index_create(const sbwtgpu_index_desc *d, int device, sbwtgpu_index 
     if (t_minimal_image) p_sparse = 0;
     if (p_sparse > SBWT_SP_MAX_DEPTH) p_sparse = SBWT_SP_MAX_DEPTH;
     if (p_sparse <= p_dev || p_dev <= 0 || n >= ((int64_t)1 << 32) || (n_mega > 1 && !big_path)) p_sparse = 0;
-    if (big_path && p_sparse != d->k) p_sparse = 0;     // (2^31 columns and more: whole k-mers with their positions, or nothing)
+    // (2^31 columns and more: whole k-mers with their positions -- in the table itself, or through the second level -- or nothing)
+    if (big_path && p_sparse != d->k && !(p_sparse == SBWT_SP_MAX_DEPTH && d->k > p_sparse && d->k - p_sparse <= 32)) p_sparse = 0;
     if (p_sparse > 0) {
         h.p_sparse = (int32_t)p_sparse;
-        const int64_t bpct = g_sparse_buckets_pct > 0 ? g_sparse_buckets_pct : (d->k > SBWT_SP_MAX_DEPTH ? 125 : 100);
+        // (2^31 columns and more with two levels: one bucket per column in both -- at 1.25 the two tables are 180 GB of a 2.25 x 10^9-
+        // column image and leave their own builder 7 GB short of its 108 GB of scratch on a 288 GB device)
+        const int64_t bpct = g_sparse_buckets_pct > 0 ? g_sparse_buckets_pct
+                                                      : (d->k > SBWT_SP_MAX_DEPTH && !(big_path && n >= ((int64_t)1 << 31) - 64) ? 125 : 100);
         h.n_sb = n * bpct / 100 + 64;       // two-entry buckets per column
         h.off_stab = h.blob_bytes;
         h.blob_bytes = align256(h.off_stab + 32 * h.n_sb);
@@ -369,7 +378,7 @@ int sbwtgpu_index_create(const sbwtgpu_index_desc *d, int device, sbwtgpu_index 
         // first level (round 3: 2 n single 32-byte entries with linear probing -- a miss walked 2.5 of them)
         // (its entries keep their flags in bit 31 of the column / origin words: columns below 2^31 only -- p_sparse > 0 already
         // implies one mega block; said again here because a wider first level must not widen this one by accident)
-        if (p_sparse == SBWT_SP_MAX_DEPTH && d->k > p_sparse && d->k - p_sparse <= 32 && n < ((int64_t)1 << 31)) {
+        if (p_sparse == SBWT_SP_MAX_DEPTH && d->k > p_sparse && d->k - p_sparse <= 32 && (n < ((int64_t)1 << 31) - 64 || big_path)) {
             h.n_sb2 = n * bpct / 100 + 64;
             h.off_stab2 = h.blob_bytes;
             h.blob_bytes = align256(h.off_stab2 + 32 * h.n_sb2);
@@ -395,13 +404,14 @@ int sbwtgpu_index_create(const sbwtgpu_index_desc *d, int device, sbwtgpu_index 
     // path order: needs suffix-group marks (given or derived) and 32-bit columns
     const bool marks = d->suffix_group_starts || (g_derive_ssup && d->k >= 2);
     int64_t pos_cap = n;
-    if (g_path_order && level == 0 && marks && ((n < ((int64_t)1 << 31) - 64 && n_mega == 1) || (big_path && p_sparse == d->k))) {
+    if (g_path_order && level == 0 && marks && ((n < ((int64_t)1 << 31) - 64 && n_mega == 1 && !big_path) || (big_path && p_sparse > 0))) {
         // room for the path order with stitched chains (copies of shared stretches: at most a fifth of the columns, and
         // positions stay below 2^31); the finished image keeps what was used.  (2^31 columns and more: disjoint paths only --
         // the copies' room and the stitching's temporaries are what such an image has no memory for)
         pos_cap = (g_path_stitch && !big_path) ? std::min<int64_t>(n + n / 5 + 64, ((int64_t)1 << 31) - 64) : n;
         if (pos_cap < n) pos_cap = n;
         h.has_path = 1;
+        h.big_layout = big_path ? 1 : 0;
         h.off_col = h.blob_bytes;
         h.off_pos = align256(h.off_col + (pos_cap + 4) * 4);
         h.off_pq = align256(h.off_pos + (n + 4) * 4);
@@ -461,6 +471,7 @@ int sbwtgpu_index_create(const sbwtgpu_index_desc *d, int device, sbwtgpu_index 
         h.n_sb2 = 0;
         h.p_filter = 0;
         h.has_path = 0;
+        h.big_layout = 0;
     }
     if (d->precalc && p_file > 0) {
         const int64_t np = (int64_t)1 << (2 * p_file);
@@ -496,7 +507,21 @@ int sbwtgpu_index_create(const sbwtgpu_index_desc *d, int device, sbwtgpu_index 
         return fail(SBWTGPU_ERR_OOM, "the smallest image of this index (%lld bytes: blocks + depth-%lld prefix table) exceeds "
                     "max_image_bytes = %lld", (long long)h.blob_bytes, (long long)h.p_dev, (long long)g_max_image_bytes);
     }
-    hipError_t e = hipMalloc((void **)&idx->blob, (size_t)h.blob_bytes);
+    // An image with a path order is built in TWO allocations (round 6): first the index proper and the path arrays (at temporary
+    // offsets right behind the mega table), then -- the path order says how long col[] is and how many transition entries there
+    // are -- the image at its final size, into which the sparse tables and the filter are built directly.  (Before, everything
+    // was built in one allocation and moved at the end: twice the image at the peak, which a 164 GB image of 2.25 x 10^9
+    // columns at k = 32 does not have.)
+    const int64_t f_off_col = h.off_col, f_blob_bytes = h.blob_bytes;       // (the one-allocation layout, for the size checks)
+    int64_t p1_bytes = h.blob_bytes;
+    if (h.has_path) {
+        h.off_col = align256(h.off_mega + 4 * n_mega * 8);
+        h.off_pos = align256(h.off_col + (pos_cap + 4) * 4);
+        h.off_pq = align256(h.off_pos + (n + 4) * 4);
+        p1_bytes = align256(h.off_pq + sbwt_path_quads(pos_cap) * 16);
+    }
+    (void)f_blob_bytes;
+    hipError_t e = hipMalloc((void **)&idx->blob, (size_t)p1_bytes);
     if (e != hipSuccess && level < 2 && (h.has_path || h.p_sparse > 0)) {
         // the derived structures are optional: without them the blocks-only kernel serves
         (void)hipGetLastError();
@@ -513,7 +538,7 @@ int sbwtgpu_index_create(const sbwtgpu_index_desc *d, int device, sbwtgpu_index 
     PhaseLog plog;
     plog("upload, counts, allocation");
     do {
-        if ((e = hipMemset(idx->blob, 0, (size_t)h.blob_bytes)) != hipSuccess) break;
+        if ((e = hipMemset(idx->blob, 0, (size_t)p1_bytes)) != hipSuccess) break;
         {
             const long long Cs[4] = {h.C[0], h.C[1], h.C[2], h.C[3]};
             sbwt_blocks_fill(static_cast<const unsigned long long *>(d_bits.p),
@@ -562,8 +587,44 @@ int sbwtgpu_index_create(const sbwtgpu_index_desc *d, int device, sbwtgpu_index 
             // col[n_pos] = 0xFFFFFFFF: the "position" whose column is -1 (the fused kernel's writer loads every result, absent
             // ones included, through col[]; the array has four entries of padding behind the last position)
             if ((e = hipMemset(idx->blob + h.off_col + (size_t)n_pos * 4, 0xFF, 16)) != hipSuccess) break;
+            // ---- the final layout: the transition table's size (three entries per branching column, one per successor of a
+            //      path's last column: counted now, filled in at the end) and the path arrays at the length the path order
+            //      turned out to have; the image moves into its final allocation (the index proper and the path arrays:
+            //      a tenth of it), the sparse tables and the filter are built there ----
+            long long nb = 0;
+            const long long n_ent = sbwt_launch_path_oth(idx->view(), reinterpret_cast<uint4 *>(idx->blob + h.off_pq), &nb, 0, 1);
+            if (n_ent < 0) { e = hipErrorUnknown; break; }
+            h.n_branch = nb;
+            h.n_trans = n_ent;
+            const int64_t n_slots = 3 * n_ent + 64;                         // load factor 1/3: ~1.25 probes per lookup
+            if (n_slots >= ((int64_t)1 << 32)) { e = hipErrorOutOfMemory; break; }
+            h.n_tslots = n_slots;
+            const int64_t col_bytes = align256((h.n_pos + 4) * 4), pos_bytes = align256((n + 4) * 4);
+            const int64_t pq_bytes = align256(sbwt_path_quads(h.n_pos) * 16);
+            const int64_t new_pos = f_off_col + col_bytes, new_pq = new_pos + pos_bytes, new_trans = new_pq + pq_bytes;
+            const int64_t full = align256(new_trans + 32 * n_slots);
+            if (g_max_image_bytes > 0 && full > g_max_image_bytes && level < 2) { e = hipErrorOutOfMemory; break; }
+            char *nblob = nullptr;
+            if ((e = hipMalloc((void **)&nblob, (size_t)full)) != hipSuccess) break;
+            const int64_t head = h.off_col;                                 // blocks, tables, mega: the same offsets in both
+            if ((e = hipMemcpy(nblob, idx->blob, (size_t)head, hipMemcpyDeviceToDevice)) != hipSuccess ||
+                (e = hipMemset(nblob + head, 0, (size_t)(f_off_col - head))) != hipSuccess ||        // the sparse tables' and the filter's room
+                (e = hipMemcpy(nblob + f_off_col, idx->blob + h.off_col, (size_t)col_bytes, hipMemcpyDeviceToDevice)) != hipSuccess ||
+                (e = hipMemcpy(nblob + new_pos, idx->blob + h.off_pos, (size_t)pos_bytes, hipMemcpyDeviceToDevice)) != hipSuccess ||
+                (e = hipMemcpy(nblob + new_pq, idx->blob + h.off_pq, (size_t)pq_bytes, hipMemcpyDeviceToDevice)) != hipSuccess) {
+                (void)hipFree(nblob);
+                break;
+            }
+            (void)hipFree(idx->blob);
+            idx->blob = nblob;
+            h.off_col = f_off_col;
+            h.off_pos = new_pos;
+            h.off_pq = new_pq;
+            h.off_trans = new_trans;
+            h.blob_bytes = full;
+            v = idx->view();
         }
-        plog("path order");
+        plog("path order, final layout");
         if (h.p_sparse > 0) {
             void *scr = nullptr;
             if ((e = hipMalloc(&scr, (size_t)sbwt_sparse_scratch_bytes(n))) != hipSuccess) break;
@@ -583,7 +644,7 @@ int sbwtgpu_index_create(const sbwtgpu_index_desc *d, int device, sbwtgpu_index 
             plog("sparse table, second level, filter");
             // (2^31 columns and more: the fused kernel's BIG instantiation needs every k-mer's position in its table entry;
             // without them -- the columns are not an SBWT's -- the image steps down like one that does not fit)
-            if (big_path && h.has_path && !h.stab_pos) { e = hipErrorOutOfMemory; break; }
+            if (big_path && h.has_path && !(h.stab_pos || (h.n_sb2 > 0 && d->k > h.p_sparse))) { e = hipErrorOutOfMemory; break; }
             // substitution-safe bits of the path: need the whole k-mers in the sparse table
             // (31 < k <= 63: whole k-mers live in the two-level table -- the wide kernels, rule 2 only)
             const bool whole_kmers = h.p_sparse == d->k || (h.n_sb2 > 0 && d->k > h.p_sparse);
@@ -612,39 +673,14 @@ int sbwtgpu_index_create(const sbwtgpu_index_desc *d, int device, sbwtgpu_index 
         }
         plog("substitution-safe bits");
         if (h.has_path) {
-            // Last: the only-successor bits, the path groups' final encoding, and the transition table.  Its size is known
-            // only now -- three entries per branching column and one per successor of a path's last column -- so the image
-            // moves once into an allocation of its final size (device-to-device, ~1 ms per GB).
+            // Last: the only-successor bits, the path groups' final encoding, and the transition table (its room was made when
+            // the image moved into its final allocation, behind the path order).
             SbwtIndexView v3 = idx->view();
             long long nb = 0;
             const long long n_ent = sbwt_launch_path_oth(v3, reinterpret_cast<uint4 *>(idx->blob + h.off_pq), &nb, 0);
-            if (n_ent < 0) { e = hipErrorUnknown; break; }
-            h.n_branch = nb;
-            h.n_trans = n_ent;
-            const int64_t n_slots = 3 * n_ent + 64;                         // load factor 1/3: ~1.25 probes per lookup
-            if (n_slots >= ((int64_t)1 << 32)) { e = hipErrorOutOfMemory; break; }
-            h.n_tslots = n_slots;
-            // the finished image keeps the path arrays at the size the path order turned out to have
-            const int64_t col_bytes = align256((h.n_pos + 4) * 4), pos_bytes = align256((n + 4) * 4);
-            const int64_t pq_bytes = align256(sbwt_path_quads(h.n_pos) * 16);
-            const int64_t new_pos = h.off_col + col_bytes, new_pq = new_pos + pos_bytes, new_trans = new_pq + pq_bytes;
-            const int64_t full = align256(new_trans + 32 * n_slots);
-            if (g_max_image_bytes > 0 && full > g_max_image_bytes && level < 2) { e = hipErrorOutOfMemory; break; }
-            char *nblob = nullptr;
-            if ((e = hipMalloc((void **)&nblob, (size_t)full)) != hipSuccess) break;
-            if ((e = hipMemcpy(nblob, idx->blob, (size_t)(h.off_col + col_bytes), hipMemcpyDeviceToDevice)) != hipSuccess ||
-                (e = hipMemcpy(nblob + new_pos, idx->blob + h.off_pos, (size_t)pos_bytes, hipMemcpyDeviceToDevice)) != hipSuccess ||
-                (e = hipMemcpy(nblob + new_pq, idx->blob + h.off_pq, (size_t)pq_bytes, hipMemcpyDeviceToDevice)) != hipSuccess) {
-                (void)hipFree(nblob);
-                break;
-            }
-            (void)hipFree(idx->blob);
-            idx->blob = nblob;
-            h.off_pos = new_pos;
-            h.off_pq = new_pq;
-            h.off_trans = new_trans;
-            h.blob_bytes = full;
-            plog("only-successor bits, final layout");
+            if (n_ent != h.n_trans) { e = hipErrorUnknown; break; }         // (the count the layout was made for)
+            const int64_t n_slots = h.n_tslots;
+            plog("only-successor bits");
             sbwt_launch_trans_insert(idx->view(), reinterpret_cast<uint4 *>(idx->blob + h.off_trans), n_slots, alt_safe, 0);
             if ((e = hipDeviceSynchronize()) != hipSuccess) break;
             h.n_paths = sbwt_count_paths(idx->view(), 0);
@@ -1067,9 +1103,10 @@ static int search_dev_common(const sbwtgpu_index *idx, const char *d_bases, int6
         const int eff_streaming = (!streaming && internal_streaming_ok(idx->h)) ? 2 : streaming;
         // (an image of 2^31 columns or more has a path order only in the form the fused kernel's BIG instantiation reads:
         // k <= 31, whole k-mers with their positions; int64 results -- the int32 calls refuse such an index)
-        const bool big_image = idx->h.n_nodes >= ((int64_t)1 << 31) - 64 && idx->h.stab_pos && idx->h.p_sparse == idx->h.k && !t_out32;
+        const bool big_image = idx->h.big_layout && idx->h.has_path && !t_out32 &&
+                               ((idx->h.stab_pos && idx->h.p_sparse == idx->h.k) || (idx->h.n_sb2 > 0 && idx->h.k > idx->h.p_sparse));
         const bool path_kernel = idx->h.has_path && eff_streaming &&
-                                 (idx->h.n_nodes < ((int64_t)1 << 31) - 128 || big_image) && n_reads < ((int64_t)1 << 31) &&
+                                 ((idx->h.n_nodes < ((int64_t)1 << 31) - 128 && !idx->h.big_layout) || big_image) && n_reads < ((int64_t)1 << 31) &&
                                  total_bases / SBWT_GROUP_BASES + 2 < ((int64_t)1 << 31) - 4;
         if (variant == 5 && path_kernel && g_sort_reads <= 0 && !(g_debug & 16)) {
             if (!d_read_off || !d_out_off) return fail(SBWTGPU_ERR_INVALID_ARG, "NULL device pointer");

@@ -329,15 +329,17 @@ def test_rank_beyond_2_pow_31_columns(gpu):
     idx.close()
 
 
-@pytest.mark.parametrize("L", [1_200_000_000, 2_250_000_000])
-def test_search_on_indexes_of_more_than_2_pow_30_and_2_pow_31_columns(gpu, L):
+@pytest.mark.parametrize("L,k", [(1_200_000_000, 31), (2_250_000_000, 31), (2_250_000_000, 32)])
+def test_search_on_indexes_of_more_than_2_pow_30_and_2_pow_31_columns(gpu, L, k):
     """The reference is int64 throughout (SBWT.hh:36-45).  One random sequence of L bases, k = 31, columns built on the GPU:
     1.2 x 10^9 columns -- the builders of the derived structures start more than 2^32 threads there (four per item), which one
     dispatch silently truncates (round 5: sliced launches; before, such an index lost most of its sparse table); 2.25 x 10^9
     columns -- beyond 2^31 the full image holds 32-bit UNSIGNED columns and positions and the fused kernel runs its BIG
     instantiation (round 5; before, such an index got the blocks-only kernel: 23 G k-mers/s).  Both must get the FULL image
     (level 0).  streaming_search and search of reads from all over the sequence (substitutions, N, lower case) on every route
-    against each other and, on a sample, against the oracle; int32 results refused beyond 2^31 columns."""
+    against each other and, on a sample, against the oracle; int32 results refused beyond 2^31 columns.
+    Round 6: k = 32 at 2.25 x 10^9 columns -- 31 < k <= 63 gets the full image there too (the second-level table without flags in
+    bit 31: position + 1, a lookup goes on past a full bucket), read by the fused kernel's WIDE + BIG instantiation."""
     import torch
     if torch.cuda.mem_get_info()[1] < (250 << 30):
         pytest.skip("needs a GPU with 288 GB: the image of 2.25e9 columns is 130 GB, its builders' scratch as much again")
@@ -345,10 +347,10 @@ def test_search_on_indexes_of_more_than_2_pow_30_and_2_pow_31_columns(gpu, L):
     gc.collect()
     torch.cuda.empty_cache()        # (what earlier tests of this process left in torch's caching allocator: the full-size suites hold 100 GB)
     genome = synth.random_genome(L, 7)
-    bits = capi.build_bits_gpu([genome.tobytes()], 31, False, True)
+    bits = capi.build_bits_gpu([genome.tobytes()], k, False, True)
     big = bits.n_nodes >= (1 << 31)
     assert big == (L > 2_000_000_000)
-    idx = capi.Index.create(bits.cols[0], bits.cols[1], bits.cols[2], bits.cols[3], bits.ssup, bits.n_nodes, 31, bits.n_kmers, 8)
+    idx = capi.Index.create(bits.cols[0], bits.cols[1], bits.cols[2], bits.cols[3], bits.ssup, bits.n_nodes, k, bits.n_kmers, 8)
     want_level = int(os.environ.get("SBWTGPU_IMAGE_LEVEL", "0"))     # (the knob sweep of tools/final_session.sh forces levels 1 and 2)
     assert idx.image_level == 0 if want_level == 0 else idx.image_level >= want_level, (idx.image_level, want_level)
     if want_level == 0 and "SBWTGPU_SEARCH_VARIANT" not in os.environ:
@@ -371,7 +373,7 @@ def test_search_on_indexes_of_more_than_2_pow_30_and_2_pow_31_columns(gpu, L):
     else:
         assert np.array_equal(idx.search_i32(bases, off)[0].astype(np.int64), got)
     # the device-resident entry point (the fused kernel itself, no host pipeline in between)
-    assert np.array_equal(_search_dev(idx, bases, off, 31, True), got)
+    assert np.array_equal(_search_dev(idx, bases, off, k, True), got)
     # reads of other lengths: pieces of the fused kernel (161 .. 422 bases), zones of the general kernel beyond, reads shorter than
     # k; the formatted text of the CLI (values of ten digits) -- against the reference-order kernel
     b2, o2 = synth.ragged_reads([genome], 600, 20, 700, 0.01, 11)
@@ -384,11 +386,11 @@ def test_search_on_indexes_of_more_than_2_pow_30_and_2_pow_31_columns(gpu, L):
     finally:
         capi.set_tuning("search_variant", -1)
     assert np.array_equal(mixed, ref_mixed)
-    assert np.array_equal(_search_dev(idx, b2, o2, 31, True), ref_mixed)
+    assert np.array_equal(_search_dev(idx, b2, o2, k, True), ref_mixed)
     assert text == b"".join(print_vector(ref_mixed[oo2[r]:oo2[r + 1]]) for r in range(len(o2) - 1))
     idx.close()
     del genome
-    orc = OracleIndex.from_bits(bits.cols[0], bits.cols[1], bits.cols[2], bits.cols[3], bits.ssup, bits.n_nodes, 31, bits.n_kmers, 8)
+    orc = OracleIndex.from_bits(bits.cols[0], bits.cols[1], bits.cols[2], bits.cols[3], bits.ssup, bits.n_nodes, k, bits.n_kmers, 8)
     sample = 700
     want = oracle_batch(orc, bases[:off[sample]], off[:sample + 1], True)
     assert np.array_equal(got[:len(want)], want)
@@ -621,6 +623,49 @@ def test_second_level_sparse_table_for_k_up_to_63(gpu, k):
     assert np.array_equal(got, oracle_batch(orc, bases, off, True))
     got, _ = idx.search(bases, off)
     assert np.array_equal(got, oracle_batch(orc, bases, off, False))
+
+
+@pytest.mark.parametrize("k", [20, 31, 32, 40, 63])
+def test_the_layout_of_2_pow_31_columns_on_a_small_index(gpu, k):
+    """The image layout of 2^31 .. 2^32 columns (32-bit unsigned columns and positions, no flag in bit 31 of any of them) forced
+    onto a small index ("big_path" 2): the fused kernel's BIG instantiations -- k <= 31, and since round 6 31 < k <= 63 (the
+    second-level table's entries hold position + 1, no overflow flag; depth-31 entries carry no position) -- against the
+    oracle, on every route, reads of 150 bases, pieces (250 bases), ragged and long reads, N and lower case."""
+    genomes = [synth.random_genome(80_000, 31)]
+    genomes.append(synth.mutate(genomes[0], 0.03, 32))
+    orc = OracleIndex.build([g.tobytes() for g in genomes], k, True, False, 4)
+    capi.set_tuning("big_path", 2)
+    try:
+        idx = gpu_index_from_oracle(orc)
+    finally:
+        capi.set_tuning("big_path", 1)
+    assert idx.image_level == 0 and idx.default_search_variant == 5
+    plain = gpu_index_from_oracle(orc)
+    import struct
+    # (SbwtBlobHeader::big_layout is the int32 at byte 160 of the exported header)
+    assert struct.unpack_from("<i", idx.export_header(), 160)[0] == 1 and struct.unpack_from("<i", plain.export_header(), 160)[0] == 0
+    for (nr, L, seed) in ((1500, 150, 5), (600, 250, 6)):
+        bases, off = synth.sample_reads(genomes, nr, L, 0.015, seed + k)
+        bases = synth.inject(bases, 40, ord("N"), 3)
+        bases = synth.inject(bases, 20, ord("a"), 4)
+        rb, ro = synth.random_reads(60, L, 9)
+        bases = np.concatenate([bases, rb])
+        off = np.concatenate([off, ro[1:] + off[-1]])
+        want = oracle_batch(orc, bases, off, True)
+        want2 = oracle_batch(orc, bases, off, False)
+        for variant in (-1, 5, 4, 1, 0):
+            capi.set_tuning("search_variant", variant)
+            try:
+                assert np.array_equal(idx.streaming_search(bases, off)[0], want), (k, L, variant)
+                assert np.array_equal(idx.search(bases, off)[0], want2), (k, L, variant)
+            finally:
+                capi.set_tuning("search_variant", -1)
+        assert np.array_equal(_search_dev(idx, bases, off, k, True), want)
+        assert np.array_equal(plain.streaming_search(bases, off)[0], want)
+    b2, o2 = synth.ragged_reads(genomes, 500, 20, 700, 0.01, 11)
+    b2 = synth.inject(b2, 30, ord("N"), 12)
+    assert np.array_equal(idx.streaming_search(b2, o2)[0], oracle_batch(orc, b2, o2, True))
+    assert np.array_equal(_search_dev(idx, b2, o2, k, True), oracle_batch(orc, b2, o2, True))
 
 
 def test_arbitrary_bytes_in_reads(gpu, genome_case):
