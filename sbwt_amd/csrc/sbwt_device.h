@@ -165,6 +165,11 @@ struct SbwtWorkHeader {
     unsigned long long n_pieces;    // pieces of long reads planned for this launch (SbwtPieceTab)
     unsigned long long pad[15];
     unsigned long long rg_long;     // of the sampled reads, those too long for the fused kernel
+    // the fused route's TICKET TABLE (round 6; SbwtTickTab): a batch with many reads of more than three pieces is cut into
+    // tickets of <= 160 bases listed in a table -- how many there are, and whether the table was too small for them
+    unsigned long long n_ftick;
+    unsigned long long ftick_over;
+    unsigned long long pad2[6];
 };
 
 // Long reads on the device.  One lane walks one read, so a read of more than 2 * piece k-mers is cut into pieces of
@@ -181,7 +186,17 @@ struct SbwtPieceTab {
     long long cap = 0;              // entries: total_bases / piece + 2 always suffice
     int piece = SBWT_PIECE;         // k-mers per zone
 };
-static_assert(sizeof(SbwtWorkHeader) == 256, "workspace header is 256 bytes");
+static_assert(sizeof(SbwtWorkHeader) == 320, "workspace header is 320 bytes");
+// The fused kernel's ticket table (k_fused_tickets, sbwt_search_fused.hip): ticket t is the piece of <= 160 bases that starts at
+// base tick[t].{x, y & 0xFFFF} (48 bits) and holds tick[t].y >> 16 bases; its results go to slot tick[t].{z, w} (64 bits) on;
+// tick_read[t] is its read (for the list of reads handed on).  defer_bits: one bit per read, set when the fused kernel hands the
+// read on (the zones of a long read are searched by the kernel behind only then).
+struct SbwtTickTab {
+    uint4 *tick = nullptr;          // nullptr: no table
+    unsigned *tick_read = nullptr;
+    unsigned *defer_bits = nullptr;
+    long long cap = 0;              // entries
+};
 
 // launchers implemented in sbwt_search.hip, sbwt_api_kernels.hip, sbwt_derived.hip, sbwt_format.hip (all asynchronous on `stream`)
 void sbwt_launch_encode(const char *d_bases, long long total_bases, uint4 *d_packed, SbwtWorkHeader *ws,
@@ -195,13 +210,15 @@ void sbwt_launch_search(const SbwtIndexView &ix, const uint4 *d_packed, const lo
 void sbwt_launch_search_fused(const SbwtIndexView &ix, const char *d_bases, long long total_bases, uint4 *d_packed,
                               const long long *d_read_off, const long long *d_out_off, long long *d_out, long long n_reads,
                               SbwtWorkHeader *ws, int streaming, hipStream_t stream, unsigned *d_defer,
-                              hipEvent_t ev_begin, hipEvent_t ev_end, SbwtPieceTab pt, int ragged_ok);
+                              hipEvent_t ev_begin, hipEvent_t ev_end, SbwtPieceTab pt, int ragged_ok, SbwtTickTab tt = SbwtTickTab());
 void sbwt_launch_encode_chained(const char *d_bases, long long total_bases, uint4 *d_packed, SbwtWorkHeader *ws,
                                 const unsigned *d_defer, const long long *d_read_off, int k, hipStream_t stream);
 void sbwt_launch_search_chained(const SbwtIndexView &ix, const uint4 *d_packed, const long long *d_read_off,
                                 const long long *d_out_off, long long *d_out, long long n_reads, SbwtWorkHeader *ws,
                                 int streaming, hipStream_t stream, const unsigned *d_defer, SbwtPieceTab pt);
 // turns the zones the check kernel listed into pieces (after the bases are packed, before the search kernel)
+void sbwt_launch_piece_bounds_tt(const uint4 *d_packed, const long long *d_read_off, const long long *d_out_off, int k,
+                                 SbwtWorkHeader *ws, SbwtPieceTab pt, int behind_fused, hipStream_t stream, const unsigned *defer_bits);
 void sbwt_launch_piece_bounds(const uint4 *d_packed, const long long *d_read_off, const long long *d_out_off, int k,
                               SbwtWorkHeader *ws, SbwtPieceTab pt, int behind_fused, hipStream_t stream);
 long long sbwt_sort_scratch_bytes(long long n_reads, int key_bits);

@@ -189,8 +189,17 @@ __device__ __forceinline__ int sbwt_fused_pieces(const SbwtWorkHeader *ws, int k
 }
 __device__ __forceinline__ int sbwt_fused_mode(const SbwtWorkHeader *ws, int k) {
     const long long len = ws->u_len;
-    if (ws->u_bad == 0) return (len >= 32 && len >= k && sbwt_fused_pieces(ws, k) > 0) ? 1 : 0;
-    return sbwt_fused_pieces(ws, k) > 0 ? 2 : 0;
+    const int pieces = sbwt_fused_pieces(ws, k);
+    if (ws->u_bad == 0 && pieces > 0) return (len >= 32 && len >= k) ? 1 : 0;
+    if (ws->u_bad != 0 && pieces > 0) return 2;
+    // 3 (round 6): reads of any lengths, too many of them longer than three pieces -- the batch was cut into tickets of <= 160 bases
+    // listed in a table (k_fused_tickets), every read of it is the fused kernel's
+    return (ws->n_ftick > 0 && ws->ftick_over == 0) ? 3 : 0;
+}
+// may k_fused_tickets build the table?  (a ragged batch the fused kernel would otherwise decline; "fused_ragged" on)
+__device__ __forceinline__ bool sbwt_fused_wants_table(const SbwtWorkHeader *ws, int k) {
+    // (reads of one length of more than three pieces included: 1 kbp or 10 kbp reads)
+    return (ws->rg_sample & 0xFFFF) > 0 && sbwt_fused_pieces(ws, k) == 0;
 }
 // the check kernels: thread t of the first blocks counts into the sample
 #define SBWT_RG_SAMPLE 4096

@@ -90,7 +90,7 @@ __global__ void __launch_bounds__(256) k_encode_chained(const unsigned char *__r
         for (i64 g = t0; g < n_groups; g += stride) packed[g] = encode_group(bases, total, g, aligned16);
         return;
     }
-    if (fmode == 2) {
+    if (fmode >= 2) {
         // reads of any lengths: a wave per read that was handed on, its lanes over the read's groups (it may be a genome)
         const i64 nd = (i64)ws->n_deferred, nw = stride >> 6;
         const int lane = threadIdx.x & 63;
@@ -1299,7 +1299,7 @@ __device__ static i64 piece_adjust(const uint4 *__restrict__ packed, i64 P0, i64
 }
 __global__ void __launch_bounds__(256) k_piece_bounds(const uint4 *__restrict__ packed, const i64 *__restrict__ read_off,
                                                       const i64 *__restrict__ out_off, int k, const SbwtWorkHeader *ws,
-                                                      SbwtPieceTab pt, int behind_fused) {
+                                                      SbwtPieceTab pt, int behind_fused, const unsigned *__restrict__ defer_bits) {
     // (the fused kernel took a batch of reads of one length, none of them long enough to be cut into zones)
     if (behind_fused && sbwt_fused_mode(ws, k) == 1 && !piece_read_is_cut(ws->u_len - k + 1, pt.piece)) return;
     const i64 z = (i64)blockIdx.x * 256 + threadIdx.x;
@@ -1307,6 +1307,14 @@ __global__ void __launch_bounds__(256) k_piece_bounds(const uint4 *__restrict__ 
     if (z >= np) return;
     const uint4 d = pt.outs[z];
     const i64 r = (i64)(((u64)d.y << 32) | (u64)d.x), j = (i64)d.z, nz = (i64)d.w;
+    // (the fused kernel took the whole batch through its ticket table: the zones of a long read are searched behind it only when
+    // that kernel handed the read on -- a read it answered itself gets empty zones)
+    if (behind_fused && defer_bits && sbwt_fused_mode(ws, k) == 3 && !((defer_bits[r >> 5] >> (r & 31)) & 1u)) {
+        const i64 P0e = read_off[r];
+        pt.pairs[z] = make_uint4((unsigned)P0e, (unsigned)((u64)P0e >> 32), (unsigned)P0e, (unsigned)((u64)P0e >> 32));
+        pt.outs[z] = make_uint4(0u, 0u, 0u, 0u);
+        return;
+    }
     const i64 P0 = read_off[r], m = read_off[r + 1] - P0 - k + 1, ob = out_off[r];
     const i64 s = j ? piece_adjust(packed, P0, j * pt.piece, m, k) : 0;
     const i64 e = (j + 1 == nz) ? m : piece_adjust(packed, P0, (j + 1) * pt.piece, m, k);
@@ -1375,11 +1383,15 @@ void sbwt_launch_search_chained(const SbwtIndexView &ix_in, const uint4 *d_packe
                            d_out_off, d_out, (i64)n_reads, ws, streaming, (const unsigned *)nullptr, d_defer, pt);
 }
 
-void sbwt_launch_piece_bounds(const uint4 *d_packed, const long long *d_read_off, const long long *d_out_off, int k,
-                              SbwtWorkHeader *ws, SbwtPieceTab pt, int behind_fused, hipStream_t stream) {
+void sbwt_launch_piece_bounds_tt(const uint4 *d_packed, const long long *d_read_off, const long long *d_out_off, int k,
+                                 SbwtWorkHeader *ws, SbwtPieceTab pt, int behind_fused, hipStream_t stream, const unsigned *defer_bits) {
     if (!pt.pairs || pt.cap <= 0) return;
     hipLaunchKernelGGL(k_piece_bounds, dim3(grid_for(pt.cap)), dim3(256), 0, stream, d_packed, d_read_off, d_out_off, k, ws, pt,
-                       behind_fused);
+                       behind_fused, defer_bits);
+}
+void sbwt_launch_piece_bounds(const uint4 *d_packed, const long long *d_read_off, const long long *d_out_off, int k,
+                              SbwtWorkHeader *ws, SbwtPieceTab pt, int behind_fused, hipStream_t stream) {
+    sbwt_launch_piece_bounds_tt(d_packed, d_read_off, d_out_off, k, ws, pt, behind_fused, stream, nullptr);
 }
 
 void sbwt_launch_search(const SbwtIndexView &ix_in, const uint4 *d_packed, const long long *d_read_off,

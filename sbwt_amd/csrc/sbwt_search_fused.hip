@@ -242,7 +242,8 @@ template <bool WIDE, bool O32, bool BIG = false, bool UNI = false, bool SORT = f
 __global__ void __launch_bounds__(256, SORT ? FZ_SORT_WGS : 5) k_search_fused(SbwtIndexView ix, const unsigned char *__restrict__ bases,
                                                           i64 total_bases, i64 *__restrict__ out, i64 n_reads,
                                                           SbwtWorkHeader *ws, unsigned *__restrict__ defer_list,
-                                                          const i64 *__restrict__ read_off, const i64 *__restrict__ out_off) {
+                                                          const i64 *__restrict__ read_off, const i64 *__restrict__ out_off,
+                                                          SbwtTickTab tt) {
     static_assert(!SORT || (!WIDE && !BIG), "lanes sorted by state: k <= 31, fewer than 2^31 columns (so far)");
     __shared__ u64 pool_codes[SBWT_FUSED_MAXG][SORT ? 128 : 256];   // the wave's pool of 64 tickets, encoded ([group][wave * 64 + ticket]; SORT: searcher waves only)
     constexpr int NSLOT = SORT ? FZ_SLOTS : 256;
@@ -263,6 +264,10 @@ __global__ void __launch_bounds__(256, SORT ? FZ_SORT_WGS : 5) k_search_fused(Sb
     const int P_batch = sbwt_fused_pieces(ws, ix.k);
     if (UNI != (fmode == 1 && P_batch == 1 && !(ix.debug & 128))) return;      // the other instantiation's batch
     const bool ragged = !UNI && fmode == 2;                 // reads of any lengths: offsets fetched with every refill
+    // (round 6) reads of any lengths, many of them long: the batch as a TABLE of tickets of <= 160 bases (k_fused_tickets): a
+    // ticket is a read of its own -- where its bases are, where its results go -- and `rd` is the ticket's number
+    const bool table = !UNI && fmode == 3 && tt.tick != nullptr;
+    if (!UNI && fmode == 3 && !table) return;
     const int tid = threadIdx.x, lane = tid & 63, wbase = tid & ~63;
     const bool follower_wave = SORT && __builtin_amdgcn_readfirstlane(tid) >= 128;     // a path-follower wave (wave-uniform, in a scalar register)
     int slot = SORT ? (follower_wave ? -1 : tid) : tid;     // SORT: the slot this lane holds; -1: none; <= -2: none, and the lane holds
@@ -294,10 +299,10 @@ __global__ void __launch_bounds__(256, SORT ? FZ_SORT_WGS : 5) k_search_fused(Sb
     };
     const int k = ix.k, p = ix.p_dev, L0 = ix.probe_len, ps = ix.p_sparse;
     // tickets: P per read (reads of more than 160 bases as pieces that overlap by k-1; sbwt_kernels_common.h)
-    const int P = UNI ? 1 : P_batch, kpp = SBWT_FUSED_MAXLEN - k + 1;
-    const bool varlen = ragged || P > 1;                    // the tickets' lengths differ: each refill notes them
-    const i64 n_tickets = n_reads * P;
-    const int ulen = ragged ? SBWT_FUSED_MAXLEN : (int)ws->u_len, m = ulen - k + 1, G = varlen ? SBWT_FUSED_MAXG : ((ulen + 31) >> 5);
+    const int P = (UNI || table) ? 1 : P_batch, kpp = SBWT_FUSED_MAXLEN - k + 1;
+    const bool varlen = ragged || table || P > 1;           // the tickets' lengths differ: each refill notes them
+    const i64 n_tickets = table ? (i64)ws->n_ftick : n_reads * P;
+    const int ulen = (ragged || table) ? SBWT_FUSED_MAXLEN : (int)ws->u_len, m = ulen - k + 1, G = varlen ? SBWT_FUSED_MAXG : ((ulen + 31) >> 5);
     const i64 u_read0 = ws->u_read0, u_out0 = ws->u_out0, u_stride = ws->u_stride;
     const bool pfon = ix.pfil && ix.p_filter == L0 && L0 > p;
     const u64 mk2 = (k - ps >= 32) ? ~0ull : low_mask(2 * ((k - ps) & 31));   // key mask of the second-level window
@@ -342,7 +347,8 @@ __global__ void __launch_bounds__(256, SORT ? FZ_SORT_WGS : 5) k_search_fused(Sb
     int mend = 0;                   // this lane answers k-mers [i, mend) of its read (mend = m unless the read was split, below)
     bool drained = false;           // wave-uniform: the ticket counter has run past the last read
     int l = 0, r = 0;               // walk interval; F_EXT ..: r = path position
-    unsigned c_ext = 0, c_brg = 0;  // per lane: k-mers answered along paths, substitutions bridged
+    unsigned c_ext = 0;             // per lane: k-mers answered along paths (low 20 bits), substitutions bridged (12 bits)
+    constexpr bool LSEG_LDS = SORT || !UNI;
     u64 pool_next = 0, pool_end = 0, pool_bad = 0;  // wave-uniform pool of read tickets; tickets of it that are handed on
     int pool_len = 0;               // varlen: the length of the piece this lane encoded at the last refill (161: too long) | piece << 16
     // (the piece number of the lane's ticket rides in i0's bits 16..23: its first k-mer within its read is piece * kpp; bit 24:
@@ -385,7 +391,7 @@ __global__ void __launch_bounds__(256, SORT ? FZ_SORT_WGS : 5) k_search_fused(Sb
     }
 #endif
     {
-        u64 e = SORT ? (c_ext & 0xFFFFFu) : c_ext, eb = SORT ? (c_ext >> 20) : c_brg;
+        u64 e = c_ext & 0xFFFFFu, eb = c_ext >> 20;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) { e += __shfl_down(e, off); eb += __shfl_down(eb, off); }
         if (lane == 0) { if (e) atomicAdd(&ws->n_ext, e); if (eb) atomicAdd(&ws->n_bridge, eb); }
@@ -404,6 +410,56 @@ __global__ void __launch_bounds__(256, SORT ? FZ_SORT_WGS : 5) k_search_fused(Sb
         if (c_search) atomicAdd(&ws->n_search, (u64)c_search);
         if (c_lf) atomicAdd(&ws->n_lf, (u64)c_lf);
         if (c_tab) atomicAdd(&ws->n_tab_hit, (u64)c_tab);
+    }
+}
+
+// The ticket table of the fused route (fused mode 3, round 6).  A batch of reads of any lengths of which more than one in eight
+// is longer than three pieces used to be the general kernel's altogether (for 31 < k <= 63 at half the fused kernel's rate: it
+// has no aligned compare).  Now every read of such a batch is cut into tickets of <= 160 bases that overlap by k-1 -- exact:
+// the fused kernel only walks upper-case ACGT, where a k-mer's result does not depend on what came before it -- and the
+// tickets are listed here: one atomic per wave reserves the wave's entries, a read of many tickets (a genome: 50 000) is
+// listed by the whole wave.  Ticket order is not read order; nothing depends on it.
+__global__ void __launch_bounds__(256) k_fused_tickets(const i64 *__restrict__ read_off, const i64 *__restrict__ out_off, i64 n_reads,
+                                                       SbwtWorkHeader *ws, int k, SbwtTickTab tt) {
+    if (!sbwt_fused_wants_table(ws, k)) return;
+    const int lane = threadIdx.x & 63;
+    const int kpp = SBWT_FUSED_MAXLEN - k + 1;
+    const i64 stride = (i64)gridDim.x * 256;
+    for (i64 r0 = (i64)blockIdx.x * 256 + (threadIdx.x & ~63); r0 < n_reads; r0 += stride) {     // (wave-uniform loop)
+        const i64 r = r0 + lane;
+        const bool valid = r < n_reads;
+        const i64 P0 = valid ? read_off[r] : 0, len = valid ? read_off[r + 1] - P0 : 0, ob = valid ? out_off[r] : 0;
+        const i64 m = len - k + 1;
+        const u64 np = m > 0 ? (u64)((m + kpp - 1) / kpp) : 0ull;
+        u64 incl = np;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const u64 v = __shfl_up(incl, o); if (lane >= o) incl += v; }
+        const u64 total = __shfl(incl, 63);
+        if (total == 0) continue;
+        u64 base = 0;
+        if (lane == 0) base = atomicAdd(&ws->n_ftick, (unsigned long long)total);
+        base = uniform64(base);
+        if (base + total > (u64)tt.cap) {              // the table is too small for this batch: the general route takes it
+            if (lane == 0) ws->ftick_over = 1ull;
+            continue;
+        }
+        const u64 first = base + incl - np;
+        auto entry = [&](i64 rr, i64 p0, i64 ln, i64 o0, u64 t0, u64 j) {
+            const i64 b = p0 + (i64)j * kpp, left = ln - (i64)j * kpp;
+            const unsigned nb = (unsigned)(left > SBWT_FUSED_MAXLEN ? SBWT_FUSED_MAXLEN : left);
+            const i64 o = o0 + (i64)j * kpp;
+            tt.tick[t0 + j] = make_uint4((unsigned)b, ((unsigned)((u64)b >> 32) & 0xFFFFu) | (nb << 16), (unsigned)o, (unsigned)((u64)o >> 32));
+            tt.tick_read[t0 + j] = (unsigned)rr;
+        };
+        for (u64 j = 0; j < np && j < 4; j++) entry(r, P0, len, ob, first, j);      // (short reads: by their own lane)
+        u64 big = __ballot(np > 4);
+        while (big) {                                   // (long reads: by the whole wave)
+            const int src = __ffsll((i64)big) - 1;
+            big &= big - 1;
+            const i64 rr = __shfl(r, src), p0 = __shfl(P0, src), ln = __shfl(len, src), o0 = __shfl(ob, src);
+            const u64 t0 = __shfl(first, src), nn = __shfl(np, src);
+            for (u64 j = 4 + (u64)lane; j < nn; j += 64) entry(rr, p0, ln, o0, t0, j);
+        }
     }
 }
 
@@ -426,11 +482,20 @@ __global__ void __launch_bounds__(256) k_check_uniform2(const i64 *__restrict__ 
 void sbwt_launch_search_fused(const SbwtIndexView &ix, const char *d_bases, long long total_bases, uint4 *d_packed,
                               const long long *d_read_off, const long long *d_out_off, long long *d_out, long long n_reads,
                               SbwtWorkHeader *ws, int streaming, hipStream_t stream, unsigned *d_defer,
-                              hipEvent_t ev_begin, hipEvent_t ev_end, SbwtPieceTab pt, int ragged_ok) {
+                              hipEvent_t ev_begin, hipEvent_t ev_end, SbwtPieceTab pt, int ragged_ok, SbwtTickTab tt) {
     if (n_reads <= 0) return;
     hipLaunchKernelGGL(k_check_uniform2, dim3(grid_for(n_reads)), dim3(256), 0, stream, d_read_off, d_out_off, (i64)n_reads, ws,
                        ix.k, pt, ragged_ok);
-    const i64 want = (n_reads + 255) / 256;
+    // the ticket table of a batch with many long reads (returns at once for every other batch)
+    if (tt.tick && n_reads < ((i64)1 << 32)) {
+        const i64 wantt = (n_reads + 255) / 256;
+        hipLaunchKernelGGL(k_fused_tickets, dim3((unsigned)(wantt < 1024 ? wantt : 1024)), dim3(256), 0, stream, d_read_off, d_out_off,
+                           (i64)n_reads, ws, ix.k, tt);
+    }
+    // (one lane per read -- or, with the ticket table of a batch of long reads, per ticket of <= 160 bases: how many there are is
+    // known on the device only, total_bases / 160 is what they are at least)
+    const i64 want_r = (n_reads + 255) / 256, want_t = tt.tick ? (total_bases / SBWT_FUSED_MAXLEN + 255) / 256 : 0;
+    const i64 want = want_r > want_t ? want_r : want_t;
     // Workgroups: five per CU fill the chip and give the most k-mers per second -- and the slowest iterations (the vector ALU is
     // shared by five waves per SIMD), which is what a launch's END is made of: the last reads' chains of 20-40 iterations.  A
     // small batch is mostly end, so it gets fewer, faster waves (measured in one process, config 2, kernel ms at 1280 workgroups
@@ -457,14 +522,14 @@ void sbwt_launch_search_fused(const SbwtIndexView &ix, const char *d_bases, long
     // whose batch it is not returns at once)
 #define FZ_LAUNCH1(W, O, B, U) hipLaunchKernelGGL((k_search_fused<W, O, B, U>), dim3(g), dim3(256), 0, stream, ix, \
                                            reinterpret_cast<const unsigned char *>(d_bases), (i64)total_bases, d_out, (i64)n_reads, ws, d_defer, \
-                                           d_read_off, d_out_off)
+                                           d_read_off, d_out_off, tt)
 #define FZ_LAUNCH(W, O, B) do { FZ_LAUNCH1(W, O, B, true); FZ_LAUNCH1(W, O, B, false); } while (0)
 #define FZ_LAUNCH_S(O) do { hipLaunchKernelGGL((k_search_fused<false, O, false, true, true>), dim3(g), dim3(256), 0, stream, ix, \
                                            reinterpret_cast<const unsigned char *>(d_bases), (i64)total_bases, d_out, (i64)n_reads, ws, d_defer, \
-                                           d_read_off, d_out_off); \
+                                           d_read_off, d_out_off, tt); \
                             hipLaunchKernelGGL((k_search_fused<false, O, false, false, true>), dim3(g), dim3(256), 0, stream, ix, \
                                            reinterpret_cast<const unsigned char *>(d_bases), (i64)total_bases, d_out, (i64)n_reads, ws, d_defer, \
-                                           d_read_off, d_out_off); } while (0)
+                                           d_read_off, d_out_off, tt); } while (0)
     const bool big = ix.big || ix.n_nodes >= ((i64)1 << 31) - 64;     // (the C ABI sends such an index here only with int64 results)
     if (big) { if (wide) FZ_LAUNCH(true, false, true); else FZ_LAUNCH(false, false, true); }
     else if (wide) { if (ix.out32) FZ_LAUNCH(true, true, false); else FZ_LAUNCH(true, false, false); }
@@ -476,6 +541,6 @@ void sbwt_launch_search_fused(const SbwtIndexView &ix, const char *d_bases, long
     if (ev_end) (void)hipEventRecord(ev_end, stream);
     // what the fused kernel did not take: everything when the reads are not of one length, else the reads it handed on
     sbwt_launch_encode_chained(d_bases, total_bases, d_packed, ws, d_defer, d_read_off, ix.k, stream);
-    sbwt_launch_piece_bounds(d_packed, d_read_off, d_out_off, ix.k, ws, pt, 1, stream);
+    sbwt_launch_piece_bounds_tt(d_packed, d_read_off, d_out_off, ix.k, ws, pt, 1, stream, tt.defer_bits);
     sbwt_launch_search_chained(ix, d_packed, d_read_off, d_out_off, d_out, n_reads, ws, streaming, stream, d_defer, pt);
 }

@@ -98,6 +98,7 @@ static int tuning_variant() {
 }
 static int g_variant_override = -1, g_probe_override = -1, g_debug = 0, g_derive_ssup = 1, g_kernel_events = 0;
 // the fused kernel with its lanes sorted by state ("fused_sort": 0 off, 1 on; env SBWTGPU_FUSED_SORT; sbwt_search_fused.hip)
+static int g_fused_table = 1;      // the fused route's ticket table for batches with many long reads ("fused_table")
 static int g_fused_sort = [] { const char *e = getenv("SBWTGPU_FUSED_SORT"); return e ? atoi(e) : SBWT_FUSED_SORT_DEFAULT; }();
 // set around a search call by the *_i32 entry points: the kernels of this call write int32 results (SbwtIndexView::out32)
 static thread_local int t_out32 = 0;
@@ -235,6 +236,7 @@ int sbwtgpu_set_tuning(const char *key, int64_t value) {
     if (!strcmp(key, "path_safe")) { g_path_safe = (int)value; return SBWTGPU_OK; }   // indexes created afterwards
     if (!strcmp(key, "path_lookahead")) { g_path_lookahead = value < 0 ? 0 : value > 64 ? 64 : (int)value; return SBWTGPU_OK; }
     if (!strcmp(key, "path_order")) { g_path_order = (int)value; return SBWTGPU_OK; }   // indexes created afterwards
+    if (!strcmp(key, "fused_table")) { g_fused_table = (int)value; return SBWTGPU_OK; }
     if (!strcmp(key, "fused_sort")) { g_fused_sort = (int)value; return SBWTGPU_OK; }
     if (!strcmp(key, "fused_ragged")) { g_fused_ragged = (int)value; return SBWTGPU_OK; }
     if (!strcmp(key, "fused_pieces")) { g_fused_pieces = value < 1 ? -1 : value > 3 ? 3 : (int)value; return SBWTGPU_OK; }
@@ -947,8 +949,15 @@ static inline int64_t ws_piece_cap(int64_t total_bases) {
     return std::max<int64_t>(total_bases / SBWT_PIECE, std::min<int64_t>(total_bases / 128, (int64_t)1 << 18)) + 2;
 }
 static inline int64_t ws_piece_bytes(int64_t total_bases) { return align256(ws_piece_cap(total_bases) * 32); }
+// the fused route's ticket table (SbwtTickTab, round 6): one ticket per 64 bases of the batch at most (a batch of long reads has
+// one per 98 .. 144 bases; a batch that would need more goes the general route), 16 + 4 bytes each, and one bit per read of the
+// list of reads handed on (one read per 32 bases, like that list)
+static inline int64_t ws_tick_cap(int64_t total_bases) { return total_bases / 64 + 64; }
+static inline int64_t ws_tick_bytes(int64_t total_bases) {
+    return align256(ws_tick_cap(total_bases) * 16) + align256(ws_tick_cap(total_bases) * 4) + align256(total_bases / 256 + 64);
+}
 static inline int64_t ws_fixed_bytes(int64_t total_bases) {
-    return align256(ws_packed_bytes(total_bases)) + ws_defer_bytes(total_bases) + ws_piece_bytes(total_bases);
+    return align256(ws_packed_bytes(total_bases)) + ws_defer_bytes(total_bases) + ws_piece_bytes(total_bases) + ws_tick_bytes(total_bases);
 }
 int64_t sbwtgpu_search_workspace_bytes(int64_t total_bases) {
     if (total_bases < 0) total_bases = 0;
@@ -964,6 +973,16 @@ static SbwtPieceTab ws_piece_tab(void *d_ws, int64_t total_bases) {
     pt.pairs = reinterpret_cast<uint4 *>(base);
     pt.outs = pt.pairs + pt.cap;
     return pt;
+}
+
+static SbwtTickTab ws_tick_tab(void *d_ws, int64_t total_bases) {
+    SbwtTickTab tt;
+    char *base = static_cast<char *>(d_ws) + align256(ws_packed_bytes(total_bases)) + ws_defer_bytes(total_bases) + ws_piece_bytes(total_bases);
+    tt.cap = ws_tick_cap(total_bases);
+    tt.tick = reinterpret_cast<uint4 *>(base);
+    tt.tick_read = reinterpret_cast<unsigned *>(base + align256(tt.cap * 16));
+    tt.defer_bits = reinterpret_cast<unsigned *>(base + align256(tt.cap * 16) + align256(tt.cap * 4));
+    return tt;
 }
 
 static const char *RANK_ONLY_MSG =
@@ -1127,6 +1146,9 @@ static int search_dev_common(const sbwtgpu_index *idx, const char *d_bases, int6
             }
             uint4 *packed = reinterpret_cast<uint4 *>(static_cast<char *>(d_ws) + sizeof(SbwtWorkHeader));
             unsigned *defer = reinterpret_cast<unsigned *>(static_cast<char *>(d_ws) + align256(ws_packed_bytes(total_bases)));
+            const SbwtTickTab tt_of_call = ws_tick_tab(d_ws, total_bases);
+            // (the bits of the reads handed on: cleared with the header)
+            HIP_TRY(hipMemsetAsync(tt_of_call.defer_bits, 0, (size_t)(total_bases / 256 + 64), st));
             hipEvent_t e0 = nullptr, e1 = nullptr;
             if (g_kernel_events) {
                 const int slot = (int)(g_ev_count % EV_RING);
@@ -1143,7 +1165,9 @@ static int search_dev_common(const sbwtgpu_index *idx, const char *d_bases, int6
                                      ws, eff_streaming, st, defer, e0, e1, ws_piece_tab(d_ws, total_bases),
                                      // (the list of reads handed on has one entry per 32 bases of the batch)
                                      ((g_fused_ragged && n_reads <= total_bases / 32) ? 1 : 0) |
-                                         ((g_fused_pieces > 0 ? g_fused_pieces : 3) << 8));
+                                         ((g_fused_pieces > 0 ? g_fused_pieces : 3) << 8),
+                                     // (the ticket table of batches with many long reads; "fused_table" 0 switches it off)
+                                     (g_fused_table && g_fused_ragged && n_reads <= total_bases / 32) ? tt_of_call : SbwtTickTab());
             hipError_t e = hipGetLastError();
             if (e != hipSuccess) return fail(SBWTGPU_ERR_HIP, "kernel launch: %s", hipGetErrorString(e));
             return SBWTGPU_OK;

@@ -807,6 +807,41 @@ def test_stitched_chains_are_derived_data(gpu, variant):
         assert chains[(1, 1)] < chains[(0, 1)], chains      # the copies did join paths
 
 
+@pytest.mark.parametrize("k", [24, 31, 40, 63])
+def test_long_reads_through_the_fused_kernels_ticket_table(gpu, k):
+    """Round 6: a batch whose reads are mostly longer than three pieces of 160 bases used to be the general
+    kernel's altogether.  Now such a batch is cut into tickets of <= 160 bases listed in a table (k_fused_tickets) and the fused
+    kernel answers it -- for 31 < k <= 63 with its aligned compare.  Reads of 300 .. 6000 bases and a whole genome as ONE read,
+    with substitutions, N and lower case (those reads are handed on: their zones are searched by the kernel behind, the others'
+    zones stay empty), short reads and reads shorter than k in between; against the oracle, against the route without the table,
+    streaming_search and search, host and device entry points, int32 results."""
+    genomes = [synth.random_genome(150_000, 41)]
+    genomes.append(synth.mutate(genomes[0], 0.03, 42))
+    orc = OracleIndex.build([g.tobytes() for g in genomes], k, True, False, 4)
+    idx = gpu_index_from_oracle(orc)
+    bases, off = synth.ragged_reads(genomes, 700, 300, 6000, 0.01, 13)
+    short_b, short_o = synth.ragged_reads(genomes, 60, 5, 200, 0.01, 14)
+    whole = synth.mutate(genomes[1], 0.005, 15)
+    bases = np.concatenate([bases, short_b, whole])
+    off = np.concatenate([off, short_o[1:] + off[-1], [off[-1] + short_o[-1] + len(whole)]])
+    bases = synth.inject(bases, 25, ord("N"), 3)
+    bases = synth.inject(bases, 10, ord("g"), 4)
+    want = oracle_batch(orc, bases, off, True)
+    want2 = oracle_batch(orc, bases, off, False)
+    for table in (1, 0):
+        capi.set_tuning("fused_table", table)
+        try:
+            assert np.array_equal(idx.streaming_search(bases, off)[0], want), (k, table)
+            assert np.array_equal(idx.search(bases, off)[0], want2), (k, table)
+            assert np.array_equal(_search_dev(idx, bases, off, k, True), want), (k, table)
+            assert np.array_equal(idx.search_i32(bases, off)[0].astype(np.int64), want), (k, table)
+        finally:
+            capi.set_tuning("fused_table", 1)
+    # clean long reads only: nothing is handed on, every zone of the kernel behind stays empty
+    cb, co = synth.ragged_reads(genomes, 300, 500, 3000, 0.02, 21)
+    assert np.array_equal(_search_dev(idx, cb, co, k, True), oracle_batch(orc, cb, co, True))
+
+
 def _search_dev(idx, bases, off, k, streaming):
     import torch
     dev = torch.device("cuda:0")

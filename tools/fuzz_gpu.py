@@ -38,6 +38,7 @@ def reset_tuning():
     capi.set_tuning("debug", 0)
     capi.set_tuning("fused_pieces", -1)
     capi.set_tuning("fused_sort", 3632)
+    capi.set_tuning("fused_table", 1)
     capi.set_tuning("path_lookahead", 8); capi.set_tuning("path_safe", 2); capi.set_tuning("image_level", 0)
     capi.set_tuning("path_stitch", 1); capi.set_tuning("path_stitch_min", 1)
 
@@ -88,14 +89,14 @@ def _fuzz(budget, seed, max_cases):
         # reads
         nr = int(rng.integers(200, 4000))
         if rng.integers(0, 2):
-            L = int(rng.integers(max(k - 2, 1), int(rng.choice([4 * k + 60, 480]))))      # (up to and past three fused pieces)
+            L = int(rng.integers(max(k - 2, 1), int(rng.choice([4 * k + 60, 480, 1500]))))      # (up to and past three fused pieces)
             long_enough = [g for g in genomes if len(g) >= L]
             if not long_enough:
                 continue
             bases, off = synth.sample_reads(long_enough, nr, L, float(rng.choice([0, 0.005, 0.02, 0.1])), int(rng.integers(1, 1 << 30)))
         else:                 # ragged lengths
             cat = np.concatenate(genomes)
-            lens = np.minimum(rng.integers(0, int(rng.choice([3 * k + 40, 330, 460])), size=nr), len(cat))
+            lens = np.minimum(rng.integers(0, int(rng.choice([3 * k + 40, 330, 460, 2000])), size=nr), len(cat))
             st = (rng.random(nr) * (len(cat) - lens + 1)).astype(np.int64)
             off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
             bases = np.empty(int(off[-1]), dtype=np.uint8)
@@ -137,6 +138,8 @@ def _fuzz(budget, seed, max_cases):
             # the fused kernel with its lanes sorted by state (k <= 31): off / no waiting, no shipping / waves wait for 48 busy lanes,
             # two finished reads in eight written by the searchers / ... by the followers' load (the default) / every one shipped
             capi.set_tuning("fused_sort", int(rng.choice([0, 1, 560, 3632, 3632, 2096, 2352])) if v == 5 else 0)
+            # the ticket table for batches with many long reads (round 6): on, as shipped / off (the general kernel takes them)
+            capi.set_tuning("fused_table", int(rng.choice([1, 1, 1, 0])))
             a = idx.streaming_search(bases, off)[0] if ssup else None
             b = idx.search(bases, off)[0]
             res[(v, -1)] = (a, b)

@@ -7,14 +7,15 @@ sys.path.insert(0, ROOT)
 import torch
 from sbwt_amd import capi, synth
 
-K = 30
+K = int(os.environ.get("K", 30))            # K=63: the second-level table and the aligned compare
+SUBS = float(os.environ.get("SUBS", 0.01))  # substitution rate of the reads
 dev = torch.device("cuda", 0)
 genomes = synth.coli3_like(int(os.environ.get("GLEN", 5_000_000)))
 bits = capi.build_bits_gpu([g.tobytes() for g in genomes], K, False, True)
 idx = capi.Index.create(bits.cols[0], bits.cols[1], bits.cols[2], bits.cols[3], bits.ssup, bits.n_nodes, K, bits.n_kmers, 8)
 
 
-def run(name, bases, off, split):
+def run(name, bases, off, split, table=1):
     lens = np.diff(off)
     oo = np.concatenate([[0], np.cumsum(np.maximum(lens - K + 1, 0))]).astype(np.int64)
     d_b = torch.from_numpy(bases).to(dev)
@@ -25,6 +26,7 @@ def run(name, bases, off, split):
     d_ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
     st = torch.cuda.current_stream().cuda_stream
     capi.set_tuning("split_long", split)
+    capi.set_tuning("fused_table", table)        # (round 6: the fused kernel's ticket table for batches of long reads)
     ts = []
     for _ in range(4):
         torch.cuda.synchronize(); t = time.perf_counter()
@@ -32,19 +34,22 @@ def run(name, bases, off, split):
                                  d_ws.data_ptr(), wsb, st, True)
         torch.cuda.synchronize(); ts.append(time.perf_counter() - t)
     capi.set_tuning("split_long", 1)
+    capi.set_tuning("fused_table", 1)
     chk = int((d_out * (torch.arange(d_out.numel(), device=dev) % 1009 + 1)).sum().item())
-    print(f"{name} split={split}: {min(ts[1:]) * 1e3:.2f} ms -> {oo[-1] / min(ts[1:]) / 1e9:.2f} G k-mers/s, found "
+    print(f"k={K} subs={SUBS} {name} split={split} table={table}: {min(ts[1:]) * 1e3:.2f} ms -> {oo[-1] / min(ts[1:]) / 1e9:.2f} G k-mers/s, found "
           f"{int((d_out >= 0).sum().item())} of {oo[-1]}, checksum {chk}", flush=True)
 
 
 whole = np.concatenate(genomes)
 woff = np.concatenate([[0], np.cumsum([len(g) for g in genomes])]).astype(np.int64)
-for split in (1, 0):
-    run("3 genomes as 3 reads", whole, woff, split)
-mut = synth.mutate(whole, 0.01, 3)
-for split in (1, 0):
-    run("the same with 1 % substitutions", mut, woff, split)
-n10 = len(mut) // 10000
-off10 = np.arange(n10 + 1, dtype=np.int64) * 10000
-for split in (1, 0):
-    run("10 kbp reads", mut[: n10 * 10000], off10, split)
+mut = synth.mutate(whole, SUBS, 3)
+for table in (1, 0):
+    run("3 genomes as 3 reads", mut, woff, 1, table)
+for L in (1000, 10000):
+    nL = len(mut) // L
+    offL = np.arange(nL + 1, dtype=np.int64) * L
+    reps = max(1, int(os.environ.get("GBASES", 1)) * 1_000_000_000 // (nL * L))       # (>= GBASES x 10^9 bases per batch)
+    b = np.tile(mut[: nL * L], reps)
+    o = np.arange(nL * reps + 1, dtype=np.int64) * L
+    for table in (1, 0):
+        run("%d bp reads (%d of them)" % (L, nL * reps), b, o, 1, table)
