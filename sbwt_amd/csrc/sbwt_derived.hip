@@ -82,6 +82,27 @@ __device__ __forceinline__ u64 block_append_slot(u64 *counter, bool ok) {
     return ok ? slot : ~0ull;
 }
 
+// Output slots of a compacting append of 0 .. 4 items per thread: one atomic per workgroup, like block_append_slot.
+__device__ __forceinline__ u64 block_append_n(u64 *counter, unsigned cnt) {
+    __shared__ unsigned wtot[4];
+    __shared__ u64 wbase_n;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    unsigned incl = cnt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const unsigned v = __shfl_up(incl, o); if (lane >= o) incl += v; }
+    if (lane == 63) wtot[wv] = incl;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned total = wtot[0] + wtot[1] + wtot[2] + wtot[3];
+        wbase_n = total ? atomicAdd(counter, (u64)total) : 0ull;
+    }
+    __syncthreads();
+    unsigned before = 0;
+    for (int w = 0; w < wv; w++) before += wtot[w];
+    const u64 slot = wbase_n + before + (u64)(incl - cnt);
+    __syncthreads();
+    return slot;
+}
 struct SpItem { u64 key; i64 l; i64 r; };
 
 __global__ void __launch_bounds__(256) k_sp_collect(const longlong2 *__restrict__ ptab, u64 n_entries,
@@ -103,20 +124,30 @@ __global__ void __launch_bounds__(256) k_sp2_seed(SpItem *items, const u64 *n) {
 }
 __global__ void __launch_bounds__(256) k_sp2_expand(SbwtIndexView ix, const SpItem2 *__restrict__ in, const u64 *n_in,
                                                     int d2, SpItem2 *__restrict__ out, u64 *n_out, u64 t0) {
+    // (one thread per item and all four chars, like k_sp_expand)
     u64 t = t0 + (u64)blockIdx.x * 256 + threadIdx.x;
-    const bool live = (t >> 2) < *n_in;
+    const bool live = t < *n_in;
     SpItem2 it = SpItem2{0ull, 0u, 0u, 0u, 0u};
-    if (live) it = in[t >> 2];
-    const int c = (int)(t & 3);
-    i64 l = 1, r = 0;
+    if (live) it = in[t];
+    i64 L[4], R[4];
+    unsigned cnt = 0;
+#pragma unroll
+    for (int c = 0; c < 4; c++) { L[c] = 1; R[c] = 0; }
     if (live) {
-        uint4 q1 = ix.blocks[(((i64)it.l >> 6) << 2) + c];
-        uint4 q2 = ix.blocks[((((i64)it.r + 1) >> 6) << 2) + c];
-        l = (i64)quad_rank<false>(ix, q1, (i64)it.l, c);
-        r = (i64)quad_rank<false>(ix, q2, (i64)it.r + 1, c) - 1;
+        const i64 bl = ((i64)it.l >> 6) << 2, br = (((i64)it.r + 1) >> 6) << 2;
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const uint4 q1 = ix.blocks[bl + c];
+            const uint4 q2 = (br == bl) ? q1 : ix.blocks[br + c];
+            L[c] = (i64)quad_rank<false>(ix, q1, (i64)it.l, c);
+            R[c] = (i64)quad_rank<false>(ix, q2, (i64)it.r + 1, c) - 1;
+            cnt += (L[c] <= R[c]) ? 1u : 0u;
+        }
     }
-    const u64 slot = block_append_slot(n_out, l <= r);
-    if (slot != ~0ull) out[slot] = SpItem2{it.key2 | ((u64)c << (2 * d2)), it.origin, (unsigned)l, (unsigned)r, 0u};
+    u64 slot = block_append_n(n_out, cnt);
+#pragma unroll
+    for (int c = 0; c < 4; c++)
+        if (L[c] <= R[c]) out[slot++] = SpItem2{it.key2 | ((u64)c << (2 * d2)), it.origin, (unsigned)L[c], (unsigned)R[c], 0u};
 }
 __global__ void __launch_bounds__(256) k_sp2_insert(const SpItem2 *__restrict__ items, const u64 *n, uint4 *table,
                                                     unsigned n_entries, const unsigned *__restrict__ pos, int *wide_flag, int big) {
@@ -155,23 +186,36 @@ __global__ void __launch_bounds__(256) k_sp_clear(uint4 *table, u64 n_entries, u
     u64 t = t0 + (u64)blockIdx.x * 256 + threadIdx.x;
     if (t < n_entries) table[t] = make_uint4(0u, (unsigned)(SBWT_SP_EMPTY >> 32), 0u, 0u);
 }
+// One level of the expansion: every prefix of depth `depth` is carried on by each of the four chars whose interval is not empty.
+// ONE thread per prefix (round 6; it was four, one per char): the four quads of a block are one 64-byte line -- a prefix whose
+// interval is one column, which is nearly every prefix from depth log4(n) + 2 on, costs one line and one thread instead of
+// four threads that each synchronise the workgroup three times for their slot (k_sp_expand was 44 % of an image's build time).
 template <bool MEGA>
 __global__ void __launch_bounds__(256) k_sp_expand(SbwtIndexView ix, const SpItem *__restrict__ in, const u64 *n_in,
                                                    int depth, SpItem *__restrict__ out, u64 *n_out, u64 t0) {
     u64 t = t0 + (u64)blockIdx.x * 256 + threadIdx.x;
-    const bool live = (t >> 2) < *n_in;
+    const bool live = t < *n_in;
     SpItem it = SpItem{0, 0, 0};
-    if (live) it = in[t >> 2];
-    const int c = (int)(t & 3);
-    i64 l = 1, r = 0;
+    if (live) it = in[t];
+    i64 L[4], R[4];
+    unsigned cnt = 0;
+#pragma unroll
+    for (int c = 0; c < 4; c++) { L[c] = 1; R[c] = 0; }
     if (live) {
-        uint4 q1 = ix.blocks[((it.l >> 6) << 2) + c];
-        uint4 q2 = ix.blocks[(((it.r + 1) >> 6) << 2) + c];
-        l = (i64)quad_rank<MEGA>(ix, q1, it.l, c);
-        r = (i64)quad_rank<MEGA>(ix, q2, it.r + 1, c) - 1;
+        const i64 bl = (it.l >> 6) << 2, br = ((it.r + 1) >> 6) << 2;
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const uint4 q1 = ix.blocks[bl + c];
+            const uint4 q2 = (br == bl) ? q1 : ix.blocks[br + c];
+            L[c] = (i64)quad_rank<MEGA>(ix, q1, it.l, c);
+            R[c] = (i64)quad_rank<MEGA>(ix, q2, it.r + 1, c) - 1;
+            cnt += (L[c] <= R[c]) ? 1u : 0u;
+        }
     }
-    const u64 slot = block_append_slot(n_out, l <= r);
-    if (slot != ~0ull) out[slot] = SpItem{it.key | ((u64)c << (2 * depth)), l, r};   // char `depth` of the prefix is c
+    u64 slot = block_append_n(n_out, cnt);
+#pragma unroll
+    for (int c = 0; c < 4; c++)
+        if (L[c] <= R[c]) out[slot++] = SpItem{it.key | ((u64)c << (2 * depth)), L[c], R[c]};   // char `depth` of the prefix is c
 }
 // Probe filter: a blocked Bloom filter (128-bit blocks, two bits per key) over every p_filter-mer the index
 // holds.  A certificate probe asks "is this window absent?": a clear bit answers yes in one gather; two set bits
@@ -682,6 +726,37 @@ __global__ void __launch_bounds__(256) k_path_head_labels(SbwtIndexView ix, cons
     }
     hlab[t] = lab;
 }
+// Is this p_filter-mer (perhaps) in the index?  (the search kernels' probe filter: no false negatives)
+__device__ __forceinline__ bool pf_maybe(const SbwtIndexView &ix, u64 key) {
+    const u64 h = sbwt_pf_hash(key);
+    const uint4 blk = ix.pfil[h >> (64 - ix.log2f)];
+    const unsigned hb = sbwt_pf_bits(h), b1 = hb & 127u, b2 = (hb >> 7) & 127u;
+    const unsigned w1 = (b1 < 64) ? (b1 < 32 ? blk.x : blk.y) : (b1 < 96 ? blk.z : blk.w);
+    const unsigned w2 = (b2 < 64) ? (b2 < 32 ? blk.x : blk.y) : (b2 < 96 ? blk.z : blk.w);
+    return ((w1 >> (b1 & 31u)) & (w2 >> (b2 & 31u)) & 1u) != 0;
+}
+// The safe-bit kernels ask, for every step u and each of the three substitutes of its char, whether ANY of the k k-mers that hold
+// the substituted base is in the index: 3k table lookups per position, nearly all of them misses (a third of an image's build
+// time).  Round 6: the probe filter first.  A k-mer that is there has every one of its L-mers in the filter (L = p_filter), so a
+// few L-windows that hold the substituted base and between them lie inside every one of the k windows -- starts c0-L+1,
+// c0-L+1+g, ..., c0 with g = k-L+1 (c0: the base's place in the 2k-1 chars around it) -- rule a substitute out when ALL of them
+// are absent; only a substitute some window could not rule out takes the exact lookups.  Returns the substitutes ruled out
+// (bit a-1).  The bits that come out are the same: the filter only ever proves absence.
+template <typename W>
+__device__ __forceinline__ unsigned safe_prefilter(const SbwtIndexView &ix, W S, int k) {
+    const int L = ix.p_filter;
+    if (!ix.pfil || L <= 0 || L > k || L > 31) return 0u;
+    const int c0 = k - 1, g = k - L + 1;
+    const u64 lm = low_mask(2 * L);
+    unsigned out = 7u;
+    for (int t = c0 - L + 1;; t = (t + g < c0) ? t + g : c0) {
+        const u64 key = (u64)(S >> (2 * t)) & lm;
+        for (u64 alt = 1; alt < 4; alt++)
+            if (((out >> (alt - 1)) & 1u) && pf_maybe(ix, key ^ (alt << (2 * (c0 - t))))) out &= ~(1u << (alt - 1));
+        if (t == c0 || !out) break;
+    }
+    return out;
+}
 // alt[u] (may be null): bit a-1 set <=> the step is safe for the one substitute ch[u] ^ a (the transition entry of that char,
 // which says "no successor", passes it on: a read with exactly that base is bridged after its transition lookup -- in a
 // pan-genome most steps have ONE real variant somewhere, and a sequencing error is usually one of the other two bases)
@@ -717,10 +792,12 @@ __global__ void __launch_bounds__(256) k_path_safe_labels(SbwtIndexView ix, unsi
     const u64 Slo = left | (right << (2 * (k - 1))), Shi = right >> (64 - 2 * (k - 1));
     const u64 km = low_mask(2 * k);
     unsigned ok = 7u;                                   // substitutes not seen in any window yet
-    for (int w = 0; w < k && ok; w++) {
+    // (the probe filter rules most substitutes out with two or three probes each; the others take the k exact lookups)
+    const unsigned ruled_out = safe_prefilter(ix, (unsigned __int128)Slo | ((unsigned __int128)Shi << 64), k);
+    for (int w = 0; w < k && (ok & ~ruled_out); w++) {
         const u64 key = ((Slo >> (2 * w)) | (w ? (Shi << (64 - 2 * w)) : 0ull)) & km;
         for (u64 alt = 1; alt < 4; alt++)
-            if (((ok >> (alt - 1)) & 1u) && sp_present(ix, key ^ (alt << (2 * (k - 1 - w))))) ok &= ~(1u << (alt - 1));
+            if (((ok & ~ruled_out) >> (alt - 1) & 1u) && sp_present(ix, key ^ (alt << (2 * (k - 1 - w))))) ok &= ~(1u << (alt - 1));
     }
     if (alt_safe) alt_safe[u] = (unsigned char)ok;
     if (ok == 7u) atomicOr(&pq_words[(size_t)q * 4 + 3], 1u << s);
@@ -836,7 +913,25 @@ __global__ void __launch_bounds__(256) k_path_safe_labels_wide(SbwtIndexView ix,
     const int rest = k - 31;                            // chars of the second-level key, 1 .. 32
     const u64 mrest = rest >= 32 ? ~0ull : low_mask(2 * rest);
     unsigned ok = 7u;                                   // substitutes not seen in any window yet
-    for (int w = 0; w < k && ok; w++) {
+    // (the probe filter first, as in k_path_safe_labels: a few L-windows that hold the substituted base rule a substitute out)
+    unsigned ruled_out = 0u;
+    {
+        const int L = ix.p_filter;
+        if (ix.pfil && L > 0 && L <= 31) {
+            const int c0 = k - 1, g = k - L + 1;
+            const u64 lm = low_mask(2 * L);
+            ruled_out = 7u;
+            for (int t = c0 - L + 1;; t = (t + g < c0) ? t + g : c0) {
+                u128 v = 2 * t < 128 ? (Slo >> (2 * t)) : (Shi >> (2 * t - 128));
+                if (t && 2 * t < 128) v |= Shi << (128 - 2 * t);
+                const u64 key = (u64)v & lm;
+                for (u64 alt = 1; alt < 4; alt++)
+                    if (((ruled_out >> (alt - 1)) & 1u) && pf_maybe(ix, key ^ (alt << (2 * (c0 - t))))) ruled_out &= ~(1u << (alt - 1));
+                if (t == c0 || !ruled_out) break;
+            }
+        }
+    }
+    for (int w = 0; w < k && (ok & ~ruled_out); w++) {
         u128 key = Slo >> (2 * w);
         if (w) key |= Shi << (128 - 2 * w);
         key &= km;
@@ -845,14 +940,14 @@ __global__ void __launch_bounds__(256) k_path_safe_labels_wide(SbwtIndexView ix,
         if (a < 31) {
             for (u64 alt = 1; alt < 4; alt++) {
                 unsigned first = 0;
-                if (((ok >> (alt - 1)) & 1u) && sp_find(ix, P ^ (alt << (2 * a)), &first) && sp2_present(ix, first, R))
+                if ((((ok & ~ruled_out) >> (alt - 1)) & 1u) && sp_find(ix, P ^ (alt << (2 * a)), &first) && sp2_present(ix, first, R))
                     ok &= ~(1u << (alt - 1));
             }
         } else {
             unsigned first = 0;
             if (sp_find(ix, P, &first))
                 for (u64 alt = 1; alt < 4; alt++)
-                    if (((ok >> (alt - 1)) & 1u) && sp2_present(ix, first, R ^ (alt << (2 * (a - 31))))) ok &= ~(1u << (alt - 1));
+                    if ((((ok & ~ruled_out) >> (alt - 1)) & 1u) && sp2_present(ix, first, R ^ (alt << (2 * (a - 31))))) ok &= ~(1u << (alt - 1));
         }
     }
     if (alt_safe) alt_safe[u] = (unsigned char)ok;
@@ -1007,7 +1102,7 @@ int sbwt_launch_build_sparse(const SbwtIndexView &ix, int p_dense, int p_sparse,
     int ci = 0;
     for (int d = p_dense; d < p_sparse; d++) {
         (void)hipMemsetAsync(counters + (ci ^ 1), 0, 8, stream);
-        const u64 threads = (u64)(ix.n_nodes + 64) * 4;
+        const u64 threads = (u64)(ix.n_nodes + 64);            // (one per prefix; there are at most n_nodes of a depth)
         for (u64 t0 = 0; t0 < threads; t0 += SBWT_LAUNCH_SLICE) {
             const unsigned g = grid_for((i64)(threads - t0 < SBWT_LAUNCH_SLICE ? threads - t0 : SBWT_LAUNCH_SLICE));
             if (ix.n_mega > 1)
@@ -1045,7 +1140,7 @@ int sbwt_launch_build_sparse(const SbwtIndexView &ix, int p_dense, int p_sparse,
         SpItem2 *in2 = reinterpret_cast<SpItem2 *>(in), *out2 = reinterpret_cast<SpItem2 *>(outl);
         for (int d = p_sparse; d < ix.k; d++) {
             (void)hipMemsetAsync(counters + (ci ^ 1), 0, 8, stream);
-            const u64 threads = (u64)(ix.n_nodes + 64) * 4;
+            const u64 threads = (u64)(ix.n_nodes + 64);
             for (u64 t0 = 0; t0 < threads; t0 += SBWT_LAUNCH_SLICE)
                 hipLaunchKernelGGL(k_sp2_expand, dim3(grid_for((i64)(threads - t0 < SBWT_LAUNCH_SLICE ? threads - t0 : SBWT_LAUNCH_SLICE))),
                                    dim3(256), 0, stream, ix, in2, counters + ci, d - p_sparse, out2, counters + (ci ^ 1), t0);
