@@ -135,7 +135,7 @@ def gpu_reads(genomes, n_reads: int, seed: int, dev: torch.device, in_genome_ord
     return out
 
 
-SEARCH_SOURCES = ("sbwt_search_fused.hip", "sbwt_search.hip", "sbwt_derived.hip", "sbwt_sort.hip", "sbwt_kernels_common.h",
+SEARCH_SOURCES = ("sbwt_search_fused.hip", "sbwt_search_fused_loop.inc", "sbwt_search.hip", "sbwt_derived.hip", "sbwt_sort.hip", "sbwt_kernels_common.h",
                   "sbwt_device.h", "sbwtgpu_capi.cpp")
 
 

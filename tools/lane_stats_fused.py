@@ -14,6 +14,12 @@ nr = ab.n_reads
 print({n: round(v / nr, 3) for n, v in zip(names, vals)})
 print("lane-iterations per read", round(tot / nr, 2), "wave-iterations", int(hdr[base + 10]), "lanes busy per iteration",
       round((tot - vals[9]) / max(1, int(hdr[base + 10])), 1))
+# read lines per read by category: one line per lane-iteration of a kind -- a lookup's two 16-byte loads share
+# their 128-byte line --, 1.25 for path runs and bridges (their two quads straddle a line one time in four), two for an interval
+# update; the result lists' col[] lines and the read's own bases are not lane-iterations (config 2: 5.4 + 1.2)
+w = [1, 1, 1, 1, 2, 1.25, 1, 1.25, 1]
+lines = {n: round(v * f / nr, 2) for n, v, f in zip(names, vals, w)}
+print("read lines per read by category (gathers only):", lines, "sum", round(sum(lines.values()), 2))
 print("after the tickets ran out: wave-iterations", int(hdr[base + 11]), "(per wave %.1f)" % (int(hdr[base + 11]) / 5120), "idle lane-iterations",
       int(hdr[base + 12]), "= %.2f per read" % (int(hdr[base + 12]) / nr))
 print("splits", int(hdr[base + 13]), "donor-capable lane-iterations in the tail", int(hdr[base + 14]))
