@@ -378,6 +378,7 @@ def run() -> int:
                     help="--kernel rank: columns of the four random bit vectors of the HBM-resident case (the image is "
                          "1 byte per column: the default 2 GiB defeats the 256 MB Infinity Cache); the config-2 index "
                          "(12.8 MB of blocks, cache resident) is measured beside it")
+    ap.add_argument("--hbm-k", type=int, default=0, help="config 6: k (default 31)")
     ap.add_argument("--hbm-genome-len", type=int, default=1_000_000_000,
                     help="--config 6: length of the one random sequence (10^9 columns = a 139 GB image)")
     ap.add_argument("--image-level", type=int, default=0, choices=[0, 1, 2],
@@ -429,6 +430,8 @@ def run() -> int:
         streaming = False
     elif args.config == 6:
         K = 31                      # SURVEY 8d "G-hbm": one uniform-random sequence, an image far beyond the Infinity Cache
+        if args.hbm_k:              # (--hbm-k 32: the two-level tables of 31 < k <= 63 at that size; the GPU builder's keys fit 64 bits up to 32)
+            K = args.hbm_k
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the search path has no CPU fallback")

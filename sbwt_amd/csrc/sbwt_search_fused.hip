@@ -315,9 +315,11 @@ __global__ void __launch_bounds__(256, SORT ? FZ_SORT_WGS : 5) k_search_fused(Sb
     int nseg = 0, i0 = 0, last_start = 0;           // segments listed; first result of the read not written yet
     unsigned sort_spins = 0;        // SORT, wave-uniform: iterations this wave found nothing to do in
     unsigned sort_waits = 0;        // ... and times in a row it has waited for more of its lanes to have work
+#ifdef SBWT_SORT_COUNTERS           // (tools/build_variant_lib.sh sortcnt -DSBWT_SORT_COUNTERS=1; tools/ab_step.py prints them)
     unsigned c_iter = 0;            // SORT, wave-uniform: iterations with a gather, and the busy lanes in them (ws->pad[11..14])
     unsigned long long c_busy = 0;
     unsigned c_lists = 0, c_part = 0;       // SORT, wave-uniform: lists written, and those of them that were not a read's last (ws->pad[9], pad[10])
+#endif
     const int sort_thr = (SORT && (ix.fused_sort & 255) > 1) ? ((ix.fused_sort & 255) < 64 ? (ix.fused_sort & 255) : 64) : 0;    // "fused_sort" & 255 = n > 1: that many busy lanes
     const int sort_ship = SORT ? ((ix.fused_sort >> 8) & 15) : 0;    // "fused_sort" >> 8: of eight follower lanes, those whose finished reads the searchers write
     u64 fm_pend = 0;                // wave-uniform: lanes whose segment list waits for the writer (handed over at the end of an iteration)
@@ -396,7 +398,7 @@ __global__ void __launch_bounds__(256, SORT ? FZ_SORT_WGS : 5) k_search_fused(Sb
         for (int off = 32; off > 0; off >>= 1) { e += __shfl_down(e, off); eb += __shfl_down(eb, off); }
         if (lane == 0) { if (e) atomicAdd(&ws->n_ext, e); if (eb) atomicAdd(&ws->n_bridge, eb); }
     }
-#ifndef SBWT_STATS
+#if defined(SBWT_SORT_COUNTERS) && !defined(SBWT_STATS)
     if (SORT && lane == 0) {
         // (what a wave class's iterations cost: their number and the busy lanes in them; tools/ab_step.py prints the ratio)
         atomicAdd(&ws->pad[follower_wave ? 13 : 11], (unsigned long long)c_iter);

@@ -4,7 +4,7 @@ TAG=$1; R=${2:-r04}; S=gpurun_out/final_$TAG
 for f in c2_bench.json c2_bench_under_rocprof.json c2_level1.json c2_level1_rocprof_summary.txt c2_level2.json c2_level2_rocprof_summary.txt \
          c2_line.json c2_rocprof_summary.txt c3_bench.json c3_bench_under_rocprof.json c3_line.json c3_rocprof_summary.txt \
          c5_bench.json c5_bench_under_rocprof.json c5_line.json c5_rocprof_summary.txt robustness.jsonl batch_size.txt knob_sweep.log \
-         lane_stats.txt timeline.txt two_in_flight.txt c6_hbm_bench.json c6_big_index_bench.json ab_prev_round.txt; do
+         lane_stats.txt timeline.txt two_in_flight.txt c6_hbm_bench.json c6_big_index_bench.json c6_big_index_k32.json long_reads.txt ab_prev_round.txt; do
   cp $S/$f profiles/${R}_$f
 done
 ( grep -E "passed|failed" $S/gputest.log | tail -2; tail -4 $S/gputest.log ) > profiles/${R}_gputest_tail.txt

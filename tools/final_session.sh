@@ -5,7 +5,7 @@
 #   part 1: the -m gpu suite, fuzz, bench lines, rocprofv3 kernel traces + PMC passes, the committed lines
 #   part 2: robustness and batch-size rows, knob sweep, instrumented builds, two batches in flight, the 10^9- and 2.25 x 10^9-column
 #           indexes, this round's library against last round's (sbwt_amd/lib/lib_prev.so, tools/build_rev_lib.sh)
-TAG=${1:-r05}
+TAG=${1:-r06}
 PART=${2:-all}
 O=gpurun_out/final_$TAG
 mkdir -p $O
@@ -72,6 +72,11 @@ fi
 # the indexes beyond the Infinity Cache and beyond 2^31 columns (SURVEY 8d "G-hbm")
 timeout 900 python bench.py --config 6 --steps 5 --warmup 1 --no-end-to-end > $O/c6_hbm_bench.json 2> $O/c6_hbm_bench.err
 timeout 1200 python bench.py --config 6 --hbm-genome-len 2250000000 --steps 5 --warmup 1 --no-end-to-end > $O/c6_big_index_bench.json 2> $O/c6_big_index_bench.err
+# ... and 31 < k <= 63 there (round 6: the full image; k = 32 is what the GPU builder's 64-bit keys hold at that size)
+timeout 1200 python bench.py --config 6 --hbm-genome-len 2250000000 --hbm-k 32 --steps 5 --warmup 1 --no-end-to-end --no-cpu-baseline > $O/c6_big_index_k32.json 2> $O/c6_big_index_k32.err
+# long reads (round 6: the fused kernel's ticket table): whole genomes, 1 kbp and 10 kbp reads, >= 10^9 bases per batch, k = 30 and 63,
+# 1 % and 5 % substitutions, with the table and without (the general kernel)
+( for K in 30 63; do for SUBS in 0.01 0.05; do K=$K SUBS=$SUBS timeout 600 python tools/long_read_bench.py 2>&1 | grep "^k="; done; done ) > $O/long_reads.txt 2>&1
 # this round's library against last round's, interleaved on this box (configs 2, 3's index type, 5)
 if [ -f sbwt_amd/lib/lib_prev.so ]; then
   ( ROUNDS=5 bash tools/ab_libs5.sh "sbwt_amd/lib/lib_prev.so sbwt_amd/lib/libsbwtgpu.so" 2 | sed "s/^/c2 /"
