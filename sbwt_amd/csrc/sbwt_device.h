@@ -169,8 +169,16 @@ struct SbwtWorkHeader {
     // tickets of <= 160 bases listed in a table -- how many there are, and whether the table was too small for them
     unsigned long long n_ftick;
     unsigned long long ftick_over;
-    unsigned long long pad2[6];
+    unsigned long long pad2[5];
+    // Which instantiation of the fused kernel suits the caller's batches (k <= 31): the LAST word of the header is not cleared
+    // with it (SBWT_WS_CLEAR_BYTES) -- it is what the call before on this workspace left there.  SBWT_HINT_MAGIC | 1: that call's
+    // reads followed their paths for at least SBWT_HINT_RATIO k-mers per search started, the work mix the SORT instantiation is
+    // faster on (by 3-14 %; on batches that mostly search -- unrelated reads, 5 % substitutions -- it is a third slower: half
+    // of its waves only follow paths).  Anything else (a fresh workspace): the unsorted kernel.  Both are launched; the one
+    // whose call it is not returns at once.
+    unsigned long long hint;
 };
+#define SBWT_WS_CLEAR_BYTES (sizeof(SbwtWorkHeader) - 8)
 
 // Long reads on the device.  One lane walks one read, so a read of more than 2 * piece k-mers is cut into pieces of
 // about `piece` k-mers (128 for small batches, so that a few genomes fill the chip, .. SBWT_PIECE for large ones, so that
@@ -197,6 +205,8 @@ struct SbwtTickTab {
     unsigned *defer_bits = nullptr;
     long long cap = 0;              // entries
 };
+#define SBWT_HINT_MAGIC 0x5B377A00u
+#define SBWT_HINT_RATIO 12
 
 // launchers implemented in sbwt_search.hip, sbwt_api_kernels.hip, sbwt_derived.hip, sbwt_format.hip (all asynchronous on `stream`)
 void sbwt_launch_encode(const char *d_bases, long long total_bases, uint4 *d_packed, SbwtWorkHeader *ws,

@@ -239,6 +239,8 @@ __device__ __forceinline__ u64 fz_encode32(const unsigned w[8], const unsigned t
 #define FZ_SORT_WGS 4
 #endif
 template <bool WIDE, bool O32, bool BIG = false, bool UNI = false, bool SORT = false>
+// (measured and dropped: the k > 31 instantiation for batches of mixed lengths with 128 VGPRs / four workgroups per CU instead of its two
+// spilled registers: ragged reads 3.82 -> 4.12 ms, 1 kbp reads 186 -> 169 G k-mers/s)
 __global__ void __launch_bounds__(256, SORT ? FZ_SORT_WGS : 5) k_search_fused(SbwtIndexView ix, const unsigned char *__restrict__ bases,
                                                           i64 total_bases, i64 *__restrict__ out, i64 n_reads,
                                                           SbwtWorkHeader *ws, unsigned *__restrict__ defer_list,
@@ -258,7 +260,7 @@ __global__ void __launch_bounds__(256, SORT ? FZ_SORT_WGS : 5) k_search_fused(Sb
     // pointer -- or to a volatile __shared__ array -- is compiled to flat_load / flat_store "sc0 sc1", which count on vmcnt as well:
     // a wait for the writer's stores at every look at a ring)
     __shared__ unsigned short q_ring[SORT ? 2 : 1][SORT ? FZ_RING : 1];   // the rings: [0] to the searchers, [1] to the followers; slot + 1, 0 = not written yet
-    __shared__ unsigned q_ctl[8];                           // [0], [1] places handed out in ring 0 / 1; [2], [3] entries written; [4] reads in flight; [5] searcher waves drained
+    __shared__ unsigned q_ctl[8];                           // [0], [1] places handed out in ring 0 / 1; [2], [3] entries written; [4] reads in flight; [5] searcher waves drained; [6] iterations with work (progress)
     const int fmode = sbwt_fused_mode(ws, ix.k);
     if (fmode == 0) return;                                 // the general route does it all
     const int P_batch = sbwt_fused_pieces(ws, ix.k);
@@ -268,6 +270,11 @@ __global__ void __launch_bounds__(256, SORT ? FZ_SORT_WGS : 5) k_search_fused(Sb
     // ticket is a read of its own -- where its bases are, where its results go -- and `rd` is the ticket's number
     const bool table = !UNI && fmode == 3 && tt.tick != nullptr;
     if (!UNI && fmode == 3 && !table) return;
+    if (!WIDE && !BIG && ix.fused_sort > 0) {
+        // the sorted or the unsorted instantiation?  "fused_sort" bit 12: always the sorted one; else by the hint the call before left
+        const bool sorted_call = (ix.fused_sort & 4096) || ws->hint == (unsigned long long)(SBWT_HINT_MAGIC | 1u);
+        if (SORT != sorted_call) return;
+    } else if (SORT) return;
     const int tid = threadIdx.x, lane = tid & 63, wbase = tid & ~63;
     const bool follower_wave = SORT && __builtin_amdgcn_readfirstlane(tid) >= 128;     // a path-follower wave (wave-uniform, in a scalar register)
     int slot = SORT ? (follower_wave ? -1 : tid) : tid;     // SORT: the slot this lane holds; -1: none; <= -2: none, and the lane holds
@@ -314,6 +321,7 @@ __global__ void __launch_bounds__(256, SORT ? FZ_SORT_WGS : 5) k_search_fused(Sb
 
     int nseg = 0, i0 = 0, last_start = 0;           // segments listed; first result of the read not written yet
     unsigned sort_spins = 0;        // SORT, wave-uniform: iterations this wave found nothing to do in
+    unsigned sort_seen = 0;         // ... the workgroup's progress counter (q_ctl[6]) when it last looked
     unsigned sort_waits = 0;        // ... and times in a row it has waited for more of its lanes to have work
 #ifdef SBWT_SORT_COUNTERS           // (tools/build_variant_lib.sh sortcnt -DSBWT_SORT_COUNTERS=1; tools/ab_step.py prints them)
     unsigned c_iter = 0;            // SORT, wave-uniform: iterations with a gather, and the busy lanes in them (ws->pad[11..14])
@@ -465,6 +473,13 @@ __global__ void __launch_bounds__(256) k_fused_tickets(const i64 *__restrict__ r
     }
 }
 
+// The hint for the next call on this workspace (SbwtWorkHeader::hint): did this call's reads mostly follow their paths?
+__global__ void k_fused_hint(SbwtWorkHeader *ws, int k) {
+    if (threadIdx.x != 0 || sbwt_fused_mode(ws, k) == 0) return;          // (the general route took the batch: nothing learnt)
+    const unsigned long long ext = ws->n_ext, walks = ws->n_search;
+    ws->hint = (unsigned long long)(SBWT_HINT_MAGIC | ((walks > 0 && ext >= (unsigned long long)SBWT_HINT_RATIO * walks) ? 1u : 0u));
+}
+
 // Do all reads have one length and all result ranges one stride?  Thread 0 also notes the first offsets.
 __global__ void __launch_bounds__(256) k_check_uniform2(const i64 *__restrict__ read_off, const i64 *__restrict__ out_off,
                                                         i64 n_reads, SbwtWorkHeader *ws, int k, SbwtPieceTab pt,
@@ -515,8 +530,8 @@ void sbwt_launch_search_fused(const SbwtIndexView &ix, const char *d_bases, long
     else if (total_bases < 250000000ll) cap = 896u;
     else if (total_bases < 500000000ll) cap = 1024u;
     const bool sorted = !ix.big && !(ix.n_nodes >= ((i64)1 << 31) - 64) && !((ix.stab2 != nullptr && ix.p_sparse < ix.k) || (ix.debug & 64)) && ix.fused_sort > 0;
-    if (sorted && cap > 256u * FZ_SORT_WGS) cap = 256u * FZ_SORT_WGS;      // (the SORT instantiation: four workgroups per CU)
-    const unsigned g = (unsigned)(want < (i64)cap ? want : (i64)cap);
+    const unsigned cap_s = cap > 256u * FZ_SORT_WGS ? 256u * FZ_SORT_WGS : cap;      // (the SORT instantiation: four workgroups per CU)
+    const unsigned g = (unsigned)(want < (i64)cap ? want : (i64)cap), g_s = (unsigned)(want < (i64)cap_s ? want : (i64)cap_s);
     if (ev_begin) (void)hipEventRecord(ev_begin, stream);
     // (k > 31: whole k-mers in the two-level table; "debug" bit 64: the wide walk for every k -- experiments and the fuzzer)
     const bool wide = (ix.stab2 != nullptr && ix.p_sparse < ix.k) || (ix.debug & 64);
@@ -526,21 +541,27 @@ void sbwt_launch_search_fused(const SbwtIndexView &ix, const char *d_bases, long
                                            reinterpret_cast<const unsigned char *>(d_bases), (i64)total_bases, d_out, (i64)n_reads, ws, d_defer, \
                                            d_read_off, d_out_off, tt)
 #define FZ_LAUNCH(W, O, B) do { FZ_LAUNCH1(W, O, B, true); FZ_LAUNCH1(W, O, B, false); } while (0)
-#define FZ_LAUNCH_S(O) do { hipLaunchKernelGGL((k_search_fused<false, O, false, true, true>), dim3(g), dim3(256), 0, stream, ix, \
+#define FZ_LAUNCH_S(O) do { hipLaunchKernelGGL((k_search_fused<false, O, false, true, true>), dim3(g_s), dim3(256), 0, stream, ix, \
                                            reinterpret_cast<const unsigned char *>(d_bases), (i64)total_bases, d_out, (i64)n_reads, ws, d_defer, \
                                            d_read_off, d_out_off, tt); \
-                            hipLaunchKernelGGL((k_search_fused<false, O, false, false, true>), dim3(g), dim3(256), 0, stream, ix, \
+                            hipLaunchKernelGGL((k_search_fused<false, O, false, false, true>), dim3(g_s), dim3(256), 0, stream, ix, \
                                            reinterpret_cast<const unsigned char *>(d_bases), (i64)total_bases, d_out, (i64)n_reads, ws, d_defer, \
                                            d_read_off, d_out_off, tt); } while (0)
     const bool big = ix.big || ix.n_nodes >= ((i64)1 << 31) - 64;     // (the C ABI sends such an index here only with int64 results)
     if (big) { if (wide) FZ_LAUNCH(true, false, true); else FZ_LAUNCH(false, false, true); }
     else if (wide) { if (ix.out32) FZ_LAUNCH(true, true, false); else FZ_LAUNCH(true, false, false); }
-    else if (ix.fused_sort > 0) { if (ix.out32) FZ_LAUNCH_S(true); else FZ_LAUNCH_S(false); }      // lanes sorted by state (k <= 31)
-    else      { if (ix.out32) FZ_LAUNCH(false, true, false); else FZ_LAUNCH(false, false, false); }
+    else {
+        // k <= 31: the unsorted instantiations and (when "fused_sort" is on) the sorted ones; each returns at once from a call that is
+        // the other's (the hint at the end of the workspace, SbwtTickTab::hint)
+        if (ix.out32) FZ_LAUNCH(false, true, false); else FZ_LAUNCH(false, false, false);
+        if (sorted) { if (ix.out32) FZ_LAUNCH_S(true); else FZ_LAUNCH_S(false); }
+    }
 #undef FZ_LAUNCH_S
 #undef FZ_LAUNCH
 #undef FZ_LAUNCH1
     if (ev_end) (void)hipEventRecord(ev_end, stream);
+    // what this call's work mix says about the next call's kernel
+    if (sorted) hipLaunchKernelGGL(k_fused_hint, dim3(1), dim3(64), 0, stream, ws, ix.k);
     // what the fused kernel did not take: everything when the reads are not of one length, else the reads it handed on
     sbwt_launch_encode_chained(d_bases, total_bases, d_packed, ws, d_defer, d_read_off, ix.k, stream);
     sbwt_launch_piece_bounds_tt(d_packed, d_read_off, d_out_off, ix.k, ws, pt, 1, stream, tt.defer_bits);

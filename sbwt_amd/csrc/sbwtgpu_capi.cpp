@@ -1133,7 +1133,9 @@ static int search_dev_common(const sbwtgpu_index *idx, const char *d_bases, int6
             DeviceGuard guard(idx->device);
             hipStream_t st = static_cast<hipStream_t>(stream);
             SbwtWorkHeader *ws = static_cast<SbwtWorkHeader *>(d_ws);
-            HIP_TRY(hipMemsetAsync(ws, 0, sizeof(SbwtWorkHeader), st));
+            // (all but the header's last word: the hint the call before left for this one, SbwtWorkHeader::hint -- the only
+            // part of a workspace that is read before it is written)
+            HIP_TRY(hipMemsetAsync(ws, 0, SBWT_WS_CLEAR_BYTES, st));
             if (g_poison) {
                 int64_t ends[2] = {0, 0};
                 HIP_TRY(hipMemcpyAsync(&ends[0], d_out_off, 8, hipMemcpyDeviceToHost, st));
@@ -1149,6 +1151,8 @@ static int search_dev_common(const sbwtgpu_index *idx, const char *d_bases, int6
             const SbwtTickTab tt_of_call = ws_tick_tab(d_ws, total_bases);
             // (the bits of the reads handed on: cleared with the header)
             HIP_TRY(hipMemsetAsync(tt_of_call.defer_bits, 0, (size_t)(total_bases / 256 + 64), st));
+            SbwtTickTab tt_for_launch = tt_of_call;
+            if (!(g_fused_table && g_fused_ragged && n_reads <= total_bases / 32)) { tt_for_launch.tick = nullptr; tt_for_launch.tick_read = nullptr; }
             hipEvent_t e0 = nullptr, e1 = nullptr;
             if (g_kernel_events) {
                 const int slot = (int)(g_ev_count % EV_RING);
@@ -1167,7 +1171,7 @@ static int search_dev_common(const sbwtgpu_index *idx, const char *d_bases, int6
                                      ((g_fused_ragged && n_reads <= total_bases / 32) ? 1 : 0) |
                                          ((g_fused_pieces > 0 ? g_fused_pieces : 3) << 8),
                                      // (the ticket table of batches with many long reads; "fused_table" 0 switches it off)
-                                     (g_fused_table && g_fused_ragged && n_reads <= total_bases / 32) ? tt_of_call : SbwtTickTab());
+                                     tt_for_launch);
             hipError_t e = hipGetLastError();
             if (e != hipSuccess) return fail(SBWTGPU_ERR_HIP, "kernel launch: %s", hipGetErrorString(e));
             return SBWTGPU_OK;

@@ -842,6 +842,68 @@ def test_long_reads_through_the_fused_kernels_ticket_table(gpu, k):
     assert np.array_equal(_search_dev(idx, cb, co, k, True), oracle_batch(orc, cb, co, True))
 
 
+@pytest.mark.parametrize("k", [20, 31])
+def test_sorted_instantiation_and_the_hint_that_picks_it(gpu, k):
+    """Round 6: `k_search_fused<..., SORT>` (lanes sorted by state: searcher waves and path-follower waves, reads handed over
+    through LDS slots and rings).  "fused_sort" | 4096 runs it whatever the workspace says: reads that follow their paths, reads
+    of unrelated sequence (the followers have nothing to do for the whole launch), 8 % substitutions, ragged lengths, pieces, tiny
+    batches (fewer reads than one wave; one read) -- against the oracle and the unsorted kernel.  As shipped the instantiation is
+    picked by the hint the call before left in the workspace's header: a second call on the same workspace with reads that
+    follow their paths runs sorted, one with unrelated reads unsorted again -- with the same results either way."""
+    import torch
+    genomes = [synth.random_genome(120_000, 51)]
+    genomes.append(synth.mutate(genomes[0], 0.04, 52))
+    orc = OracleIndex.build([g.tobytes() for g in genomes], k, True, False, 4)
+    idx = gpu_index_from_oracle(orc)
+    batches = []
+    batches.append(synth.sample_reads(genomes, 3000, 150, 0.01, 1))
+    batches.append(synth.sample_reads(genomes, 3000, 150, 0.08, 2))
+    batches.append(synth.random_reads(2000, 150, 3))
+    batches.append(synth.ragged_reads(genomes, 2500, 10, 160, 0.02, 4))
+    batches.append(synth.sample_reads(genomes, 1200, 300, 0.01, 5))
+    batches.append(synth.sample_reads(genomes, 40, 150, 0.01, 6))
+    batches.append(synth.sample_reads(genomes, 1, 150, 0.0, 7))
+    nb, no = synth.sample_reads(genomes, 2000, 150, 0.01, 8)
+    batches.append((synth.inject(nb, 50, ord("N"), 9), no))
+    try:
+        for bi, (bases, off) in enumerate(batches):
+            want = oracle_batch(orc, bases, off, True)
+            for fs in (7728, 4097, 6192, 0):
+                capi.set_tuning("fused_sort", fs)
+                assert np.array_equal(_search_dev(idx, bases, off, k, True), want), (k, bi, fs)
+                assert np.array_equal(idx.streaming_search(bases, off)[0], want), (k, bi, fs)
+            capi.set_tuning("fused_sort", 7728)
+            assert np.array_equal(idx.search_i32(bases, off)[0].astype(np.int64), want), (k, bi)
+    finally:
+        capi.set_tuning("fused_sort", 3632)
+    # the hint: one workspace, three calls
+    dev = torch.device("cuda:0")
+    a_b, a_o = synth.sample_reads(genomes, 3000, 150, 0.002, 11)      # (few substitutions: > 12 k-mers along paths per search started)
+    r_b, r_o = batches[2]
+    nmax = max(len(a_b), len(r_b))
+    wsb = capi.search_workspace_bytes(nmax)
+    d_ws = torch.zeros(wsb, dtype=torch.uint8, device=dev)
+
+    def call(bases, off):
+        oo = capi.out_offsets(off, k)
+        d_b = torch.from_numpy(np.ascontiguousarray(bases)).to(dev)
+        d_ro, d_oo = torch.from_numpy(off.astype(np.int64)).to(dev), torch.from_numpy(oo).to(dev)
+        d_out = torch.full((int(oo[-1]),), -7, dtype=torch.int64, device=dev)
+        idx.streaming_search_dev(d_b.data_ptr(), d_b.numel(), d_ro.data_ptr(), len(off) - 1, d_out.data_ptr(), d_oo.data_ptr(),
+                                 d_ws.data_ptr(), wsb, torch.cuda.current_stream().cuda_stream, True)
+        torch.cuda.synchronize()
+        return d_out.cpu().numpy(), int(d_ws[312:316].view(torch.int32).item()) & 0xFFFFFFFF      # (SbwtWorkHeader::hint: the header's last word)
+    w_a, w_r = oracle_batch(orc, a_b, a_o, True), oracle_batch(orc, r_b, r_o, True)
+    got, hint = call(a_b, a_o)                       # a fresh workspace: the unsorted kernel; its reads follow their paths
+    assert np.array_equal(got, w_a) and hint == 0x5B377A01, hex(hint)
+    got, hint = call(a_b, a_o)                       # ... so this call runs sorted, and says the same of the next
+    assert np.array_equal(got, w_a) and hint == 0x5B377A01, hex(hint)
+    got, hint = call(r_b, r_o)                       # unrelated reads, sorted once; the hint turns
+    assert np.array_equal(got, w_r) and hint == 0x5B377A00, hex(hint)
+    got, hint = call(r_b, r_o)
+    assert np.array_equal(got, w_r) and hint == 0x5B377A00, hex(hint)
+
+
 def _search_dev(idx, bases, off, k, streaming):
     import torch
     dev = torch.device("cuda:0")

@@ -33,7 +33,12 @@ else:
 idx = capi.Index.create(bits.cols[0], bits.cols[1], bits.cols[2], bits.cols[3], bits.ssup, bits.n_nodes, K, bits.n_kmers, 8)
 print("index: n_nodes", idx.n_nodes, "image MB", idx.blob_bytes / 1e6, "B/col", idx.blob_bytes / idx.n_nodes, "paths", idx.n_paths,
       "branching", idx.n_branch, flush=True)
+if os.environ.get("SUBS"):          # SUBS=0.0 / 0.05: the reads' substitution rate (default: bench.py's 1 %)
+    B.SUB_RATE = float(os.environ["SUBS"])
 d_bases = B.gpu_reads(genomes, n_reads, 42, dev, in_genome_order=bool(os.environ.get("SORTED")))
+if os.environ.get("ABSENT"):        # ABSENT=1: uniform-random reads (nothing of them is in the index: searches only, no path is followed)
+    g = torch.Generator(device=dev); g.manual_seed(9)
+    d_bases = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)[torch.randint(0, 4, (n_reads * L,), device=dev, generator=g)]
 m = L - K + 1
 d_roff = torch.arange(n_reads + 1, dtype=torch.int64, device=dev) * L
 d_ooff = torch.arange(n_reads + 1, dtype=torch.int64, device=dev) * m
@@ -80,8 +85,10 @@ capi.set_tuning("kernel_events", 1)
 for rnd in range(rounds + 1):
     for c in configs:
         capi.set_tuning("search_variant", c[0]); capi.set_tuning("debug", c[1] if len(c) > 1 else 0)
+        # (third entry: "fused_sort" -- 0 the unsorted kernel, 7728 = 3632 | 4096 the sorted one whatever the workspace's hint says,
+        # 3632 as shipped: by the hint the call before left; without a third entry the library's default, 3632)
         try:
-            capi.set_tuning("fused_sort", c[2] if len(c) > 2 else 0)   # (third entry: the fused kernel with its lanes sorted by state)
+            capi.set_tuning("fused_sort", c[2] if len(c) > 2 else 3632)
         except capi.SbwtGpuError:
             pass                                                       # (a library of an earlier round)
         if rnd == 0:

@@ -135,9 +135,10 @@ def _fuzz(budget, seed, max_cases):
             capi.set_tuning("debug", (int(rng.choice([0, 0, 32, 64])) | int(rng.choice([0, 128])) |
                                       (int(rng.choice([0, 0, 1, 3, 40, 1280])) << 8)) if v == 5 else 0)
             capi.set_tuning("fused_pieces", int(rng.choice([-1, 1, 2, 3])) if v == 5 else -1)
-            # the fused kernel with its lanes sorted by state (k <= 31): off / no waiting, no shipping / waves wait for 48 busy lanes,
-            # two finished reads in eight written by the searchers / ... by the followers' load (the default) / every one shipped
-            capi.set_tuning("fused_sort", int(rng.choice([0, 1, 560, 3632, 3632, 2096, 2352])) if v == 5 else 0)
+            # the fused kernel with its lanes sorted by state (k <= 31; + 4096: always, whatever the workspace's hint says): off / no
+            # waiting, no shipping / waves wait for 48 busy lanes, two finished reads in eight written by the searchers / ... by the
+            # followers' load / every one shipped / as shipped: by the hint the call before left in the workspace
+            capi.set_tuning("fused_sort", int(rng.choice([0, 4097, 4656, 7728, 7728, 6192, 6448, 3632])) if v == 5 else 0)
             # the ticket table for batches with many long reads (round 6): on, as shipped / off (the general kernel takes them)
             capi.set_tuning("fused_table", int(rng.choice([1, 1, 1, 0])))
             a = idx.streaming_search(bases, off)[0] if ssup else None
