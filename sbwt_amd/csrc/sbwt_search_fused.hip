@@ -238,7 +238,10 @@ __device__ __forceinline__ u64 fz_encode32(const unsigned w[8], const unsigned t
 #define FZ_RING 512
 #define FZ_SORT_WGS 4
 #endif
-template <bool WIDE, bool O32, bool BIG = false, bool UNI = false, bool SORT = false>
+// TAB (round 6): the instantiation for batches that are cut into a ticket table (fused mode 3; a !UNI one).  Its own instantiation
+// because the table's code in the refill cost the batches of mixed lengths and of pieces 2-3 % (ragged 80-150: 4.05 -> 4.12 ms,
+// 250 bp reads 5.66 -> 5.84) -- three kernels are launched per call now, two of which return at once.
+template <bool WIDE, bool O32, bool BIG = false, bool UNI = false, bool SORT = false, bool TAB = false>
 // (measured and dropped: the k > 31 instantiation for batches of mixed lengths with 128 VGPRs / four workgroups per CU instead of its two
 // spilled registers: ragged reads 3.82 -> 4.12 ms, 1 kbp reads 186 -> 169 G k-mers/s)
 __global__ void __launch_bounds__(256, SORT ? FZ_SORT_WGS : 5) k_search_fused(SbwtIndexView ix, const unsigned char *__restrict__ bases,
@@ -268,11 +271,14 @@ __global__ void __launch_bounds__(256, SORT ? FZ_SORT_WGS : 5) k_search_fused(Sb
     const bool ragged = !UNI && fmode == 2;                 // reads of any lengths: offsets fetched with every refill
     // (round 6) reads of any lengths, many of them long: the batch as a TABLE of tickets of <= 160 bases (k_fused_tickets): a
     // ticket is a read of its own -- where its bases are, where its results go -- and `rd` is the ticket's number
-    const bool table = !UNI && fmode == 3 && tt.tick != nullptr;
-    if (!UNI && fmode == 3 && !table) return;
+    static_assert(!TAB || !UNI, "the ticket table's instantiation is a general one");
+    const bool table = TAB && fmode == 3 && tt.tick != nullptr;
+    if (TAB != (fmode == 3)) return;                        // (a table batch is the TAB instantiation's, and nothing else is)
     if (!WIDE && !BIG && ix.fused_sort > 0) {
         // the sorted or the unsorted instantiation?  "fused_sort" bit 12: always the sorted one; else by the hint the call before left
-        const bool sorted_call = (ix.fused_sort & 4096) || ws->hint == (unsigned long long)(SBWT_HINT_MAGIC | 1u);
+        // (not for batches of pieces -- reads of 161 .. 480 bases as two or three tickets each: measured 5 % slower sorted)
+        const bool sorted_call = (ix.fused_sort & 4096) ||
+                                 (ws->hint == (unsigned long long)(SBWT_HINT_MAGIC | 1u) && (UNI || TAB || P_batch == 1));
         if (SORT != sorted_call) return;
     } else if (SORT) return;
     const int tid = threadIdx.x, lane = tid & 63, wbase = tid & ~63;
@@ -540,11 +546,17 @@ void sbwt_launch_search_fused(const SbwtIndexView &ix, const char *d_bases, long
 #define FZ_LAUNCH1(W, O, B, U) hipLaunchKernelGGL((k_search_fused<W, O, B, U>), dim3(g), dim3(256), 0, stream, ix, \
                                            reinterpret_cast<const unsigned char *>(d_bases), (i64)total_bases, d_out, (i64)n_reads, ws, d_defer, \
                                            d_read_off, d_out_off, tt)
-#define FZ_LAUNCH(W, O, B) do { FZ_LAUNCH1(W, O, B, true); FZ_LAUNCH1(W, O, B, false); } while (0)
+#define FZ_LAUNCH(W, O, B) do { FZ_LAUNCH1(W, O, B, true); FZ_LAUNCH1(W, O, B, false); \
+                                if (tt.tick) hipLaunchKernelGGL((k_search_fused<W, O, B, false, false, true>), dim3(g), dim3(256), 0, stream, ix, \
+                                           reinterpret_cast<const unsigned char *>(d_bases), (i64)total_bases, d_out, (i64)n_reads, ws, d_defer, \
+                                           d_read_off, d_out_off, tt); } while (0)
 #define FZ_LAUNCH_S(O) do { hipLaunchKernelGGL((k_search_fused<false, O, false, true, true>), dim3(g_s), dim3(256), 0, stream, ix, \
                                            reinterpret_cast<const unsigned char *>(d_bases), (i64)total_bases, d_out, (i64)n_reads, ws, d_defer, \
                                            d_read_off, d_out_off, tt); \
                             hipLaunchKernelGGL((k_search_fused<false, O, false, false, true>), dim3(g_s), dim3(256), 0, stream, ix, \
+                                           reinterpret_cast<const unsigned char *>(d_bases), (i64)total_bases, d_out, (i64)n_reads, ws, d_defer, \
+                                           d_read_off, d_out_off, tt); \
+                            if (tt.tick) hipLaunchKernelGGL((k_search_fused<false, O, false, false, true, true>), dim3(g_s), dim3(256), 0, stream, ix, \
                                            reinterpret_cast<const unsigned char *>(d_bases), (i64)total_bases, d_out, (i64)n_reads, ws, d_defer, \
                                            d_read_off, d_out_off, tt); } while (0)
     const bool big = ix.big || ix.n_nodes >= ((i64)1 << 31) - 64;     // (the C ABI sends such an index here only with int64 results)

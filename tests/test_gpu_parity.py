@@ -639,11 +639,12 @@ def test_the_layout_of_2_pow_31_columns_on_a_small_index(gpu, k):
         idx = gpu_index_from_oracle(orc)
     finally:
         capi.set_tuning("big_path", 1)
-    assert idx.image_level == 0 and idx.default_search_variant == 5
     plain = gpu_index_from_oracle(orc)
-    import struct
-    # (SbwtBlobHeader::big_layout is the int32 at byte 160 of the exported header)
-    assert struct.unpack_from("<i", idx.export_header(), 160)[0] == 1 and struct.unpack_from("<i", plain.export_header(), 160)[0] == 0
+    if int(os.environ.get("SBWTGPU_IMAGE_LEVEL", "0")) == 0:          # (the knob sweep of tools/final_session.sh forces levels 1 and 2)
+        assert idx.image_level == 0 and idx.default_search_variant == 5
+        import struct
+        # (SbwtBlobHeader::big_layout is the int32 at byte 160 of the exported header)
+        assert struct.unpack_from("<i", idx.export_header(), 160)[0] == 1 and struct.unpack_from("<i", plain.export_header(), 160)[0] == 0
     for (nr, L, seed) in ((1500, 150, 5), (600, 250, 6)):
         bases, off = synth.sample_reads(genomes, nr, L, 0.015, seed + k)
         bases = synth.inject(bases, 40, ord("N"), 3)
@@ -876,6 +877,8 @@ def test_sorted_instantiation_and_the_hint_that_picks_it(gpu, k):
             assert np.array_equal(idx.search_i32(bases, off)[0].astype(np.int64), want), (k, bi)
     finally:
         capi.set_tuning("fused_sort", 3632)
+    if int(os.environ.get("SBWTGPU_IMAGE_LEVEL", "0")) != 0 or idx.image_level != 0:
+        return                      # (no path order: the fused route, and with it the hint, is not in play)
     # the hint: one workspace, three calls
     dev = torch.device("cuda:0")
     a_b, a_o = synth.sample_reads(genomes, 3000, 150, 0.002, 11)      # (few substitutions: > 12 k-mers along paths per search started)
