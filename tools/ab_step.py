@@ -88,7 +88,7 @@ for rnd in range(rounds + 1):
         # (third entry: "fused_sort" -- 0 the unsorted kernel, 7728 = 3632 | 4096 the sorted one whatever the workspace's hint says,
         # 3632 as shipped: by the hint the call before left; without a third entry the library's default, 3632)
         try:
-            capi.set_tuning("fused_sort", c[2] if len(c) > 2 else 3632)
+            capi.set_tuning("fused_sort", c[2] if len(c) > 2 else int(os.environ.get("SBWTGPU_FUSED_SORT", 3632)))
         except capi.SbwtGpuError:
             pass                                                       # (a library of an earlier round)
         if rnd == 0:
@@ -121,5 +121,5 @@ for c, v in times.items():
     kt = ktimes[c]
     if os.environ.get("PRINT_ALL"):      # the steps in order: does the box slow down while it runs?
         print("steps ms:", " ".join("%.2f" % x for x in v))
-    print(f"variant={c[0]} debug={c[1] if len(c) > 1 else 0} sort={c[2] if len(c) > 2 else "default"}: step median {np.median(v):.3f} ms min {min(v):.3f} ms -> "
+    print(f"variant={c[0]} debug={c[1] if len(c) > 1 else 0} sort={c[2] if len(c) > 2 else 'default'}: step median {np.median(v):.3f} ms min {min(v):.3f} ms -> "
           f"{n_kmers / np.median(v) / 1e6:.2f} G kmers/s" + (f"; fused kernel median {np.median(kt):.3f} ms" if kt else ""))

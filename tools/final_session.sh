@@ -64,7 +64,8 @@ if [ -f sbwt_amd/lib/lib_stats.so ]; then
 fi
 if [ -f sbwt_amd/lib/lib_timeline.so ]; then
   ( export SBWTGPU_LIB=$PWD/sbwt_amd/lib/lib_timeline.so
-    for n in 10000000 1000000; do NREADS=$n python tools/timeline_fused.py 2>&1 | grep -v "^config\|^index\|amdgpu.ids"; done ) > $O/timeline.txt 2>&1
+    echo "(the unsorted instantiation, SBWTGPU_FUSED_SORT=0: follower waves of the sorted one never see the ticket counter themselves)"
+    for n in 10000000 1000000; do SBWTGPU_FUSED_SORT=0 NREADS=$n python tools/timeline_fused.py 2>&1 | grep -v "^config\|^index\|amdgpu.ids"; done ) > $O/timeline.txt 2>&1
 fi
 ( NREADS=10000000 python tools/overlap_steps.py 2>&1 | grep "^reads"
   NREADS=1000000 STEPS=50 python tools/overlap_steps.py 2>&1 | grep "^reads"
