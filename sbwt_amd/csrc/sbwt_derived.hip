@@ -3,6 +3,7 @@
 // path order with its packed chars, substitution-safe bits and transition table (DESIGN.md sections 2-3).
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include "sbwt_kernels_common.h"
 #include "sbwt_scan.h"
 
@@ -437,6 +438,7 @@ __global__ void __launch_bounds__(256) k_path_keep(i64 n, unsigned *__restrict__
     if (v >= n) return;
     const unsigned sv = succ[v];
     if (sv != PATH_NONE && prv[sv] != (unsigned)v) succ[v] = PATH_NONE;
+    if (!jb) return;                                    // (the splitter ranking below makes its own entries)
     const unsigned pv = prv[v];
     // { jump (heads point at themselves), distance to it, smallest column seen, - }: one 16-byte gather per doubling step
     jb[v] = make_uint4((pv == PATH_NONE) ? (unsigned)v : pv, (pv == PATH_NONE) ? 0u : 1u, (unsigned)v, 0u);
@@ -447,6 +449,88 @@ __global__ void __launch_bounds__(256) k_path_jump(i64 n, const uint4 *__restric
     const uint4 a = in[v], b = in[a.x];
     out[v] = make_uint4(b.x, a.y + b.y, a.z < b.z ? a.z : b.z, 0u);
     if (b.x != a.x && moved) *moved = 1;                // (every writer stores the same value)
+}
+// ---- the same { head, distance, smallest column } per column by SPLITTERS instead of doubling over every column (round 6).
+// Doubling gathers 16 bytes per column and round: log2(n) + 1 rounds when the graph is one long path (10^9 columns: 31 rounds,
+// 0.85 s of a 2.9 s image; 2.25 x 10^9 with one cycle to cut: 65 rounds, 4.0 s of 11.9).  Here the heads and one column in 64
+// (by a hash of its number) are splitters: every splitter walks to the next one (64 steps on average) and leaves there how far
+// it came and the smallest column it saw; the SPLITTERS are ranked by doubling (n / 64 of them); every splitter walks its
+// stretch again and writes the entries.  Two random reads and one random write per column instead of 31 of each.  The
+// entries of columns on open paths are those of the doubling ({ head, distance }; the third word, used for cycles only, is the
+// cycle's smallest column on cycles as there), so the path order is the same bit for bit (tests: test_gpu_derived).
+// A cycle without a splitter on it is found at the end (entries still unset) and walked by each of its columns; a walk of more
+// than RANK_LIMIT steps -- (63/64)^65536: a hash that fails the graph -- raises the flag and the doubling runs instead, as it
+// does for graphs of very short paths (more splitters than n / 8: the doubling is done after a few rounds there).
+#define RANK_SENT 0xFFFFFFFFu
+#define RANK_LIMIT (1 << 16)
+__device__ __forceinline__ bool rank_sampled(unsigned v) {
+    unsigned h = v * 0x9E3779B1u;
+    h ^= h >> 15; h *= 0x85EBCA77u; h ^= h >> 13;
+    return (h & 63u) == 0u;
+}
+__global__ void __launch_bounds__(256) k_rank_list(i64 n, const unsigned *__restrict__ prv, unsigned *__restrict__ S, u64 *m,
+                                                   uint4 *__restrict__ ja, uint4 *__restrict__ jb) {
+    const i64 v = (i64)blockIdx.x * 256 + threadIdx.x;
+    const bool in = v < n;
+    const bool head = in && prv[v] == PATH_NONE;
+    const bool spl = in && (head || rank_sampled((unsigned)v));
+    const u64 slot = block_append_n(m, spl ? 1u : 0u);
+    if (spl) S[slot] = (unsigned)v;
+    if (in) {
+        const uint4 e = head ? make_uint4((unsigned)v, 0u, (unsigned)v, 0u) : make_uint4(RANK_SENT, 0u, 0u, 0u);
+        ja[v] = e;
+        jb[v] = e;
+    }
+}
+__global__ void __launch_bounds__(256) k_rank_walk1(const u64 *__restrict__ m, const unsigned *__restrict__ S,
+                                                    const unsigned *__restrict__ succ, uint4 *ja, int *flag, unsigned limit) {
+    const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (i >= *m) return;
+    const unsigned s = S[i];
+    unsigned u = succ[s], d = 1, mn = 0xFFFFFFFFu;
+    while (u != PATH_NONE && !rank_sampled(u)) {
+        mn = u < mn ? u : mn;
+        u = succ[u];
+        if (++d > limit) { *flag = 2; return; }
+    }
+    if (u != PATH_NONE) ja[u] = make_uint4(s, d, u < mn ? u : mn, 0u);    // (a column has one predecessor: one writer)
+}
+__global__ void __launch_bounds__(256) k_rank_jump(const u64 *__restrict__ m, const unsigned *__restrict__ S,
+                                                   const uint4 *__restrict__ in, uint4 *__restrict__ out) {
+    const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (i >= *m) return;
+    const unsigned v = S[i];
+    const uint4 a = in[v];
+    if (a.x == RANK_SENT) { out[v] = a; return; }       // (never written: a walk gave up, the flag is up)
+    const uint4 b = in[a.x];
+    if (b.x == RANK_SENT) { out[v] = a; return; }
+    out[v] = make_uint4(b.x, a.y + b.y, a.z < b.z ? a.z : b.z, 0u);
+}
+__global__ void __launch_bounds__(256) k_rank_walk2(const u64 *__restrict__ m, const unsigned *__restrict__ S,
+                                                    const unsigned *__restrict__ succ, uint4 *fin, int *flag, unsigned limit) {
+    const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (i >= *m) return;
+    const unsigned s = S[i];
+    const uint4 e = fin[s];
+    if (e.x == RANK_SENT) return;
+    unsigned u = succ[s], d = 1;
+    while (u != PATH_NONE && !rank_sampled(u)) {
+        fin[u] = make_uint4(e.x, e.y + d, e.z, 0u);
+        u = succ[u];
+        if (++d > limit) { *flag = 2; return; }
+    }
+}
+__global__ void __launch_bounds__(256) k_rank_leftover(i64 n, const unsigned *__restrict__ succ, uint4 *fin, int *flag, unsigned limit) {
+    const i64 v = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (v >= n) return;
+    if (fin[v].x != RANK_SENT) return;
+    unsigned u = succ[v], mn = (unsigned)v, steps = 0;  // on a cycle no splitter lies on
+    while (u != (unsigned)v) {
+        if (u == PATH_NONE || ++steps > limit) { *flag = 2; return; }
+        mn = u < mn ? u : mn;
+        u = succ[u];
+    }
+    fin[v] = make_uint4((unsigned)v, 0u, mn, 0u);
 }
 __global__ void __launch_bounds__(256) k_path_cut(i64 n, const uint4 *__restrict__ jb, unsigned *prv, unsigned *succ, int *flag) {
     const i64 v = (i64)blockIdx.x * 256 + threadIdx.x;
@@ -1076,7 +1160,11 @@ static void derived_log(hipStream_t stream, const char *what, long long a = 0, c
     const hipError_t e = hipStreamSynchronize(stream);
     u64 c = 0;
     if (d_count) (void)hipMemcpy(&c, d_count, 8, hipMemcpyDeviceToHost);
-    fprintf(stderr, "sbwtgpu:   derived: %s %lld (count %llu)%s\n", what, a, (unsigned long long)c, e == hipSuccess ? "" : " -- STREAM ERROR");
+    static std::chrono::steady_clock::time_point last = std::chrono::steady_clock::now();
+    const auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "sbwtgpu:   derived: %s %lld (count %llu)%s  [+%.3f s]\n", what, a, (unsigned long long)c,
+            e == hipSuccess ? "" : " -- STREAM ERROR", std::chrono::duration<double>(now - last).count());
+    last = now;
 }
 // scratch of the sparse-table build: two item lists of n_nodes entries + two counters
 long long sbwt_sparse_scratch_bytes(long long n_nodes) { return 2 * (n_nodes + 64) * (long long)sizeof(SpItem) + 256; }
@@ -1385,11 +1473,47 @@ int sbwt_launch_build_path(const SbwtIndexView &ix, unsigned *d_col, unsigned *d
     } else {
         hipLaunchKernelGGL(k_path_succ, dim3(g), dim3(256), 0, stream, ix, succ, sch, prv);
     }
+    derived_log(stream, "path order: successors chosen, columns", n);
     int rounds = 1;
     while (((i64)1 << rounds) < n) rounds++;
     rounds++;
     int cur = 0;
+    // (SBWTGPU_PATH_RANK=0: the doubling over every column, which is also the fallback; 2: splitters even where most columns are
+    // heads; read per call so that a test can build all three)
+    const int rank_splitters = [] { const char *e = getenv("SBWTGPU_PATH_RANK"); return e ? atoi(e) : 1; }();
+    // (SBWTGPU_PATH_RANK_LIMIT: the longest walk, for tests of the way back to the doubling)
+    const unsigned rank_limit = [] { const char *e = getenv("SBWTGPU_PATH_RANK_LIMIT"); return e && atoi(e) > 0 ? (unsigned)atoi(e) : (unsigned)RANK_LIMIT; }();
+    int *rflag = flag + 8;
+    u64 *m_dev = reinterpret_cast<u64 *>(flag + 32);
+    unsigned *S = reinterpret_cast<unsigned *>(len);    // (`len` is not in use before k_path_len: 8 bytes per column)
     for (int attempt = 0; attempt < 3; attempt++) {
+        cur = 0;
+        bool ranked = false;
+        if (rank_splitters) {
+            hipLaunchKernelGGL(k_path_keep, dim3(g), dim3(256), 0, stream, n, succ, prv, (uint4 *)nullptr);
+            (void)hipMemsetAsync(flag, 0, 4096, stream);
+            hipLaunchKernelGGL(k_rank_list, dim3(g), dim3(256), 0, stream, n, prv, S, m_dev, jb[0], jb[1]);
+            u64 m = 0;
+            if (hipMemcpyAsync(&m, m_dev, 8, hipMemcpyDeviceToHost, stream) != hipSuccess) return -1;
+            if (hipStreamSynchronize(stream) != hipSuccess) return -1;
+            if (m > 0 && (m <= (u64)n / 8 || rank_splitters >= 2)) {      // (2: whatever the share of splitters -- tests)
+                const unsigned gm = (unsigned)((m + 255) / 256);
+                hipLaunchKernelGGL(k_rank_walk1, dim3(gm), dim3(256), 0, stream, m_dev, S, succ, jb[0], rflag, rank_limit);
+                int rr = 1;
+                while (((u64)1 << rr) < m) rr++;
+                rr++;
+                for (int r = 0; r < rr; r++, cur ^= 1)
+                    hipLaunchKernelGGL(k_rank_jump, dim3(gm), dim3(256), 0, stream, m_dev, S, jb[cur], jb[cur ^ 1]);
+                hipLaunchKernelGGL(k_rank_walk2, dim3(gm), dim3(256), 0, stream, m_dev, S, succ, jb[cur], rflag, rank_limit);
+                hipLaunchKernelGGL(k_rank_leftover, dim3(g), dim3(256), 0, stream, n, succ, jb[cur], rflag, rank_limit);
+                int h_r = 0;
+                if (hipMemcpyAsync(&h_r, rflag, 4, hipMemcpyDeviceToHost, stream) != hipSuccess) return -1;
+                if (hipStreamSynchronize(stream) != hipSuccess) return -1;
+                ranked = (h_r == 0);
+                derived_log(stream, ranked ? "path order: ranked by splitters, attempt" : "path order: the splitter ranking gave up, attempt", attempt, m_dev);
+            }
+        }
+        if (!ranked) {
         cur = 0;
         hipLaunchKernelGGL(k_path_keep, dim3(g), dim3(256), 0, stream, n, succ, prv, jb[0]);
         for (int r = 0; r < rounds; r++) {
@@ -1406,11 +1530,13 @@ int sbwt_launch_build_path(const SbwtIndexView &ix, unsigned *d_col, unsigned *d
                 if (!h_moved) break;
             }
         }
+        }   // !ranked
         (void)hipMemsetAsync(flag, 0, 4, stream);
         hipLaunchKernelGGL(k_path_cut, dim3(g), dim3(256), 0, stream, n, jb[cur], prv, succ, flag);
         int h_flag = 0;
         if (hipMemcpyAsync(&h_flag, flag, 4, hipMemcpyDeviceToHost, stream) != hipSuccess) return -1;
         if (hipStreamSynchronize(stream) != hipSuccess) return -1;
+        derived_log(stream, "path order: cycles cut (flag)", h_flag);
         if (!h_flag) break;
         if (attempt == 2) return -2;                    // cannot happen: one cut per cycle opens every cycle
     }
@@ -1419,6 +1545,7 @@ int sbwt_launch_build_path(const SbwtIndexView &ix, unsigned *d_col, unsigned *d
     hipLaunchKernelGGL(k_scan_block_sums, dim3((unsigned)nb), dim3(256), 0, stream, reinterpret_cast<const i64 *>(len), n, bsum);
     hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, stream, bsum, nb);
     hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nb), dim3(256), 0, stream, reinterpret_cast<const i64 *>(len), n, bsum, pbase);
+    derived_log(stream, "path order: path lengths scanned", n);
     *n_pos = n;
     if (stitch && pos_cap > n) {
         unsigned *col_o = nullptr, *pos_o = nullptr;
@@ -1441,6 +1568,7 @@ int sbwt_launch_build_path(const SbwtIndexView &ix, unsigned *d_col, unsigned *d
     hipLaunchKernelGGL(k_path_place, dim3(g), dim3(256), 0, stream, n, jb[cur], pbase, succ, sch, d_pos,
                        d_col, reinterpret_cast<unsigned *>(d_pq));
     if (hipStreamSynchronize(stream) != hipSuccess) return -1;
+    derived_log(stream, "path order: placed", n);
     return 0;
 }
 // The ONLY bits, then the path groups' final encoding (k_path_reencode); returns the number of transition entries

@@ -537,6 +537,26 @@ int sbwtgpu_index_create(const sbwtgpu_index_desc *d, int device, sbwtgpu_index 
     }
     int rc = SBWTGPU_OK;
     unsigned char *alt_safe = nullptr;                 // per-position verdicts of the safe-bit pass, for the transition table
+    // One scratch allocation serves the path order, the sparse tables and the safe bits in turn (round 6): fresh device memory
+    // costs 20-30 ms per GB on this driver once an allocation goes beyond what the process has had before (2.25 x 10^9 columns: 128 GB
+    // for the path order and 108 GB for the sparse tables were 5.9 s of an 10.8 s image).  It is let go early only where the final
+    // image does not fit beside it (2.25 x 10^9 columns at k = 32: 167 GB).  SBWTGPU_SCRATCH_ARENA=0: an allocation per phase, as before.
+    static const int use_arena = [] { const char *e = getenv("SBWTGPU_SCRATCH_ARENA"); return e ? atoi(e) : 1; }();
+    void *arena = nullptr;
+    size_t arena_bytes = 0;
+    auto arena_drop = [&] { if (arena) (void)hipFree(arena); arena = nullptr; arena_bytes = 0; };
+    auto arena_get = [&](size_t need, size_t later) -> void * {        // (later: what the phases behind this one will ask for)
+        if (arena && arena_bytes >= need) return arena;
+        arena_drop();
+        const size_t want = (use_arena && later > need) ? later : need;
+        if (hipMalloc(&arena, want) == hipSuccess) { arena_bytes = want; return arena; }
+        (void)hipGetLastError();
+        arena = nullptr;
+        if (want > need && hipMalloc(&arena, need) == hipSuccess) { arena_bytes = need; return arena; }
+        (void)hipGetLastError();
+        arena = nullptr;
+        return nullptr;
+    };
     PhaseLog plog;
     plog("upload, counts, allocation");
     do {
@@ -576,14 +596,16 @@ int sbwtgpu_index_create(const sbwtgpu_index_desc *d, int device, sbwtgpu_index 
         }
         plog("dense prefix table(s)");
         if (h.has_path) {
-            void *scr = nullptr;
-            if ((e = hipMalloc(&scr, (size_t)sbwt_path_scratch_bytes(n))) != hipSuccess) break;
+            void *scr = arena_get((size_t)sbwt_path_scratch_bytes(n), h.p_sparse > 0 ? (size_t)sbwt_sparse_scratch_bytes(n) : 0);
+            if (!scr) { e = hipErrorOutOfMemory; break; }
+            if (g_verbose >= 2) plog("  (path order: scratch allocated)");
             long long n_pos = n;
             int prc = sbwt_launch_build_path(v, reinterpret_cast<unsigned *>(idx->blob + h.off_col),
                                              reinterpret_cast<unsigned *>(idx->blob + h.off_pos),
                                              reinterpret_cast<uint4 *>(idx->blob + h.off_pq), pos_cap, &n_pos, g_path_stitch,
                                              g_path_stitch_min, scr, g_path_lookahead, 0);
-            (void)hipFree(scr);
+            if (g_verbose >= 2) plog("  (path order: built)");
+            if (!use_arena) arena_drop();
             if (prc != 0) { e = hipErrorUnknown; break; }
             h.n_pos = n_pos;
             // col[n_pos] = 0xFFFFFFFF: the "position" whose column is -1 (the fused kernel's writer loads every result, absent
@@ -607,7 +629,19 @@ int sbwtgpu_index_create(const sbwtgpu_index_desc *d, int device, sbwtgpu_index 
             const int64_t full = align256(new_trans + 32 * n_slots);
             if (g_max_image_bytes > 0 && full > g_max_image_bytes && level < 2) { e = hipErrorOutOfMemory; break; }
             char *nblob = nullptr;
-            if ((e = hipMalloc((void **)&nblob, (size_t)full)) != hipSuccess) break;
+            if (g_verbose >= 2) plog("  (transition entries counted)");
+            e = hipMalloc((void **)&nblob, (size_t)full);
+            if (e != hipSuccess && arena) {             // (no room beside the scratch: the scratch goes first)
+                (void)hipGetLastError();
+                arena_drop();
+                e = hipMalloc((void **)&nblob, (size_t)full);
+            }
+            if (e != hipSuccess) break;
+            if (arena) {                                // (what is still to come -- alt_safe, the builders' small buffers -- must not fail for it)
+                size_t fr = 0, tot = 0;
+                if (hipMemGetInfo(&fr, &tot) != hipSuccess || fr < (size_t)h.n_pos * 2 + ((size_t)4 << 30)) arena_drop();
+            }
+            if (g_verbose >= 2) plog("  (final allocation)");
             const int64_t head = h.off_col;                                 // blocks, tables, mega: the same offsets in both
             if ((e = hipMemcpy(nblob, idx->blob, (size_t)head, hipMemcpyDeviceToDevice)) != hipSuccess ||
                 (e = hipMemset(nblob + head, 0, (size_t)(f_off_col - head))) != hipSuccess ||        // the sparse tables' and the filter's room
@@ -617,6 +651,7 @@ int sbwtgpu_index_create(const sbwtgpu_index_desc *d, int device, sbwtgpu_index 
                 (void)hipFree(nblob);
                 break;
             }
+            if (g_verbose >= 2) plog("  (moved)");
             (void)hipFree(idx->blob);
             idx->blob = nblob;
             h.off_col = f_off_col;
@@ -628,8 +663,9 @@ int sbwtgpu_index_create(const sbwtgpu_index_desc *d, int device, sbwtgpu_index 
         }
         plog("path order, final layout");
         if (h.p_sparse > 0) {
-            void *scr = nullptr;
-            if ((e = hipMalloc(&scr, (size_t)sbwt_sparse_scratch_bytes(n))) != hipSuccess) break;
+            void *scr = arena_get((size_t)sbwt_sparse_scratch_bytes(n), 0);
+            if (!scr) { e = hipErrorOutOfMemory; break; }
+            if (g_verbose >= 2) plog("  (sparse tables: scratch allocated)");
             int src = sbwt_launch_build_sparse(v, (int)p_dev, (int)h.p_sparse, (long long)h.n_sb,
                                                reinterpret_cast<uint4 *>(idx->blob + h.off_stab), scr,
                                                h.has_path ? reinterpret_cast<const unsigned *>(idx->blob + h.off_pos) : nullptr,
@@ -638,7 +674,8 @@ int sbwtgpu_index_create(const sbwtgpu_index_desc *d, int device, sbwtgpu_index 
                                                (long long)h.n_sb2,
                                                h.n_sb2 > 0 ? reinterpret_cast<uint4 *>(idx->blob + h.off_stab2) : nullptr, 0);
             e = hipDeviceSynchronize();
-            (void)hipFree(scr);
+            if (g_verbose >= 2) plog("  (sparse tables: built)");
+            if (!use_arena) arena_drop();
             if (src == -3) { h.n_sb2 = 0; src = 0; }   // some k-mer spans several columns: no second level
             if (src < 0 && e == hipSuccess) e = hipErrorUnknown;
             if (e != hipSuccess) break;
@@ -655,9 +692,15 @@ int sbwtgpu_index_create(const sbwtgpu_index_desc *d, int device, sbwtgpu_index 
                 // (rule 2 keeps the path heads' labels and their list in scratch)
                 void *hscr = nullptr;
                 const bool wide_safe = d->k > h.p_sparse;
-                if ((g_path_safe >= 2 || wide_safe) && hipMalloc(&hscr, (size_t)sbwt_path_safe_scratch_bytes(h.n_pos, (int)d->k)) != hipSuccess) {
-                    (void)hipGetLastError();
-                    hscr = nullptr;                     // no room for rule 2: the narrow rule needs none
+                const size_t safe_bytes = (size_t)sbwt_path_safe_scratch_bytes(h.n_pos, (int)d->k);
+                const bool hscr_in_arena = arena && arena_bytes >= safe_bytes;
+                if (!hscr_in_arena) arena_drop();       // (too small to serve: its room may be what the allocation below needs)
+                if (g_path_safe >= 2 || wide_safe) {
+                    if (hscr_in_arena) hscr = arena;
+                    else if (hipMalloc(&hscr, safe_bytes) != hipSuccess) {
+                        (void)hipGetLastError();
+                        hscr = nullptr;                 // no room for rule 2: the narrow rule needs none
+                    }
                 }
                 // ... and hands the per-substitute verdicts to the transition table's negative entries through alt_safe (a byte
                 // per position; without it only the steps that are safe for all three substitutes bridge)
@@ -668,7 +711,7 @@ int sbwtgpu_index_create(const sbwtgpu_index_desc *d, int device, sbwtgpu_index 
                 sbwt_launch_path_safe(v2, reinterpret_cast<uint4 *>(idx->blob + h.off_pq), hscr ? (wide_safe ? 2 : g_path_safe) : 1, hscr, alt_safe, 0);
                 e = hipDeviceSynchronize();
                 const bool had_scratch = hscr != nullptr;
-                if (hscr) (void)hipFree(hscr);
+                if (hscr && !hscr_in_arena) (void)hipFree(hscr);
                 if (e != hipSuccess) break;
                 h.has_safe = (wide_safe && !had_scratch) ? 0 : 1;    // (no room for the head labels of long k-mers: no safe bits)
             }
@@ -692,6 +735,7 @@ int sbwtgpu_index_create(const sbwtgpu_index_desc *d, int device, sbwtgpu_index 
         if ((e = hipGetLastError()) != hipSuccess) break;
         e = hipDeviceSynchronize();
     } while (0);
+    arena_drop();
     if (alt_safe) (void)hipFree(alt_safe);
     if (e == hipErrorOutOfMemory && level < 2 && (h.has_path || h.p_sparse > 0)) {
         (void)hipGetLastError();                       // scratch of a derived structure did not fit: build without them

@@ -1077,3 +1077,68 @@ def test_fused_kernel_takes_reads_of_161_to_400_bases_as_pieces(gpu, k):
     bases = synth.inject(bases, 120, ord("N"), 4)
     bases = synth.inject(bases, 120, ord("t"), 5)
     run(bases, off)
+
+
+@pytest.mark.parametrize("case", ["periodic3", "periodic8", "periodic31", "genomes30", "pan31", "one_path20"])
+def test_path_order_by_splitters_equals_the_doubling_over_every_column(gpu, case):
+    """Round 6: the list ranking behind the path order (head of its path and distance from it, per column) is done by splitters
+    (sbwt_derived.hip k_rank_*: heads + one column in 64 walk to the next splitter, the splitters are ranked by doubling, the
+    stretches are walked again) instead of doubling over every column.  Same path order, bit for bit: col[], pos[] and the path
+    groups of images built with SBWTGPU_PATH_RANK = 0 (doubling), 2 (splitters whatever their share) and unset (splitters
+    unless more than one column in eight is one) -- on graphs with cycles of every size (with and without a splitter on them),
+    on many short paths and on one long path."""
+    import struct
+    rng = random.Random(77)
+    if case.startswith("periodic"):
+        k = int(case[8:])
+        unit = "".join(rng.choice("ACGT") for _ in range(k + 5))
+        flank = lambda n: "".join(rng.choice("ACGT") for _ in range(n))
+        seqs = ["A" * 120, "AC" * 80, "ACG" * 60, "ACGT" * 50, "AACCGGTT" * 30, unit * 14, flank(60) + "GATTACA" * 25 + flank(60),
+                flank(40) + unit * 6 + flank(40), ("".join(rng.choice("ACGT") for _ in range(700))) * 3]      # (a cycle of 700 columns)
+        orc = OracleIndex.build([b(s) for s in seqs], k, True, False, min(k, 2))
+    elif case == "genomes30":
+        genomes = [synth.random_genome(120_000, 5)]
+        genomes.append(synth.mutate(genomes[0], 0.03, 6))
+        orc = OracleIndex.build([g.tobytes() for g in genomes], 30, True, False, 6)
+    elif case == "pan31":
+        genomes = synth.pan_like(12, 40_000)
+        orc = OracleIndex.build([g.tobytes() for g in genomes], 31, True, False, 6)
+    else:
+        orc = OracleIndex.build([synth.random_genome(300_000, 9).tobytes()], 20, False, False, 6)
+    old = os.environ.get("SBWTGPU_PATH_RANK")
+    images = {}
+    try:
+        for mode in ("0", "2", None, "gave_up"):
+            os.environ.pop("SBWTGPU_PATH_RANK_LIMIT", None)
+            if mode is None:
+                os.environ.pop("SBWTGPU_PATH_RANK", None)
+            elif mode == "gave_up":                     # walks of at most 8 steps: some walk gives up, the doubling takes over
+                os.environ["SBWTGPU_PATH_RANK"] = "2"
+                os.environ["SBWTGPU_PATH_RANK_LIMIT"] = "8"
+            else:
+                os.environ["SBWTGPU_PATH_RANK"] = mode
+            idx = gpu_index_from_oracle(orc)
+            hdr = idx.export_header()
+            has_path, = struct.unpack_from("<i", hdr, 164)
+            off_col, off_pos, off_pq = struct.unpack_from("<3q", hdr, 168)
+            n_pos, = struct.unpack_from("<q", hdr, 248)
+            if not has_path:
+                pytest.skip("an image without a path order (SBWTGPU_IMAGE_LEVEL >= 1)")
+            blob = idx.blob_tensor()
+            images[mode] = (idx.n_paths, n_pos, blob[off_pos:off_pos + 4 * idx.n_nodes].cpu().numpy().copy(),
+                            blob[off_col:off_col + 4 * n_pos].cpu().numpy().copy(),
+                            blob[off_pq:off_pq + 16 * (n_pos // 32 + 1)].cpu().numpy().copy())
+            idx.close()
+    finally:
+        os.environ.pop("SBWTGPU_PATH_RANK_LIMIT", None)
+        if old is None:
+            os.environ.pop("SBWTGPU_PATH_RANK", None)
+        else:
+            os.environ["SBWTGPU_PATH_RANK"] = old
+    ref = images["0"]
+    assert ref[0] > 0
+    for mode in ("2", None, "gave_up"):
+        got = images[mode]
+        assert got[0] == ref[0] and got[1] == ref[1], (mode, got[:2], ref[:2])
+        for a, b_ in zip(got[2:], ref[2:]):
+            assert np.array_equal(a, b_), mode

@@ -51,7 +51,7 @@ for c in ("c2", "c5", "c3", "c2_line", "c5_line", "c3_line", "c2_level1", "c2_le
         print(c, "ERR", e)
 PY
 # results must not depend on the builder / route knobs: the parity tests under non-default environments
-for e in SBWTGPU_PATH_LOOKAHEAD=0 SBWTGPU_IMAGE_LEVEL=1 SBWTGPU_IMAGE_LEVEL=2 SBWTGPU_PATH_SAFE=0 SBWTGPU_PATH_STITCH=0 SBWTGPU_FUSED_RAGGED=0 SBWTGPU_SPLIT_LONG=0 SBWTGPU_FUSED_PIECES=3 SBWTGPU_FUSED_PIECES=1; do
+for e in SBWTGPU_PATH_LOOKAHEAD=0 SBWTGPU_PATH_RANK=0 SBWTGPU_SCRATCH_ARENA=0 SBWTGPU_IMAGE_LEVEL=1 SBWTGPU_IMAGE_LEVEL=2 SBWTGPU_PATH_SAFE=0 SBWTGPU_PATH_STITCH=0 SBWTGPU_FUSED_RAGGED=0 SBWTGPU_SPLIT_LONG=0 SBWTGPU_FUSED_PIECES=3 SBWTGPU_FUSED_PIECES=1; do
   env $e timeout 600 python -m pytest tests/test_gpu_parity.py tests/test_gpu_workloads.py -x -q -m gpu 2>&1 | tail -1 | sed "s/^/$e: /"
 done | tee $O/knob_sweep.log
 # instrumented builds (tools/build_stats_lib.sh [timeline]; not the shipped library): lane-iterations by kind, the tail by
