@@ -171,10 +171,11 @@ struct SbwtWorkHeader {
     unsigned long long ftick_over;
     unsigned long long pad2[5];
     // Which instantiation of the fused kernel suits the caller's batches (k <= 31): the LAST word of the header is not cleared
-    // with it (SBWT_WS_CLEAR_BYTES) -- it is what the call before on this workspace left there.  SBWT_HINT_MAGIC | 1: that call's
-    // reads followed their paths for at least SBWT_HINT_RATIO k-mers per search started, the work mix the SORT instantiation is
-    // faster on (by 3-14 %; on batches that mostly search -- unrelated reads, 5 % substitutions -- it is a third slower: half
-    // of its waves only follow paths).  Anything else (a fresh workspace): the unsorted kernel.  Both are launched; the one
+    // with it (SBWT_WS_CLEAR_BYTES) -- it is what the calls before on this workspace left there.  SBWT_HINT_MAGIC | c: the last c
+    // calls in a row (counted up to SBWT_HINT_CALLS) had reads that followed their paths for at least SBWT_HINT_RATIO k-mers per
+    // search started, the work mix the SORT instantiation is faster on (by 3-14 %; on batches that mostly search -- unrelated
+    // reads, 5 % substitutions -- it is a third slower: half of its waves only follow paths).  c == SBWT_HINT_CALLS: the sorted
+    // kernel; anything else (a fresh workspace, batches of alternating kinds): the unsorted one.  Both are launched; the one
     // whose call it is not returns at once.
     unsigned long long hint;
 };
@@ -207,6 +208,7 @@ struct SbwtTickTab {
 };
 #define SBWT_HINT_MAGIC 0x5B377A00u
 #define SBWT_HINT_RATIO 12
+#define SBWT_HINT_CALLS 2
 
 // launchers implemented in sbwt_search.hip, sbwt_api_kernels.hip, sbwt_derived.hip, sbwt_format.hip (all asynchronous on `stream`)
 void sbwt_launch_encode(const char *d_bases, long long total_bases, uint4 *d_packed, SbwtWorkHeader *ws,

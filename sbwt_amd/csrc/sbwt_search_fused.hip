@@ -278,7 +278,7 @@ __global__ void __launch_bounds__(256, SORT ? FZ_SORT_WGS : 5) k_search_fused(Sb
         // the sorted or the unsorted instantiation?  "fused_sort" bit 12: always the sorted one; else by the hint the call before left
         // (not for batches of pieces -- reads of 161 .. 480 bases as two or three tickets each: measured 5 % slower sorted)
         const bool sorted_call = (ix.fused_sort & 4096) ||
-                                 (ws->hint == (unsigned long long)(SBWT_HINT_MAGIC | 1u) && (UNI || TAB || P_batch == 1));
+                                 (ws->hint == (unsigned long long)(SBWT_HINT_MAGIC | (unsigned)SBWT_HINT_CALLS) && (UNI || TAB || P_batch == 1));
         if (SORT != sorted_call) return;
     } else if (SORT) return;
     const int tid = threadIdx.x, lane = tid & 63, wbase = tid & ~63;
@@ -482,8 +482,12 @@ __global__ void __launch_bounds__(256) k_fused_tickets(const i64 *__restrict__ r
 // The hint for the next call on this workspace (SbwtWorkHeader::hint): did this call's reads mostly follow their paths?
 __global__ void k_fused_hint(SbwtWorkHeader *ws, int k) {
     if (threadIdx.x != 0 || sbwt_fused_mode(ws, k) == 0) return;          // (the general route took the batch: nothing learnt)
-    const unsigned long long ext = ws->n_ext, walks = ws->n_search;
-    ws->hint = (unsigned long long)(SBWT_HINT_MAGIC | ((walks > 0 && ext >= (unsigned long long)SBWT_HINT_RATIO * walks) ? 1u : 0u));
+    const unsigned long long ext = ws->n_ext, walks = ws->n_search, prev = ws->hint;
+    const bool fits = walks > 0 && ext >= (unsigned long long)SBWT_HINT_RATIO * walks;
+    // how many calls in a row (up to SBWT_HINT_CALLS) had the sorted kernel's work mix; one that has not starts the count again:
+    // the wrong kernel costs 5 % one way and 40 % the other, so a workspace whose batches alternate stays on the unsorted one
+    const unsigned run = ((prev & ~0xFFull) == (unsigned long long)SBWT_HINT_MAGIC) ? (unsigned)(prev & 0xFFull) : 0u;
+    ws->hint = (unsigned long long)(SBWT_HINT_MAGIC | (fits ? (run < SBWT_HINT_CALLS ? run + 1u : (unsigned)SBWT_HINT_CALLS) : 0u));
 }
 
 // Do all reads have one length and all result ranges one stride?  Thread 0 also notes the first offsets.

@@ -879,7 +879,7 @@ def test_sorted_instantiation_and_the_hint_that_picks_it(gpu, k):
         capi.set_tuning("fused_sort", 3632)
     if int(os.environ.get("SBWTGPU_IMAGE_LEVEL", "0")) != 0 or idx.image_level != 0:
         return                      # (no path order: the fused route, and with it the hint, is not in play)
-    # the hint: one workspace, three calls
+    # the hint: one workspace, a sequence of calls
     dev = torch.device("cuda:0")
     a_b, a_o = synth.sample_reads(genomes, 3000, 150, 0.002, 11)      # (few substitutions: > 12 k-mers along paths per search started)
     r_b, r_o = batches[2]
@@ -899,12 +899,19 @@ def test_sorted_instantiation_and_the_hint_that_picks_it(gpu, k):
     w_a, w_r = oracle_batch(orc, a_b, a_o, True), oracle_batch(orc, r_b, r_o, True)
     got, hint = call(a_b, a_o)                       # a fresh workspace: the unsorted kernel; its reads follow their paths
     assert np.array_equal(got, w_a) and hint == 0x5B377A01, hex(hint)
-    got, hint = call(a_b, a_o)                       # ... so this call runs sorted, and says the same of the next
-    assert np.array_equal(got, w_a) and hint == 0x5B377A01, hex(hint)
-    got, hint = call(r_b, r_o)                       # unrelated reads, sorted once; the hint turns
+    got, hint = call(a_b, a_o)                       # ... a second call in a row like that (still unsorted): the next one runs sorted
+    assert np.array_equal(got, w_a) and hint == 0x5B377A02, hex(hint)
+    got, hint = call(a_b, a_o)                       # sorted; the count stays at its cap
+    assert np.array_equal(got, w_a) and hint == 0x5B377A02, hex(hint)
+    got, hint = call(r_b, r_o)                       # unrelated reads, sorted once; the count starts again
     assert np.array_equal(got, w_r) and hint == 0x5B377A00, hex(hint)
     got, hint = call(r_b, r_o)
     assert np.array_equal(got, w_r) and hint == 0x5B377A00, hex(hint)
+    for _ in range(3):                               # batches of alternating kinds: never two in a row that fit, never sorted
+        got, hint = call(a_b, a_o)
+        assert np.array_equal(got, w_a) and hint == 0x5B377A01, hex(hint)
+        got, hint = call(r_b, r_o)
+        assert np.array_equal(got, w_r) and hint == 0x5B377A00, hex(hint)
 
 
 def _search_dev(idx, bases, off, k, streaming):

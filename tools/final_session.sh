@@ -18,7 +18,7 @@ timeout 900 python bench.py --config 3 --steps 5 > $O/c3_bench.json 2> $O/c3_ben
 PMC="FETCH_SIZE|WRITE_SIZE|TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum TCC_EA0_RDREQ_128B_sum|TCC_HIT_sum TCC_MISS_sum|SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES"
 prof() {   # prof <name> <config> <level> <variant> <reads> <bench args...>
   local name=$1 cfg=$2 lvl=$3 var=$4 reads=$5; shift 5
-  PMC_GROUPS="$PMC" bash tools/profile.sh ${TAG}_$name "$@" --warmup 1 --no-cpu-baseline --no-end-to-end --no-two-in-flight --no-int32-leg > /dev/null 2>&1
+  PMC_GROUPS="$PMC" bash tools/profile.sh ${TAG}_$name "$@" --warmup 2 --no-cpu-baseline --no-end-to-end --no-two-in-flight --no-int32-leg > /dev/null 2>&1
   cp gpurun_out/prof_${TAG}_$name/summary.txt $O/${name}_rocprof_summary.txt
   cp gpurun_out/prof_${TAG}_$name/trace_bench.json $O/${name}_bench_under_rocprof.json
   python tools/make_traffic_json.py $O/${name}_rocprof_summary.txt $cfg $reads ${TAG}_${name}_rocprof_summary.txt $lvl $var > /dev/null 2>> $O/traffic.err
@@ -71,10 +71,10 @@ fi
   NREADS=1000000 STEPS=50 python tools/overlap_steps.py 2>&1 | grep "^reads"
   K=63 STREAMING=0 NREADS=10000000 python tools/overlap_steps.py 2>&1 | grep "^reads" ) > $O/two_in_flight.txt 2>&1
 # the indexes beyond the Infinity Cache and beyond 2^31 columns (SURVEY 8d "G-hbm")
-timeout 900 python bench.py --config 6 --steps 5 --warmup 1 --no-end-to-end > $O/c6_hbm_bench.json 2> $O/c6_hbm_bench.err
-timeout 1200 python bench.py --config 6 --hbm-genome-len 2250000000 --steps 5 --warmup 1 --no-end-to-end > $O/c6_big_index_bench.json 2> $O/c6_big_index_bench.err
+timeout 900 python bench.py --config 6 --steps 5 --warmup 2 --no-end-to-end > $O/c6_hbm_bench.json 2> $O/c6_hbm_bench.err
+timeout 1200 python bench.py --config 6 --hbm-genome-len 2250000000 --steps 5 --warmup 2 --no-end-to-end > $O/c6_big_index_bench.json 2> $O/c6_big_index_bench.err
 # ... and 31 < k <= 63 there (round 6: the full image; k = 32 is what the GPU builder's 64-bit keys hold at that size)
-timeout 1200 python bench.py --config 6 --hbm-genome-len 2250000000 --hbm-k 32 --steps 5 --warmup 1 --no-end-to-end --no-cpu-baseline > $O/c6_big_index_k32.json 2> $O/c6_big_index_k32.err
+timeout 1200 python bench.py --config 6 --hbm-genome-len 2250000000 --hbm-k 32 --steps 5 --warmup 2 --no-end-to-end --no-cpu-baseline > $O/c6_big_index_k32.json 2> $O/c6_big_index_k32.err
 # long reads (round 6: the fused kernel's ticket table): whole genomes, 1 kbp and 10 kbp reads, >= 10^9 bases per batch, k = 30 and 63,
 # 1 % and 5 % substitutions, with the table and without (the general kernel)
 ( for K in 30 63; do for SUBS in 0.01 0.05; do K=$K SUBS=$SUBS timeout 600 python tools/long_read_bench.py 2>&1 | grep "^k="; done; done ) > $O/long_reads.txt 2>&1

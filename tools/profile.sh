@@ -5,7 +5,7 @@
 # usage: tools/profile.sh <tag> [bench args...]
 set -u
 TAG=${1:-r01}; shift || true
-ARGS=${@:---steps 3 --warmup 1 --no-cpu-baseline --no-end-to-end --no-two-in-flight --no-int32-leg}
+ARGS=${@:---steps 3 --warmup 2 --no-cpu-baseline --no-end-to-end --no-two-in-flight --no-int32-leg}
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p $OUT
